@@ -1,0 +1,399 @@
+/*
+ * lsim.h -- C-ABI of the MI355X-native vectorised legged-robot simulator ("leggedsim").
+ *
+ * Drop-in boundary for the hot path of xyyandhtl/IsaacgymLoco: everything that
+ * LeggedRobot.step() (legged_gym/envs/base/legged_robot.py:122-176) does between
+ * receiving `actions` and returning the observation tuple, i.e. the Isaac Gym tensor
+ * API calls listed in SURVEY.md 2.3 plus the torch post-physics stack.
+ *
+ * The reference has no FFI of its own on this path (it calls the closed-source
+ * `isaacgym.gymapi` pybind module); each entry point below names the reference
+ * call(s) it replaces.  Plain pointers and sizes only -- no torch types.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative LSIM_E_* code; the text of the
+ *     last error of a handle is available from lsim_last_error().  No exceptions cross
+ *     the ABI.  One caller thread per handle.
+ *   - all device work is enqueued on the caller-supplied HIP stream (pass
+ *     torch.cuda.current_stream().cuda_stream); no call synchronises the host unless
+ *     documented.
+ *   - device memory: the caller may pass one pre-allocated arena (lsim_query_arena gives
+ *     the size) so that a PyTorch host can alias every buffer zero-copy the way the
+ *     reference aliases simulator state with gymtorch.wrap_tensor (LR:930-944); with
+ *     arena == NULL the library allocates (hipMalloc) and owns it.
+ *   - quaternions are xyzw; root/body velocities are world-frame (LR:929-941).
+ */
+#ifndef LSIM_H
+#define LSIM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LSIM_ABI_VERSION 1
+
+/* ---- fixed sizes of the robot family on this path (12-DoF quadrupeds) ---- */
+#define LSIM_NUM_DOF 12
+#define LSIM_NUM_BODIES 17      /* base + 4 x (hip, thigh, calf, foot); LR:1143 */
+#define LSIM_NUM_LEGS 4
+#define LSIM_NUM_ACTIONS 12
+#define LSIM_ONE_STEP_OBS 45    /* LRC:51 */
+#define LSIM_OBS_HISTORY 6      /* LRC:52 */
+#define LSIM_NUM_OBS 270
+#define LSIM_MAX_HEIGHT_PTS_X 32
+#define LSIM_MAX_HEIGHT_PTS_Y 32
+#define LSIM_NUM_HEIGHT_PTS 187 /* 17 x 11, AGC:79-80; the obs layout hard-codes 187 (LR:895) */
+#define LSIM_NUM_PRIV_OBS 238   /* 45 + 3 + 3 + 187, LRC:53 */
+#define LSIM_NUM_AMP_OBS 30     /* LR:416 */
+#define LSIM_NUM_BASE_HEIGHT_PTS 63 /* 7 x 9, LR:1308-1312 */
+#define LSIM_MAX_COLLISION_POINTS 64
+#define LSIM_MAX_CONTACTS 16
+#define LSIM_TERRAIN_LEVELS_MAX 32
+#define LSIM_TERRAIN_TYPES_MAX 32
+
+/* error codes */
+#define LSIM_OK 0
+#define LSIM_E_INVALID (-1)
+#define LSIM_E_NOMEM (-2)
+#define LSIM_E_HIP (-3)
+#define LSIM_E_UNSUPPORTED (-4)
+#define LSIM_E_ABI (-5)
+
+/* ---- reward terms: every `_reward_<name>` defined in LR:1444-1770, in the
+ * alphabetical order in which the reference evaluates and accumulates them
+ * (class_to_dict iterates dir(), HLP:49 -> LR:1050-1055 -> LR:369-373). ---- */
+enum lsim_reward_id {
+    LSIM_R_ACTION_RATE = 0,
+    LSIM_R_ANG_VEL_XY,
+    LSIM_R_ANG_VEL_XY_UP,
+    LSIM_R_BASE_HEIGHT,
+    LSIM_R_BASE_HEIGHT_UP,
+    LSIM_R_CALF_POSE,
+    LSIM_R_CALF_POSE_UP,
+    LSIM_R_COLLISION,
+    LSIM_R_COLLISION_UP,
+    LSIM_R_DOF_ACC,
+    LSIM_R_DOF_POS_DIF,
+    LSIM_R_DOF_POS_LIMITS,
+    LSIM_R_DOF_VEL,
+    LSIM_R_DOF_VEL_LIMITS,
+    LSIM_R_FEET_AIR_TIME,
+    LSIM_R_FEET_CONTACT_FORCES,
+    LSIM_R_FEET_MIRROR,
+    LSIM_R_FEET_MIRROR_UP,
+    LSIM_R_FEET_SLIDE,
+    LSIM_R_FEET_SLIDE_UP,
+    LSIM_R_FEET_STUMBLE,
+    LSIM_R_FEET_STUMBLE_UP,
+    LSIM_R_FOOT_CLEARANCE_BASE,
+    LSIM_R_FOOT_CLEARANCE_BASE_UP,
+    LSIM_R_FOOT_CLEARANCE_TERRAIN,
+    LSIM_R_FOOT_CLEARANCE_TERRAIN_UP,
+    LSIM_R_HAS_CONTACT,
+    LSIM_R_HIP_ACTION_MAGNITUDE,
+    LSIM_R_HIP_POS,
+    LSIM_R_HIP_POS_UP,
+    LSIM_R_JOINT_POWER,
+    LSIM_R_LIN_VEL_Z,
+    LSIM_R_LIN_VEL_Z_UP,
+    LSIM_R_ORIENTATION,
+    LSIM_R_ORIENTATION_UP,
+    LSIM_R_POWER,
+    LSIM_R_POWER_DISTRIBUTION,
+    LSIM_R_SMOOTHNESS,
+    LSIM_R_STAND_NICE,
+    LSIM_R_STAND_STILL,
+    LSIM_R_STUCK,
+    LSIM_R_TERMINATION,
+    LSIM_R_THIGH_POSE,
+    LSIM_R_THIGH_POSE_UP,
+    LSIM_R_TORQUE_LIMITS,
+    LSIM_R_TORQUES,
+    LSIM_R_TORQUES_DIF,
+    LSIM_R_TORQUES_DISTRIBUTION,
+    LSIM_R_TRACKING_ANG_VEL,
+    LSIM_R_TRACKING_LIN_VEL,
+    LSIM_R_UPWARD,
+    LSIM_NUM_REWARD_TERMS
+};
+
+/* ---- counter-based RNG draw sites (Philox4x32-10, key = (seed, rank)) ----
+ * counter = (env, common_step_counter, tag, idx >> 2), lane = idx & 3,
+ * u = (x >> 8) * 2^-24 in [0,1).  One tag per torch draw site of the reference
+ * (stream order listed in SURVEY.md 8a quirk 12). */
+enum lsim_rng_tag {
+    LSIM_RNG_DELAY = 1,        /* LR:134            idx 0                                  */
+    LSIM_RNG_CMD = 2,          /* LR:641-651        idx 0 vx, 1 vy, 2 heading|yaw, 3 vx_hi */
+    LSIM_RNG_PUSH = 3,         /* LR:827            idx 0..1                               */
+    LSIM_RNG_DISTURB = 4,      /* LR:842            idx 0..2                               */
+    LSIM_RNG_TERM_NOISE = 5,   /* LR:451, LR:457    idx 0..44 obs, 45..231 heights         */
+    LSIM_RNG_RESET_LEVEL = 6,  /* LR:864            idx 0                                  */
+    LSIM_RNG_RESET_DOF = 7,    /* LR:699, LR:709    idx 0..11 pos ratio, 12..23 vel        */
+    LSIM_RNG_RESET_ROOT = 8,   /* LR:730-812        idx 0..2 xyz, 3..5 rpy, 6..11 vel      */
+    LSIM_RNG_RESET_CMD = 9,    /* LR:320 -> 641-651 same idx as LSIM_RNG_CMD               */
+    LSIM_RNG_RESET_DR = 10,    /* LR:337-341, 535   idx 0 kp, 1 kd, 2 motor factor, 3 friction, 4 restitution */
+    LSIM_RNG_OBS_NOISE = 11,   /* LR:394, LR:400    idx 0..44 obs, 45..231 heights         */
+    LSIM_RNG_INIT = 12,        /* LR:999-1028, 1232 idx 0..11 motor_strength, 12 kp, 13 kd, 14 motor factor,
+                                  15 payload, 16..18 com, 19 friction bucket id, 20 terrain level;
+                                  step word = 0xFFFFFFFF                                    */
+    LSIM_RNG_INIT_BUCKET = 13  /* LR:511            env word = bucket index, idx 0         */
+};
+
+/* ---- robot model: the URDF after Isaac Gym's fixed-joint collapse ----
+ * body order: 0 base, then for leg l in (FL, FR, RL, RR): 1+4l hip, 2+4l thigh, 3+4l calf, 4+4l foot.
+ * dof order : 3l + (0 hip, 1 thigh, 2 calf)  (LR:1145). */
+typedef struct lsim_body {
+    float mass;
+    float com[3];        /* in the body (link) frame */
+    float inertia[6];    /* about the com, body axes: xx, xy, xz, yy, yz, zz */
+    float joint_pos[3];  /* origin of this body's frame in the parent frame (rpy is 0 for all joints) */
+    float joint_axis[3]; /* revolute axis (unit), zero vector for base / fixed feet */
+    int32_t parent;      /* -1 for base */
+    int32_t dof;         /* -1 for base and for the fixed foot */
+} lsim_body;
+
+typedef struct lsim_collision_point {
+    float pos[3];   /* sphere centre in the body frame */
+    float radius;   /* 0 for box corners */
+    int32_t body;   /* body index the contact force is reported on */
+    int32_t pad;
+} lsim_collision_point;
+
+typedef struct lsim_robot_model {
+    lsim_body bodies[LSIM_NUM_BODIES];
+    float dof_pos_lower[LSIM_NUM_DOF];  /* hard URDF limits (rad) */
+    float dof_pos_upper[LSIM_NUM_DOF];
+    float dof_vel_limit[LSIM_NUM_DOF];
+    float dof_effort_limit[LSIM_NUM_DOF];
+    int32_t num_collision_points;       /* ordered by priority: overflow beyond LSIM_MAX_CONTACTS is dropped from the end */
+    int32_t pad;
+    lsim_collision_point points[LSIM_MAX_COLLISION_POINTS];
+    int32_t feet_bodies[LSIM_NUM_LEGS];   /* LR:1209-1211 */
+    uint32_t penalised_body_mask;         /* LR:1213-1215 */
+    uint32_t termination_body_mask;       /* LR:1217-1219 */
+} lsim_robot_model;
+
+/* ---- flat configuration: the values of the reference's nested config classes that the
+ * path reads (LeggedRobotCfg LRC:48 and the Aliengo subclasses AGC/AGS/AGA). ---- */
+typedef struct lsim_config {
+    int32_t abi_version;      /* LSIM_ABI_VERSION */
+    int32_t num_envs;         /* LRC:50 */
+    uint32_t seed;            /* LRC:258 */
+    uint32_t rank;            /* second Philox key word: one stream per data-parallel rank */
+
+    /* control (LRC:117-127, AGC:94-100) */
+    float sim_dt;             /* 0.005, LRC:239 */
+    int32_t decimation;       /* 4 */
+    int32_t control_type;     /* 0 'P', 1 'V', 2 'T' (LR:676-687) */
+    float action_scale;
+    float hip_reduction;
+    float p_gains[LSIM_NUM_DOF];
+    float d_gains[LSIM_NUM_DOF];
+    float torque_limits[LSIM_NUM_DOF];   /* LR:571 */
+    float default_dof_pos[LSIM_NUM_DOF]; /* LR:980-996 */
+    float clip_actions;       /* LRC:216 */
+    float clip_observations;
+
+    /* domain randomisation (AGC:148-214) */
+    int32_t delay;
+    int32_t randomize_kp;  float kp_range[2];
+    int32_t randomize_kd;  float kd_range[2];
+    int32_t randomize_motor_strength; float motor_strength_range[2];
+    int32_t randomize_friction; float friction_range[2];
+    int32_t randomize_restitution; float restitution_range[2];
+    int32_t randomize_payload_mass; float payload_mass_range[2];
+    int32_t randomize_com_displacement; float com_displacement_range[2];
+    int32_t push_robots; int32_t push_interval; float max_push_vel_xy;        /* LR:627, LR:1263 */
+    int32_t disturbance; int32_t disturbance_interval; float disturbance_range[2]; /* LR:631 */
+
+    /* reset (LR:690-820) */
+    int32_t has_dof_init_pos_ratio; float dof_init_pos_ratio_range[2];
+    int32_t randomize_dof_vel; float dof_init_vel_range[2];  /* effective range read at LR:708 */
+    int32_t has_base_init_pos_range; float base_init_pos_range[3][2];
+    int32_t has_base_init_rot_range; float base_init_rot_range[3][2];
+    float base_init_vel_range[6][2];
+    float base_init_state[13];      /* LR:1160-1161 */
+
+    /* commands (AGC:102-115) */
+    float command_ranges[4][2];     /* lin_vel_x, lin_vel_y, ang_vel_yaw, heading */
+    int32_t heading_command;
+    int32_t resampling_steps;       /* int(resampling_time / dt), LR:612 */
+    int32_t commands_curriculum;
+    float max_forward_curriculum, max_backward_curriculum, max_lat_curriculum;
+
+    /* terrain (AGC:67-91) */
+    int32_t mesh_type;              /* 0 plane, 1 heightfield, 2 trimesh */
+    float horizontal_scale, vertical_scale, border_size;
+    int32_t grid_rows, grid_cols;   /* tot_rows, tot_cols, TER:59-60 */
+    int32_t terrain_num_rows, terrain_num_cols;  /* levels, types */
+    float terrain_length, terrain_width;         /* env_length, env_width */
+    int32_t terrain_curriculum;
+    int32_t max_init_terrain_level;
+    int32_t measure_heights;
+    int32_t num_points_x, num_points_y;          /* 17, 11 */
+    float measured_points_x[LSIM_MAX_HEIGHT_PTS_X];
+    float measured_points_y[LSIM_MAX_HEIGHT_PTS_Y];
+    float slope_threshold;          /* trimesh vertical-wall correction, TER:72-75 */
+    float terrain_friction, terrain_restitution;
+
+    /* termination (AGC:141-146, LR:249-286) */
+    int32_t term_base_vel_violate_commands, term_out_of_border, term_fall_down;
+    int32_t max_episode_length;     /* ceil(episode_length_s / dt), LR:1261 */
+    int32_t send_timeouts;
+
+    /* rewards (AGC:216-270) */
+    float reward_scales[LSIM_NUM_REWARD_TERMS];  /* already multiplied by dt (LR:1046); 0 = inactive */
+    int32_t only_positive_rewards;
+    float tracking_sigma, soft_dof_pos_limit, soft_dof_vel_limit, soft_torque_limit;
+    float base_height_target, max_contact_force, foot_height_target_base, foot_height_target_terrain;
+    int32_t stairsup_start_idx, stairsup_end_idx, pit_start_idx, gap_end_idx;   /* LR:79-90 */
+    float episode_length_s;
+
+    /* observations (AGC:272-291) */
+    float obs_scale_lin_vel, obs_scale_ang_vel, obs_scale_dof_pos, obs_scale_dof_vel, obs_scale_height;
+    int32_t add_noise;
+    /* entries of noise_scale_vec (LR:883-910) as the host computed them in double precision:
+       ang_vel (obs 3:6), gravity (6:9), dof_pos (9:21), dof_vel (21:33), heights (45+6 .. +187); commands/actions are 0 */
+    float noise_vec_ang_vel, noise_vec_gravity, noise_vec_dof_pos, noise_vec_dof_vel, noise_vec_height;
+
+    /* simulator (LRC:238-255); the solver is the build's own (DESIGN.md "Physics") */
+    float gravity[3];
+    int32_t solver_iterations;
+    float contact_offset, max_depenetration_velocity, erp, contact_slop;
+    int32_t using_amp;              /* LRC:36: step() also produces terminal AMP states */
+    int32_t reserved[8];
+} lsim_config;
+
+/* ---- device buffers.  Shapes are per handle (N = num_envs); dtype codes below. ---- */
+#define LSIM_DT_F32 0
+#define LSIM_DT_I64 1
+#define LSIM_DT_U8 2   /* torch.bool compatible */
+#define LSIM_DT_I32 3
+#define LSIM_DT_I16 4
+
+enum lsim_buffer_id {
+    LSIM_BUF_OBS = 0,            /* f32 [N,270]   obs_buf, newest frame first (LR:403) */
+    LSIM_BUF_PRIV_OBS,           /* f32 [N,238]   privileged_obs_buf (LR:404) */
+    LSIM_BUF_REW,                /* f32 [N]       rew_buf (LR:368-380) */
+    LSIM_BUF_RESET,              /* u8  [N]       reset_buf (LR:255, LR:329) */
+    LSIM_BUF_TIME_OUT,           /* u8  [N]       time_out_buf (LR:260) */
+    LSIM_BUF_EXTRAS_TIME_OUTS,   /* u8  [N]       extras["time_outs"]: only refreshed on steps with >=1 reset (LR:358-359) */
+    LSIM_BUF_EPISODE_LENGTH,     /* i64 [N]       episode_length_buf (BT:73), caller-writable (HIMR:90-91) */
+    LSIM_BUF_ROOT_STATES,        /* f32 [N,13]    gym root state tensor (LR:930) */
+    LSIM_BUF_DOF_STATE,          /* f32 [N,12,2]  gym dof state tensor (LR:932) */
+    LSIM_BUF_RIGID_BODY_STATES,  /* f32 [N,17,13] (LR:938) */
+    LSIM_BUF_CONTACT_FORCES,     /* f32 [N,17,3]  net contact force per body, last sub-step (LR:944) */
+    LSIM_BUF_TORQUES,            /* f32 [N,12]    last sub-step torques (LR:146) */
+    LSIM_BUF_ACTIONS,            /* f32 [N,12]    clipped actions (LR:130) */
+    LSIM_BUF_LAST_ACTIONS,       /* f32 [N,12] */
+    LSIM_BUF_LAST_LAST_ACTIONS,  /* f32 [N,12] */
+    LSIM_BUF_LAST_DOF_POS,       /* f32 [N,12] */
+    LSIM_BUF_LAST_DOF_VEL,       /* f32 [N,12] */
+    LSIM_BUF_LAST_TORQUES,       /* f32 [N,12] */
+    LSIM_BUF_LAST_ROOT_VEL,      /* f32 [N,6] */
+    LSIM_BUF_COMMANDS,           /* f32 [N,4]     (LR:967) */
+    LSIM_BUF_BASE_LIN_VEL,       /* f32 [N,3]     (LR:198) */
+    LSIM_BUF_BASE_ANG_VEL,       /* f32 [N,3] */
+    LSIM_BUF_PROJECTED_GRAVITY,  /* f32 [N,3] */
+    LSIM_BUF_FEET_AIR_TIME,      /* f32 [N,4] */
+    LSIM_BUF_LAST_CONTACTS,      /* u8  [N,4] */
+    LSIM_BUF_CONTACT_FILT,       /* u8  [N,4] */
+    LSIM_BUF_MEASURED_HEIGHTS,   /* f32 [N,187]   (LR:624) */
+    LSIM_BUF_PENDING_FORCE,      /* f32 [N,3]     body-local force on the base drawn at LR:842-844, consumed (and cleared) by the
+                                                  first sub-step of the next step; the reference's self.disturbance is zero
+                                                  again after every step (LR:235), its value survives only inside priv obs */
+    LSIM_BUF_TERRAIN_LEVELS,     /* i64 [N] */
+    LSIM_BUF_TERRAIN_TYPES,      /* i64 [N] */
+    LSIM_BUF_ENV_ORIGINS,        /* f32 [N,3] */
+    LSIM_BUF_KP_FACTORS,         /* f32 [N] */
+    LSIM_BUF_KD_FACTORS,         /* f32 [N] */
+    LSIM_BUF_MOTOR_STRENGTH,     /* f32 [N,12]    drawn once (LR:999-1007) */
+    LSIM_BUF_MOTOR_STRENGTH_FACTORS, /* f32 [N]   redrawn at reset, never used (quirk 8) */
+    LSIM_BUF_FRICTION,           /* f32 [N] */
+    LSIM_BUF_RESTITUTION,        /* f32 [N] */
+    LSIM_BUF_PAYLOAD,            /* f32 [N] */
+    LSIM_BUF_COM_DISPLACEMENT,   /* f32 [N,3] */
+    LSIM_BUF_EPISODE_SUMS,       /* f32 [N,LSIM_NUM_REWARD_TERMS] */
+    LSIM_BUF_TERM_PRIV_OBS,      /* f32 [N,238]   rows valid where reset_buf (LR:227) */
+    LSIM_BUF_TERM_AMP_OBS,       /* f32 [N,30]    rows valid where reset_buf (LR:228) */
+    LSIM_BUF_AMP_OBS,            /* f32 [N,30]    get_amp_observations() of the post-step state (LR:406-416) */
+    LSIM_BUF_DELAY_STEPS,        /* i32 [N]       last drawn action delay (LR:134) */
+    LSIM_BUF_STATS,              /* f32 [LSIM_STATS_SIZE] device-side per-step reductions, see below */
+    LSIM_BUF_HEIGHT_GRID,        /* i16 [rows,cols] */
+    LSIM_BUF_TERRAIN_ORIGINS,    /* f32 [levels,types,3] */
+    LSIM_NUM_BUFFERS
+};
+
+/* layout of LSIM_BUF_STATS (all f32, rewritten by every lsim_step):
+ *   [0]                      number of envs reset this step
+ *   [1 .. 1+T)               sum over reset envs of episode_sums[k] / clip(ep_len,1)   (LR:349; divide by [0] and dt)
+ *   [1+T]                    sum over all envs of terrain_levels                        (LR:353)
+ *   [2+T .. 10+T)            command_ranges[4][2] live values (LR:877-880)
+ *   [10+T]                   sum over reset envs of episode_sums[tracking_lin_vel]      (LR:875)
+ *   [11+T]                   running count of steps with >=1 reset since creation
+ */
+#define LSIM_STATS_RESET_COUNT 0
+#define LSIM_STATS_EPISODE_SUMS 1
+#define LSIM_STATS_LEVEL_SUM (1 + LSIM_NUM_REWARD_TERMS)
+#define LSIM_STATS_CMD_RANGES (2 + LSIM_NUM_REWARD_TERMS)
+#define LSIM_STATS_TRACK_SUM (10 + LSIM_NUM_REWARD_TERMS)
+#define LSIM_STATS_RESET_STEPS (11 + LSIM_NUM_REWARD_TERMS)
+#define LSIM_STATS_SIZE (16 + LSIM_NUM_REWARD_TERMS)
+
+/* flags of lsim_step_ex */
+#define LSIM_STEP_DEFAULT 0u
+#define LSIM_STEP_SKIP_PHYSICS 1u   /* test hook: use ROOT/DOF/RIGID_BODY/CONTACT buffers as injected by the caller
+                                       instead of simulating; still computes torques (E3) for the 4 sub-steps */
+#define LSIM_STEP_NO_RESET 2u       /* test hook: compute reset_buf but do not reset_idx */
+
+typedef struct lsim_sim* lsim_handle;
+
+/* sizeof() of the two structs as compiled into the library -- lets a foreign binding verify its mirror. */
+int lsim_sizeof_config(void);
+int lsim_sizeof_model(void);
+int lsim_abi_version(void);
+
+/* bytes of device memory one simulator instance needs (all buffers, 256-B aligned). */
+int lsim_query_arena(const lsim_config* cfg, size_t* bytes_out);
+
+/* replaces gym.create_sim + add_triangle_mesh/add_heightfield/add_ground + load_asset + create_env/create_actor
+ * + acquire_*_tensor + prepare_sim (LR:467, LR:1069-1104, LR:1135, LR:1184-1205, LR:917-920, BT:85) and the
+ * buffer allocation of BaseTask.__init__/LeggedRobot._init_buffers (BT:70-79, LR:913-1032).
+ * height_grid: host int16 [grid_rows*grid_cols] (may be NULL for mesh_type plane);
+ * terrain_origins: host float [terrain_num_rows*terrain_num_cols*3] (may be NULL for plane). */
+int lsim_create(const lsim_config* cfg, const lsim_robot_model* model,
+                const int16_t* height_grid, const float* terrain_origins,
+                void* arena_dev, int device_id, lsim_handle* out);
+
+/* replaces gymtorch.wrap_tensor(acquire_*) (LR:930-944): device pointer + shape of one buffer. */
+int lsim_get_buffer(lsim_handle h, int buffer_id, void** dev_ptr, int64_t shape[4], int* ndim, int* dtype);
+
+/* LeggedRobot.reset_idx(all envs) as called by BaseTask.reset (BT:113); the caller follows it with one
+ * zero-action lsim_step to complete reset() (BT:114). */
+int lsim_reset_all(lsim_handle h, void* hip_stream);
+
+/* LeggedRobot.step(actions) (LR:122-176): replaces set_dof_actuation_force_tensor/simulate/fetch_results/
+ * refresh_* x4 (LR:146-152), refresh_* (LR:187-190), set_*_indexed (LR:714, LR:818), set_actor_root_state_tensor
+ * (LR:828), apply_rigid_body_force_tensors (LR:844) and the whole post_physics_step (LR:178-247).
+ * actions_dev: device float [N,12].  Asynchronous on hip_stream. */
+int lsim_step(lsim_handle h, const float* actions_dev, void* hip_stream);
+int lsim_step_ex(lsim_handle h, const float* actions_dev, uint32_t flags, void* hip_stream);
+
+/* host-side scalars (no device sync): common_step_counter (LR:194). */
+int lsim_get_step_counter(lsim_handle h, int64_t* counter_out);
+int lsim_set_step_counter(lsim_handle h, int64_t counter);
+
+/* name of a reward term / buffer (for bindings and logs); NULL if out of range. */
+const char* lsim_reward_name(int reward_id);
+const char* lsim_buffer_name(int buffer_id);
+
+const char* lsim_last_error(lsim_handle h);
+void lsim_destroy(lsim_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LSIM_H */

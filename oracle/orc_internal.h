@@ -1,0 +1,34 @@
+/* TEST INFRASTRUCTURE (oracle) -- not part of the product.  See oracle/README.md. */
+#ifndef ORC_INTERNAL_H
+#define ORC_INTERNAL_H
+#include <stdint.h>
+#include "../include/lsim.h"
+#include "../include/lsim_layout.h"
+
+typedef struct orc_sim {
+    lsim_config cfg;
+    lsim_robot_model model;
+    void* buf[LSIM_NUM_BUFFERS];
+    int64_t step_counter;       /* common_step_counter, LR:948 */
+    int init_done;              /* LR:97, LR:116 */
+    double command_ranges[4][2];/* python floats in the reference (LR:1256) */
+    int active_terms[LSIM_NUM_REWARD_TERMS];  /* alphabetical, termination excluded (LR:1050-1055) */
+    int num_active;
+    char err[256];
+} orc_sim;
+
+#define ORC_F(s, id) ((float*)(s)->buf[id])
+#define ORC_U8(s, id) ((uint8_t*)(s)->buf[id])
+#define ORC_I64(s, id) ((int64_t*)(s)->buf[id])
+#define ORC_I32(s, id) ((int32_t*)(s)->buf[id])
+#define ORC_I16(s, id) ((int16_t*)(s)->buf[id])
+
+/* orc_physics.c: one 5 ms articulated-body sub-step of env `e` (the build's own solver; dynamics
+ * parity with PhysX is unpinned -- SURVEY.md 8c).  tau: 12 joint efforts.  apply_force: consume pending_force. */
+void orc_physics_substep(orc_sim* s, int e, const float tau[12], int apply_force);
+/* recompute rigid_body_states of env e from root/dof state (forward kinematics + velocities) */
+void orc_refresh_body_states(orc_sim* s, int e);
+/* terrain surface query used by the contact model: height and unit normal under world point (x,y) */
+void orc_terrain_query(const orc_sim* s, double x, double y, double* h, double n[3]);
+
+#endif

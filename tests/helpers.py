@@ -1,0 +1,41 @@
+"""Shared test helpers: build configs / oracle sims (test infrastructure)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from isaacgymloco_amd import abi  # noqa: E402
+from isaacgymloco_amd.envs import config as C, terrain as T, lsim_config as LC  # noqa: E402
+from isaacgymloco_amd.robots import aliengo  # noqa: E402
+
+
+def quiet_cfg(task="aliengo", flat=True):
+    """Task config with every random perturbation switched off (deterministic physics checks)."""
+    cfg = C.TASKS[task][0]()
+    dr = cfg.domain_rand
+    for k in ("randomize_payload_mass", "randomize_com_displacement", "randomize_friction", "randomize_restitution",
+              "randomize_motor_strength", "randomize_kp", "randomize_kd", "disturbance", "push_robots", "delay",
+              "randomize_dof_vel"):
+        setattr(dr, k, False)
+    dr.dof_init_pos_ratio_range = [1.0, 1.0]
+    dr.base_init_pos_range = dict(x=[0.0, 0.0], y=[0.0, 0.0], z=[0.0, 0.0])
+    dr.base_init_rot_range = dict(roll=[0.0, 0.0], pitch=[0.0, 0.0], yaw=[0.0, 0.0])
+    dr.base_init_vel_range = dict(x=[0.0, 0.0], y=[0.0, 0.0], z=[0.0, 0.0], roll=[0.0, 0.0], pitch=[0.0, 0.0], yaw=[0.0, 0.0])
+    cfg.noise.add_noise = False
+    cfg.noise.noise_scales.height_measurements = 0.0
+    if flat:
+        cfg.terrain.terrain_proportions = [1.0, 0.0, 0.0, 0.0]
+    return cfg
+
+
+def make_oracle(cfg, num_envs, seed=1, terrain_seed=1, using_amp=False):
+    from oracle import oracle
+    ter = T.Terrain(cfg.terrain, num_envs, seed=terrain_seed)
+    model = aliengo.build_model()
+    lc = LC.make_lsim_config(cfg, num_envs=num_envs, terrain=ter, model=model, seed=seed, using_amp=using_amp)
+    sim = oracle.OracleSim(lc, model, ter.heightsamples, ter.env_origins)
+    return sim, lc, model, ter
