@@ -53,6 +53,13 @@ def _parse(text):
                 members[item] = val
         enums[m.group(1)] = members
         defines.update(members)
+    for m in re.finditer(r"^\s*#define\s+(\w+)\s+(.+?)\s*$", text, flags=re.M):   # second pass: defines that use enum members
+        name, expr = m.group(1), re.sub(r"(\d+)u\b", r"\1", m.group(2))
+        if name not in defines:
+            try:
+                defines[name] = int(eval(expr, {}, dict(defines)))
+            except Exception:
+                pass
     structs = {}
     for m in re.finditer(r"typedef\s+struct\s+(\w+)\s*\{(.*?)\}\s*(\w+)\s*;", text, flags=re.S):
         fields = []

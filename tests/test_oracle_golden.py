@@ -1,0 +1,39 @@
+"""Pin the CPU oracle (oracle/lsim_oracle.c) against golden vectors captured from the reference's own
+LeggedRobot.step() torch code (tools/gen_golden.py).  Runs on CPU."""
+import numpy as np
+import pytest
+
+import golden_replay as GR
+from helpers import LC, aliengo
+
+
+def make_oracle_from_fixture(name):
+    from oracle import oracle
+    fx = GR.load(name)
+    cfg = GR.scenario_cfg(name)
+    N = int(fx["num_envs"])
+    model = aliengo.build_model()
+    ter = GR.FixtureTerrain(fx)
+    lc = LC.make_lsim_config(cfg, num_envs=N, terrain=ter, model=model, seed=int(fx["seed"]))
+    sim = oracle.OracleSim(lc, model, ter.heightsamples, ter.env_origins)
+    return fx, sim
+
+
+@pytest.mark.parametrize("name", GR.SCENARIOS)
+def test_oracle_matches_reference_step(name):
+    fx, sim = make_oracle_from_fixture(name)
+
+    def get(n):
+        return np.array(sim.buf[n])
+
+    def put(n, a):
+        sim.buf[n][...] = a
+    worst = {}
+    nsteps = 0
+    for t, ref in GR.replay(fx, sim, get, put):
+        errs = GR.compare_step(t, ref, get)
+        for k, v in errs.items():
+            worst[k] = max(worst.get(k, 0.0), v)
+        nsteps += 1
+    assert nsteps == fx["in_actions"].shape[0]
+    print(name, "max abs err:", {k: f"{v:.2e}" for k, v in worst.items()})
