@@ -415,8 +415,10 @@ def run_scenario(name, task, ref_cfg_cls, N, segments, seed=1, tweak=None, using
                 actions = rs.normal(0, 1.0, size=(N, 12)).astype(np.float32)
                 if i % 5 == 0:
                     actions[0] *= 300.0   # exercises clip_actions
-            ep_before = env.episode_length_buf.numpy().copy()
             counter_before = env.common_step_counter
+            if counter_before + 1 == 1000 and N > 3:            # guarantee a reset on the curriculum step (LR:307)
+                env.episode_length_buf[3] = 1000
+            ep_before = env.episode_length_buf.numpy().copy()
             gen.step(actions)                                   # evolves a realistic simulator state
             root = gen.buf["root_states"].copy(); dof = gen.buf["dof_state"].copy()
             body = gen.buf["rigid_body_states"].copy(); contact = gen.buf["contact_forces"].copy()
