@@ -1,0 +1,149 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/sec of the Aliengo hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs 4096] [--task aliengo] [--mode env|train]
+
+One "step" = one LeggedRobot.step() over the whole batch of envs of a rank (4 physics sub-steps + post-physics +
+reset + observations), driven the way the reference's runner drives it (HIMR:105-157).  Prints ONE JSON line from rank 0.
+Multi-GPU: one process per GPU (torchrun), environments sharded with no data-path collective (weak scaling); in
+train mode the PPO gradients are all-reduced over RCCL.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+ALGO_BYTES_PER_ENV_STEP = 6900.0   # 3.07 KB read + 3.79 KB written per env-step (fused design)
+HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def cpu_baseline(task, sample_envs=64, budget_s=12.0):
+    """Time the CPU oracle (build's scalar C twin of the same step; kind='port') on the host cores of this box."""
+    import numpy as np
+    from helpers import C, make_oracle
+    cfg = C.TASKS[task][0]()
+    orc, lc, model, ter = make_oracle(cfg, sample_envs, seed=1)
+    orc.reset_all()
+    rs = np.random.RandomState(0)
+    acts = rs.normal(0, 1, (sample_envs, 12)).astype(np.float32)
+    orc.step(acts)
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < budget_s:
+        orc.step(acts)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": sample_envs * n / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": f"{n} steps x {sample_envs} envs of the same task on 1 host core ({os.cpu_count()} present), CPU oracle (scalar C, fp64 physics)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
+    ap.add_argument("--task", default="aliengo")
+    ap.add_argument("--mode", default="auto", choices=["auto", "env", "train"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from isaacgymloco_amd.envs import config as C
+    from isaacgymloco_amd.envs.legged_robot import LeggedRobot
+    mode = args.mode
+    try:
+        from isaacgymloco_amd.learn.runner import HIMOnPolicyRunner  # noqa: F401
+        have_learner = True
+    except Exception:
+        have_learner = False
+    if mode == "auto":
+        mode = "train" if have_learner else "env"
+
+    cfg = C.TASKS[args.task][0]()
+    cfg.env.num_envs = args.envs
+    env = LeggedRobot(cfg, sim_device=f"cuda:{local_rank}", seed=1, rank=rank, using_amp=(args.task == "aliengo_amp"))
+    N, K, W = args.envs, args.steps, args.warmup
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    extra = {}
+    if mode == "env":
+        env.reset()
+        # HIMR:90-91 init_at_random_ep_len=True: spread the resets
+        env.episode_length_buf = torch.randint_like(env.episode_length_buf, high=int(env.max_episode_length))
+        g = torch.Generator(device=dev).manual_seed(1 + rank)
+        acts = [torch.randn(N, 12, device=dev, generator=g) for _ in range(16)]   # untrained policy: N(0,1) (init_noise_std=1, AGC:299)
+        for i in range(W):
+            env.step_device(acts[i % 16])
+        env._L.lsim_set_profiling(env._h, K)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(K):
+            env.step_device(acts[i % 16])
+        barrier()
+        elapsed = time.perf_counter() - t0
+        ms_a = (ctypes.c_float * K)()
+        ms_b = (ctypes.c_float * K)()
+        n = ctypes.c_int(K)
+        env._L.lsim_read_profile(env._h, ms_a, ms_b, ctypes.byref(n))
+        ka = sum(ms_a[i] for i in range(n.value)) / max(n.value, 1)
+        kb = sum(ms_b[i] for i in range(n.value)) / max(n.value, 1)
+        extra = {"kernel_a_ms": ka, "kernel_b_ms": kb}
+        workload = f"{args.task}: LeggedRobot.step() back-to-back, N(0,1) actions, {N} envs/GPU (no policy/learner in the loop)"
+    else:
+        from isaacgymloco_amd.learn.bench_train import run_train_bench
+        elapsed, extra, workload = run_train_bench(env, cfg, args, dev, rank, world, barrier)
+        ka = extra.get("kernel_a_ms", float("nan"))
+
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        value = world * N * K / elapsed
+        achieved = ALGO_BYTES_PER_ENV_STEP * N / (ka * 1e-3) / 1e9 if ka == ka and ka > 0 else None
+        out = {
+            "metric": "env-steps/sec (whole node)", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": workload, "task": args.task, "envs_per_gpu": N, "mode": mode, "parallelism": f"dp{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                         "kernel": "lsim_k_step_a", "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * N,
+                         "kernel_avg_ms": ka,
+                         "note": "latency/issue-bound at N=4096: compulsory traffic is ~28 MB per step (SURVEY.md 8d)"},
+        }
+        out.update({k: v for k, v in extra.items() if k not in out})
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.task if args.task in C.TASKS else "aliengo")
+            except Exception as e:  # the baseline is a reported extra, never the thing measured
+                out["cpu_baseline"] = {"value": None, "error": str(e)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -321,19 +321,21 @@ enum lsim_buffer_id {
     LSIM_BUF_TERM_AMP_OBS,       /* f32 [N,30]    rows valid where reset_buf (LR:228) */
     LSIM_BUF_AMP_OBS,            /* f32 [N,30]    get_amp_observations() of the post-step state (LR:406-416) */
     LSIM_BUF_DELAY_STEPS,        /* i32 [N]       last drawn action delay (LR:134) */
-    LSIM_BUF_STATS,              /* f32 [LSIM_STATS_SIZE] device-side per-step reductions, see below */
+    LSIM_BUF_STATS,              /* f32 [2,LSIM_STATS_SIZE] device-side per-step reductions, see below */
     LSIM_BUF_HEIGHT_GRID,        /* i16 [rows,cols] */
     LSIM_BUF_TERRAIN_ORIGINS,    /* f32 [levels,types,3] */
     LSIM_NUM_BUFFERS
 };
 
-/* layout of LSIM_BUF_STATS (all f32, rewritten by every lsim_step):
+/* layout of one row of LSIM_BUF_STATS.  Two rows ping-pong: every lsim_step / lsim_reset_all call fills the row
+ * lsim_get_stats_row() reports after the call and clears the other row for the next call, so a row stays valid
+ * until the next call has run (read it, or copy it on the stream, before stepping again).
  *   [0]                      number of envs reset this step
  *   [1 .. 1+T)               sum over reset envs of episode_sums[k] / clip(ep_len,1)   (LR:349; divide by [0] and dt)
- *   [1+T]                    sum over all envs of terrain_levels                        (LR:353)
+ *   [1+T]                    reserved (the host forms mean(terrain_levels), LR:353, from LSIM_BUF_TERRAIN_LEVELS)
  *   [2+T .. 10+T)            command_ranges[4][2] live values (LR:877-880)
  *   [10+T]                   sum over reset envs of episode_sums[tracking_lin_vel]      (LR:875)
- *   [11+T]                   running count of steps with >=1 reset since creation
+ *   [11+T]                   reserved
  */
 #define LSIM_STATS_RESET_COUNT 0
 #define LSIM_STATS_EPISODE_SUMS 1
@@ -385,6 +387,16 @@ int lsim_step_ex(lsim_handle h, const float* actions_dev, uint32_t flags, void* 
 /* host-side scalars (no device sync): common_step_counter (LR:194). */
 int lsim_get_step_counter(lsim_handle h, int64_t* counter_out);
 int lsim_set_step_counter(lsim_handle h, int64_t counter);
+/* which row (0/1) of LSIM_BUF_STATS the most recent lsim_step / lsim_reset_all filled. */
+int lsim_get_stats_row(lsim_handle h, int* row_out);
+
+/* measurement aid (replaces the reference's time.time() bracketing, HIMR:106-147): with capacity > 0 every following
+ * lsim_step records HIP events around its kernels on the caller's stream (no host sync); lsim_read_profile waits for
+ * the last recorded step and returns per-step durations in milliseconds of kernel A (physics + post-physics) and
+ * kernel B (reset + observations) for the most recent min(n_steps, capacity) steps; *n_inout: in = array length,
+ * out = number of entries written.  capacity == 0 disables and frees the events. */
+int lsim_set_profiling(lsim_handle h, int capacity);
+int lsim_read_profile(lsim_handle h, float* ms_kernel_a, float* ms_kernel_b, int* n_inout);
 
 /* name of a reward term / buffer (for bindings and logs); NULL if out of range. */
 const char* lsim_reward_name(int reward_id);

@@ -72,7 +72,7 @@ static inline int lsim_buffer_desc(const lsim_config* cfg, int id, int64_t shape
         case LSIM_BUF_TERM_AMP_OBS:
         case LSIM_BUF_AMP_OBS: s1 = LSIM_NUM_AMP_OBS; nd = 2; break;
         case LSIM_BUF_DELAY_STEPS: dt = LSIM_DT_I32; break;
-        case LSIM_BUF_STATS: s0 = LSIM_STATS_SIZE; break;
+        case LSIM_BUF_STATS: s0 = 2; s1 = LSIM_STATS_SIZE; nd = 2; break;
         case LSIM_BUF_HEIGHT_GRID:
             s0 = cfg->grid_rows > 0 ? cfg->grid_rows : 1; s1 = cfg->grid_cols > 0 ? cfg->grid_cols : 1;
             nd = 2; dt = LSIM_DT_I16; break;

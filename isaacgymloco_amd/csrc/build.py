@@ -1,0 +1,37 @@
+"""Build liblsim.so (the HIP library behind include/lsim.h) in-tree for gfx950.
+
+    python -m isaacgymloco_amd.csrc.build [--force]
+
+hipcc cross-compiles without a GPU; the .so travels to the GPU box with the repo snapshot."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+LIB = os.path.join(HERE, "liblsim.so")
+SOURCES = ["lsim_hip.hip"]
+HEADERS = ["ls_math.h", "ls_shared.h", "ls_physics.h", "ls_post.h", "ls_kernels.h", "ls_api_impl.h"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-pass-failed"]
+
+
+def stale():
+    if not os.path.exists(LIB):
+        return True
+    deps = [os.path.join(HERE, f) for f in SOURCES + HEADERS] + [os.path.join(ROOT, "include", f) for f in ("lsim.h", "lsim_layout.h")]
+    return any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not stale():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "hipcc")
+    cmd = [hipcc] + FLAGS + [os.path.join(HERE, s) for s in SOURCES] + ["-o", LIB]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=HERE)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,202 @@
+// ls_api_impl.h -- implementation of the C-ABI declared in include/lsim.h, written against a small backend
+// interface so that the HIP library (lsim_hip.hip) and the tests-only lane emulator (tests/emu/emu_lsim.cpp)
+// share the host logic.  The including file must define, before including this header:
+//   LS_API(name)                     symbol name (lsim_##name for the product)
+//   lsbk_malloc / lsbk_free / lsbk_h2d / lsbk_memset       device-memory primitives, return 0 on success
+//   lsbk_launch_a / lsbk_launch_b / lsbk_launch_reduce (lsim_sim*, const LsStepArgs&, void* stream)
+//   lsbk_set_device(int), lsbk_prof_mark(lsim_sim*, int which, void* stream), lsbk_prof_free(lsim_sim*)
+#pragma once
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/lsim_layout.h"
+#include "ls_shared.h"
+
+struct lsim_sim {
+    lsim_config cfg;
+    lsim_robot_model model;
+    LsCtx host_ctx;
+    LsCtx* dev_ctx;
+    char* arena;
+    bool owns_arena;
+    size_t offsets[LSIM_NUM_BUFFERS];
+    int device_id;
+    int64_t step_counter;
+    int init_done;
+    int stats_row;
+    void* prof;        // backend-owned profiling state (HIP events), may be null
+    char err[256];
+};
+
+static const size_t LS_ALIGN = 256;
+
+static int ls_check_cfg(const lsim_config* c) {
+    if (c->abi_version != LSIM_ABI_VERSION) return LSIM_E_ABI;
+    if (c->num_envs <= 0 || c->decimation <= 0 || c->decimation > 16) return LSIM_E_INVALID;
+    if (c->mesh_type != 0 && (c->grid_rows < 2 || c->grid_cols < 2)) return LSIM_E_INVALID;
+    if (c->measure_heights && c->num_points_x * c->num_points_y != LSIM_NUM_HEIGHT_PTS) return LSIM_E_INVALID;
+    if (c->resampling_steps <= 0 || c->max_episode_length <= 0) return LSIM_E_INVALID;
+    if (c->terrain_num_rows > LSIM_TERRAIN_LEVELS_MAX || c->terrain_num_cols > LSIM_TERRAIN_TYPES_MAX) return LSIM_E_INVALID;
+    return LSIM_OK;
+}
+
+static size_t ls_layout(const lsim_config* c, size_t* offsets) {
+    size_t off = 0;
+    for (int id = 0; id < LSIM_NUM_BUFFERS; ++id) {
+        if (offsets) offsets[id] = off;
+        size_t b = lsim_buffer_bytes(c, id);
+        off += (b + LS_ALIGN - 1) / LS_ALIGN * LS_ALIGN;
+    }
+    return off;
+}
+
+extern "C" int LS_API(sizeof_config)(void) { return (int)sizeof(lsim_config); }
+extern "C" int LS_API(sizeof_model)(void) { return (int)sizeof(lsim_robot_model); }
+extern "C" int LS_API(abi_version)(void) { return LSIM_ABI_VERSION; }
+
+extern "C" int LS_API(query_arena)(const lsim_config* cfg, size_t* bytes_out) {
+    if (!cfg || !bytes_out) return LSIM_E_INVALID;
+    int rc = ls_check_cfg(cfg);
+    if (rc != LSIM_OK) return rc;
+    *bytes_out = ls_layout(cfg, nullptr);
+    return LSIM_OK;
+}
+
+#define LS_FAIL(s, code, ...) do { snprintf((s)->err, sizeof((s)->err), __VA_ARGS__); return (code); } while (0)
+
+template <class T>
+static int ls_upload(lsim_sim* s, int id, const std::vector<T>& v) {
+    return lsbk_h2d(s->arena + s->offsets[id], v.data(), v.size() * sizeof(T));
+}
+
+extern "C" int LS_API(create)(const lsim_config* cfg, const lsim_robot_model* model, const int16_t* height_grid,
+                              const float* terrain_origins, void* arena_dev, int device_id, lsim_sim** out) {
+    if (!cfg || !model || !out) return LSIM_E_INVALID;
+    int rc = ls_check_cfg(cfg);
+    if (rc != LSIM_OK) return rc;
+    if (cfg->mesh_type != 0 && (!height_grid || !terrain_origins)) return LSIM_E_INVALID;
+    if (model->num_collision_points > LSIM_MAX_COLLISION_POINTS || model->num_collision_points < 0) return LSIM_E_INVALID;
+    lsim_sim* s = (lsim_sim*)calloc(1, sizeof(lsim_sim));
+    if (!s) return LSIM_E_NOMEM;
+    s->cfg = *cfg; s->model = *model; s->device_id = device_id;
+    const lsim_config& c = s->cfg;
+    const int N = c.num_envs;
+    if (lsbk_set_device(device_id) != 0) { free(s); return LSIM_E_HIP; }
+    size_t total = ls_layout(&c, s->offsets);
+    if (arena_dev) { s->arena = (char*)arena_dev; s->owns_arena = false; }
+    else {
+        if (lsbk_malloc((void**)&s->arena, total) != 0) { free(s); return LSIM_E_NOMEM; }
+        s->owns_arena = true;
+    }
+    if (lsbk_memset(s->arena, 0, total) != 0) { if (s->owns_arena) lsbk_free(s->arena); free(s); return LSIM_E_HIP; }
+
+    // ---- init-time draws (LR:999-1032, LR:1172-1179, LR:506-513, LR:1232-1239), identical to the oracle's
+    const uint32_t W = 0xFFFFFFFFu;
+    auto u = [&](int env, uint32_t tag, uint32_t idx) { return ls_u01(c.seed, c.rank, (uint32_t)env, W, tag, idx); };
+    std::vector<float> ms(12 * N), kp(N), kd(N), msf(N), pay(N), com(3 * N), fr(N), root(13 * N), org(3 * N, 0.0f);
+    std::vector<int64_t> lvl(N, 0), typ(N, 0);
+    std::vector<uint8_t> rst(N, 1);
+    for (int e = 0; e < N; ++e) {
+        for (int j = 0; j < 12; ++j)
+            ms[12 * e + j] = c.randomize_motor_strength ? rand_range(u(e, LSIM_RNG_INIT, j), c.motor_strength_range[0], c.motor_strength_range[1]) : 1.0f;
+        kp[e] = c.randomize_kp ? rand_range(u(e, LSIM_RNG_INIT, 12), c.kp_range[0], c.kp_range[1]) : 1.0f;
+        kd[e] = c.randomize_kd ? rand_range(u(e, LSIM_RNG_INIT, 13), c.kd_range[0], c.kd_range[1]) : 1.0f;
+        msf[e] = c.randomize_motor_strength ? rand_range(u(e, LSIM_RNG_INIT, 14), c.motor_strength_range[0], c.motor_strength_range[1]) : 1.0f;
+        pay[e] = c.randomize_payload_mass ? rand_range(u(e, LSIM_RNG_INIT, 15), c.payload_mass_range[0], c.payload_mass_range[1]) : 0.0f;
+        for (int k = 0; k < 3; ++k)
+            com[3 * e + k] = c.randomize_com_displacement ? rand_range(u(e, LSIM_RNG_INIT, 16 + k), c.com_displacement_range[0], c.com_displacement_range[1]) : 0.0f;
+        if (c.randomize_friction) {
+            int bucket = (int)(u(e, LSIM_RNG_INIT, 19) * 64.0f);
+            fr[e] = rand_range(u(bucket, LSIM_RNG_INIT_BUCKET, 0), c.friction_range[0], c.friction_range[1]);
+        } else fr[e] = 1.0f;
+        if (c.mesh_type != 0) {
+            int max_init = c.terrain_curriculum ? c.max_init_terrain_level : c.terrain_num_rows - 1;
+            lvl[e] = (int64_t)(u(e, LSIM_RNG_INIT, 20) * (float)(max_init + 1));
+            int64_t t = (int64_t)floorf((float)e / ((float)N / (float)c.terrain_num_cols));
+            typ[e] = t > c.terrain_num_cols - 1 ? c.terrain_num_cols - 1 : t;
+            for (int k = 0; k < 3; ++k) org[3 * e + k] = terrain_origins[(lvl[e] * c.terrain_num_cols + typ[e]) * 3 + k];
+        }
+        for (int k = 0; k < 13; ++k) root[13 * e + k] = c.base_init_state[k];
+        for (int k = 0; k < 3; ++k) root[13 * e + k] += org[3 * e + k];
+    }
+    std::vector<float> stats(2 * LSIM_STATS_SIZE, 0.0f);
+    for (int r = 0; r < 2; ++r) for (int i = 0; i < 4; ++i) for (int k = 0; k < 2; ++k) stats[r * LSIM_STATS_SIZE + LSIM_STATS_CMD_RANGES + 2 * i + k] = c.command_ranges[i][k];
+    int bad = 0;
+    bad |= ls_upload(s, LSIM_BUF_MOTOR_STRENGTH, ms); bad |= ls_upload(s, LSIM_BUF_KP_FACTORS, kp); bad |= ls_upload(s, LSIM_BUF_KD_FACTORS, kd);
+    bad |= ls_upload(s, LSIM_BUF_MOTOR_STRENGTH_FACTORS, msf); bad |= ls_upload(s, LSIM_BUF_PAYLOAD, pay); bad |= ls_upload(s, LSIM_BUF_COM_DISPLACEMENT, com);
+    bad |= ls_upload(s, LSIM_BUF_FRICTION, fr); bad |= ls_upload(s, LSIM_BUF_ROOT_STATES, root); bad |= ls_upload(s, LSIM_BUF_ENV_ORIGINS, org);
+    bad |= ls_upload(s, LSIM_BUF_TERRAIN_LEVELS, lvl); bad |= ls_upload(s, LSIM_BUF_TERRAIN_TYPES, typ); bad |= ls_upload(s, LSIM_BUF_RESET, rst);
+    bad |= ls_upload(s, LSIM_BUF_STATS, stats);
+    if (c.mesh_type != 0) {
+        bad |= lsbk_h2d(s->arena + s->offsets[LSIM_BUF_HEIGHT_GRID], height_grid, lsim_buffer_bytes(&c, LSIM_BUF_HEIGHT_GRID));
+        bad |= lsbk_h2d(s->arena + s->offsets[LSIM_BUF_TERRAIN_ORIGINS], terrain_origins, lsim_buffer_bytes(&c, LSIM_BUF_TERRAIN_ORIGINS));
+    }
+    // ---- device context
+    LsCtx& h = s->host_ctx;
+    memset(&h, 0, sizeof(h));
+    h.cfg = c; h.model = s->model;
+    for (int id = 0; id < LSIM_NUM_BUFFERS; ++id) h.buf[id] = s->arena + s->offsets[id];
+    h.accum = (float*)h.buf[LSIM_BUF_STATS];
+    h.num_active = 0;
+    for (int id = 0; id < LSIM_NUM_REWARD_TERMS; ++id)
+        if (id != LSIM_R_TERMINATION && c.reward_scales[id] != 0.0f) h.active_terms[h.num_active++] = id;
+    if (lsbk_malloc((void**)&s->dev_ctx, sizeof(LsCtx)) != 0) bad = 1;
+    else bad |= lsbk_h2d(s->dev_ctx, &h, sizeof(LsCtx));
+    if (bad) { if (s->owns_arena) lsbk_free(s->arena); if (s->dev_ctx) lsbk_free(s->dev_ctx); free(s); return LSIM_E_HIP; }
+    s->step_counter = 0;
+    s->init_done = 1;   // construction completes before the runner's first reset (LR:116, HIMR:84)
+    *out = s;
+    return LSIM_OK;
+}
+
+extern "C" int LS_API(get_buffer)(lsim_sim* s, int id, void** dev_ptr, int64_t shape[4], int* ndim, int* dtype) {
+    if (!s || !dev_ptr || id < 0 || id >= LSIM_NUM_BUFFERS) return LSIM_E_INVALID;
+    *dev_ptr = s->arena + s->offsets[id];
+    return lsim_buffer_desc(&s->cfg, id, shape, ndim, dtype);
+}
+
+extern "C" int LS_API(step_ex)(lsim_sim* s, const float* actions_dev, uint32_t flags, void* stream) {
+    if (!s || !actions_dev) return LSIM_E_INVALID;
+    s->step_counter += 1;   // LR:194
+    LsStepArgs a;
+    memset(&a, 0, sizeof(a));
+    a.actions = actions_dev; a.step_counter = s->step_counter; a.flags = flags; a.init_done = s->init_done;
+    a.row_in = s->stats_row; a.row_out = s->stats_row ^ 1; a.reset_all = 0;
+    s->stats_row = a.row_out;
+    lsbk_prof_mark(s, 0, stream);
+    if (lsbk_launch_a(s, a, stream) != 0) LS_FAIL(s, LSIM_E_HIP, "kernel A launch failed");
+    lsbk_prof_mark(s, 1, stream);
+    if (lsbk_launch_b(s, a, stream) != 0) LS_FAIL(s, LSIM_E_HIP, "kernel B launch failed");
+    lsbk_prof_mark(s, 2, stream);
+    return LSIM_OK;
+}
+extern "C" int LS_API(step)(lsim_sim* s, const float* actions_dev, void* stream) { return LS_API(step_ex)(s, actions_dev, LSIM_STEP_DEFAULT, stream); }
+
+extern "C" int LS_API(reset_all)(lsim_sim* s, void* stream) {
+    if (!s) return LSIM_E_INVALID;
+    LsStepArgs a;
+    memset(&a, 0, sizeof(a));
+    a.actions = nullptr; a.step_counter = s->step_counter; a.flags = 0; a.init_done = s->init_done;
+    a.row_in = s->stats_row; a.row_out = s->stats_row ^ 1; a.reset_all = 1;
+    s->stats_row = a.row_out;
+    if (lsbk_launch_reduce(s, a, stream) != 0) LS_FAIL(s, LSIM_E_HIP, "reduction kernel launch failed");
+    if (lsbk_launch_b(s, a, stream) != 0) LS_FAIL(s, LSIM_E_HIP, "reset kernel launch failed");
+    return LSIM_OK;
+}
+
+extern "C" int LS_API(get_step_counter)(lsim_sim* s, int64_t* out) { if (!s || !out) return LSIM_E_INVALID; *out = s->step_counter; return LSIM_OK; }
+extern "C" int LS_API(set_step_counter)(lsim_sim* s, int64_t v) { if (!s) return LSIM_E_INVALID; s->step_counter = v; return LSIM_OK; }
+extern "C" int LS_API(get_stats_row)(lsim_sim* s, int* row) { if (!s || !row) return LSIM_E_INVALID; *row = s->stats_row; return LSIM_OK; }
+extern "C" const char* LS_API(reward_name)(int id) { return (id >= 0 && id < LSIM_NUM_REWARD_TERMS) ? lsim_reward_names[id] : nullptr; }
+extern "C" const char* LS_API(buffer_name)(int id) { return (id >= 0 && id < LSIM_NUM_BUFFERS) ? lsim_buffer_names[id] : nullptr; }
+extern "C" const char* LS_API(last_error)(lsim_sim* s) { return s ? s->err : "null handle"; }
+extern "C" void LS_API(destroy)(lsim_sim* s) {
+    if (!s) return;
+    lsbk_prof_free(s);
+    if (s->owns_arena && s->arena) lsbk_free(s->arena);
+    if (s->dev_ctx) lsbk_free(s->dev_ctx);
+    free(s);
+}

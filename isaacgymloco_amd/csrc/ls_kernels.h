@@ -1,0 +1,404 @@
+// ls_kernels.h -- the two per-step kernels as sequences of wave phases (one wavefront = one robot).
+//
+//   kernel A  ls_wave_step_a : LR:129-152 (clip, delay model, 4 x {PD torque, physics sub-step}) + LR:187-228
+//                              (derived state, callback, termination, rewards, termination observations)
+//   kernel B  ls_wave_step_b : LR:229-241 (reset_idx, compute_observations, last_* roll) + LR:167-171 (clip)
+//   The kernel boundary between A and B is the one global dependency of the step: whether ANY env reset
+//   (extras["time_outs"], LR:358) and the command-curriculum reduction over the reset set (LR:307-308, 868-880).
+//
+// LS_PHASE(call): on the GPU every lane runs `call` then the wave synchronises on LDS; under LS_EMU (tests only)
+// the 64 lanes are looped.  `lane`, `rg` (LaneRegs&) are in scope inside `call`.
+#pragma once
+#include "ls_physics.h"
+#include "ls_post.h"
+
+#if defined(LS_EMU)
+#define LS_LANES_PARAM LaneRegs* L
+#define LS_PHASE(call) do { for (int lane = 0; lane < 64; ++lane) { LaneRegs& rg = L[lane]; (void)rg; call; } } while (0)
+#define LS_COLLECTIVE(gpu_call, emu_call) do { emu_call; } while (0)
+#define LS_ATOMIC_ADD(ptr, v) (*(ptr) += (v))
+#define LS_WAVE_FN static inline
+#else
+#define LS_LANES_PARAM LaneRegs& rg, const int lane
+#define LS_PHASE(call) do { call; __syncthreads(); } while (0)
+#define LS_COLLECTIVE(gpu_call, emu_call) do { gpu_call; __syncthreads(); } while (0)
+#define LS_ATOMIC_ADD(ptr, v) atomicAdd((ptr), (v))
+#define LS_WAVE_FN __device__ __forceinline__
+#endif
+
+// ---- load the robot's state into LDS, clip the actions (LR:129-130), draw the action delay (LR:134)
+LS_FN void ph_load_a(const LsCtx& cx, WaveShared& sh, LaneRegs& rg, int lane, int env, const LsStepArgs& a) {
+    const lsim_config& c = cx.cfg;
+    if (lane < 13) sh.root[lane] = LSB(cx, LSIM_BUF_ROOT_STATES, float)[13 * env + lane];
+    if (lane < 12) {
+        const float* dof = LSB(cx, LSIM_BUF_DOF_STATE, float) + 24 * env;
+        sh.q[lane] = dof[2 * lane];
+        sh.qd[lane] = dof[2 * lane + 1];
+        float act = clampf(a.actions[12 * env + lane], -c.clip_actions, c.clip_actions);
+        sh.act[lane] = act;
+        LSB(cx, LSIM_BUF_ACTIONS, float)[12 * env + lane] = act;
+        sh.last_act[lane] = LSB(cx, LSIM_BUF_LAST_ACTIONS, float)[12 * env + lane];
+        sh.ms[lane] = LSB(cx, LSIM_BUF_MOTOR_STRENGTH, float)[12 * env + lane];
+    }
+    if (lane == 13) {
+        sh.kpf = LSB(cx, LSIM_BUF_KP_FACTORS, float)[env];
+        sh.kdf = LSB(cx, LSIM_BUF_KD_FACTORS, float)[env];
+        sh.mu = 0.5f * (c.terrain_friction + LSB(cx, LSIM_BUF_FRICTION, float)[env]);   // PhysX default combine mode: average
+        sh.payload = LSB(cx, LSIM_BUF_PAYLOAD, float)[env];
+    }
+    if (lane == 14) {
+        float* pf = LSB(cx, LSIM_BUF_PENDING_FORCE, float) + 3 * env;
+        for (int k = 0; k < 3; ++k) {
+            sh.comd[k] = LSB(cx, LSIM_BUF_COM_DISPLACEMENT, float)[3 * env + k];
+            sh.pend[k] = pf[k];
+            if (!(a.flags & LSIM_STEP_SKIP_PHYSICS)) pf[k] = 0.0f;   // consumed by the first sub-step
+        }
+    }
+    if (lane == 15) {
+        int delay = (int)(ls_draw(cx, env, (uint32_t)a.step_counter, LSIM_RNG_DELAY, 0) * (float)c.decimation);
+        sh.delay = delay;
+        LSB(cx, LSIM_BUF_DELAY_STEPS, int32_t)[env] = delay;
+    }
+    if (lane >= 16 && lane < 16 + LS_NB) {
+        const lsim_body& b = cx.model.bodies[lane - 16];
+        LsBodyLds& o = sh.body[lane - 16];
+        o.mass = b.mass;
+        for (int k = 0; k < 3; ++k) { o.com[k] = b.com[k]; o.jpos[k] = b.joint_pos[k]; o.axis[k] = b.joint_axis[k]; }
+        for (int k = 0; k < 6; ++k) o.inertia[k] = b.inertia[k];
+    }
+    if (lane < cx.model.num_collision_points) {
+        const lsim_collision_point& p = cx.model.points[lane];
+        rg.cp_pos[0] = p.pos[0]; rg.cp_pos[1] = p.pos[1]; rg.cp_pos[2] = p.pos[2];
+        rg.cp_r = p.radius; rg.cp_body = p.body;
+    }
+    rg.cp_active = 0;
+    rg.row_kind = -1;
+}
+
+// ---- LeggedRobot._compute_torques (LR:658-688) with the delayed action of sub-step `sub` (LR:138); lane = dof
+LS_FN void ph_torques(const LsCtx& cx, WaveShared& sh, int lane, int env, int sub) {
+    if (lane >= 12) return;
+    const lsim_config& c = cx.cfg;
+    float act = sh.act[lane], last = sh.last_act[lane];
+    float a = c.delay ? last + (act - last) * ((sub >= sh.delay) ? 1.0f : 0.0f) : act;
+    a = sh.ms[lane] * a;
+    float as = a * c.action_scale;
+    if (lane % 3 == 0) as *= c.hip_reduction;
+    float target = c.default_dof_pos[lane] + as;
+    float q = sh.q[lane], qd = sh.qd[lane], t;
+    if (c.control_type == 0) t = c.p_gains[lane] * sh.kpf * (target - q) - c.d_gains[lane] * sh.kdf * qd;
+    else if (c.control_type == 1) t = c.p_gains[lane] * (as - qd) - c.d_gains[lane] * (qd - LSB(cx, LSIM_BUF_LAST_DOF_VEL, float)[12 * env + lane]) / c.sim_dt;
+    else t = as;
+    sh.tau[lane] = clampf(t, -c.torque_limits[lane], c.torque_limits[lane]);
+}
+
+// ---- after the last sub-step: publish the simulator state tensors (LR:187-190 refresh_* equivalents)
+LS_FN void ph_store_sim_state(const LsCtx& cx, WaveShared& sh, int lane, int env) {
+    if (lane < 13) LSB(cx, LSIM_BUF_ROOT_STATES, float)[13 * env + lane] = sh.root[lane];
+    if (lane < 12) {
+        float* dof = LSB(cx, LSIM_BUF_DOF_STATE, float) + 24 * env;
+        dof[2 * lane] = sh.q[lane]; dof[2 * lane + 1] = sh.qd[lane];
+        sh.dofs[2 * lane] = sh.q[lane]; sh.dofs[2 * lane + 1] = sh.qd[lane];
+        LSB(cx, LSIM_BUF_TORQUES, float)[12 * env + lane] = sh.tau[lane];
+    }
+    if (lane < 3 * LS_NB) LSB(cx, LSIM_BUF_CONTACT_FORCES, float)[3 * LS_NB * env + lane] = sh.cf[lane / 3][lane % 3];
+}
+LS_FN void ph_body_states_all(const LsCtx& cx, WaveShared& sh, int lane, int env) {
+    float* out = LSB(cx, LSIM_BUF_RIGID_BODY_STATES, float) + 13 * LS_NB * env;
+    ph_body_states(sh, lane, out);
+    if (lane < LS_NB)
+        for (int f = 0; f < 4; ++f)
+            if (cx.model.feet_bodies[f] == lane) {
+                const float* o = out + 13 * lane;
+                for (int k = 0; k < 3; ++k) { sh.feet[f][k] = o[k]; sh.feet[f][3 + k] = o[7 + k]; }
+            }
+}
+// LSIM_STEP_SKIP_PHYSICS: take the simulator tensors as injected by the caller
+LS_FN void ph_load_injected(const LsCtx& cx, WaveShared& sh, int lane, int env) {
+    if (lane < 12) {
+        sh.dofs[2 * lane] = sh.q[lane]; sh.dofs[2 * lane + 1] = sh.qd[lane];
+        LSB(cx, LSIM_BUF_TORQUES, float)[12 * env + lane] = sh.tau[lane];
+    }
+    if (lane < 3 * LS_NB) sh.cf[lane / 3][lane % 3] = LSB(cx, LSIM_BUF_CONTACT_FORCES, float)[3 * LS_NB * env + lane];
+    if (lane < 24) {
+        int f = lane / 6, k = lane % 6;
+        const float* bs = LSB(cx, LSIM_BUF_RIGID_BODY_STATES, float) + 13 * (LS_NB * env + cx.model.feet_bodies[f]);
+        sh.feet[f][k] = k < 3 ? bs[k] : bs[7 + k - 3];
+    }
+}
+
+LS_FN void ph_store_root_cmd_ranges(const LsCtx& cx, WaveShared& sh, int lane, int env, const LsStepArgs& a) {
+    if (lane < 8) sh.ranges[lane] = cx.accum[a.row_in * LSIM_STATS_SIZE + LSIM_STATS_CMD_RANGES + lane];
+}
+
+// ---- termination observations / terminal AMP states of the pre-reset state + per-step reductions (LR:227-228)
+LS_FN void ph_term_outputs(const LsCtx& cx, WaveShared& sh, int lane, int env, const LsStepArgs& a) {
+    if (lane < 13) LSB(cx, LSIM_BUF_ROOT_STATES, float)[13 * env + lane] = sh.root[lane];   // push may have changed the velocity
+    if (!sh.reset) return;
+    float* tp = LSB(cx, LSIM_BUF_TERM_PRIV_OBS, float) + LSIM_NUM_PRIV_OBS * env;
+    for (int k = lane; k < LSIM_NUM_PRIV_OBS; k += 64) tp[k] = sh.cur[k];
+    if (lane < LSIM_NUM_AMP_OBS) {
+        float v;
+        if (lane < 12) v = sh.dofs[2 * lane];
+        else if (lane < 15) v = sh.blv[lane - 12];
+        else if (lane < 18) v = sh.bav[lane - 15];
+        else v = sh.dofs[2 * (lane - 18) + 1];
+        LSB(cx, LSIM_BUF_TERM_AMP_OBS, float)[LSIM_NUM_AMP_OBS * env + lane] = v;
+    }
+    if (lane == 0 && !(a.flags & LSIM_STEP_NO_RESET)) {
+        float* acc = cx.accum + a.row_out * LSIM_STATS_SIZE;
+        LS_ATOMIC_ADD(acc + LSIM_STATS_RESET_COUNT, 1.0f);
+        LS_ATOMIC_ADD(acc + LSIM_STATS_TRACK_SUM, LSB(cx, LSIM_BUF_EPISODE_SUMS, float)[env * LSIM_NUM_REWARD_TERMS + LSIM_R_TRACKING_LIN_VEL]);
+    }
+}
+
+LS_WAVE_FN void ls_wave_step_a(const LsCtx& cx, const LsStepArgs& a, const int env, WaveShared& sh, LS_LANES_PARAM) {
+    const lsim_config& c = cx.cfg;
+    const float dt = c.sim_dt;
+    const bool skip = (a.flags & LSIM_STEP_SKIP_PHYSICS) != 0;
+    LS_PHASE(ph_load_a(cx, sh, rg, lane, env, a));
+    for (int sub = 0; sub < c.decimation; ++sub) {
+        LS_PHASE(ph_torques(cx, sh, lane, env, sub));
+        if (skip) continue;
+        LS_PHASE(ph_kinematics(sh, lane));
+        LS_PHASE(ph_body_inertia(cx, sh, lane, sub == 0));
+        LS_PHASE(ph_leg_composite(sh, lane));
+        LS_PHASE(ph_base_assemble(sh, lane));
+        LS_PHASE(ph_base_factor(sh, lane));
+        LS_PHASE(ph_free_leg(sh, lane));
+        LS_PHASE(ph_free_base(sh, lane));
+        LS_PHASE(ph_free_finish(sh, lane, dt));
+        LS_PHASE(ph_collide(cx, sh, rg, lane));
+        LS_COLLECTIVE(wc_compact_contacts(sh, rg, lane), wc_compact_contacts(sh, L));
+        LS_PHASE(ph_limits(cx, sh, lane));
+        LS_PHASE(ph_rows(cx, sh, rg, lane, dt));
+        LS_PHASE(ph_delassus(sh, rg, lane));
+        LS_COLLECTIVE(wc_pgs(sh, rg, lane, c.solver_iterations), wc_pgs(sh, L, c.solver_iterations));
+        LS_PHASE(ph_apply_impulses(sh, lane));
+        LS_PHASE(ph_contact_forces(sh, lane, dt));
+        LS_PHASE(ph_integrate(cx, sh, lane, dt));
+    }
+    if (!skip) {
+        LS_PHASE(ph_kinematics(sh, lane));
+        LS_PHASE(ph_body_states_all(cx, sh, lane, env));
+        LS_PHASE(ph_store_sim_state(cx, sh, lane, env));
+    } else {
+        LS_PHASE(ph_load_injected(cx, sh, lane, env));
+    }
+    // ---- post_physics_step (LR:178-228)
+    LS_PHASE(ph_store_root_cmd_ranges(cx, sh, lane, env, a));
+    LS_PHASE(ph_post_state(cx, sh, lane, env));
+    LS_PHASE(ph_callback(cx, sh, lane, env, a, sh.ranges));
+    LS_PHASE(if (c.measure_heights) ph_heights(cx, sh, lane, env, true); ph_base_height_pts(cx, sh, lane));
+    LS_PHASE(ph_termination(cx, sh, lane, env));
+    LS_PHASE(ph_reward_terms(cx, sh, lane, env));
+    LS_PHASE(ph_reward_total(cx, sh, lane, env));
+    LS_PHASE(if (sh.reset) ph_build_obs(cx, sh, lane, env, (uint32_t)a.step_counter, LSIM_RNG_TERM_NOISE, sh.cur));
+    LS_PHASE(ph_term_outputs(cx, sh, lane, env, a));
+}
+
+// =============================================================================================== kernel B
+LS_FN void ph_load_b(const LsCtx& cx, WaveShared& sh, int lane, int env, const LsStepArgs& a) {
+    const lsim_config& c = cx.cfg;
+    if (lane < 13) sh.root[lane] = LSB(cx, LSIM_BUF_ROOT_STATES, float)[13 * env + lane];
+    if (lane < 24) sh.dofs[lane] = LSB(cx, LSIM_BUF_DOF_STATE, float)[24 * env + lane];
+    if (lane < 12) sh.act[lane] = LSB(cx, LSIM_BUF_ACTIONS, float)[12 * env + lane];
+    if (lane < 3) {
+        sh.blv[lane] = LSB(cx, LSIM_BUF_BASE_LIN_VEL, float)[3 * env + lane];
+        sh.bav[lane] = LSB(cx, LSIM_BUF_BASE_ANG_VEL, float)[3 * env + lane];
+        sh.grav[lane] = LSB(cx, LSIM_BUF_PROJECTED_GRAVITY, float)[3 * env + lane];
+        const bool disturbed = !a.reset_all && c.disturbance && (a.step_counter % c.disturbance_interval == 0);
+        sh.disturbance[lane] = disturbed ? LSB(cx, LSIM_BUF_PENDING_FORCE, float)[3 * env + lane] : 0.0f;
+    }
+    if (lane < 4) sh.cmd[lane] = LSB(cx, LSIM_BUF_COMMANDS, float)[4 * env + lane];
+    for (int k = lane; k < LS_NHP; k += 64) sh.heights[k] = LSB(cx, LSIM_BUF_MEASURED_HEIGHTS, float)[LS_NHP * env + k];
+    if (lane == 32) {
+        const float* acc_out = cx.accum + a.row_out * LSIM_STATS_SIZE;
+        const float* acc_in = cx.accum + a.row_in * LSIM_STATS_SIZE;
+        int reset = LSB(cx, LSIM_BUF_RESET, uint8_t)[env];
+        sh.reset = reset;
+        sh.eplen = (int)LSB(cx, LSIM_BUF_EPISODE_LENGTH, int64_t)[env];
+        float nreset = a.reset_all ? (float)c.num_envs : acc_out[LSIM_STATS_RESET_COUNT];
+        const bool no_reset = (a.flags & LSIM_STEP_NO_RESET) != 0;
+        sh.do_reset = a.reset_all || (reset && !no_reset);
+        sh.any_reset = a.reset_all || (!no_reset && nreset > 0.5f);
+        // command curriculum (LR:307-308, LR:868-880): every wave derives the same new ranges from the reduced sums
+        float r[8];
+        for (int k = 0; k < 8; ++k) r[k] = acc_in[LSIM_STATS_CMD_RANGES + k];
+        if (sh.any_reset && c.commands_curriculum && (a.step_counter % c.max_episode_length == 0)) {
+            float mean = acc_out[LSIM_STATS_TRACK_SUM] / nreset;
+            if (mean / (float)c.max_episode_length > 0.8f * c.reward_scales[LSIM_R_TRACKING_LIN_VEL]) {
+                r[0] = fmaxf(fminf(r[0] - 0.1f, 0.0f), -c.max_backward_curriculum);
+                r[1] = fmaxf(fminf(r[1] + 0.1f, c.max_forward_curriculum), 0.0f);
+                r[2] = fmaxf(fminf(r[2] - 0.1f, 0.0f), -c.max_lat_curriculum);
+                r[3] = fmaxf(fminf(r[3] + 0.1f, c.max_lat_curriculum), 0.0f);
+            }
+        }
+        for (int k = 0; k < 8; ++k) sh.ranges[k] = r[k];
+    }
+}
+
+// env 0 publishes the ranges of this step and clears the accumulator row the NEXT step will use
+LS_FN void ph_b_housekeeping(const LsCtx& cx, WaveShared& sh, int lane, int env, const LsStepArgs& a) {
+    if (env != 0) return;
+    float* out = cx.accum + a.row_out * LSIM_STATS_SIZE;
+    if (lane < 8) out[LSIM_STATS_CMD_RANGES + lane] = sh.ranges[lane];
+    if (a.reset_all && lane == 8) out[LSIM_STATS_RESET_COUNT] = (float)cx.cfg.num_envs;
+    float* nxt = cx.accum + a.row_in * LSIM_STATS_SIZE;   // the next call accumulates into the row this call read
+    if (lane == 9) nxt[LSIM_STATS_RESET_COUNT] = 0.0f;
+    if (lane == 10) nxt[LSIM_STATS_TRACK_SUM] = 0.0f;
+    for (int k = lane; k < LSIM_NUM_REWARD_TERMS; k += 64) nxt[LSIM_STATS_EPISODE_SUMS + k] = 0.0f;
+}
+
+// LeggedRobot._update_terrain_curriculum (LR:846-866), lane 0 of a resetting env
+LS_FN void ph_b_terrain_curriculum(const LsCtx& cx, WaveShared& sh, int lane, int env, const LsStepArgs& a) {
+    const lsim_config& c = cx.cfg;
+    if (lane != 0 || !sh.do_reset || !c.terrain_curriculum || c.mesh_type == 0 || !a.init_done) return;
+    float* org = LSB(cx, LSIM_BUF_ENV_ORIGINS, float) + 3 * env;
+    int64_t* lvlp = LSB(cx, LSIM_BUF_TERRAIN_LEVELS, int64_t) + env;
+    int64_t type = LSB(cx, LSIM_BUF_TERRAIN_TYPES, int64_t)[env];
+    float dx = sh.root[0] - org[0], dy = sh.root[1] - org[1];
+    float dist = sqrtf(dx * dx + dy * dy);
+    int up = dist > c.terrain_length / 2.0f;
+    int down = (dist < sqrtf(sh.cmd[0] * sh.cmd[0] + sh.cmd[1] * sh.cmd[1]) * c.episode_length_s * 0.5f) && !up;
+    int64_t lvl = *lvlp + (int64_t)up - (int64_t)down;
+    if (lvl >= c.terrain_num_rows) lvl = (int64_t)(ls_draw(cx, env, (uint32_t)a.step_counter, LSIM_RNG_RESET_LEVEL, 0) * (float)c.terrain_num_rows);
+    else if (lvl < 0) lvl = 0;
+    *lvlp = lvl;
+    const float* to = LSB(cx, LSIM_BUF_TERRAIN_ORIGINS, float) + (lvl * c.terrain_num_cols + type) * 3;
+    for (int k = 0; k < 3; ++k) org[k] = to[k];
+}
+
+// reset_idx body for a resetting env (LR:316-361); lane roles in the comments
+LS_FN void ph_b_reset(const LsCtx& cx, WaveShared& sh, int lane, int env, const LsStepArgs& a) {
+    if (!sh.do_reset) return;
+    const lsim_config& c = cx.cfg;
+    const uint32_t stepw = (uint32_t)a.step_counter;
+    if (lane < 12) {  // _reset_dofs (LR:690-716)
+        float pos = c.default_dof_pos[lane];
+        if (c.has_dof_init_pos_ratio)
+            pos = pos * rand_range(ls_draw(cx, env, stepw, LSIM_RNG_RESET_DOF, (uint32_t)lane), c.dof_init_pos_ratio_range[0], c.dof_init_pos_ratio_range[1]);
+        float vel = 0.0f;
+        if (c.randomize_dof_vel) {
+            float lo = c.dof_init_vel_range[0], hi = c.dof_init_vel_range[1];
+            vel = ls_draw(cx, env, stepw, LSIM_RNG_RESET_DOF, (uint32_t)(12 + lane)) * fabsf(hi - lo) + fminf(lo, hi);
+        }
+        sh.dofs[2 * lane] = pos; sh.dofs[2 * lane + 1] = vel;
+        float* dof = LSB(cx, LSIM_BUF_DOF_STATE, float) + 24 * env;
+        dof[2 * lane] = pos; dof[2 * lane + 1] = vel;
+        LSB(cx, LSIM_BUF_LAST_ACTIONS, float)[12 * env + lane] = 0.0f;       // LR:323-327
+        LSB(cx, LSIM_BUF_LAST_LAST_ACTIONS, float)[12 * env + lane] = 0.0f;
+        LSB(cx, LSIM_BUF_LAST_DOF_POS, float)[12 * env + lane] = 0.0f;
+        LSB(cx, LSIM_BUF_LAST_DOF_VEL, float)[12 * env + lane] = 0.0f;
+        LSB(cx, LSIM_BUF_LAST_TORQUES, float)[12 * env + lane] = 0.0f;
+    } else if (lane == 12) {  // _reset_root_states (LR:718-820)
+        const float* org = LSB(cx, LSIM_BUF_ENV_ORIGINS, float) + 3 * env;
+        float u[12];
+        for (int b = 0; b < 3; ++b) ls_u01x4(c.seed, c.rank, (uint32_t)env, stepw, LSIM_RNG_RESET_ROOT, (uint32_t)b, u + 4 * b);
+        float r[13];
+        for (int k = 0; k < 13; ++k) r[k] = c.base_init_state[k];
+        for (int k = 0; k < 3; ++k) r[k] += org[k];
+        if (c.mesh_type != 0) {
+            if (c.has_base_init_pos_range) for (int k = 0; k < 3; ++k) r[k] += rand_range(u[k], c.base_init_pos_range[k][0], c.base_init_pos_range[k][1]);
+            else for (int k = 0; k < 2; ++k) r[k] += rand_range(u[k], -1.0f, 1.0f);
+        }
+        if (c.has_base_init_rot_range) {
+            float rpy[3];
+            for (int k = 0; k < 3; ++k) rpy[k] = rand_range(u[3 + k], c.base_init_rot_range[k][0], c.base_init_rot_range[k][1]);
+            quat_from_euler_xyz(rpy[0], rpy[1], rpy[2], r + 3);
+        }
+        for (int k = 0; k < 6; ++k) r[7 + k] = rand_range(u[6 + k], c.base_init_vel_range[k][0], c.base_init_vel_range[k][1]);
+        for (int k = 0; k < 13; ++k) { sh.root[k] = r[k]; LSB(cx, LSIM_BUF_ROOT_STATES, float)[13 * env + k] = r[k]; }
+    } else if (lane == 13) {  // _resample_commands (LR:320)
+        float* cmd = LSB(cx, LSIM_BUF_COMMANDS, float) + 4 * env;
+        float cm[4] = {sh.cmd[0], sh.cmd[1], sh.cmd[2], sh.cmd[3]};
+        ls_resample_commands(cx, env, stepw, LSIM_RNG_RESET_CMD, sh.ranges, cm);
+        for (int k = 0; k < 4; ++k) { cmd[k] = cm[k]; }
+        // sh.cmd is refreshed in the next phase (lane 13 owns it here, other lanes may still read the old value)
+        sh.rewv[0] = cm[0]; sh.rewv[1] = cm[1]; sh.rewv[2] = cm[2]; sh.rewv[3] = cm[3];
+    } else if (lane == 14) {  // domain-randomisation redraw (LR:336-343, LR:533-537)
+        float u[8];
+        ls_u01x4(c.seed, c.rank, (uint32_t)env, stepw, LSIM_RNG_RESET_DR, 0, u);
+        ls_u01x4(c.seed, c.rank, (uint32_t)env, stepw, LSIM_RNG_RESET_DR, 1, u + 4);
+        if (c.randomize_kp) LSB(cx, LSIM_BUF_KP_FACTORS, float)[env] = rand_range(u[0], c.kp_range[0], c.kp_range[1]);
+        if (c.randomize_kd) LSB(cx, LSIM_BUF_KD_FACTORS, float)[env] = rand_range(u[1], c.kd_range[0], c.kd_range[1]);
+        if (c.randomize_motor_strength) LSB(cx, LSIM_BUF_MOTOR_STRENGTH_FACTORS, float)[env] = rand_range(u[2], c.motor_strength_range[0], c.motor_strength_range[1]);
+        if (c.randomize_friction) LSB(cx, LSIM_BUF_FRICTION, float)[env] = rand_range(u[3], c.friction_range[0], c.friction_range[1]);
+        if (c.randomize_restitution) LSB(cx, LSIM_BUF_RESTITUTION, float)[env] = rand_range(u[4], c.restitution_range[0], c.restitution_range[1]);
+    } else if (lane == 15) {
+        for (int f = 0; f < 4; ++f) LSB(cx, LSIM_BUF_FEET_AIR_TIME, float)[4 * env + f] = 0.0f;   // LR:328
+        LSB(cx, LSIM_BUF_RESET, uint8_t)[env] = 1;                                                 // LR:329
+    }
+}
+// extras["episode"] sums (LR:346-350); lane = reward term
+LS_FN void ph_b_episode_stats(const LsCtx& cx, WaveShared& sh, int lane, int env, const LsStepArgs& a) {
+    if (!sh.do_reset) return;
+    if (lane == 13) for (int k = 0; k < 4; ++k) sh.cmd[k] = sh.rewv[k];
+    float den = (float)(sh.eplen < 1 ? 1 : sh.eplen);
+    float* acc = cx.accum + a.row_out * LSIM_STATS_SIZE;
+    for (int k = lane; k < LSIM_NUM_REWARD_TERMS; k += 64) {
+        float* es = LSB(cx, LSIM_BUF_EPISODE_SUMS, float) + env * LSIM_NUM_REWARD_TERMS + k;
+        float v = *es;
+        if (v != 0.0f) LS_ATOMIC_ADD(acc + LSIM_STATS_EPISODE_SUMS + k, v / den);
+        *es = 0.0f;
+    }
+}
+
+// observation history: the 225 values that shift by one frame are staged in LDS first (LR:403)
+LS_FN void ph_b_stage_history(const LsCtx& cx, WaveShared& sh, int lane, int env) {
+    const float* obs = LSB(cx, LSIM_BUF_OBS, float) + LSIM_NUM_OBS * env;
+    float* scratch = &sh.u.I6[0][0];
+    for (int k = lane; k < LSIM_NUM_OBS - LSIM_ONE_STEP_OBS; k += 64) scratch[k] = obs[k];
+}
+// publish observations (LR:403-404 + clip LR:167-171), AMP features (LR:406-416), last_* roll (LR:235-241)
+LS_FN void ph_b_store(const LsCtx& cx, WaveShared& sh, int lane, int env, const LsStepArgs& a) {
+    const lsim_config& c = cx.cfg;
+    const float clipv = c.clip_observations;
+    float* obs = LSB(cx, LSIM_BUF_OBS, float) + LSIM_NUM_OBS * env;
+    const float* scratch = &sh.u.I6[0][0];
+    for (int k = lane; k < LSIM_NUM_OBS - LSIM_ONE_STEP_OBS; k += 64) obs[k + LSIM_ONE_STEP_OBS] = clampf(scratch[k], -clipv, clipv);
+    if (lane < LSIM_ONE_STEP_OBS) obs[lane] = clampf(sh.cur[lane], -clipv, clipv);
+    float* priv = LSB(cx, LSIM_BUF_PRIV_OBS, float) + LSIM_NUM_PRIV_OBS * env;
+    for (int k = lane; k < LSIM_NUM_PRIV_OBS; k += 64) priv[k] = clampf(sh.cur[k], -clipv, clipv);
+    if (lane < LSIM_NUM_AMP_OBS) {
+        float v;
+        if (lane < 12) v = sh.dofs[2 * lane];
+        else if (lane < 15) v = sh.blv[lane - 12];
+        else if (lane < 18) v = sh.bav[lane - 15];
+        else v = sh.dofs[2 * (lane - 18) + 1];
+        LSB(cx, LSIM_BUF_AMP_OBS, float)[LSIM_NUM_AMP_OBS * env + lane] = v;
+    }
+    if (lane >= 48 && lane < 60) {
+        int j = lane - 48;
+        float la = LSB(cx, LSIM_BUF_LAST_ACTIONS, float)[12 * env + j];
+        LSB(cx, LSIM_BUF_LAST_LAST_ACTIONS, float)[12 * env + j] = la;
+        LSB(cx, LSIM_BUF_LAST_ACTIONS, float)[12 * env + j] = sh.act[j];
+        LSB(cx, LSIM_BUF_LAST_DOF_POS, float)[12 * env + j] = sh.dofs[2 * j];
+        LSB(cx, LSIM_BUF_LAST_DOF_VEL, float)[12 * env + j] = sh.dofs[2 * j + 1];
+        LSB(cx, LSIM_BUF_LAST_TORQUES, float)[12 * env + j] = LSB(cx, LSIM_BUF_TORQUES, float)[12 * env + j];
+    }
+    if (lane >= 42 && lane < 48) LSB(cx, LSIM_BUF_LAST_ROOT_VEL, float)[6 * env + lane - 42] = sh.root[7 + lane - 42];
+    if (lane == 40 && sh.do_reset) LSB(cx, LSIM_BUF_EPISODE_LENGTH, int64_t)[env] = 0;                       // LR:361
+    if (lane == 41 && sh.any_reset && c.send_timeouts)                                                        // LR:358-359
+        LSB(cx, LSIM_BUF_EXTRAS_TIME_OUTS, uint8_t)[env] = LSB(cx, LSIM_BUF_TIME_OUT, uint8_t)[env];
+}
+// tail of a bare reset_idx(all) (BT:113): no observation / last_* roll
+LS_FN void ph_b_store_reset_all(const LsCtx& cx, WaveShared& sh, int lane, int env, const LsStepArgs& a) {
+    if (lane == 40) LSB(cx, LSIM_BUF_EPISODE_LENGTH, int64_t)[env] = 0;
+    if (lane == 41 && cx.cfg.send_timeouts) LSB(cx, LSIM_BUF_EXTRAS_TIME_OUTS, uint8_t)[env] = LSB(cx, LSIM_BUF_TIME_OUT, uint8_t)[env];
+}
+
+LS_WAVE_FN void ls_wave_step_b(const LsCtx& cx, const LsStepArgs& a, const int env, WaveShared& sh, LS_LANES_PARAM) {
+    const lsim_config& c = cx.cfg;
+    LS_PHASE(ph_load_b(cx, sh, lane, env, a));
+    LS_PHASE(ph_b_housekeeping(cx, sh, lane, env, a); ph_b_terrain_curriculum(cx, sh, lane, env, a));
+    LS_PHASE(ph_b_reset(cx, sh, lane, env, a));
+    LS_PHASE(ph_b_episode_stats(cx, sh, lane, env, a));
+    LS_PHASE(if (sh.do_reset && c.measure_heights) ph_heights(cx, sh, lane, env, true));
+    if (a.reset_all) {   // reset_idx only: the observation roll belongs to the step that follows (BT:114)
+        LS_PHASE(ph_b_store_reset_all(cx, sh, lane, env, a));
+        return;
+    }
+    LS_PHASE(ph_build_obs(cx, sh, lane, env, (uint32_t)a.step_counter, LSIM_RNG_OBS_NOISE, sh.cur); ph_b_stage_history(cx, sh, lane, env));
+    LS_PHASE(ph_b_store(cx, sh, lane, env, a));
+}

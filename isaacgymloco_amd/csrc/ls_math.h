@@ -1,0 +1,159 @@
+// ls_math.h -- small fixed-size math for the leggedsim kernels (fp32).
+// Compiles as device code under hipcc and as plain C++ under g++ (tests/emu lane emulator).
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define LS_FN __host__ __device__ __forceinline__
+#else
+#define LS_FN static inline
+#endif
+
+struct V3 {
+    float x, y, z;
+};
+LS_FN V3 v3(float x, float y, float z) { V3 r = {x, y, z}; return r; }
+LS_FN V3 v3p(const float* p) { V3 r = {p[0], p[1], p[2]}; return r; }
+LS_FN void v3st(float* p, V3 a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; }
+LS_FN V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+LS_FN V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+LS_FN V3 operator*(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+LS_FN V3 operator*(float s, V3 a) { return v3(a.x * s, a.y * s, a.z * s); }
+LS_FN float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+LS_FN V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+LS_FN float clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+// row-major 3x3
+struct M3 {
+    float m[9];
+};
+LS_FN V3 mul(const M3& R, V3 v) {
+    return v3(R.m[0] * v.x + R.m[1] * v.y + R.m[2] * v.z, R.m[3] * v.x + R.m[4] * v.y + R.m[5] * v.z, R.m[6] * v.x + R.m[7] * v.y + R.m[8] * v.z);
+}
+LS_FN M3 mul(const M3& A, const M3& B) {
+    M3 C;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) C.m[3 * i + j] = A.m[3 * i] * B.m[j] + A.m[3 * i + 1] * B.m[3 + j] + A.m[3 * i + 2] * B.m[6 + j];
+    return C;
+}
+LS_FN M3 m3p(const float* p) { M3 r; for (int i = 0; i < 9; ++i) r.m[i] = p[i]; return r; }
+LS_FN void m3st(float* p, const M3& a) { for (int i = 0; i < 9; ++i) p[i] = a.m[i]; }
+
+LS_FN M3 quat_to_R(const float* q) {  // xyzw
+    float x = q[0], y = q[1], z = q[2], w = q[3];
+    M3 R;
+    R.m[0] = 1 - 2 * (y * y + z * z); R.m[1] = 2 * (x * y - z * w); R.m[2] = 2 * (x * z + y * w);
+    R.m[3] = 2 * (x * y + z * w); R.m[4] = 1 - 2 * (x * x + z * z); R.m[5] = 2 * (y * z - x * w);
+    R.m[6] = 2 * (x * z - y * w); R.m[7] = 2 * (y * z + x * w); R.m[8] = 1 - 2 * (x * x + y * y);
+    return R;
+}
+LS_FN void R_to_quat(const M3& Rm, float* q) {
+    const float* R = Rm.m;
+    float tr = R[0] + R[4] + R[8];
+    if (tr > 0) { float s = sqrtf(tr + 1.0f) * 2; q[3] = 0.25f * s; q[0] = (R[7] - R[5]) / s; q[1] = (R[2] - R[6]) / s; q[2] = (R[3] - R[1]) / s; }
+    else if (R[0] > R[4] && R[0] > R[8]) { float s = sqrtf(1.0f + R[0] - R[4] - R[8]) * 2; q[3] = (R[7] - R[5]) / s; q[0] = 0.25f * s; q[1] = (R[1] + R[3]) / s; q[2] = (R[2] + R[6]) / s; }
+    else if (R[4] > R[8]) { float s = sqrtf(1.0f + R[4] - R[0] - R[8]) * 2; q[3] = (R[2] - R[6]) / s; q[0] = (R[1] + R[3]) / s; q[1] = 0.25f * s; q[2] = (R[5] + R[7]) / s; }
+    else { float s = sqrtf(1.0f + R[8] - R[0] - R[4]) * 2; q[3] = (R[3] - R[1]) / s; q[0] = (R[2] + R[6]) / s; q[1] = (R[5] + R[7]) / s; q[2] = 0.25f * s; }
+}
+LS_FN M3 axis_angle_R(V3 a, float th) {
+    float c = cosf(th), s = sinf(th), t = 1 - c;
+    M3 R;
+    R.m[0] = c + t * a.x * a.x; R.m[1] = t * a.x * a.y - s * a.z; R.m[2] = t * a.x * a.z + s * a.y;
+    R.m[3] = t * a.x * a.y + s * a.z; R.m[4] = c + t * a.y * a.y; R.m[5] = t * a.y * a.z - s * a.x;
+    R.m[6] = t * a.x * a.z - s * a.y; R.m[7] = t * a.y * a.z + s * a.x; R.m[8] = c + t * a.z * a.z;
+    return R;
+}
+
+// ---- the reference's quaternion helpers (isaacgym.torch_utils / legged_gym.utils.math), same op order as the torch code ----
+LS_FN V3 quat_rotate_inverse(const float* q, V3 v) {  // torch_utils.quat_rotate_inverse
+    float w = q[3];
+    V3 qv = v3(q[0], q[1], q[2]);
+    float s = 2.0f * (w * w) - 1.0f;
+    V3 c = cross(qv, v);
+    float d = dot(qv, v);
+    return v3(v.x * s - c.x * w * 2.0f + qv.x * d * 2.0f, v.y * s - c.y * w * 2.0f + qv.y * d * 2.0f, v.z * s - c.z * w * 2.0f + qv.z * d * 2.0f);
+}
+LS_FN V3 quat_apply(const float* q, V3 v) {  // torch_utils.quat_apply
+    V3 qv = v3(q[0], q[1], q[2]);
+    V3 t = cross(qv, v) * 2.0f;
+    V3 u = cross(qv, t);
+    return v3(v.x + q[3] * t.x + u.x, v.y + q[3] * t.y + u.y, v.z + q[3] * t.z + u.z);
+}
+LS_FN V3 quat_apply_yaw(const float* q, V3 v) {  // MTH:38-42
+    float n = sqrtf(q[2] * q[2] + q[3] * q[3]);
+    if (n < 1e-9f) n = 1e-9f;
+    float qy[4] = {0.0f, 0.0f, q[2] / n, q[3] / n};
+    return quat_apply(qy, v);
+}
+LS_FN float wrap_to_pi(float a) {  // MTH:45-48 with torch.remainder semantics
+    const float two_pi = 6.2831855f;
+    float r = fmodf(a, two_pi);
+    if (r != 0.0f && r < 0.0f) r += two_pi;
+    if (r > 3.1415927f) r -= two_pi;
+    return r;
+}
+LS_FN void quat_from_euler_xyz(float roll, float pitch, float yaw, float* q) {
+    float cy = cosf(yaw * 0.5f), sy = sinf(yaw * 0.5f), cr = cosf(roll * 0.5f), sr = sinf(roll * 0.5f);
+    float cp = cosf(pitch * 0.5f), sp = sinf(pitch * 0.5f);
+    q[3] = cy * cr * cp + sy * sr * sp;
+    q[0] = cy * sr * cp - sy * cr * sp;
+    q[1] = cy * cr * sp + sy * sr * cp;
+    q[2] = sy * cr * cp - cy * sr * sp;
+}
+
+// ---- spatial (Pluecker) algebra, [angular; linear], world-aligned axes about the base origin ----
+struct S6 {
+    V3 a, l;
+};
+LS_FN S6 s6(V3 a, V3 l) { S6 r = {a, l}; return r; }
+LS_FN S6 s6p(const float* p) { return s6(v3p(p), v3p(p + 3)); }
+LS_FN void s6st(float* p, S6 v) { v3st(p, v.a); v3st(p + 3, v.l); }
+LS_FN S6 operator+(S6 x, S6 y) { return s6(x.a + y.a, x.l + y.l); }
+LS_FN S6 operator-(S6 x, S6 y) { return s6(x.a - y.a, x.l - y.l); }
+LS_FN S6 operator*(S6 x, float s) { return s6(x.a * s, x.l * s); }
+LS_FN float dot(S6 x, S6 y) { return dot(x.a, y.a) + dot(x.l, y.l); }
+LS_FN S6 crm(S6 v, S6 m) { return s6(cross(v.a, m.a), cross(v.a, m.l) + cross(v.l, m.a)); }   // motion cross product
+LS_FN S6 crf(S6 v, S6 f) { return s6(cross(v.a, f.a) + cross(v.l, f.l), cross(v.a, f.l)); }   // force cross product
+LS_FN S6 m6v(const float* I, S6 v) {  // row-major 6x6 times spatial vector
+    float x[6] = {v.a.x, v.a.y, v.a.z, v.l.x, v.l.y, v.l.z}, o[6];
+    for (int i = 0; i < 6; ++i) {
+        float s = 0;
+        for (int k = 0; k < 6; ++k) s += I[6 * i + k] * x[k];
+        o[i] = s;
+    }
+    return s6(v3(o[0], o[1], o[2]), v3(o[3], o[4], o[5]));
+}
+
+// ---- Philox4x32-10 (include/lsim.h RNG spec) ----
+LS_FN uint32_t ls_mulhi(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umulhi(a, b);
+#else
+    return (uint32_t)(((uint64_t)a * b) >> 32);
+#endif
+}
+LS_FN void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = ls_mulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+        uint32_t hi1 = ls_mulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+        uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+LS_FN float u32_to_u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+// all four uniforms of block (idx >> 2)
+LS_FN void ls_u01x4(uint32_t seed, uint32_t rank, uint32_t env, uint32_t step, uint32_t tag, uint32_t block, float out[4]) {
+    uint32_t c[4] = {env, step, tag, block};
+    philox4x32_10(c, seed, rank);
+    for (int i = 0; i < 4; ++i) out[i] = u32_to_u01(c[i]);
+}
+LS_FN float ls_u01(uint32_t seed, uint32_t rank, uint32_t env, uint32_t step, uint32_t tag, uint32_t idx) {
+    uint32_t c[4] = {env, step, tag, idx >> 2};
+    philox4x32_10(c, seed, rank);
+    return u32_to_u01(c[idx & 3u]);
+}
+// isaacgym.torch_utils.torch_rand_float: span formed on the host in double, then fp32 (upper-lower)*u + lower
+LS_FN float rand_range(float u, float lo, float hi) { return (hi - lo) * u + lo; }

@@ -1,0 +1,518 @@
+// ls_physics.h -- one 5 ms articulated-body sub-step of one robot, executed by one wavefront.
+// Replaces gym.simulate()/fetch_results()/refresh_dof_state_tensor() (LR:149-152, PhysX in the reference).
+//
+// Algorithm (same model as oracle/orc_physics.c, different -- structured -- solver):
+//   the floating base couples four independent 3-dof chains, so
+//     M = [ Mbb  Mb1 .. Mb4 ]      Schur complement on the base:  Sb = Mbb - sum_l Mbl Mll^-1 Mlb
+//         [ M1b  M11        ]      every solve with M costs four 3x3 and one 6x6 Cholesky solve.
+//         [ ..        ..    ]
+//   All spatial quantities are expressed in world-aligned axes about the base origin, so composite
+//   inertias and bias forces accumulate up the tree by plain addition (no frame transforms).
+// Lane roles per phase:  K: leg chain (lanes 0-3)   B: body (0-16)   L: leg (0-3)   E: matrix element (0-41)
+//                        P: collision point (0-55)  R: constraint row (0-59)        V: generalized velocity (0-17)
+#pragma once
+#include "ls_shared.h"
+
+LS_FN int ls_leg_of_body(int b) { return (b - 1) >> 2; }   // b >= 1
+LS_FN int ls_depth_of_body(int b) { return (b - 1) & 3; }  // 0 hip, 1 thigh, 2 calf, 3 foot
+
+// ---- phase K: forward kinematics, motion subspaces, twists, bias accelerations (lane = leg; lane 4 = base)
+LS_FN void ph_kinematics(WaveShared& sh, int lane) {
+    if (lane == 4) {
+        M3 R0 = quat_to_R(sh.root + 3);
+        m3st(sh.R[0], R0);
+        sh.p[0][0] = sh.p[0][1] = sh.p[0][2] = 0.0f;
+        s6st(sh.V[0], s6(v3p(sh.root + 10), v3p(sh.root + 7)));
+        s6st(sh.Ab[0], s6(v3(0, 0, 0), v3(0, 0, 0)));
+    }
+    if (lane >= 4) return;
+    M3 R = quat_to_R(sh.root + 3);
+    V3 p = v3(0, 0, 0);
+    S6 V = s6(v3p(sh.root + 10), v3p(sh.root + 7));
+    S6 Ab = s6(v3(0, 0, 0), v3(0, 0, 0));
+    for (int k = 0; k < 4; ++k) {
+        int b = 1 + 4 * lane + k;
+        const LsBodyLds& bd = sh.body[b];
+        p = p + mul(R, v3p(bd.jpos));
+        if (k < 3) {
+            int d = 3 * lane + k;
+            V3 ax = v3p(bd.axis);
+            V3 aw = mul(R, ax);
+            R = mul(R, axis_angle_R(ax, sh.q[d]));
+            S6 S = s6(aw, cross(p, aw));
+            s6st(sh.S[d], S);
+            S6 vj = S * sh.qd[d];
+            V = V + vj;
+            Ab = Ab + crm(V, vj);
+        }
+        m3st(sh.R[b], R);
+        v3st(sh.p[b], p);
+        s6st(sh.V[b], V);
+        s6st(sh.Ab[b], Ab);
+    }
+}
+
+// ---- phase B: spatial inertia about the base origin and bias force of each body (lane = body)
+LS_FN void ph_body_inertia(const LsCtx& cx, WaveShared& sh, int lane, bool apply_force) {
+    if (lane >= LS_NB) return;
+    const LsBodyLds& bd = sh.body[lane];
+    float mass = bd.mass;
+    V3 cl = v3p(bd.com);
+    float sc = 1.0f;
+    if (lane == 0) {  // payload / COM randomisation (LR:591-596); inertia scaled with the mass
+        mass = bd.mass + sh.payload;
+        cl = cl + v3p(sh.comd);
+        sc = mass / bd.mass;
+    }
+    M3 R = m3p(sh.R[lane]);
+    V3 c = mul(R, cl) + v3p(sh.p[lane]);
+    M3 Il;
+    Il.m[0] = bd.inertia[0] * sc; Il.m[1] = bd.inertia[1] * sc; Il.m[2] = bd.inertia[2] * sc;
+    Il.m[3] = Il.m[1]; Il.m[4] = bd.inertia[3] * sc; Il.m[5] = bd.inertia[4] * sc;
+    Il.m[6] = Il.m[2]; Il.m[7] = Il.m[5]; Il.m[8] = bd.inertia[5] * sc;
+    M3 Rt;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Rt.m[3 * i + j] = R.m[3 * j + i];
+    M3 Iw = mul(mul(R, Il), Rt);
+    float* I6 = sh.u.I6[lane];
+    float cx9[9] = {0, -c.z, c.y, c.z, 0, -c.x, -c.y, c.x, 0};
+    float cv[3] = {c.x, c.y, c.z};
+    float cc = dot(c, c);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            I6[6 * i + j] = Iw.m[3 * i + j] + mass * ((i == j ? cc : 0.0f) - cv[i] * cv[j]);
+            I6[6 * i + 3 + j] = mass * cx9[3 * i + j];
+            I6[6 * (3 + i) + j] = mass * cx9[3 * j + i];
+            I6[6 * (3 + i) + 3 + j] = (i == j) ? mass : 0.0f;
+        }
+    S6 V = s6p(sh.V[lane]);
+    S6 a = s6p(sh.Ab[lane]) - s6(v3(0, 0, 0), v3p(cx.cfg.gravity));
+    S6 F = m6v(I6, a) + crf(V, m6v(I6, V));
+    if (lane == 0) {
+        v3st(sh.com0, c);
+        if (apply_force) {  // body-local disturbance force at the base COM (LR:844)
+            V3 fw = mul(R, v3p(sh.pend));
+            F = F - s6(cross(c, fw), fw);
+        }
+    }
+    s6st(sh.Fb[lane], F);
+}
+
+// 3x3 SPD Cholesky (l00,l10,l11,l20,l21,l22) and solve
+LS_FN void chol3(const float* M /*m00,m10,m11,m20,m21,m22*/, float* L) {
+    L[0] = sqrtf(M[0]);
+    L[1] = M[1] / L[0];
+    L[2] = sqrtf(M[2] - L[1] * L[1]);
+    L[3] = M[3] / L[0];
+    L[4] = (M[4] - L[3] * L[1]) / L[2];
+    L[5] = sqrtf(M[5] - L[3] * L[3] - L[4] * L[4]);
+}
+LS_FN void chol3_solve(const float* L, float* b) {
+    b[0] = b[0] / L[0];
+    b[1] = (b[1] - L[1] * b[0]) / L[2];
+    b[2] = (b[2] - L[3] * b[0] - L[4] * b[1]) / L[5];
+    b[2] = b[2] / L[5];
+    b[1] = (b[1] - L[4] * b[2]) / L[2];
+    b[0] = (b[0] - L[1] * b[1] - L[3] * b[2]) / L[0];
+}
+// 6x6 Cholesky solve with the lower factor stored row-major in a 36-float array
+LS_FN void chol6_solve(const float* L, float* b) {
+    for (int i = 0; i < 6; ++i) {
+        float v = b[i];
+        for (int k = 0; k < i; ++k) v -= L[6 * i + k] * b[k];
+        b[i] = v / L[6 * i + i];
+    }
+    for (int i = 5; i >= 0; --i) {
+        float v = b[i];
+        for (int k = i + 1; k < 6; ++k) v -= L[6 * k + i] * b[k];
+        b[i] = v / L[6 * i + i];
+    }
+}
+
+// ---- phase L: composite inertias / bias forces up each leg, leg mass block, its factor and Schur pieces (lane = leg)
+LS_FN void ph_leg_composite(WaveShared& sh, int lane) {
+    if (lane >= 4) return;
+    float Ic[36];
+    S6 fb = s6(v3(0, 0, 0), v3(0, 0, 0));
+    for (int e = 0; e < 36; ++e) Ic[e] = 0.0f;
+    S6 F[3];
+    float h[3];
+    for (int k = 3; k >= 0; --k) {
+        int b = 1 + 4 * lane + k;
+        const float* I6 = sh.u.I6[b];
+        for (int e = 0; e < 36; ++e) Ic[e] += I6[e];
+        fb = fb + s6p(sh.Fb[b]);
+        if (k < 3) {
+            S6 S = s6p(sh.S[3 * lane + k]);
+            F[k] = m6v(Ic, S);
+            h[k] = dot(S, fb);
+        }
+    }
+    S6 Sh = s6p(sh.S[3 * lane]), St = s6p(sh.S[3 * lane + 1]), Sc = s6p(sh.S[3 * lane + 2]);
+    float Mll[6] = {dot(Sh, F[0]), dot(Sh, F[1]), dot(St, F[1]), dot(Sh, F[2]), dot(St, F[2]), dot(Sc, F[2])};
+    float L[6];
+    chol3(Mll, L);
+    for (int e = 0; e < 6; ++e) sh.Lll[lane][e] = L[e];
+    for (int e = 0; e < 36; ++e) sh.Ichip[lane][e] = Ic[e];
+    s6st(sh.legF[lane], fb);
+    for (int k = 0; k < 3; ++k) sh.hl[lane][k] = h[k];
+    float Fm[3][6];
+    for (int k = 0; k < 3; ++k) { s6st(Fm[k], F[k]); for (int r = 0; r < 6; ++r) sh.Mbl[lane][3 * r + k] = Fm[k][r]; }
+    // G = Mll^-1 Mlb^T (3x6): column c of Mlb^T is (F_h[c], F_t[c], F_c[c])
+    float G[18];
+    for (int c = 0; c < 6; ++c) {
+        float col[3] = {Fm[0][c], Fm[1][c], Fm[2][c]};
+        chol3_solve(L, col);
+        G[c] = col[0]; G[6 + c] = col[1]; G[12 + c] = col[2];
+    }
+    for (int e = 0; e < 18; ++e) sh.G[lane][e] = G[e];
+    for (int r = 0; r < 6; ++r)
+        for (int c = 0; c < 6; ++c) sh.A[lane][6 * r + c] = Fm[0][r] * G[c] + Fm[1][r] * G[6 + c] + Fm[2][r] * G[12 + c];
+}
+
+// ---- phase E: assemble the base Schur complement and total base bias force (lane = element)
+LS_FN void ph_base_assemble(WaveShared& sh, int lane) {
+    if (lane < 36) {
+        float s = sh.u.I6[0][lane];
+        for (int l = 0; l < 4; ++l) s += sh.Ichip[l][lane] - sh.A[l][lane];
+        sh.Sb[lane] = s;
+    } else if (lane < 42) {
+        int k = lane - 36;
+        float s = sh.Fb[0][k];
+        for (int l = 0; l < 4; ++l) s += sh.legF[l][k];
+        sh.hb[k] = s;
+    }
+}
+
+// ---- phase: Cholesky of the 6x6 Schur complement (lane 0), in place, lower factor row-major
+LS_FN void ph_base_factor(WaveShared& sh, int lane) {
+    if (lane != 0) return;
+    float A[36];
+    for (int e = 0; e < 36; ++e) A[e] = sh.Sb[e];
+    for (int j = 0; j < 6; ++j) {
+        float d = A[6 * j + j];
+        for (int k = 0; k < j; ++k) d -= A[6 * j + k] * A[6 * j + k];
+        d = sqrtf(fmaxf(d, 1e-12f));
+        A[6 * j + j] = d;
+        for (int i = j + 1; i < 6; ++i) {
+            float v = A[6 * i + j];
+            for (int k = 0; k < j; ++k) v -= A[6 * i + k] * A[6 * j + k];
+            A[6 * i + j] = v / d;
+        }
+    }
+    for (int e = 0; e < 36; ++e) sh.Sb[e] = A[e];
+}
+
+// ---- free velocity: three small phases
+LS_FN void ph_free_leg(WaveShared& sh, int lane) {  // lane = leg: y_l = Mll^-1 (tau_l - h_l)
+    if (lane >= 4) return;
+    float y[3];
+    for (int k = 0; k < 3; ++k) y[k] = sh.tau[3 * lane + k] - sh.hl[lane][k];
+    chol3_solve(sh.Lll[lane], y);
+    for (int k = 0; k < 3; ++k) sh.yl[lane][k] = y[k];
+}
+LS_FN void ph_free_base(WaveShared& sh, int lane) {  // lane 0: a_b = Sb^-1 (-h_b - sum_l Mbl y_l)
+    if (lane != 0) return;
+    float rb[6];
+    for (int r = 0; r < 6; ++r) {
+        float s = -sh.hb[r];
+        for (int l = 0; l < 4; ++l) s -= sh.Mbl[l][3 * r] * sh.yl[l][0] + sh.Mbl[l][3 * r + 1] * sh.yl[l][1] + sh.Mbl[l][3 * r + 2] * sh.yl[l][2];
+        rb[r] = s;
+    }
+    chol6_solve(sh.Sb, rb);
+    for (int r = 0; r < 6; ++r) sh.ab[r] = rb[r];
+}
+LS_FN void ph_free_finish(WaveShared& sh, int lane, float dt) {  // lane = generalized velocity index
+    if (lane >= LS_NV) return;
+    float v, a;
+    if (lane < 6) {
+        v = (lane < 3) ? sh.root[10 + lane] : sh.root[7 + lane - 3];
+        a = sh.ab[lane];
+    } else {
+        int d = lane - 6, l = d / 3, k = d % 3;
+        v = sh.qd[d];
+        a = sh.yl[l][k];
+        for (int c = 0; c < 6; ++c) a -= sh.G[l][6 * k + c] * sh.ab[c];
+    }
+    sh.vfree[lane] = v + dt * a;
+}
+
+// ---- terrain surface under a world point: triangulated height grid, diagonal (i,j)-(i+1,j+1)
+LS_FN void ls_terrain_query(const LsCtx& cx, float x, float y, float& h, V3& n) {
+    const lsim_config& c = cx.cfg;
+    if (c.mesh_type == 0) { h = 0.0f; n = v3(0, 0, 1); return; }
+    const int16_t* g = (const int16_t*)cx.buf[LSIM_BUF_HEIGHT_GRID];
+    float hs = c.horizontal_scale, vs = c.vertical_scale;
+    float gx = (x + c.border_size) / hs, gy = (y + c.border_size) / hs;
+    float fi = clampf(floorf(gx), 0.0f, (float)(c.grid_rows - 2)), fj = clampf(floorf(gy), 0.0f, (float)(c.grid_cols - 2));
+    int i = (int)fi, j = (int)fj;
+    float u = clampf(gx - fi, 0.0f, 1.0f), v = clampf(gy - fj, 0.0f, 1.0f);
+    float h00 = g[i * c.grid_cols + j] * vs, h10 = g[(i + 1) * c.grid_cols + j] * vs;
+    float h01 = g[i * c.grid_cols + j + 1] * vs, h11 = g[(i + 1) * c.grid_cols + j + 1] * vs;
+    float dhx, dhy;
+    if (u >= v) { dhx = h10 - h00; dhy = h11 - h10; h = h00 + u * dhx + v * dhy; }
+    else { dhx = h11 - h01; dhy = h01 - h00; h = h00 + v * dhy + u * dhx; }
+    float nx = -dhx / hs, ny = -dhy / hs, inv = 1.0f / sqrtf(nx * nx + ny * ny + 1.0f);
+    n = v3(nx * inv, ny * inv, inv);
+}
+
+LS_FN void ls_tangent_basis(V3 n, V3& t1, V3& t2) {
+    V3 ref = (fabsf(n.x) > 0.9f) ? v3(0, 1, 0) : v3(1, 0, 0);
+    t1 = cross(n, ref);
+    float l = sqrtf(dot(t1, t1));
+    t1 = t1 * (1.0f / l);
+    t2 = cross(n, t1);
+}
+
+// ---- phase P: narrow phase, one collision point per lane
+LS_FN void ph_collide(const LsCtx& cx, WaveShared& sh, LaneRegs& r, int lane) {
+    r.cp_active = 0;
+    if (lane >= cx.model.num_collision_points) return;
+    int b = r.cp_body;
+    V3 pw = mul(m3p(sh.R[b]), v3p(r.cp_pos)) + v3p(sh.p[b]);
+    float h;
+    V3 n;
+    ls_terrain_query(cx, sh.root[0] + pw.x, sh.root[1] + pw.y, h, n);
+    float dist = (sh.root[2] + pw.z - h) * n.z - r.cp_r;
+    if (dist < cx.cfg.contact_offset) {
+        r.cp_active = 1;
+        r.cp_dist = dist;
+        v3st(r.cp_n, n);
+        v3st(r.cp_x, pw - n * r.cp_r);
+    }
+}
+
+// ---- wave collective: ordered compaction of the active points into at most LS_MAXC contacts
+#if defined(LS_EMU)
+static inline void wc_compact_contacts(WaveShared& sh, LaneRegs* L) {
+    int nc = 0;
+    for (int lane = 0; lane < 64 && nc < LS_MAXC; ++lane)
+        if (L[lane].cp_active) {
+            sh.cbody[nc] = L[lane].cp_body; sh.cdist[nc] = L[lane].cp_dist;
+            for (int k = 0; k < 3; ++k) { sh.cn[nc][k] = L[lane].cp_n[k]; sh.cpos[nc][k] = L[lane].cp_x[k]; }
+            ++nc;
+        }
+    sh.nc = nc;
+}
+#else
+LS_FN void wc_compact_contacts(WaveShared& sh, LaneRegs& r, int lane) {
+    unsigned long long m = __ballot(r.cp_active != 0);
+    int rank = __popcll(m & ((1ull << lane) - 1ull));
+    if (r.cp_active && rank < LS_MAXC) {
+        sh.cbody[rank] = r.cp_body; sh.cdist[rank] = r.cp_dist;
+        for (int k = 0; k < 3; ++k) { sh.cn[rank][k] = r.cp_n[k]; sh.cpos[rank][k] = r.cp_x[k]; }
+    }
+    if (lane == 0) { int n = __popcll(m); sh.nc = n < LS_MAXC ? n : LS_MAXC; }
+}
+#endif
+
+// ---- phase: joint-limit rows (lane 0 builds the short ordered list)
+LS_FN void ph_limits(const LsCtx& cx, WaveShared& sh, int lane) {
+    if (lane != 0) return;
+    int n = 0;
+    for (int j = 0; j < 12; ++j) {
+        float lo = sh.q[j] - cx.model.dof_pos_lower[j], hi = cx.model.dof_pos_upper[j] - sh.q[j];
+        if (lo < 0.1f) { sh.limdof[n] = j; sh.limgap[n] = lo; sh.limsgn[n] = 1.0f; ++n; }
+        else if (hi < 0.1f) { sh.limdof[n] = j; sh.limgap[n] = hi; sh.limsgn[n] = -1.0f; ++n; }
+    }
+    sh.nlim = n;
+    sh.nrows = 3 * sh.nc + n;
+}
+
+// ---- phase R1: constraint row Jacobian, Y = M^-1 J^T (structured solve), right-hand side (lane = row)
+LS_FN void ph_rows(const LsCtx& cx, WaveShared& sh, LaneRegs& r, int lane, float dt) {
+    r.row_kind = -1;
+    if (lane >= sh.nrows) return;
+    const lsim_config& c = cx.cfg;
+    float vt;
+    int leg;
+    float Jb[6] = {0, 0, 0, 0, 0, 0}, Jl[3] = {0, 0, 0};
+    V3 d = v3(0, 0, 0);
+    if (lane < 3 * sh.nc) {
+        int k = lane / 3, a = lane - 3 * k;
+        V3 n = v3p(sh.cn[k]), t1, t2;
+        ls_tangent_basis(n, t1, t2);
+        d = (a == 0) ? n : (a == 1 ? t1 : t2);
+        V3 x = v3p(sh.cpos[k]);
+        S6 f = s6(cross(x, d), d);
+        s6st(Jb, f);
+        int b = sh.cbody[k];
+        leg = (b == 0) ? -1 : ls_leg_of_body(b);
+        if (b > 0) {
+            int depth = ls_depth_of_body(b);
+            int nd = depth > 2 ? 3 : depth + 1;
+            for (int j = 0; j < nd; ++j) Jl[j] = dot(s6p(sh.S[3 * leg + j]), f);
+        }
+        r.row_kind = a;
+        if (a == 0) {
+            float dist = sh.cdist[k];
+            if (dist >= 0.0f) vt = -dist / dt;
+            else vt = fminf(c.max_depenetration_velocity, c.erp * fmaxf(-dist - c.contact_slop, 0.0f) / dt);
+        } else vt = 0.0f;
+    } else {
+        int i = lane - 3 * sh.nc;
+        int j = sh.limdof[i];
+        leg = j / 3;
+        Jl[j - 3 * leg] = sh.limsgn[i];
+        float gap = sh.limgap[i];
+        vt = gap >= 0.0f ? -gap / dt : fminf(1.0f, c.erp * (-gap) / dt);
+        r.row_kind = 3;
+    }
+    r.row_leg = leg;
+    for (int k = 0; k < 6; ++k) r.Jb[k] = Jb[k];
+    for (int k = 0; k < 3; ++k) r.Jl[k] = Jl[k];
+    v3st(sh.u.c.dirs[lane], d);
+    // Y = M^-1 J^T
+    float y[3] = {0, 0, 0}, rb[6];
+    for (int k = 0; k < 6; ++k) rb[k] = Jb[k];
+    if (leg >= 0) {
+        for (int k = 0; k < 3; ++k) y[k] = Jl[k];
+        chol3_solve(sh.Lll[leg], y);
+        for (int k = 0; k < 6; ++k) rb[k] -= sh.Mbl[leg][3 * k] * y[0] + sh.Mbl[leg][3 * k + 1] * y[1] + sh.Mbl[leg][3 * k + 2] * y[2];
+    }
+    chol6_solve(sh.Sb, rb);
+    float* Y = sh.u.c.Y[lane];
+    for (int k = 0; k < 6; ++k) Y[k] = rb[k];
+    for (int l = 0; l < 4; ++l)
+        for (int k = 0; k < 3; ++k) {
+            float s = (l == leg) ? y[k] : 0.0f;
+            for (int cc = 0; cc < 6; ++cc) s -= sh.G[l][6 * k + cc] * rb[cc];
+            Y[6 + 3 * l + k] = s;
+        }
+    float jv = 0.0f;
+    for (int k = 0; k < 6; ++k) jv += Jb[k] * sh.vfree[k];
+    if (leg >= 0) for (int k = 0; k < 3; ++k) jv += Jl[k] * sh.vfree[6 + 3 * leg + k];
+    r.brow = jv - vt;
+}
+
+// ---- phase R2: Delassus row W_i. = J_i Y^T (lane = row i)
+LS_FN void ph_delassus(WaveShared& sh, LaneRegs& r, int lane) {
+    if (lane >= sh.nrows) return;
+    const int R = sh.nrows;
+    const int leg = r.row_leg;
+    const int lo = leg >= 0 ? 6 + 3 * leg : 6;
+    const float jl0 = leg >= 0 ? r.Jl[0] : 0.0f, jl1 = leg >= 0 ? r.Jl[1] : 0.0f, jl2 = leg >= 0 ? r.Jl[2] : 0.0f;
+    float wd = 0.0f;
+#if !defined(LS_EMU)
+#pragma unroll
+#endif
+    for (int j = 0; j < LS_MAXR; ++j) {   // fully unrolled on the GPU so that W[] is register-resident
+        if (j < R) {
+            const float* Y = sh.u.c.Y[j];
+            float w = 0.0f;
+            for (int k = 0; k < 6; ++k) w += r.Jb[k] * Y[k];
+            w += jl0 * Y[lo] + jl1 * Y[lo + 1] + jl2 * Y[lo + 2];
+            if (j == lane) { w += 1e-6f; wd = w; }   // constraint-force mixing keeps the diagonal positive
+            r.W[j] = w;
+        }
+    }
+    r.wdiag = wd;
+}
+
+// ---- wave collective: projected Gauss-Seidel sweep in impulse space
+//      w_i = b_i + sum_j W_ij lam_j is kept up to date by every lane; rows are relaxed in order r = 0..R-1.
+#if defined(LS_EMU)
+static inline void wc_pgs(WaveShared& sh, LaneRegs* L, int iters) {
+    const int R = sh.nrows;
+    float lam[LS_MAXR], w[LS_MAXR];
+    for (int i = 0; i < R; ++i) { lam[i] = 0.0f; w[i] = L[i].brow; }
+    for (int it = 0; it < iters; ++it)
+        for (int r = 0; r < R; ++r) {
+            float nl = lam[r] - w[r] / L[r].wdiag;
+            int kind = L[r].row_kind;
+            if (kind == 0 || kind == 3) nl = fmaxf(nl, 0.0f);
+            else { float lim = sh.mu * lam[r - kind]; nl = clampf(nl, -lim, lim); }
+            float delta = nl - lam[r];
+            lam[r] = nl;
+            for (int i = 0; i < R; ++i) w[i] += L[i].W[r] * delta;
+        }
+    for (int i = 0; i < R; ++i) sh.lam[i] = lam[i];
+}
+#else
+LS_FN float ls_readlane(float v, int srclane) {  // srclane is wave-uniform
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), srclane));
+}
+LS_FN void wc_pgs(WaveShared& sh, LaneRegs& rg, int lane, int iters) {
+    const int R = sh.nrows;
+    const bool act = lane < R;
+    float lam = 0.0f, lam_n = 0.0f, w = act ? rg.brow : 0.0f;
+    const float inv_d = act ? 1.0f / rg.wdiag : 0.0f;
+    const int kind = rg.row_kind;
+    const bool fric = (kind == 1 || kind == 2);
+    const int nsrc = fric ? lane - kind : -1;   // row holding this contact's normal impulse
+    const float mu = sh.mu;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < LS_MAXR; ++r) {   // fully unrolled: W[r] stays in a register, r is an immediate for readlane
+            if (r < R) {
+                float nl = lam - w * inv_d;
+                if (fric) { float lim = mu * lam_n; nl = clampf(nl, -lim, lim); }
+                else nl = fmaxf(nl, 0.0f);
+                float delta = ls_readlane(nl - lam, r);
+                if (lane == r) lam = nl;
+                if (nsrc == r) lam_n += delta;      // friction lanes track their normal impulse without a shuffle
+                w += rg.W[r] * delta;
+            }
+        }
+    }
+    if (act) sh.lam[lane] = lam;
+}
+#endif
+
+// ---- phase V: constrained velocity (lane = generalized velocity index)
+LS_FN void ph_apply_impulses(WaveShared& sh, int lane) {
+    if (lane >= LS_NV) return;
+    float v = sh.vfree[lane];
+    for (int r = 0; r < sh.nrows; ++r) v += sh.u.c.Y[r][lane] * sh.lam[r];
+    sh.vnew[lane] = v;
+}
+
+// ---- phase B: net contact force per body, world frame (LR:944) (lane = body)
+LS_FN void ph_contact_forces(WaveShared& sh, int lane, float dt) {
+    if (lane >= LS_NB) return;
+    V3 f = v3(0, 0, 0);
+    for (int k = 0; k < sh.nc; ++k)
+        if (sh.cbody[k] == lane)
+            for (int a = 0; a < 3; ++a) f = f + v3p(sh.u.c.dirs[3 * k + a]) * (sh.lam[3 * k + a] / dt);
+    v3st(sh.cf[lane], f);
+}
+
+// ---- phase: integrate (lanes 0-11 joints, lane 12 base)
+LS_FN void ph_integrate(const LsCtx& cx, WaveShared& sh, int lane, float dt) {
+    if (lane < 12) {
+        float lim = cx.model.dof_vel_limit[lane];
+        float v = clampf(sh.vnew[6 + lane], -lim, lim);
+        sh.q[lane] += dt * v;
+        sh.qd[lane] = v;
+    } else if (lane == 12) {
+        V3 w = v3p(sh.vnew), vl = v3p(sh.vnew + 3);
+        V3 dp = vl * dt;
+        V3 vo = vl + cross(w, dp);   // velocity of the base origin after it moved by dp
+        float* q = sh.root + 3;
+        float qn = 1.0f / sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+        float q0 = q[0] * qn, q1 = q[1] * qn, q2 = q[2] * qn, q3 = q[3] * qn;
+        float h = 0.5f * dt;
+        float n0 = q0 + h * (w.x * q3 + w.y * q2 - w.z * q1);
+        float n1 = q1 + h * (-w.x * q2 + w.y * q3 + w.z * q0);
+        float n2 = q2 + h * (w.x * q1 - w.y * q0 + w.z * q3);
+        float n3 = q3 + h * (-w.x * q0 - w.y * q1 - w.z * q2);
+        float nn = 1.0f / sqrtf(n0 * n0 + n1 * n1 + n2 * n2 + n3 * n3);
+        q[0] = n0 * nn; q[1] = n1 * nn; q[2] = n2 * nn; q[3] = n3 * nn;
+        sh.root[0] += dp.x; sh.root[1] += dp.y; sh.root[2] += dp.z;
+        v3st(sh.root + 7, vo);
+        v3st(sh.root + 10, w);
+    }
+}
+
+// ---- phase B: world state of every body (rigid_body_states, LR:938) from the kinematics phase (lane = body)
+LS_FN void ph_body_states(WaveShared& sh, int lane, float* out /* [17][13] of this env */) {
+    if (lane >= LS_NB) return;
+    float* o = out + 13 * lane;
+    V3 p = v3p(sh.p[lane]);
+    S6 V = s6p(sh.V[lane]);
+    V3 vel = V.l + cross(V.a, p);
+    o[0] = sh.root[0] + p.x; o[1] = sh.root[1] + p.y; o[2] = sh.root[2] + p.z;
+    if (lane == 0) { for (int k = 0; k < 4; ++k) o[3 + k] = sh.root[3 + k]; }
+    else R_to_quat(m3p(sh.R[lane]), o + 3);
+    v3st(o + 7, vel);
+    v3st(o + 10, V.a);
+}

@@ -1,0 +1,444 @@
+// ls_post.h -- the reference's torch post-physics stack as wave phases (one wavefront per robot).
+// Every function cites the lines of legged_gym/envs/base/legged_robot.py ("LR") it restates; the CPU oracle
+// (oracle/lsim_oracle.c) states the same logic as scalar loops and both are pinned by tests/golden.
+#pragma once
+#include "ls_shared.h"
+
+#define LSB(cx, id, T) ((T*)(cx).buf[id])
+#define LS_NHP LSIM_NUM_HEIGHT_PTS
+
+LS_FN float ls_draw(const LsCtx& cx, int env, uint32_t stepw, uint32_t tag, uint32_t idx) {
+    return ls_u01(cx.cfg.seed, cx.cfg.rank, (uint32_t)env, stepw, tag, idx);
+}
+
+// LR:1342-1355: (x + border) / hscale truncated toward zero, clip, min of 3 samples, * vscale
+LS_FN float ls_sample_height_min3(const LsCtx& cx, float x, float y) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+    const lsim_config& c = cx.cfg;
+    float fx = (x + c.border_size) / c.horizontal_scale;
+    float fy = (y + c.border_size) / c.horizontal_scale;
+    int px = (int)fx, py = (int)fy;
+    px = px < 0 ? 0 : (px > c.grid_rows - 2 ? c.grid_rows - 2 : px);
+    py = py < 0 ? 0 : (py > c.grid_cols - 2 ? c.grid_cols - 2 : py);
+    const int16_t* g = LSB(cx, LSIM_BUF_HEIGHT_GRID, const int16_t);
+    int16_t h1 = g[px * c.grid_cols + py], h2 = g[(px + 1) * c.grid_cols + py], h3 = g[px * c.grid_cols + py + 1];
+    int16_t h = h1 < h2 ? h1 : h2;
+    h = h < h3 ? h : h3;
+    return (float)h * c.vertical_scale;
+}
+
+LS_FN V3 ls_yaw_point(const float* root, float px, float py) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+    V3 w = quat_apply_yaw(root + 3, v3(px, py, 0.0f));
+    return v3(w.x + root[0], w.y + root[1], 0.0f);
+}
+
+// LeggedRobot._get_heights (LR:1318-1355): lanes stride over the 187 points
+LS_FN void ph_heights(const LsCtx& cx, WaveShared& sh, int lane, int env, bool store_global) {
+    const lsim_config& c = cx.cfg;
+    float* mh = LSB(cx, LSIM_BUF_MEASURED_HEIGHTS, float) + LS_NHP * env;
+    for (int k = lane; k < LS_NHP; k += 64) {
+        float h = 0.0f;
+        if (c.mesh_type != 0) {
+            int ix = k / c.num_points_y, iy = k - ix * c.num_points_y;
+            V3 w = ls_yaw_point(sh.root, c.measured_points_x[ix], c.measured_points_y[iy]);
+            h = ls_sample_height_min3(cx, w.x, w.y);
+        }
+        sh.heights[k] = h;
+        if (store_global) mh[k] = h;
+    }
+}
+// LeggedRobot._get_base_heights (LR:1357-1398): 7 x 9 points, (z - h) per point; the mean is taken by the reward lane
+LS_FN void ph_base_height_pts(const LsCtx& cx, WaveShared& sh, int lane) {
+    if (lane >= LSIM_NUM_BASE_HEIGHT_PTS) return;
+    if (cx.cfg.mesh_type == 0) { sh.bh[lane] = sh.root[2]; return; }
+    int ix = lane / 9, iy = lane - 9 * ix;
+    float px = -0.15f + 0.05f * (float)ix, py = -0.2f + 0.05f * (float)iy;
+    // the reference builds the grid from literal lists (LR:1308-1309); use the same fp32 literals
+    const float xs[7] = {-0.15f, -0.1f, -0.05f, 0.f, 0.05f, 0.1f, 0.15f};
+    const float ys[9] = {-0.2f, -0.15f, -0.1f, -0.05f, 0.f, 0.05f, 0.1f, 0.15f, 0.2f};
+    px = xs[ix]; py = ys[iy];
+    V3 w = ls_yaw_point(sh.root, px, py);
+    sh.bh[lane] = sh.root[2] - ls_sample_height_min3(cx, w.x, w.y);
+}
+
+// LeggedRobot._resample_commands (LR:634-656) for this env; `ranges` = live command ranges [4][2]
+LS_FN void ls_resample_commands(const LsCtx& cx, int env, uint32_t stepw, uint32_t tag, const float* ranges, float* cmd) {
+    float u[4];
+    ls_u01x4(cx.cfg.seed, cx.cfg.rank, (uint32_t)env, stepw, tag, 0, u);
+    cmd[0] = rand_range(u[0], -1.0f, 1.0f);
+    cmd[1] = rand_range(u[1], ranges[2], ranges[3]);
+    if (cx.cfg.heading_command) cmd[3] = rand_range(u[2], ranges[6], ranges[7]);
+    else cmd[2] = rand_range(u[2], ranges[4], ranges[5]);
+    if ((float)env < (float)((double)cx.cfg.num_envs * 0.2)) {
+        cmd[0] = rand_range(u[3], ranges[0], ranges[1]);
+        cmd[1] *= (fabsf(cmd[0]) < 1.0f) ? 1.0f : 0.0f;
+    }
+    float m = (sqrtf(cmd[0] * cmd[0] + cmd[1] * cmd[1]) > 0.2f) ? 1.0f : 0.0f;
+    cmd[0] *= m; cmd[1] *= m;
+}
+
+// ---- Q1: derived base state, contact filter, episode counter (LR:193-209)
+LS_FN void ph_post_state(const LsCtx& cx, WaveShared& sh, int lane, int env) {
+    if (lane == 0) {
+        int64_t* ep = LSB(cx, LSIM_BUF_EPISODE_LENGTH, int64_t) + env;
+        int64_t v = *ep + 1;
+        *ep = v;
+        sh.eplen = (int)v;
+    } else if (lane == 1) {
+        V3 v = quat_rotate_inverse(sh.root + 3, v3p(sh.root + 7));
+        v3st(sh.blv, v); v3st(LSB(cx, LSIM_BUF_BASE_LIN_VEL, float) + 3 * env, v);
+    } else if (lane == 2) {
+        V3 v = quat_rotate_inverse(sh.root + 3, v3p(sh.root + 10));
+        v3st(sh.bav, v); v3st(LSB(cx, LSIM_BUF_BASE_ANG_VEL, float) + 3 * env, v);
+    } else if (lane == 3) {
+        V3 v = quat_rotate_inverse(sh.root + 3, v3(0.0f, 0.0f, -1.0f));
+        v3st(sh.grav, v); v3st(LSB(cx, LSIM_BUF_PROJECTED_GRAVITY, float) + 3 * env, v);
+    } else if (lane < 8) {
+        int f = lane - 4;
+        uint8_t* lc = LSB(cx, LSIM_BUF_LAST_CONTACTS, uint8_t) + 4 * env + f;
+        uint8_t contact = sh.cf[cx.model.feet_bodies[f]][2] > 1.0f;
+        LSB(cx, LSIM_BUF_CONTACT_FILT, uint8_t)[4 * env + f] = contact | *lc;
+        *lc = contact;
+    }
+}
+
+// ---- Q2: _post_physics_step_callback minus heights (LR:607-632): lane 0 commands, lane 1 push, lane 2 disturbance
+LS_FN void ph_callback(const LsCtx& cx, WaveShared& sh, int lane, int env, const LsStepArgs& a, const float* ranges) {
+    const lsim_config& c = cx.cfg;
+    const uint32_t stepw = (uint32_t)a.step_counter;
+    if (lane == 0) {
+        float* cmd = LSB(cx, LSIM_BUF_COMMANDS, float) + 4 * env;
+        float cm[4] = {cmd[0], cmd[1], cmd[2], cmd[3]};
+        if (sh.eplen % c.resampling_steps == 0) ls_resample_commands(cx, env, stepw, LSIM_RNG_CMD, ranges, cm);
+        if (c.heading_command) {
+            V3 f = quat_apply(sh.root + 3, v3(1.0f, 0.0f, 0.0f));
+            float heading = atan2f(f.y, f.x);
+            cm[2] = clampf(0.5f * wrap_to_pi(cm[3] - heading), -2.0f, 2.0f);
+        }
+        for (int k = 0; k < 4; ++k) { cmd[k] = cm[k]; sh.cmd[k] = cm[k]; }
+    } else if (lane == 1) {
+        if (c.push_robots && (a.step_counter % c.push_interval == 0)) {  // LR:822-828
+            float u[4];
+            ls_u01x4(c.seed, c.rank, (uint32_t)env, stepw, LSIM_RNG_PUSH, 0, u);
+            sh.root[7] = rand_range(u[0], -c.max_push_vel_xy, c.max_push_vel_xy);
+            sh.root[8] = rand_range(u[1], -c.max_push_vel_xy, c.max_push_vel_xy);
+        }
+    } else if (lane == 2) {
+        float d[3] = {0.0f, 0.0f, 0.0f};
+        if (c.disturbance && (a.step_counter % c.disturbance_interval == 0)) {  // LR:838-844
+            float u[4];
+            ls_u01x4(c.seed, c.rank, (uint32_t)env, stepw, LSIM_RNG_DISTURB, 0, u);
+            float* pf = LSB(cx, LSIM_BUF_PENDING_FORCE, float) + 3 * env;
+            for (int k = 0; k < 3; ++k) { d[k] = rand_range(u[k], c.disturbance_range[0], c.disturbance_range[1]); pf[k] = d[k]; }
+        }
+        for (int k = 0; k < 3; ++k) sh.disturbance[k] = d[k];
+    }
+}
+
+// ---- Q4: check_termination (LR:249-286), lane 0
+LS_FN void ph_termination(const LsCtx& cx, WaveShared& sh, int lane, int env) {
+    if (lane != 0) return;
+    const lsim_config& c = cx.cfg;
+    int r = 0;
+    for (int b = 0; b < LS_NB; ++b)
+        if ((cx.model.termination_body_mask >> b) & 1u) {
+            V3 f = v3p(sh.cf[b]);
+            if (sqrtf(dot(f, f)) > 1.0f) r = 1;
+        }
+    int to = sh.eplen > c.max_episode_length;
+    r |= to;
+    if (c.term_base_vel_violate_commands) {
+        float ve = sh.blv[0] - sh.cmd[0];
+        int v = ((ve > 2.0f) && (sh.cmd[0] < 0.0f)) || ((ve < -2.0f) && (sh.cmd[0] > 0.0f));
+        v = v && (LSB(cx, LSIM_BUF_TERRAIN_LEVELS, int64_t)[env] > 3);
+        r |= v;
+    }
+    if (c.term_out_of_border) {  // TER:220-227
+        float xs = c.terrain_length * (float)c.terrain_num_rows + c.border_size / 2.0f;
+        float ys = c.terrain_width * (float)c.terrain_num_cols + c.border_size / 2.0f;
+        int in = sh.root[0] >= 0.0f && sh.root[1] >= 0.0f && sh.root[0] < xs && sh.root[1] < ys;
+        r |= !in;
+    }
+    if (c.term_fall_down) r |= sh.root[9] < -5.0f;
+    sh.reset = r; sh.timeout = to;
+    LSB(cx, LSIM_BUF_RESET, uint8_t)[env] = (uint8_t)r;
+    LSB(cx, LSIM_BUF_TIME_OUT, uint8_t)[env] = (uint8_t)to;
+}
+
+// ---------------------------------------------------------------------------------------------- rewards
+struct LsRewCtx {
+    const float *dof, *act, *last_act, *last_last_act, *last_dof_pos, *last_dof_vel, *tau, *last_tau;
+    const uint8_t* filt;
+};
+LS_FN float ls_up(const WaveShared& sh) { return clampf(-sh.grav[2], 0.0f, 1.0f); }
+LS_FN float ls_cmd_norm(const WaveShared& sh) { return sqrtf(sh.cmd[0] * sh.cmd[0] + sh.cmd[1] * sh.cmd[1]); }
+
+LS_FN float ls_foot_slide_like(const LsCtx& cx, const WaveShared& sh, const LsRewCtx& x, bool with_height) {  // LR:1610-1619 / LR:1682-1698
+    float acc = 0.0f;
+    for (int f = 0; f < 4; ++f) {
+        const float* bs = sh.feet[f];
+        V3 vb = quat_rotate_inverse(sh.root + 3, v3(bs[3] - sh.root[7], bs[4] - sh.root[8], bs[5] - sh.root[9]));
+        float lat = sqrtf(vb.x * vb.x + vb.y * vb.y);
+        if (with_height) {
+            V3 pb = quat_rotate_inverse(sh.root + 3, v3(bs[0] - sh.root[0], bs[1] - sh.root[1], bs[2] - sh.root[2]));
+            float he = pb.z - cx.cfg.foot_height_target_base;
+            acc += (he * he) * lat;
+        } else acc += (x.filt[f] ? 1.0f : 0.0f) * lat;
+    }
+    return acc;
+}
+LS_FN float ls_foot_clearance_terrain(const LsCtx& cx, const WaveShared& sh, int shifts) {  // LR:1717-1743 incl. quirk 3 (in-place += border)
+    const lsim_config& c = cx.cfg;
+    float acc = 0.0f;
+    for (int f = 0; f < 4; ++f) {
+        const float* bs = sh.feet[f];
+        float fh;
+        if (c.mesh_type == 0) fh = bs[2];
+        else {
+            float px = bs[0], py = bs[1], pz = bs[2];
+            for (int s = 0; s < shifts; ++s) { px += c.border_size; py += c.border_size; pz += c.border_size; }
+            int ix = (int)(px / c.horizontal_scale), iy = (int)(py / c.horizontal_scale);
+            ix = ix < 0 ? 0 : (ix > c.grid_rows - 2 ? c.grid_rows - 2 : ix);
+            iy = iy < 0 ? 0 : (iy > c.grid_cols - 2 ? c.grid_cols - 2 : iy);
+            const int16_t* g = LSB(cx, LSIM_BUF_HEIGHT_GRID, const int16_t);
+            int16_t h1 = g[ix * c.grid_cols + iy], h2 = g[(ix + 1) * c.grid_cols + iy], h3 = g[ix * c.grid_cols + iy + 1];
+            int16_t h = h1 < h2 ? h1 : h2; h = h < h3 ? h : h3;
+            fh = pz - (float)h * c.vertical_scale;
+        }
+        float lat = sqrtf(bs[3] * bs[3] + bs[4] * bs[4]);
+        float d = fh - c.foot_height_target_terrain;
+        acc += lat * (d * d);
+    }
+    return acc;
+}
+LS_FN float ls_sum_abs_dev(const LsCtx& cx, const LsRewCtx& x, int first) {
+    float acc = 0.0f;
+    for (int l = 0; l < 4; ++l) { int j = 3 * l + first; acc += fabsf(x.dof[2 * j] - cx.cfg.default_dof_pos[j]); }
+    return acc;
+}
+LS_FN float ls_stumble(const LsCtx& cx, const WaveShared& sh, int env, float ratio) {  // LR:1589-1608
+    const lsim_config& c = cx.cfg;
+    int any = 0;
+    for (int f = 0; f < 4; ++f) {
+        const float* F = sh.cf[cx.model.feet_bodies[f]];
+        if (sqrtf(F[0] * F[0] + F[1] * F[1]) > ratio * fabsf(F[2])) any = 1;
+    }
+    float r = (any && LSB(cx, LSIM_BUF_TERRAIN_LEVELS, int64_t)[env] > 3) ? 1.0f : 0.0f;
+    int in_slice = (env >= c.stairsup_start_idx && env < c.stairsup_end_idx) || (env >= c.pit_start_idx && env < c.gap_end_idx);
+    return in_slice ? r : 0.0f;
+}
+LS_FN float ls_var12(const float* v) {
+    float m = 0.0f;
+    for (int j = 0; j < 12; ++j) m += v[j];
+    m /= 12.0f;
+    float a = 0.0f;
+    for (int j = 0; j < 12; ++j) a += (v[j] - m) * (v[j] - m);
+    return a / 11.0f;
+}
+
+// one `_reward_<name>()` (LR:1444-1770)
+LS_FN float ls_reward_term(const LsCtx& cx, WaveShared& sh, const LsRewCtx& x, int id, int env, int fct_shifts) {
+    const lsim_config& c = cx.cfg;
+    const float dt = c.sim_dt * (float)c.decimation;
+    float acc = 0.0f;
+    switch (id) {
+        case LSIM_R_TRACKING_LIN_VEL: {
+            float small = ls_cmd_norm(sh) < 0.1f ? 0.0f : 1.0f;
+            float ex = sh.cmd[0] * small - sh.blv[0], ey = sh.cmd[1] * small - sh.blv[1];
+            return expf(-(ex * ex + ey * ey) / c.tracking_sigma);
+        }
+        case LSIM_R_TRACKING_ANG_VEL: { float e = sh.cmd[2] - sh.bav[2]; return expf(-(e * e) / c.tracking_sigma); }
+        case LSIM_R_FEET_AIR_TIME: {  // LR:1459-1470 (mutates last_contacts and feet_air_time)
+            float* air = LSB(cx, LSIM_BUF_FEET_AIR_TIME, float) + 4 * env;
+            uint8_t* lc = LSB(cx, LSIM_BUF_LAST_CONTACTS, uint8_t) + 4 * env;
+            float r = 0.0f;
+            uint8_t filt[4];
+            for (int f = 0; f < 4; ++f) {
+                uint8_t contact = sh.cf[cx.model.feet_bodies[f]][2] > 1.0f;
+                filt[f] = contact | lc[f];
+                lc[f] = contact;
+                float a = air[f];
+                float first = (a > 0.0f && filt[f]) ? 1.0f : 0.0f;
+                a += dt;
+                r += (a - 0.5f) * first;
+                air[f] = a;
+            }
+            r *= (ls_cmd_norm(sh) > 0.1f) ? 1.0f : 0.0f;
+            for (int f = 0; f < 4; ++f) air[f] *= filt[f] ? 0.0f : 1.0f;
+            return r;
+        }
+        case LSIM_R_UPWARD: return 1.0f - sh.grav[2];
+        case LSIM_R_HAS_CONTACT: {
+            float n = 0.0f;
+            for (int f = 0; f < 4; ++f) n += x.filt[f] ? 1.0f : 0.0f;
+            return ((ls_cmd_norm(sh) < 0.1f) ? 1.0f : 0.0f) * n / 4.0f;
+        }
+        case LSIM_R_LIN_VEL_Z: return sh.blv[2] * sh.blv[2];
+        case LSIM_R_LIN_VEL_Z_UP: return sh.blv[2] * sh.blv[2] * ls_up(sh);
+        case LSIM_R_ANG_VEL_XY: return sh.bav[0] * sh.bav[0] + sh.bav[1] * sh.bav[1];
+        case LSIM_R_ANG_VEL_XY_UP: return (sh.bav[0] * sh.bav[0] + sh.bav[1] * sh.bav[1]) * ls_up(sh);
+        case LSIM_R_ORIENTATION: return sh.grav[0] * sh.grav[0] + sh.grav[1] * sh.grav[1];
+        case LSIM_R_ORIENTATION_UP: return (sh.grav[0] * sh.grav[0] + sh.grav[1] * sh.grav[1]) * ls_up(sh);
+        case LSIM_R_BASE_HEIGHT:
+        case LSIM_R_BASE_HEIGHT_UP: {
+            float bh;
+            if (c.mesh_type == 0) bh = sh.root[2];
+            else { float s = 0.0f; for (int k = 0; k < LSIM_NUM_BASE_HEIGHT_PTS; ++k) s += sh.bh[k]; bh = s / 63.0f; }
+            float d = bh - c.base_height_target;
+            return id == LSIM_R_BASE_HEIGHT ? d * d : d * d * ls_up(sh);
+        }
+        case LSIM_R_DOF_VEL: for (int j = 0; j < 12; ++j) acc += x.dof[2 * j + 1] * x.dof[2 * j + 1]; return acc;
+        case LSIM_R_DOF_ACC: for (int j = 0; j < 12; ++j) { float a = (x.last_dof_vel[j] - x.dof[2 * j + 1]) / dt; acc += a * a; } return acc;
+        case LSIM_R_DOF_VEL_LIMITS:
+            for (int j = 0; j < 12; ++j) acc += clampf(fabsf(x.dof[2 * j + 1]) - cx.model.dof_vel_limit[j] * c.soft_dof_vel_limit, 0.0f, 1.0f);
+            return acc;
+        case LSIM_R_DOF_POS_DIF: for (int j = 0; j < 12; ++j) { float d = x.last_dof_pos[j] - x.dof[2 * j]; acc += d * d; } return acc;
+        case LSIM_R_DOF_POS_LIMITS:
+            for (int j = 0; j < 12; ++j) {
+                float lo = cx.model.dof_pos_lower[j], hi = cx.model.dof_pos_upper[j];
+                float m = (lo + hi) / 2.0f, r = hi - lo;
+                float slo = m - 0.5f * r * c.soft_dof_pos_limit, shi = m + 0.5f * r * c.soft_dof_pos_limit;
+                float q = x.dof[2 * j];
+                float o = -fminf(q - slo, 0.0f);
+                o += fmaxf(q - shi, 0.0f);
+                acc += o;
+            }
+            return acc;
+        case LSIM_R_ACTION_RATE: for (int j = 0; j < 12; ++j) { float d = x.last_act[j] - x.act[j]; acc += d * d; } return acc;
+        case LSIM_R_SMOOTHNESS:
+            for (int j = 0; j < 12; ++j) { float d = x.act[j] - x.last_act[j] - x.last_act[j] + x.last_last_act[j]; acc += d * d; }
+            return acc;
+        case LSIM_R_TORQUES: for (int j = 0; j < 12; ++j) acc += x.tau[j] * x.tau[j]; return acc;
+        case LSIM_R_TORQUES_DISTRIBUTION: { float v[12]; for (int j = 0; j < 12; ++j) v[j] = fabsf(x.tau[j]); return ls_var12(v); }
+        case LSIM_R_TORQUES_DIF: for (int j = 0; j < 12; ++j) { float d = x.tau[j] - x.last_tau[j]; acc += d * d; } return acc;
+        case LSIM_R_TORQUE_LIMITS: for (int j = 0; j < 12; ++j) acc += fmaxf(fabsf(x.tau[j]) - c.torque_limits[j] * c.soft_torque_limit, 0.0f); return acc;
+        case LSIM_R_JOINT_POWER: for (int j = 0; j < 12; ++j) acc += fabsf(x.dof[2 * j + 1]) * fabsf(x.tau[j]); return acc;
+        case LSIM_R_POWER: for (int j = 0; j < 12; ++j) acc += fabsf(x.tau[j] * x.dof[2 * j + 1]); return acc;
+        case LSIM_R_POWER_DISTRIBUTION: { float v[12]; for (int j = 0; j < 12; ++j) v[j] = fabsf(x.tau[j] * x.dof[2 * j + 1]); return ls_var12(v); }
+        case LSIM_R_COLLISION:
+        case LSIM_R_COLLISION_UP:
+            for (int b = 0; b < LS_NB; ++b)
+                if ((cx.model.penalised_body_mask >> b) & 1u) { V3 f = v3p(sh.cf[b]); acc += (sqrtf(dot(f, f)) > 0.1f) ? 1.0f : 0.0f; }
+            return id == LSIM_R_COLLISION ? acc : acc * ls_up(sh);
+        case LSIM_R_TERMINATION: return (sh.reset && !sh.timeout) ? 1.0f : 0.0f;
+        case LSIM_R_FEET_CONTACT_FORCES:
+            for (int f = 0; f < 4; ++f) { V3 F = v3p(sh.cf[cx.model.feet_bodies[f]]); acc += fmaxf(sqrtf(dot(F, F)) - c.max_contact_force, 0.0f); }
+            return acc;
+        case LSIM_R_FEET_STUMBLE: return ls_stumble(cx, sh, env, 5.0f);
+        case LSIM_R_FEET_STUMBLE_UP: return ls_stumble(cx, sh, env, 4.0f) * ls_up(sh);
+        case LSIM_R_FEET_SLIDE: return ls_foot_slide_like(cx, sh, x, false);
+        case LSIM_R_FEET_SLIDE_UP: return ls_foot_slide_like(cx, sh, x, false) * ls_up(sh);
+        case LSIM_R_FEET_MIRROR:
+        case LSIM_R_FEET_MIRROR_UP: {
+            const float* d = x.dof;
+            float a1 = d[2] - d[20], a2 = d[4] - d[22], b1 = d[8] - d[14], b2 = d[10] - d[16];
+            float r = 0.5f * ((a1 * a1 + a2 * a2) + (b1 * b1 + b2 * b2));
+            return id == LSIM_R_FEET_MIRROR ? r : r * ls_up(sh);
+        }
+        case LSIM_R_STAND_STILL:
+        case LSIM_R_STAND_NICE:
+            for (int j = 0; j < 12; ++j) acc += fabsf(x.dof[2 * j] - c.default_dof_pos[j]);
+            acc *= (ls_cmd_norm(sh) < 0.1f) ? 1.0f : 0.0f;
+            return id == LSIM_R_STAND_STILL ? acc : acc * (1.0f - sh.grav[2]);
+        case LSIM_R_STUCK: return ((fabsf(sh.blv[0]) < 0.1f) && (fabsf(sh.cmd[0]) > 0.1f)) ? 1.0f : 0.0f;
+        case LSIM_R_HIP_ACTION_MAGNITUDE: for (int l = 0; l < 4; ++l) { float m = fmaxf(fabsf(x.act[3 * l]) - 1.0f, 0.0f); acc += m * m; } return acc;
+        case LSIM_R_HIP_POS: return ls_sum_abs_dev(cx, x, 0);
+        case LSIM_R_HIP_POS_UP: return ls_sum_abs_dev(cx, x, 0) * ls_up(sh);
+        case LSIM_R_THIGH_POSE: return ls_sum_abs_dev(cx, x, 1);
+        case LSIM_R_THIGH_POSE_UP: return ls_sum_abs_dev(cx, x, 1) * ls_up(sh);
+        case LSIM_R_CALF_POSE: return ls_sum_abs_dev(cx, x, 2);
+        case LSIM_R_CALF_POSE_UP: return ls_sum_abs_dev(cx, x, 2) * ls_up(sh);
+        case LSIM_R_FOOT_CLEARANCE_BASE: return ls_foot_slide_like(cx, sh, x, true);
+        case LSIM_R_FOOT_CLEARANCE_BASE_UP: return ls_foot_slide_like(cx, sh, x, true) * ls_up(sh);
+        case LSIM_R_FOOT_CLEARANCE_TERRAIN: return ls_foot_clearance_terrain(cx, sh, fct_shifts);
+        case LSIM_R_FOOT_CLEARANCE_TERRAIN_UP: return ls_foot_clearance_terrain(cx, sh, fct_shifts) * ls_up(sh);
+        default: return 0.0f;
+    }
+}
+
+// ---- Q5: compute_reward (LR:363-380).  Lane i evaluates active term i; lane 0 then accumulates in the reference's order.
+LS_FN void ph_reward_terms(const LsCtx& cx, WaveShared& sh, int lane, int env) {
+    if (lane >= cx.num_active) return;
+    const int id = cx.active_terms[lane];
+    LsRewCtx x;
+    x.dof = sh.dofs;
+    x.act = sh.act;
+    x.last_act = LSB(cx, LSIM_BUF_LAST_ACTIONS, const float) + 12 * env;
+    x.last_last_act = LSB(cx, LSIM_BUF_LAST_LAST_ACTIONS, const float) + 12 * env;
+    x.last_dof_pos = LSB(cx, LSIM_BUF_LAST_DOF_POS, const float) + 12 * env;
+    x.last_dof_vel = LSB(cx, LSIM_BUF_LAST_DOF_VEL, const float) + 12 * env;
+    x.tau = sh.tau;
+    x.last_tau = LSB(cx, LSIM_BUF_LAST_TORQUES, const float) + 12 * env;
+    x.filt = LSB(cx, LSIM_BUF_CONTACT_FILT, const uint8_t) + 4 * env;
+    // quirk 3: each earlier active foot_clearance_terrain* term has already shifted self.feet_pos by +border
+    int shifts = 1;
+    if (id == LSIM_R_FOOT_CLEARANCE_TERRAIN_UP && cx.cfg.reward_scales[LSIM_R_FOOT_CLEARANCE_TERRAIN] != 0.0f) shifts = 2;
+    float v = ls_reward_term(cx, sh, x, id, env, shifts) * cx.cfg.reward_scales[id];
+    sh.rewv[lane] = v;
+    LSB(cx, LSIM_BUF_EPISODE_SUMS, float)[env * LSIM_NUM_REWARD_TERMS + id] += v;
+}
+LS_FN void ph_reward_total(const LsCtx& cx, WaveShared& sh, int lane, int env) {
+    if (lane != 0) return;
+    const lsim_config& c = cx.cfg;
+    float rew = 0.0f;
+    for (int i = 0; i < cx.num_active; ++i) rew += sh.rewv[i];
+    if (c.only_positive_rewards) rew = fmaxf(rew, 0.0f);
+    if (c.reward_scales[LSIM_R_TERMINATION] != 0.0f) {
+        float v = ((sh.reset && !sh.timeout) ? 1.0f : 0.0f) * c.reward_scales[LSIM_R_TERMINATION];
+        rew += v;
+        LSB(cx, LSIM_BUF_EPISODE_SUMS, float)[env * LSIM_NUM_REWARD_TERMS + LSIM_R_TERMINATION] += v;
+    }
+    LSB(cx, LSIM_BUF_REW, float)[env] = rew;
+}
+
+// ---------------------------------------------------------------------------------------------- observations
+// entry e of the 238-vector of compute_observations (LR:382-401) before noise
+LS_FN float ls_obs_entry(const LsCtx& cx, const WaveShared& sh, int e, const float* dof, const float* act, const float* heights) {
+    const lsim_config& c = cx.cfg;
+    if (e < 2) return sh.cmd[e] * c.obs_scale_lin_vel;
+    if (e == 2) return sh.cmd[2] * c.obs_scale_ang_vel;
+    if (e < 6) return sh.bav[e - 3] * c.obs_scale_ang_vel;
+    if (e < 9) return sh.grav[e - 6];
+    if (e < 21) return (dof[2 * (e - 9)] - c.default_dof_pos[e - 9]) * c.obs_scale_dof_pos;
+    if (e < 33) return dof[2 * (e - 21) + 1] * c.obs_scale_dof_vel;
+    if (e < 45) return act[e - 33];
+    if (e < 48) return sh.blv[e - 45] * c.obs_scale_lin_vel;
+    if (e < 51) return sh.disturbance[e - 48];
+    return clampf(sh.root[2] - 0.5f - heights[e - 51], -1.0f, 1.0f) * c.obs_scale_height;
+}
+LS_FN float ls_noise_scale(const lsim_config& c, int idx) {  // noise_scale_vec (LR:883-910) by draw index
+    if (idx < 3) return 0.0f;
+    if (idx < 6) return c.noise_vec_ang_vel;
+    if (idx < 9) return c.noise_vec_gravity;
+    if (idx < 21) return c.noise_vec_dof_pos;
+    if (idx < 33) return c.noise_vec_dof_vel;
+    if (idx < 45) return 0.0f;
+    return c.noise_vec_height;
+}
+// lanes 0..57 own one Philox block (4 noisy entries) each, lanes 58..63 the six noise-free entries 45..50
+LS_FN void ph_build_obs(const LsCtx& cx, WaveShared& sh, int lane, int env, uint32_t stepw, uint32_t tag, float* out) {
+    const lsim_config& c = cx.cfg;
+    const float* dof = sh.dofs;
+    const float* act = sh.act;
+    if (lane >= 58) {
+        int e = 45 + (lane - 58);
+        out[e] = ls_obs_entry(cx, sh, e, dof, act, sh.heights);
+        return;
+    }
+    float u[4];
+    ls_u01x4(c.seed, c.rank, (uint32_t)env, stepw, tag, (uint32_t)lane, u);
+    for (int i = 0; i < 4; ++i) {
+        int idx = 4 * lane + i;
+        int e = idx < 45 ? idx : idx + 6;
+        if (e >= LSIM_NUM_PRIV_OBS) break;
+        if (e >= 51 && !c.measure_heights) { out[e] = 0.0f; continue; }
+        float v = ls_obs_entry(cx, sh, e, dof, act, sh.heights);
+        if (idx >= 45 || c.add_noise) v += (2.0f * u[i] - 1.0f) * ls_noise_scale(c, idx);  // LR:400 is not gated by add_noise
+        out[e] = v;
+    }
+}

@@ -1,0 +1,121 @@
+// ls_shared.h -- per-robot on-chip state of the leggedsim kernels.
+//
+// Execution model (DESIGN.md "Kernel structure"): ONE WAVEFRONT PER ROBOT (blockDim = 64).
+// A kernel is a sequence of *phases*; inside a phase every lane does independent work on its own
+// item (a leg, a body, a collision point, a constraint row, an observation slot ...) and lanes exchange
+// data only through `WaveShared` (LDS) at phase boundaries.  The few true wave collectives (ballot
+// compaction, the Gauss-Seidel sweep) are written against wave intrinsics in ls_physics.h.
+// Because phases are plain functions of (shared, lane-private state, lane index), the same source is
+// also compiled by g++ for tests/emu, which runs the 64 lanes of a phase in a loop -- a development aid to
+// check the lane orchestration on CPU; it is not a product path.
+#pragma once
+#include "../../include/lsim.h"
+#include "ls_math.h"
+
+#define LS_NB LSIM_NUM_BODIES
+#define LS_NV 18
+#define LS_MAXC LSIM_MAX_CONTACTS
+#define LS_MAXR (3 * LSIM_MAX_CONTACTS + LSIM_NUM_DOF)  // 60 <= 64 lanes
+
+// constant per simulator instance; lives in device global memory, read through uniform (scalar) loads
+struct LsCtx {
+    lsim_config cfg;
+    lsim_robot_model model;
+    void* buf[LSIM_NUM_BUFFERS];
+    float* accum;                     // [2][LSIM_STATS_SIZE] ping-pong per-step reductions (== buf[LSIM_BUF_STATS])
+    int32_t active_terms[LSIM_NUM_REWARD_TERMS];
+    int32_t num_active;
+    float cmd_span_init[4];
+};
+
+// per-launch arguments (by value)
+struct LsStepArgs {
+    const float* actions;     // [N,12]
+    int64_t step_counter;     // common_step_counter AFTER this step's increment (LR:194)
+    uint32_t flags;           // LSIM_STEP_*
+    int32_t init_done;        // LR:853
+    int32_t row_in;           // accumulator row holding the previous step's command ranges
+    int32_t row_out;          // accumulator row this step writes (step_counter & 1)
+    int32_t reset_all;        // kernel B only: BaseTask.reset's reset_idx(all) (BT:113)
+};
+
+// body model entries staged in LDS once per kernel
+struct LsBodyLds {
+    float mass, com[3], inertia[6], jpos[3], axis[3];
+};
+
+struct WaveShared {
+    // ---- carried across the step
+    float root[13];
+    float q[12], qd[12];
+    float act[12], last_act[12], ms[12];
+    float tau[12];
+    float kpf, kdf, mu, payload;
+    float comd[3], pend[3];
+    int delay;
+    LsBodyLds body[LS_NB];
+    // ---- kinematics / dynamics of the current sub-step (world axes, positions relative to the base origin)
+    float R[LS_NB][9];
+    float p[LS_NB][3];
+    float S[12][6];          // motion subspace per dof
+    float V[LS_NB][6];       // body twists
+    float Ab[LS_NB][6];      // bias accelerations
+    float Fb[LS_NB][6];      // bias forces (per body, then leg totals in legF)
+    float com0[3];           // base COM (world axes)
+    union {
+        float I6[LS_NB][36];                 // spatial inertias (dead after the composite pass)
+        struct {
+            float Y[LS_MAXR][LS_NV];         // M^-1 J^T rows
+            float dirs[LS_MAXR][3];
+        } c;
+    } u;
+    float Ichip[4][36];      // composite inertia of each leg subtree
+    float A[4][36];          // Mbl Mll^-1 Mlb
+    float Mbl[4][18];        // 6x3: columns F_hip, F_thigh, F_calf
+    float G[4][18];          // 3x6: Mll^-1 Mlb^T
+    float Lll[4][6];         // Cholesky of the 3x3 leg block (l00,l10,l11,l20,l21,l22)
+    float hl[4][3];
+    float legF[4][6];
+    float yl[4][3];
+    float Sb[36];            // Schur complement on the base, then its Cholesky factor (lower)
+    float hb[6], rb[6], ab[6];
+    float vfree[LS_NV], vnew[LS_NV];
+    // ---- contacts
+    int nc, nrows;
+    int cbody[LS_MAXC];
+    float cpos[LS_MAXC][3], cn[LS_MAXC][3], cdist[LS_MAXC];
+    int limdof[12];
+    float limgap[12], limsgn[12];
+    int nlim;
+    float lam[LS_MAXR];
+    float cf[LS_NB][3];
+    unsigned int flags64[2];
+    // ---- post-physics scratch
+    float blv[3], bav[3], grav[3];
+    float cmd[4];
+    float dofs[24];          // interleaved (pos, vel) copy of the final joint state (layout of the gym dof tensor)
+    float feet[4][6];        // world position / linear velocity of the feet (rows of rigid_body_states)
+    float ranges[8];         // live command ranges [4][2]
+    int eplen, do_reset, any_reset;
+    float heights[LSIM_NUM_HEIGHT_PTS];
+    float bh[LSIM_NUM_BASE_HEIGHT_PTS];
+    float disturbance[3];
+    float cur[LSIM_NUM_PRIV_OBS];
+    float rewv[LSIM_NUM_REWARD_TERMS];
+    int reset, timeout;
+};
+
+// lane-private state that survives phase boundaries (VGPRs on the GPU, an array element in tests/emu)
+struct LaneRegs {
+    // collision point owned by this lane
+    float cp_pos[3], cp_r;
+    int cp_body;
+    int cp_active;
+    float cp_dist, cp_n[3], cp_x[3];
+    // constraint row owned by this lane
+    int row_kind;            // 0 normal, 1/2 friction, 3 joint limit, -1 none
+    int row_leg;             // leg whose dofs the row touches, -1 for the base body
+    float Jb[6], Jl[3];
+    float brow, wdiag;
+    float W[LS_MAXR];
+};

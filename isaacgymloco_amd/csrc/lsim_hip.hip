@@ -1,0 +1,127 @@
+// lsim_hip.hip -- the MI355X (gfx950) library behind include/lsim.h.
+// One wavefront (64-thread workgroup) per robot; per-robot scratch in LDS (WaveShared); XCD-aware block -> env map.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC lsim_hip.hip -o liblsim.so   (see build.py)
+#include <hip/hip_runtime.h>
+
+#define LS_API(name) lsim_##name
+struct lsim_sim;
+struct LsStepArgs;
+static int lsbk_set_device(int d) { return hipSetDevice(d) == hipSuccess ? 0 : 1; }
+static int lsbk_malloc(void** p, size_t n) { return hipMalloc(p, n) == hipSuccess ? 0 : 1; }
+static void lsbk_free(void* p) { (void)hipFree(p); }
+static int lsbk_h2d(void* d, const void* s, size_t n) { return hipMemcpy(d, s, n, hipMemcpyHostToDevice) == hipSuccess ? 0 : 1; }
+static int lsbk_memset(void* d, int v, size_t n) { return hipMemset(d, v, n) == hipSuccess ? 0 : 1; }
+static int lsbk_launch_a(lsim_sim* s, const LsStepArgs& a, void* stream);
+static int lsbk_launch_b(lsim_sim* s, const LsStepArgs& a, void* stream);
+static int lsbk_launch_reduce(lsim_sim* s, const LsStepArgs& a, void* stream);
+static void lsbk_prof_mark(lsim_sim* s, int which, void* stream);
+static void lsbk_prof_free(lsim_sim* s);
+
+#include "ls_api_impl.h"
+#include "ls_kernels.h"
+
+// Each XCD (8 per chip, block b is dispatched to XCD b % 8) works on one contiguous slice of the env range, so a
+// robot's state lines stay in one XCD's L2 and neighbouring robots do not false-share lines across XCD L2s.
+__device__ __forceinline__ int ls_env_of_block(int b, int num_envs) {
+    const int chunk = (num_envs + 7) >> 3;
+    return (b & 7) * chunk + (b >> 3);
+}
+
+__global__ __launch_bounds__(64) void lsim_k_step_a(const LsCtx* __restrict__ ctx, LsStepArgs a) {
+    __shared__ WaveShared sh;
+    const int env = ls_env_of_block((int)blockIdx.x, ctx->cfg.num_envs);
+    if (env >= ctx->cfg.num_envs) return;
+    LaneRegs rg;
+    ls_wave_step_a(*ctx, a, env, sh, rg, (int)threadIdx.x);
+}
+
+__global__ __launch_bounds__(64) void lsim_k_step_b(const LsCtx* __restrict__ ctx, LsStepArgs a) {
+    __shared__ WaveShared sh;
+    const int env = ls_env_of_block((int)blockIdx.x, ctx->cfg.num_envs);
+    if (env >= ctx->cfg.num_envs) return;
+    LaneRegs rg;
+    ls_wave_step_b(*ctx, a, env, sh, rg, (int)threadIdx.x);
+}
+
+// reset_idx(all): sum of episode_sums["tracking_lin_vel"] over all envs for the command curriculum (LR:875)
+__global__ __launch_bounds__(256) void lsim_k_track_sum(const LsCtx* __restrict__ ctx, LsStepArgs a) {
+    __shared__ float part[256];
+    const LsCtx& cx = *ctx;
+    float acc = 0.0f;
+    for (int env = (int)(blockIdx.x * blockDim.x + threadIdx.x); env < cx.cfg.num_envs; env += (int)(gridDim.x * blockDim.x))
+        acc += LSB(cx, LSIM_BUF_EPISODE_SUMS, float)[env * LSIM_NUM_REWARD_TERMS + LSIM_R_TRACKING_LIN_VEL];
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd(cx.accum + a.row_out * LSIM_STATS_SIZE + LSIM_STATS_TRACK_SUM, part[0]);
+}
+
+static int ls_grid(const lsim_sim* s) { return 8 * ((s->cfg.num_envs + 7) / 8); }
+
+static int lsbk_launch_a(lsim_sim* s, const LsStepArgs& a, void* stream) {
+    hipLaunchKernelGGL(lsim_k_step_a, dim3(ls_grid(s)), dim3(64), 0, (hipStream_t)stream, (const LsCtx*)s->dev_ctx, a);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+static int lsbk_launch_b(lsim_sim* s, const LsStepArgs& a, void* stream) {
+    hipLaunchKernelGGL(lsim_k_step_b, dim3(ls_grid(s)), dim3(64), 0, (hipStream_t)stream, (const LsCtx*)s->dev_ctx, a);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+static int lsbk_launch_reduce(lsim_sim* s, const LsStepArgs& a, void* stream) {
+    int blocks = (s->cfg.num_envs + 255) / 256;
+    if (blocks > 64) blocks = 64;
+    hipLaunchKernelGGL(lsim_k_track_sum, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const LsCtx*)s->dev_ctx, a);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+// ---- measurement aid: HIP events around the two kernels of each step, on the caller's stream (lsim_set_profiling)
+struct LsProf {
+    int capacity;
+    long long count;          // steps recorded so far
+    hipEvent_t* ev;           // [capacity][3]
+};
+static void lsbk_prof_mark(lsim_sim* s, int which, void* stream) {
+    LsProf* p = (LsProf*)s->prof;
+    if (!p) return;
+    int slot = (int)(p->count % p->capacity);
+    (void)hipEventRecord(p->ev[3 * slot + which], (hipStream_t)stream);
+    if (which == 2) p->count += 1;
+}
+static void lsbk_prof_free(lsim_sim* s) {
+    LsProf* p = (LsProf*)s->prof;
+    if (!p) return;
+    for (int i = 0; i < 3 * p->capacity; ++i) (void)hipEventDestroy(p->ev[i]);
+    free(p->ev);
+    free(p);
+    s->prof = nullptr;
+}
+extern "C" int lsim_set_profiling(lsim_sim* s, int capacity) {
+    if (!s || capacity < 0) return LSIM_E_INVALID;
+    lsbk_prof_free(s);
+    if (capacity == 0) return LSIM_OK;
+    LsProf* p = (LsProf*)calloc(1, sizeof(LsProf));
+    p->capacity = capacity;
+    p->ev = (hipEvent_t*)calloc((size_t)3 * capacity, sizeof(hipEvent_t));
+    for (int i = 0; i < 3 * capacity; ++i)
+        if (hipEventCreate(&p->ev[i]) != hipSuccess) return LSIM_E_HIP;
+    s->prof = p;
+    return LSIM_OK;
+}
+extern "C" int lsim_read_profile(lsim_sim* s, float* ms_a, float* ms_b, int* n_inout) {
+    if (!s || !ms_a || !ms_b || !n_inout) return LSIM_E_INVALID;
+    LsProf* p = (LsProf*)s->prof;
+    if (!p) { *n_inout = 0; return LSIM_OK; }
+    long long avail = p->count < p->capacity ? p->count : p->capacity;
+    int n = (int)(avail < *n_inout ? avail : *n_inout);
+    for (int i = 0; i < n; ++i) {
+        long long step = p->count - n + i;
+        int slot = (int)(step % p->capacity);
+        if (hipEventSynchronize(p->ev[3 * slot + 2]) != hipSuccess) return LSIM_E_HIP;
+        if (hipEventElapsedTime(&ms_a[i], p->ev[3 * slot], p->ev[3 * slot + 1]) != hipSuccess) return LSIM_E_HIP;
+        if (hipEventElapsedTime(&ms_b[i], p->ev[3 * slot + 1], p->ev[3 * slot + 2]) != hipSuccess) return LSIM_E_HIP;
+    }
+    *n_inout = n;
+    return LSIM_OK;
+}

@@ -1,0 +1,244 @@
+"""LeggedRobot: drop-in for legged_gym.envs.base.legged_robot.LeggedRobot on top of the HIP simulator.
+
+Same constructor signature, methods and attribute names as the reference class (LR:54-176, BaseTask BT:40-115, the
+VecEnv contract rsl_rl/env/vec_env.py:36-60 and the extra attributes the runners / play.py read):
+
+    env = LeggedRobot(cfg, sim_params, physics_engine, sim_device, headless)
+    obs, priv = env.reset()
+    obs, priv, rew, dones, extras, term_ids, term_priv_obs[, terminal_amp] = env.step(actions)
+
+Every tensor attribute is a zero-copy torch view of device memory owned by the simulator arena -- the role
+gymtorch.wrap_tensor plays in the reference (LR:930-944).  All simulation, reward, reset and observation work is done
+by the HIP kernels behind include/lsim.h (isaacgymloco_amd/csrc); this file only binds pointers, launches steps on
+the current torch stream and assembles the reference's return tuple.  There is no CPU fallback.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from .. import abi, lib
+from ..robots import aliengo
+from . import lsim_config as LC
+from .terrain import Terrain
+
+_TORCH_DT = {abi.DT_F32: torch.float32, abi.DT_I64: torch.int64, abi.DT_U8: torch.uint8, abi.DT_I32: torch.int32, abi.DT_I16: torch.int16}
+
+
+class LeggedRobot:
+    def __init__(self, cfg, sim_params=None, physics_engine=None, sim_device="cuda:0", headless=True,
+                 *, seed=1, rank=0, using_amp=False, terrain=None, terrain_seed=None):
+        if not torch.cuda.is_available():
+            raise lib.LsimError("LeggedRobot needs a ROCm GPU: the simulator is a HIP library with no CPU path")
+        self._L = lib.load()
+        self.cfg = cfg
+        self.sim_params = sim_params
+        self.physics_engine = physics_engine
+        self.sim_device = sim_device
+        self.device = sim_device
+        self.headless = headless
+        self.using_amp = bool(using_amp)
+        self.viewer = None
+        self.gym = None
+        self.num_envs = int(cfg.env.num_envs)
+        self.num_obs = cfg.env.num_observations
+        self.num_privileged_obs = cfg.env.num_privileged_obs
+        self.num_actions = cfg.env.num_actions
+        self.num_one_step_obs = cfg.env.num_one_step_observations
+        self.num_one_step_privileged_obs = cfg.env.num_one_step_privileged_obs
+        self.history_length = int(self.num_obs / self.num_one_step_obs)
+        self.num_dof = self.num_dofs = 12
+        self.num_bodies = 17
+        self.dof_names = list(aliengo.DOF_NAMES)
+        # _parse_cfg (LR:1252-1263)
+        self.dt = cfg.control.decimation * cfg.sim.dt
+        self.obs_scales = cfg.normalization.obs_scales
+        self.max_episode_length_s = cfg.env.episode_length_s
+        self.max_episode_length = np.ceil(self.max_episode_length_s / self.dt)
+        self.reward_scales = {k: v * self.dt for k, v in cfg.rewards.scales.to_dict().items() if v != 0}
+        self.command_ranges = {k: list(v) for k, v in cfg.commands.ranges.to_dict().items()}
+
+        dev = torch.device(sim_device)
+        self._dev_index = dev.index if dev.index is not None else torch.cuda.current_device()
+        self.terrain = terrain if terrain is not None else Terrain(cfg.terrain, self.num_envs, seed=seed if terrain_seed is None else terrain_seed)
+        self.model = aliengo.build_model(tuple(cfg.asset.penalize_contacts_on), tuple(cfg.asset.terminate_after_contacts_on), cfg.asset.foot_name)
+        self.lcfg = LC.make_lsim_config(cfg, num_envs=self.num_envs, terrain=self.terrain, model=self.model, seed=seed, rank=rank, using_amp=using_amp)
+
+        nbytes = ctypes.c_size_t()
+        lib.check(self._L.lsim_query_arena(ctypes.byref(self.lcfg), ctypes.byref(nbytes)), what="lsim_query_arena")
+        self._arena = torch.zeros(nbytes.value, dtype=torch.uint8, device=dev)
+        grid_p = orig_p = None
+        if self.lcfg.mesh_type != 0:
+            self._grid = np.ascontiguousarray(self.terrain.heightsamples, dtype=np.int16)
+            self._orig = np.ascontiguousarray(self.terrain.env_origins, dtype=np.float32)
+            grid_p, orig_p = self._grid.ctypes.data, self._orig.ctypes.data
+        self._h = ctypes.c_void_p()
+        torch.cuda.synchronize(dev)
+        lib.check(self._L.lsim_create(ctypes.byref(self.lcfg), ctypes.byref(self.model), grid_p, orig_p,
+                                      self._arena.data_ptr(), self._dev_index, ctypes.byref(self._h)), what="lsim_create")
+        torch.cuda.synchronize(dev)
+        self._bind_buffers()
+        self.extras = {}
+        self.common_step_counter = 0
+        self.init_done = True
+
+    # ------------------------------------------------------------------ buffers
+    def _bind_buffers(self):
+        base = self._arena.data_ptr()
+        self.buf = {}
+        for name, bid in abi.BUFFER_IDS.items():
+            ptr, shape, nd, dt = ctypes.c_void_p(), (ctypes.c_int64 * 4)(), ctypes.c_int(), ctypes.c_int()
+            lib.check(self._L.lsim_get_buffer(self._h, bid, ctypes.byref(ptr), shape, ctypes.byref(nd), ctypes.byref(dt)), self._h, "lsim_get_buffer")
+            shp = tuple(shape[i] for i in range(nd.value))
+            tdt = _TORCH_DT[dt.value]
+            n = int(np.prod(shp)) * torch.empty((), dtype=tdt).element_size()
+            off = ptr.value - base
+            self.buf[name] = self._arena[off:off + n].view(tdt).view(shp)
+        b = self.buf
+        N = self.num_envs
+        # names of the reference (BT:70-79, LR:930-1032)
+        self.obs_buf, self.privileged_obs_buf, self.rew_buf = b["obs"], b["priv_obs"], b["rew"]
+        self.reset_buf = b["reset"].view(torch.bool)
+        self.time_out_buf = b["time_out"].view(torch.bool)
+        self._extras_time_outs = b["extras_time_outs"].view(torch.bool)
+        self._episode_length_buf = b["episode_length"]
+        self.root_states, self.dof_state = b["root_states"], b["dof_state"].view(N * 12, 2)
+        self.dof_pos, self.dof_vel = b["dof_state"][..., 0], b["dof_state"][..., 1]
+        self.base_quat = self.root_states[:, 3:7]
+        self.rigid_body_states = b["rigid_body_states"].view(N * 17, 13)
+        self.contact_forces = b["contact_forces"]
+        self.torques, self.actions = b["torques"], b["actions"]
+        self.last_actions, self.last_last_actions = b["last_actions"], b["last_last_actions"]
+        self.last_dof_pos, self.last_dof_vel, self.last_torques, self.last_root_vel = b["last_dof_pos"], b["last_dof_vel"], b["last_torques"], b["last_root_vel"]
+        self.commands = b["commands"]
+        self.base_lin_vel, self.base_ang_vel, self.projected_gravity = b["base_lin_vel"], b["base_ang_vel"], b["projected_gravity"]
+        self.feet_air_time = b["feet_air_time"]
+        self.last_contacts, self.contact_filt = b["last_contacts"].view(torch.bool), b["contact_filt"].view(torch.bool)
+        self.measured_heights = b["measured_heights"]
+        self.terrain_levels, self.terrain_types, self.env_origins = b["terrain_levels"], b["terrain_types"], b["env_origins"]
+        self.Kp_factors, self.Kd_factors = b["kp_factors"].view(N, 1), b["kd_factors"].view(N, 1)
+        self.motor_strength, self.motor_strength_factors = b["motor_strength"], b["motor_strength_factors"].view(N, 1)
+        self.friction_coeffs, self.restitution_coeffs = b["friction"].view(N, 1), b["restitution"].view(N, 1)
+        self.payload, self.com_displacement = b["payload"].view(N, 1), b["com_displacement"]
+        self.episode_sums = {name: b["episode_sums"][:, abi.REWARD_IDS[name]] for name in self.reward_scales}
+        self.termination_privileged_obs_buf, self.terminal_amp_states_buf, self.amp_obs_buf = b["term_priv_obs"], b["term_amp_obs"], b["amp_obs"]
+        dev = self._arena.device
+        self.feet_indices = torch.tensor(list(self.model.feet_bodies), dtype=torch.long, device=dev)
+        self.penalised_contact_indices = torch.tensor([i for i in range(17) if (self.model.penalised_body_mask >> i) & 1], dtype=torch.long, device=dev)
+        self.termination_contact_indices = torch.tensor([i for i in range(17) if (self.model.termination_body_mask >> i) & 1], dtype=torch.long, device=dev)
+        self.default_dof_pos = torch.tensor([self.lcfg.default_dof_pos[i] for i in range(12)], device=dev).unsqueeze(0)
+        self.p_gains = torch.tensor([self.lcfg.p_gains[i] for i in range(12)], device=dev)
+        self.d_gains = torch.tensor([self.lcfg.d_gains[i] for i in range(12)], device=dev)
+        self.torque_limits = torch.tensor([self.model.dof_effort_limit[i] for i in range(12)], device=dev)
+        self.dof_vel_limits = torch.tensor([self.model.dof_vel_limit[i] for i in range(12)], device=dev)
+        lim = torch.tensor([[self.model.dof_pos_lower[i], self.model.dof_pos_upper[i]] for i in range(12)], device=dev)
+        m, r = (lim[:, 0] + lim[:, 1]) / 2, lim[:, 1] - lim[:, 0]          # soft limits, LR:574-578
+        s = self.cfg.rewards.soft_dof_pos_limit
+        self.dof_pos_limits = torch.stack((m - 0.5 * r * s, m + 0.5 * r * s), dim=1)
+
+    @property
+    def episode_length_buf(self):
+        return self._episode_length_buf
+
+    @episode_length_buf.setter
+    def episode_length_buf(self, value):      # HIMR:90-91 rebinds the attribute; keep the simulator's buffer
+        self._episode_length_buf.copy_(value.to(self._episode_length_buf.dtype))
+
+    @property
+    def feet_pos(self):                        # LR:203 (re-gathered every step in the reference)
+        return self.buf["rigid_body_states"][:, self.feet_indices, 0:3]
+
+    @property
+    def feet_vel(self):                        # LR:204
+        return self.buf["rigid_body_states"][:, self.feet_indices, 7:10]
+
+    @property
+    def disturbance(self):                     # (N,17,3) view semantics of LR:1017: only row 0 can be non-zero
+        d = torch.zeros(self.num_envs, self.num_bodies, 3, device=self._arena.device)
+        return d
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self._arena.device).cuda_stream)
+
+    # ------------------------------------------------------------------ VecEnv surface
+    def get_observations(self):
+        return self.obs_buf
+
+    def get_privileged_observations(self):
+        return self.privileged_obs_buf
+
+    def get_amp_observations(self):
+        return self.amp_obs_buf
+
+    def reset_idx(self, env_ids):
+        if len(env_ids) != self.num_envs:
+            raise NotImplementedError("host-driven partial resets are not part of the path; resets happen inside step()")
+        lib.check(self._L.lsim_reset_all(self._h, self._stream()), self._h, "lsim_reset_all")
+        self._refresh_extras(force_valid=True)
+
+    def reset(self):
+        """BaseTask.reset (BT:111-115): reset_idx(all) then one zero-action step."""
+        self.reset_idx(torch.arange(self.num_envs, device=self._arena.device))
+        obs, priv, *_ = self.step(torch.zeros(self.num_envs, self.num_actions, device=self._arena.device))
+        return obs, priv
+
+    def step_device(self, actions, flags=0):
+        """Enqueue one LeggedRobot.step() on the current stream without any host synchronisation.
+        Fixed-capacity outputs: reset_buf is the mask of terminated envs, termination_privileged_obs_buf /
+        terminal_amp_states_buf rows are valid where the mask is set."""
+        if actions.dtype != torch.float32 or not actions.is_contiguous() or actions.device != self._arena.device:
+            actions = actions.to(device=self._arena.device, dtype=torch.float32).contiguous()
+        lib.check(self._L.lsim_step_ex(self._h, actions.data_ptr(), ctypes.c_uint32(flags), self._stream()), self._h, "lsim_step")
+        self.common_step_counter += 1
+        self._last_actions_ref = actions   # keep alive until the kernels ran
+        return self.obs_buf, self.privileged_obs_buf, self.rew_buf, self.reset_buf
+
+    def step(self, actions):
+        """LeggedRobot.step (LR:122-176): same 7-tuple (8 with terminal AMP states when using_amp)."""
+        self.step_device(actions)
+        env_ids = self.reset_buf.nonzero(as_tuple=False).flatten()   # the reference's own host sync (LR:225)
+        self._refresh_extras(force_valid=len(env_ids) > 0)
+        out = (self.obs_buf, self.privileged_obs_buf, self.rew_buf, self.reset_buf, self.extras, env_ids,
+               self.termination_privileged_obs_buf[env_ids])
+        if self.using_amp:
+            out = out + (self.terminal_amp_states_buf[env_ids],)
+        return out
+
+    def stats_row(self):
+        row = ctypes.c_int()
+        self._L.lsim_get_stats_row(self._h, ctypes.byref(row))
+        return self.buf["stats"][row.value]
+
+    def _refresh_extras(self, force_valid=False):
+        """extras["episode"] / extras["time_outs"] (LR:346-359).  Like the reference, the dict is only replaced on steps
+        with at least one reset; values are device tensors (no host sync here)."""
+        if self.cfg.env.send_timeouts:
+            self.extras["time_outs"] = self._extras_time_outs
+        if not force_valid:
+            return
+        S = abi.STATS
+        st = self.stats_row().clone()
+        n = torch.clamp(st[S["reset_count"]], min=1.0)
+        ep = {}
+        for name in self.reward_scales:
+            ep["rew_" + name] = st[S["episode_sums"] + abi.REWARD_IDS[name]] / n / self.dt
+        if self.cfg.terrain.curriculum:
+            ep["terrain_level"] = torch.mean(self.terrain_levels.float())
+        if self.cfg.commands.curriculum:
+            ep["max_command_x"] = st[S["cmd_ranges"] + 1]
+        self.extras["episode"] = ep
+
+    def update_reward_curriculum(self, current_iter):   # LR:830-836; flag is False in every shipped config
+        pass
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            torch.cuda.synchronize(self._arena.device)
+            self._L.lsim_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

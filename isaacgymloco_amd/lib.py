@@ -1,0 +1,54 @@
+"""ctypes binding of liblsim.so (include/lsim.h).  There is NO fallback: if the HIP library is missing or was built
+against another header the import of the simulator fails loudly."""
+import ctypes
+import os
+
+from . import abi
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "liblsim.so")
+_lib = None
+
+
+class LsimError(RuntimeError):
+    pass
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LsimError(f"{LIB_PATH} not found: build the HIP extension first (python -m isaacgymloco_amd.csrc.build); "
+                        "there is no CPU fallback for the simulator")
+    L = ctypes.CDLL(LIB_PATH)
+    abi.check_abi(L, prefix="lsim")
+    L.lsim_abi_version.restype = ctypes.c_int
+    if L.lsim_abi_version() != abi.ABI_VERSION:
+        raise LsimError("liblsim.so ABI version mismatch; rebuild")
+    vp, i32, u32, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_int64
+    L.lsim_query_arena.argtypes = [ctypes.POINTER(abi.LsimConfig), ctypes.POINTER(ctypes.c_size_t)]
+    L.lsim_create.argtypes = [ctypes.POINTER(abi.LsimConfig), ctypes.POINTER(abi.LsimRobotModel), vp, vp, vp, i32, ctypes.POINTER(vp)]
+    L.lsim_get_buffer.argtypes = [vp, i32, ctypes.POINTER(vp), ctypes.POINTER(i64), ctypes.POINTER(i32), ctypes.POINTER(i32)]
+    L.lsim_reset_all.argtypes = [vp, vp]
+    L.lsim_step.argtypes = [vp, vp, vp]
+    L.lsim_step_ex.argtypes = [vp, vp, u32, vp]
+    L.lsim_get_step_counter.argtypes = [vp, ctypes.POINTER(i64)]
+    L.lsim_set_step_counter.argtypes = [vp, i64]
+    L.lsim_get_stats_row.argtypes = [vp, ctypes.POINTER(i32)]
+    L.lsim_last_error.argtypes = [vp]
+    L.lsim_last_error.restype = ctypes.c_char_p
+    L.lsim_reward_name.restype = ctypes.c_char_p
+    L.lsim_buffer_name.restype = ctypes.c_char_p
+    L.lsim_destroy.argtypes = [vp]
+    L.lsim_destroy.restype = None
+    _lib = L
+    return L
+
+
+def check(rc, handle=None, what="lsim call"):
+    if rc != 0:
+        msg = ""
+        if handle is not None and _lib is not None:
+            m = _lib.lsim_last_error(handle)
+            msg = m.decode() if m else ""
+        raise LsimError(f"{what} failed with code {rc} {msg}")

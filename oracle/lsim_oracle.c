@@ -492,8 +492,10 @@ static void update_terrain_curriculum(orc_sim* s, int e, uint32_t stepw) { /* LR
 
 /* ------------------------------------------------------------------ the step */
 
+static float* stats_row(orc_sim* s) { return ORC_F(s, LSIM_BUF_STATS) + s->stats_row * LSIM_STATS_SIZE; }
+
 static void refresh_stats_ranges(orc_sim* s) {
-    float* st = ORC_F(s, LSIM_BUF_STATS);
+    float* st = stats_row(s);
     for (int i = 0; i < 4; ++i) for (int k = 0; k < 2; ++k) st[LSIM_STATS_CMD_RANGES + 2 * i + k] = (float)s->command_ranges[i][k];
 }
 
@@ -501,7 +503,7 @@ static void refresh_stats_ranges(orc_sim* s) {
 static void reset_idx(orc_sim* s, const uint8_t* mask, int n_reset, uint32_t stepw) {
     const lsim_config* c = &s->cfg;
     const int N = c->num_envs;
-    float* st = ORC_F(s, LSIM_BUF_STATS);
+    float* st = stats_row(s);
     if (n_reset == 0) return; /* LR:298 */
     if (c->terrain_curriculum && c->mesh_type != 0)
         for (int e = 0; e < N; ++e) if (mask[e]) update_terrain_curriculum(s, e, stepw);
@@ -574,8 +576,9 @@ static void post_physics_step(orc_sim* s, uint32_t flags) {
     (void)dt;
     s->step_counter += 1;
     const uint32_t stepw = (uint32_t)s->step_counter;
-    float* st = ORC_F(s, LSIM_BUF_STATS);
+    float* st = stats_row(s);
     st[LSIM_STATS_RESET_COUNT] = 0.0f;
+    refresh_stats_ranges(s);
     uint8_t* reset = ORC_U8(s, LSIM_BUF_RESET);
     uint8_t* tout = ORC_U8(s, LSIM_BUF_TIME_OUT);
     int n_reset = 0;
@@ -796,6 +799,7 @@ int orc_create(const lsim_config* cfg, const lsim_robot_model* model, const int1
         orc_refresh_body_states(s, e);
     }
     refresh_stats_ranges(s);
+    s->stats_row = 1; refresh_stats_ranges(s); s->stats_row = 0;
     s->step_counter = 0;
     s->init_done = 1; /* __init__ completes before the runner's first reset (LR:116, HIMR:84) */
     *out = s;
@@ -808,8 +812,12 @@ int orc_get_buffer(orc_sim* s, int id, void** ptr, int64_t shape[4], int* ndim, 
     return lsim_buffer_desc(&s->cfg, id, shape, ndim, dtype);
 }
 
+int orc_get_stats_row(orc_sim* s, int* row) { *row = s->stats_row; return LSIM_OK; }
+
 int orc_reset_all(orc_sim* s) { /* BT:113: reset_idx(arange(N)) */
     const int N = s->cfg.num_envs;
+    s->stats_row ^= 1;
+    refresh_stats_ranges(s);
     uint8_t* mask = (uint8_t*)malloc((size_t)N);
     memset(mask, 1, (size_t)N);
     reset_idx(s, mask, N, (uint32_t)s->step_counter);
@@ -821,6 +829,7 @@ int orc_step_ex(orc_sim* s, const float* actions, uint32_t flags) {
     const lsim_config* c = &s->cfg;
     const int N = c->num_envs;
     const uint32_t stepw = (uint32_t)(s->step_counter + 1);
+    s->stats_row ^= 1;
     for (int e = 0; e < N; ++e) {
         float* act = ORC_F(s, LSIM_BUF_ACTIONS) + N_DOF * e;
         const float* last = ORC_F(s, LSIM_BUF_LAST_ACTIONS) + N_DOF * e;

@@ -86,6 +86,12 @@ class OracleSim:
     def step_counter(self, v):
         lib().orc_set_step_counter(self._h, ctypes.c_int64(v))
 
+    @property
+    def stats_row(self):
+        v = ctypes.c_int()
+        lib().orc_get_stats_row(self._h, ctypes.byref(v))
+        return v.value
+
     def set_init_done(self, v):
         lib().orc_set_init_done(self._h, ctypes.c_int(int(v)))
 

@@ -11,6 +11,7 @@ typedef struct orc_sim {
     void* buf[LSIM_NUM_BUFFERS];
     int64_t step_counter;       /* common_step_counter, LR:948 */
     int init_done;              /* LR:97, LR:116 */
+    int stats_row;              /* row of LSIM_BUF_STATS filled by the latest call */
     double command_ranges[4][2];/* python floats in the reference (LR:1256) */
     int active_terms[LSIM_NUM_REWARD_TERMS];  /* alphabetical, termination excluded (LR:1050-1055) */
     int num_active;

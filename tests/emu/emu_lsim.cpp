@@ -1,0 +1,52 @@
+// TEST INFRASTRUCTURE -- CPU lane emulator for the kernel sources in isaacgymloco_amd/csrc/.
+// Compiles the very same phase functions that run on the GPU (ls_kernels.h) with g++, executing the 64 lanes
+// of each phase in a loop (LS_EMU).  Purpose: validate the lane orchestration / LDS hand-offs of the HIP
+// kernels against the oracle in the CPU-only build container.  It is NOT a product path: nothing under
+// isaacgymloco_amd/ loads this library, and the Python env refuses to run without the HIP library.
+#define LS_EMU 1
+#define LS_API(name) emu_##name
+#include <stdlib.h>
+#include <string.h>
+struct lsim_sim;
+struct LsStepArgs;
+static int lsbk_set_device(int) { return 0; }
+static int lsbk_malloc(void** p, size_t n) { *p = malloc(n); return *p ? 0 : 1; }
+static void lsbk_free(void* p) { free(p); }
+static int lsbk_h2d(void* d, const void* s, size_t n) { memcpy(d, s, n); return 0; }
+static int lsbk_memset(void* d, int v, size_t n) { memset(d, v, n); return 0; }
+static int lsbk_launch_a(lsim_sim* s, const LsStepArgs& a, void* stream);
+static int lsbk_launch_b(lsim_sim* s, const LsStepArgs& a, void* stream);
+static int lsbk_launch_reduce(lsim_sim* s, const LsStepArgs& a, void* stream);
+static void lsbk_prof_mark(lsim_sim*, int, void*) {}
+static void lsbk_prof_free(lsim_sim*) {}
+#include "../../isaacgymloco_amd/csrc/ls_api_impl.h"
+#include "../../isaacgymloco_amd/csrc/ls_kernels.h"
+
+static int lsbk_launch_a(lsim_sim* s, const LsStepArgs& a, void*) {
+    static WaveShared sh;
+    static LaneRegs L[64];
+    for (int env = 0; env < s->cfg.num_envs; ++env) {
+        memset(&sh, 0xCD, sizeof(sh));   // poison: phases must not rely on stale LDS
+        memset(L, 0xCD, sizeof(L));
+        ls_wave_step_a(*s->dev_ctx, a, env, sh, L);
+    }
+    return 0;
+}
+static int lsbk_launch_b(lsim_sim* s, const LsStepArgs& a, void*) {
+    static WaveShared sh;
+    static LaneRegs L[64];
+    for (int env = 0; env < s->cfg.num_envs; ++env) {
+        memset(&sh, 0xCD, sizeof(sh));
+        memset(L, 0xCD, sizeof(L));
+        ls_wave_step_b(*s->dev_ctx, a, env, sh, L);
+    }
+    return 0;
+}
+static int lsbk_launch_reduce(lsim_sim* s, const LsStepArgs& a, void*) {   // reset_all: track sum over all envs (LR:875)
+    const LsCtx& cx = *s->dev_ctx;
+    float acc = 0.0f;
+    for (int env = 0; env < s->cfg.num_envs; ++env) acc += LSB(cx, LSIM_BUF_EPISODE_SUMS, float)[env * LSIM_NUM_REWARD_TERMS + LSIM_R_TRACKING_LIN_VEL];
+    cx.accum[a.row_out * LSIM_STATS_SIZE + LSIM_STATS_TRACK_SUM] = acc;
+    return 0;
+}
+extern "C" int emu_sizeof_shared(void) { return (int)sizeof(WaveShared); }

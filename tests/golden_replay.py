@@ -92,7 +92,7 @@ def replay(fx, backend, get, put):
         yield t, {k[4:]: fx[k][t] for k in fx.files if k.startswith("out_")}
 
 
-def compare_step(t, ref, get, dt=0.02):
+def compare_step(t, ref, get, stats_row, dt=0.02):
     """Assert one replayed step against the reference outputs; returns max abs errors for reporting."""
     errs = {}
     for key, name in EXACT_CHECKS:
@@ -110,7 +110,7 @@ def compare_step(t, ref, get, dt=0.02):
             np.testing.assert_allclose(get("term_amp_obs")[mask], ref["term_amp"][mask], rtol=2e-5, atol=1e-5, err_msg=f"step {t}: terminal AMP states")
     es = get("episode_sums")
     np.testing.assert_allclose(es, ref["episode_sums"], rtol=2e-5, atol=2e-5, err_msg=f"step {t}: episode_sums")
-    st = get("stats")
+    st = get("stats")[stats_row]
     S = abi.STATS
     np.testing.assert_allclose(st[S["cmd_ranges"]:S["cmd_ranges"] + 8].reshape(4, 2), ref["command_ranges"], rtol=1e-6, atol=1e-6, err_msg=f"step {t}: command_ranges")
     if mask.any():   # extras["episode"] (LR:346-353): mean over reset envs of sum / len / dt
@@ -120,5 +120,5 @@ def compare_step(t, ref, get, dt=0.02):
         valid = ~np.isnan(ref["ep_stats"])
         np.testing.assert_allclose(mine[valid], ref["ep_stats"][valid], rtol=1e-4, atol=1e-5, err_msg=f"step {t}: extras[episode]")
         if not np.isnan(ref["level_mean"]):
-            np.testing.assert_allclose(st[S["level_sum"]] / len(mask), ref["level_mean"], rtol=1e-6)
+            np.testing.assert_allclose(get("terrain_levels").astype(np.float32).mean(), ref["level_mean"], rtol=1e-6)
     return errs

@@ -1,0 +1,32 @@
+"""CPU lane-emulation of the HIP kernel sources (isaacgymloco_amd/csrc/ls_*.h) against the reference golden
+vectors and against the oracle's physics.  Development aid for the GPU kernels' lane orchestration; the
+authoritative parity tests are the -m gpu ones that call the HIP library through the C-ABI."""
+import numpy as np
+import pytest
+
+import golden_replay as GR
+from helpers import LC, aliengo, make_oracle, quiet_cfg, abi
+
+
+def make_emu_from_fixture(name):
+    import emu_binding
+    fx = GR.load(name)
+    cfg = GR.scenario_cfg(name)
+    N = int(fx["num_envs"])
+    model = aliengo.build_model()
+    ter = GR.FixtureTerrain(fx)
+    lc = LC.make_lsim_config(cfg, num_envs=N, terrain=ter, model=model, seed=int(fx["seed"]))
+    return fx, emu_binding.EmuSim(lc, model, ter.heightsamples, ter.env_origins)
+
+
+@pytest.mark.parametrize("name", GR.SCENARIOS)
+def test_emu_matches_reference_step(name):
+    fx, sim = make_emu_from_fixture(name)
+
+    def get(n):
+        return np.array(sim.buf[n])
+
+    def put(n, a):
+        sim.buf[n][...] = a
+    for t, ref in GR.replay(fx, sim, get, put):
+        GR.compare_step(t, ref, get, sim.stats_row)

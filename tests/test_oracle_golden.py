@@ -31,7 +31,7 @@ def test_oracle_matches_reference_step(name):
     worst = {}
     nsteps = 0
     for t, ref in GR.replay(fx, sim, get, put):
-        errs = GR.compare_step(t, ref, get)
+        errs = GR.compare_step(t, ref, get, sim.stats_row)
         for k, v in errs.items():
             worst[k] = max(worst.get(k, 0.0), v)
         nsteps += 1
