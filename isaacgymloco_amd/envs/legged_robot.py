@@ -79,6 +79,8 @@ class LeggedRobot:
         torch.cuda.synchronize(dev)
         self._bind_buffers()
         self.extras = {}
+        if cfg.env.send_timeouts:
+            self.extras["time_outs"] = self._extras_time_outs
         self.common_step_counter = 0
         self.init_done = True
 
@@ -185,7 +187,8 @@ class LeggedRobot:
     def step_device(self, actions, flags=0):
         """Enqueue one LeggedRobot.step() on the current stream without any host synchronisation.
         Fixed-capacity outputs: reset_buf is the mask of terminated envs, termination_privileged_obs_buf /
-        terminal_amp_states_buf rows are valid where the mask is set."""
+        terminal_amp_states_buf rows are valid where the mask is set.  The returned tensors are the LIVE simulator
+        buffers (overwritten by the next step): clone what must survive."""
         if actions.dtype != torch.float32 or not actions.is_contiguous() or actions.device != self._arena.device:
             actions = actions.to(device=self._arena.device, dtype=torch.float32).contiguous()
         lib.check(self._L.lsim_step_ex(self._h, actions.data_ptr(), ctypes.c_uint32(flags), self._stream()), self._h, "lsim_step")
@@ -198,7 +201,9 @@ class LeggedRobot:
         self.step_device(actions)
         env_ids = self.reset_buf.nonzero(as_tuple=False).flatten()   # the reference's own host sync (LR:225)
         self._refresh_extras(force_valid=len(env_ids) > 0)
-        out = (self.obs_buf, self.privileged_obs_buf, self.rew_buf, self.reset_buf, self.extras, env_ids,
+        # the reference rebinds obs_buf / privileged_obs_buf to fresh tensors every step (LR:168-171, LR:403-404) and its
+        # runner keeps the returned objects across the next step (HIMP:100-101): hand out copies, not the live buffers
+        out = (self.obs_buf.clone(), self.privileged_obs_buf.clone(), self.rew_buf.clone(), self.reset_buf.clone(), self.extras, env_ids,
                self.termination_privileged_obs_buf[env_ids])
         if self.using_amp:
             out = out + (self.terminal_amp_states_buf[env_ids],)

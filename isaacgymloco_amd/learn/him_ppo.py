@@ -1,0 +1,169 @@
+"""HIMPPO: clipped PPO with adaptive-KL learning rate plus the HIM estimator update.
+Same surface and update rule as rsl_rl.algorithms.HIMPPO (HIMP:38-198): act / process_env_step / compute_returns /
+update, value-clip, entropy bonus, KL-adaptive lr x/1.5 (HIMP:144-156), grad-clip, estimator stepped first with the PPO lr.
+
+Data parallel (not in the reference): `dist_ctx` averages gradients over ranks with ONE flattened
+all-reduce per optimiser step (RCCL over xGMI; latency-bound payload of 2.2 MB), synchronises the KL estimate before
+the lr decision and the advantage statistics, so every rank takes identical optimiser steps.
+"""
+import torch
+import torch.nn as nn
+
+from .storage import HIMRolloutStorage
+
+
+class DistCtx:
+    """Thin helper around torch.distributed for gradient / scalar averaging (world_size 1 => no-ops)."""
+
+    def __init__(self):
+        import torch.distributed as dist
+        self.dist = dist
+        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.world = dist.get_world_size() if self.enabled else 1
+        self._flat = {}
+
+    def average_grads(self, params):
+        if not self.enabled:
+            return
+        params = [p for p in params if p.grad is not None]
+        key = tuple(id(p) for p in params)
+        n = sum(p.numel() for p in params)
+        flat = self._flat.get(key)
+        if flat is None or flat.numel() != n or flat.device != params[0].device:
+            flat = torch.empty(n, device=params[0].device, dtype=torch.float32)
+            self._flat[key] = flat
+        off = 0
+        for p in params:
+            flat[off:off + p.numel()].copy_(p.grad.reshape(-1))
+            off += p.numel()
+        self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM)
+        flat.div_(self.world)
+        off = 0
+        for p in params:
+            p.grad.copy_(flat[off:off + p.numel()].view_as(p.grad))
+            off += p.numel()
+
+    def average_scalar(self, t):
+        if not self.enabled:
+            return t
+        t = t.clone()
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return t / self.world
+
+    def sum_triple(self, a, b, c):
+        if not self.enabled:
+            return a, b, c
+        v = torch.stack((a, b, c)).to(torch.float64)
+        self.dist.all_reduce(v, op=self.dist.ReduceOp.SUM)
+        v = v.to(torch.float32)
+        return v[0], v[1], v[2]
+
+    def broadcast_module(self, module):
+        if not self.enabled:
+            return
+        for t in list(module.parameters()) + list(module.buffers()):
+            self.dist.broadcast(t.data, src=0)
+
+
+class HIMPPO:
+    def __init__(self, actor_critic, num_learning_epochs=1, num_mini_batches=1, clip_param=0.2, gamma=0.998, lam=0.95,
+                 value_loss_coef=1.0, entropy_coef=0.0, learning_rate=1e-3, max_grad_norm=1.0, use_clipped_value_loss=True,
+                 schedule="fixed", desired_kl=0.01, device="cpu", dist_ctx=None):
+        self.device = device
+        self.desired_kl, self.schedule, self.learning_rate = desired_kl, schedule, learning_rate
+        self.actor_critic = actor_critic.to(device)
+        self.storage = None
+        self.optimizer = torch.optim.Adam(self.actor_critic.parameters(), lr=learning_rate)
+        self.transition = HIMRolloutStorage.Transition()
+        self.clip_param, self.num_learning_epochs, self.num_mini_batches = clip_param, num_learning_epochs, num_mini_batches
+        self.value_loss_coef, self.entropy_coef, self.gamma, self.lam = value_loss_coef, entropy_coef, gamma, lam
+        self.max_grad_norm, self.use_clipped_value_loss = max_grad_norm, use_clipped_value_loss
+        self.dist_ctx = dist_ctx
+        if dist_ctx is not None and dist_ctx.enabled:
+            dist_ctx.broadcast_module(self.actor_critic)
+            self.actor_critic.estimator.grad_sync = dist_ctx.average_grads
+
+    def init_storage(self, num_envs, num_transitions_per_env, actor_obs_shape, critic_obs_shape, action_shape):
+        self.storage = HIMRolloutStorage(num_envs, num_transitions_per_env, actor_obs_shape, critic_obs_shape, action_shape, self.device)
+        if self.dist_ctx is not None and self.dist_ctx.enabled:
+            self.storage.advantage_sync = self.dist_ctx.sum_triple
+
+    def test_mode(self):
+        self.actor_critic.eval()
+
+    def train_mode(self):
+        self.actor_critic.train()
+
+    def act(self, obs, critic_obs):
+        t, ac = self.transition, self.actor_critic
+        t.actions = ac.act(obs).detach()
+        t.values = ac.evaluate(critic_obs).detach()
+        t.actions_log_prob = ac.get_actions_log_prob(t.actions).detach()
+        t.action_mean, t.action_sigma = ac.action_mean.detach(), ac.action_std.detach()
+        t.observations, t.critic_observations = obs, critic_obs   # recorded before env.step()
+        return t.actions
+
+    def process_env_step(self, rewards, dones, infos, next_critic_obs):
+        t = self.transition
+        t.next_critic_observations = next_critic_obs.clone()
+        t.rewards = rewards.clone()
+        t.dones = dones
+        if "time_outs" in infos:   # bootstrap on time-outs (HIMP:110-111)
+            t.rewards += self.gamma * torch.squeeze(t.values * infos["time_outs"].unsqueeze(1).to(self.device), 1)
+        self.storage.add_transitions(t)
+        t.clear()
+        self.actor_critic.reset(dones)
+
+    def compute_returns(self, last_critic_obs):
+        last_values = self.actor_critic.evaluate(last_critic_obs).detach()
+        self.storage.compute_returns(last_values, self.gamma, self.lam)
+
+    def _adapt_lr(self, mu, sigma, old_mu, old_sigma):
+        with torch.inference_mode():
+            kl = torch.sum(torch.log(sigma / old_sigma + 1.0e-5) + (torch.square(old_sigma) + torch.square(old_mu - mu)) / (2.0 * torch.square(sigma)) - 0.5, dim=-1)
+            kl_mean = torch.mean(kl)
+            if self.dist_ctx is not None:
+                kl_mean = self.dist_ctx.average_scalar(kl_mean)
+            kl_mean = kl_mean.item()
+        if kl_mean > self.desired_kl * 2.0:
+            self.learning_rate = max(1e-5, self.learning_rate / 1.5)
+        elif self.desired_kl / 2.0 > kl_mean > 0.0:
+            self.learning_rate = min(1e-2, self.learning_rate * 1.5)
+        for g in self.optimizer.param_groups:
+            g["lr"] = self.learning_rate
+
+    def update(self):
+        ac = self.actor_critic
+        sums = torch.zeros(4, device=self.device)
+        last_est = last_swap = None
+        for (obs, critic_obs, actions, next_critic_obs, target_values, advantages, returns, old_logp, old_mu, old_sigma) in \
+                self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs):
+            ac.act(obs)
+            logp = ac.get_actions_log_prob(actions)
+            value = ac.evaluate(critic_obs)
+            mu, sigma, entropy = ac.action_mean, ac.action_std, ac.entropy
+            if self.desired_kl is not None and self.schedule == "adaptive":
+                self._adapt_lr(mu, sigma, old_mu, old_sigma)
+            est, swap = ac.estimator.update(obs, next_critic_obs, lr=self.learning_rate)
+            adv = torch.squeeze(advantages)
+            ratio = torch.exp(logp - torch.squeeze(old_logp))
+            surrogate_loss = torch.max(-adv * ratio, -adv * torch.clamp(ratio, 1.0 - self.clip_param, 1.0 + self.clip_param)).mean()
+            if self.use_clipped_value_loss:
+                clipped = target_values + (value - target_values).clamp(-self.clip_param, self.clip_param)
+                value_loss = torch.max((value - returns).pow(2), (clipped - returns).pow(2)).mean()
+            else:
+                value_loss = (returns - value).pow(2).mean()
+            loss = surrogate_loss + self.value_loss_coef * value_loss - self.entropy_coef * entropy.mean()
+            self.optimizer.zero_grad()
+            loss.backward()
+            if self.dist_ctx is not None:
+                self.dist_ctx.average_grads(list(ac.parameters()))   # clip AFTER the all-reduce (HIMP:183)
+            nn.utils.clip_grad_norm_(ac.parameters(), self.max_grad_norm)
+            self.optimizer.step()
+            sums += torch.stack((value_loss.detach(), surrogate_loss.detach(), est, swap))
+            last_est, last_swap = est, swap
+        n = self.num_learning_epochs * self.num_mini_batches
+        sums = (sums / n).tolist()
+        self.storage.clear()
+        # the reference returns the LAST minibatch's estimator losses in slots 3 and 4 (HIMP:198)
+        return sums[0], sums[1], float(last_est), float(last_swap)

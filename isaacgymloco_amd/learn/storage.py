@@ -1,0 +1,104 @@
+"""Rollout storage for the HIM PPO learner: (T, N, .) device tensors, GAE(lambda) sweep, minibatch sampling.
+Same contract as rsl_rl.storage.HIMRolloutStorage (HST:36-177): field names, add_transitions, compute_returns,
+mini_batch_generator (one randperm reused for every epoch, HST:140-164)."""
+import torch
+
+
+class Transition:
+    __slots__ = ("observations", "critic_observations", "actions", "rewards", "dones", "values", "actions_log_prob",
+                 "action_mean", "action_sigma", "next_critic_observations")
+
+    def __init__(self):
+        self.clear()
+
+    def clear(self):
+        for k in self.__slots__:
+            setattr(self, k, None)
+
+
+class HIMRolloutStorage:
+    Transition = Transition
+
+    def __init__(self, num_envs, num_transitions_per_env, obs_shape, privileged_obs_shape, actions_shape, device="cpu"):
+        T, N = num_transitions_per_env, num_envs
+        self.device = device
+        self.obs_shape, self.privileged_obs_shape, self.actions_shape = obs_shape, privileged_obs_shape, actions_shape
+        self.num_transitions_per_env, self.num_envs = T, N
+
+        def z(*shape, dtype=torch.float32):
+            return torch.zeros(T, N, *shape, device=device, dtype=dtype)
+        self.observations = z(*obs_shape)
+        if privileged_obs_shape[0] is not None:
+            self.privileged_observations = z(*privileged_obs_shape)
+            self.next_privileged_observations = z(*privileged_obs_shape)
+        else:
+            self.privileged_observations = self.next_privileged_observations = None
+        self.rewards, self.actions = z(1), z(*actions_shape)
+        self.dones = z(1, dtype=torch.uint8)
+        self.actions_log_prob, self.values, self.returns, self.advantages = z(1), z(1), z(1), z(1)
+        self.mu, self.sigma = z(*actions_shape), z(*actions_shape)
+        self.step = 0
+        self.advantage_sync = None   # data-parallel hook: callable(sum, sumsq, count) -> reduced triple
+
+    def add_transitions(self, t):
+        if self.step >= self.num_transitions_per_env:
+            raise AssertionError("Rollout buffer overflow")
+        i = self.step
+        self.observations[i].copy_(t.observations)
+        if self.privileged_observations is not None:
+            self.privileged_observations[i].copy_(t.critic_observations)
+            self.next_privileged_observations[i].copy_(t.next_critic_observations)
+        self.actions[i].copy_(t.actions)
+        self.rewards[i].copy_(t.rewards.view(-1, 1))
+        self.dones[i].copy_(t.dones.view(-1, 1))
+        self.values[i].copy_(t.values)
+        self.actions_log_prob[i].copy_(t.actions_log_prob.view(-1, 1))
+        self.mu[i].copy_(t.action_mean)
+        self.sigma[i].copy_(t.action_sigma)
+        self.step += 1
+
+    def clear(self):
+        self.step = 0
+
+    def compute_returns(self, last_values, gamma, lam):
+        """GAE(lambda) reverse sweep (HST:113-123) and advantage normalisation over the whole batch (HST:126-127)."""
+        T = self.num_transitions_per_env
+        not_done = 1.0 - self.dones.float()
+        adv = torch.zeros_like(last_values)
+        nxt = last_values
+        for s in range(T - 1, -1, -1):
+            delta = self.rewards[s] + not_done[s] * gamma * nxt - self.values[s]
+            adv = delta + not_done[s] * gamma * lam * adv
+            self.returns[s] = adv + self.values[s]
+            nxt = self.values[s]
+        a = self.returns - self.values
+        if self.advantage_sync is None:
+            self.advantages = (a - a.mean()) / (a.std() + 1e-8)
+        else:   # global statistics over all ranks (unbiased std, like Tensor.std())
+            s1, s2, n = self.advantage_sync(a.sum(), (a * a).sum(), torch.tensor(float(a.numel()), device=a.device))
+            mean = s1 / n
+            var = (s2 - n * mean * mean) / (n - 1.0)
+            self.advantages = (a - mean) / (var.clamp_min(0).sqrt() + 1e-8)
+
+    def get_statistics(self):
+        done = self.dones.clone()
+        done[-1] = 1
+        flat = done.permute(1, 0, 2).reshape(-1, 1)
+        idx = torch.cat((flat.new_tensor([-1], dtype=torch.int64), flat.nonzero(as_tuple=False)[:, 0]))
+        return (idx[1:] - idx[:-1]).float().mean(), self.rewards.mean()
+
+    def mini_batch_generator(self, num_mini_batches, num_epochs=8):
+        batch = self.num_envs * self.num_transitions_per_env
+        mb = batch // num_mini_batches
+        perm = torch.randperm(num_mini_batches * mb, requires_grad=False, device=self.device)
+        obs = self.observations.flatten(0, 1)
+        if self.privileged_observations is not None:
+            critic, next_critic = self.privileged_observations.flatten(0, 1), self.next_privileged_observations.flatten(0, 1)
+        else:
+            critic = next_critic = obs
+        fields = (obs, critic, self.actions.flatten(0, 1), next_critic, self.values.flatten(0, 1), self.advantages.flatten(0, 1),
+                  self.returns.flatten(0, 1), self.actions_log_prob.flatten(0, 1), self.mu.flatten(0, 1), self.sigma.flatten(0, 1))
+        for _ in range(num_epochs):
+            for i in range(num_mini_batches):
+                idx = perm[i * mb:(i + 1) * mb]
+                yield tuple(f[idx] for f in fields)
