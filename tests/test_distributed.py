@@ -1,0 +1,99 @@
+"""N>1 path on CPU: world_size-2 gloo processes must take identical optimiser steps (gradient all-reduce, synchronised
+KL / advantage statistics), and match a single process that sees the concatenated batch for the gradient average."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import ROOT
+
+
+class FakeEnv:
+    """Deterministic stand-in for the simulator (CPU): per-rank different data, same shapes as the real env."""
+    num_obs, num_privileged_obs, num_one_step_obs, num_actions, max_episode_length, dt = 270, 238, 45, 12, 1000.0, 0.02
+
+    def __init__(self, num_envs, seed):
+        self.num_envs = num_envs
+        self.g = torch.Generator().manual_seed(seed)
+        self.episode_length_buf = torch.zeros(num_envs, dtype=torch.long)
+        self.extras = {}
+
+    def _r(self, *s):
+        return torch.randn(*s, generator=self.g)
+
+    def reset(self):
+        return self.get_observations(), self.get_privileged_observations()
+
+    def get_observations(self):
+        return self._r(self.num_envs, 270)
+
+    def get_privileged_observations(self):
+        return self._r(self.num_envs, 238)
+
+    def step(self, a):
+        d = torch.rand(self.num_envs, generator=self.g) < 0.1
+        ids = d.nonzero().flatten()
+        self.extras["time_outs"] = torch.zeros(self.num_envs, dtype=torch.bool)
+        return self._r(self.num_envs, 270), self._r(self.num_envs, 238), self._r(self.num_envs), d, self.extras, ids, self._r(len(ids), 238)
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from isaacgymloco_amd.learn.bench_train import train_cfg_dict
+    from isaacgymloco_amd.learn.runner import HIMOnPolicyRunner
+    tc = train_cfg_dict("aliengo")
+    tc["runner"]["num_steps_per_env"] = 6
+    tc["algorithm"]["num_learning_epochs"] = 2
+    tc["algorithm"]["num_mini_batches"] = 2
+    torch.manual_seed(100 + rank)          # different initial weights per rank: the broadcast must fix that
+    runner = HIMOnPolicyRunner(FakeEnv(8, seed=7 + rank), tc, log_dir=None, device="cpu")
+    torch.manual_seed(5 + rank)
+    runner.learn(2, init_at_random_ep_len=False)
+    sd = {k: v.clone() for k, v in runner.alg.actor_critic.state_dict().items()}
+    torch.save({"sd": sd, "lr": runner.alg.learning_rate}, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_stay_in_lockstep(tmp_path):
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a = torch.load(os.path.join(tmp_path, "rank0.pt"))
+    b = torch.load(os.path.join(tmp_path, "rank1.pt"))
+    assert a["lr"] == b["lr"]
+    for k in a["sd"]:
+        torch.testing.assert_close(a["sd"][k], b["sd"][k], rtol=0, atol=0, msg=k)
+
+
+def _grad_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from isaacgymloco_amd.learn.him_ppo import DistCtx
+    ctx = DistCtx()
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(5, 3)
+    x = torch.arange(20, dtype=torch.float32).reshape(4, 5)[2 * rank:2 * rank + 2] / 10.0
+    lin(x).pow(2).mean().backward()
+    ctx.average_grads(list(lin.parameters()))
+    s1, s2, n = ctx.sum_triple(x.sum(), (x * x).sum(), torch.tensor(float(x.numel())))
+    torch.save({"g": lin.weight.grad.clone(), "stats": torch.stack((s1, s2, n))}, os.path.join(out_dir, f"g{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_gradient_average_equals_full_batch(tmp_path):
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_grad_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(5, 3)
+    x = torch.arange(20, dtype=torch.float32).reshape(4, 5) / 10.0
+    lin(x).pow(2).mean().backward()
+    for r in range(2):
+        d = torch.load(os.path.join(tmp_path, f"g{r}.pt"))
+        torch.testing.assert_close(d["g"], lin.weight.grad, rtol=1e-6, atol=1e-7)
+        torch.testing.assert_close(d["stats"], torch.stack((x.sum(), (x * x).sum(), torch.tensor(20.0))), rtol=1e-6, atol=1e-6)

@@ -1,0 +1,48 @@
+"""Robot model table: derived constants (mass after Isaac Gym's fixed-joint collapse) and, when the reference
+checkout is present (build container only), a re-derivation from its URDF."""
+import os
+import xml.etree.ElementTree as ET
+
+import numpy as np
+import pytest
+
+from helpers import aliengo
+
+URDF = "/root/reference/legged_gym/resources/robots/aliengo/urdf/aliengo.urdf"
+
+
+def test_masses_and_topology():
+    m = aliengo.build_model()
+    masses = [b.mass for b in m.bodies]
+    assert abs(sum(masses) - 24.937) < 1e-3                      # 24.94 kg
+    assert abs(masses[0] - 12.229) < 1e-3 and abs(masses[1] - 2.139) < 1e-3 and abs(masses[2] - 0.771) < 1e-3
+    assert [m.bodies[i].parent for i in range(17)] == [-1, 0, 1, 2, 3, 0, 5, 6, 7, 0, 9, 10, 11, 0, 13, 14, 15]
+    assert [m.bodies[i].dof for i in range(17)] == [-1, 0, 1, 2, -1, 3, 4, 5, -1, 6, 7, 8, -1, 9, 10, 11, -1]
+    assert list(m.feet_bodies) == [4, 8, 12, 16]
+    assert m.termination_body_mask == 1 and bin(m.penalised_body_mask).count("1") == 9
+    assert m.num_collision_points == 56
+
+
+@pytest.mark.skipif(not os.path.exists(URDF), reason="reference checkout not present")
+def test_table_matches_reference_urdf():
+    root = ET.parse(URDF).getroot()
+    links = {l.get("name"): l for l in root.findall("link")}
+    joints = {j.get("name"): j for j in root.findall("joint")}
+    bodies = aliengo.body_table()
+    for leg in aliengo.LEGS:
+        hip = links[f"{leg}_hip"].find("inertial")
+        b = bodies[aliengo.BODY_NAMES.index(f"{leg}_hip")]
+        m_rotor = float(links[f"{leg}_thigh_rotor"].find("inertial").find("mass").get("value"))
+        assert abs(b["mass"] - (float(hip.find("mass").get("value")) + m_rotor)) < 1e-9
+        jo = [float(x) for x in joints[f"{leg}_hip_joint"].find("origin").get("xyz").split()]
+        np.testing.assert_allclose(b["joint_pos"], jo, atol=1e-12)
+        lim = joints[f"{leg}_calf_joint"].find("limit")
+        assert float(lim.get("lower")) == aliengo.LIMITS["calf"][0] and float(lim.get("effort")) == aliengo.LIMITS["calf"][3]
+        calf = links[f"{leg}_calf"].find("inertial")
+        c = bodies[aliengo.BODY_NAMES.index(f"{leg}_calf")]
+        np.testing.assert_allclose(c["com"], [float(x) for x in calf.find("origin").get("xyz").split()], atol=1e-12)
+        th = links[f"{leg}_thigh"].find("inertial").find("inertia")
+        # thigh inertia products mirror with the leg side
+        assert np.sign(float(th.get("ixy"))) == np.sign(aliengo._mirror(aliengo.THIGH, 1.0, aliengo._SY[leg])["inertia"][1])
+    trunk = float(links["trunk"].find("inertial").find("mass").get("value"))
+    assert abs(bodies[0]["mass"] - (trunk + 0.001 + 4 * 0.146)) < 1e-9

@@ -1,0 +1,119 @@
+"""Physical invariants of the build's dynamics (no reference oracle exists for PhysX): checked on the CPU
+oracle and on the lane-emulated kernel sources.  These are NOT reference parity."""
+import numpy as np
+import pytest
+
+from helpers import make_oracle, quiet_cfg, abi, LC, aliengo, T
+
+G = 9.81
+
+
+def _make(kind, cfg, N, seed=1):
+    orc, lc, model, ter = make_oracle(cfg, N, seed=seed)
+    if kind == "oracle":
+        return orc, model
+    import emu_binding
+    return emu_binding.EmuSim(lc, model, ter.heightsamples, ter.env_origins), model
+
+
+def _total_momentum(sim, model, e=0):
+    """linear momentum and angular momentum about the world origin from rigid_body_states (COM motion + spin)."""
+    bs = sim.buf["rigid_body_states"][e].astype(np.float64)
+    P, Lm = np.zeros(3), np.zeros(3)
+    for i in range(17):
+        b = model.bodies[i]
+        q = bs[i, 3:7]
+        x, y, z, w = q
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                      [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+        c = bs[i, 0:3] + R @ np.array(b.com)
+        om = bs[i, 10:13]
+        vc = bs[i, 7:10] + np.cross(om, c - bs[i, 0:3])
+        I = np.array(b.inertia)
+        Il = np.array([[I[0], I[1], I[2]], [I[1], I[3], I[4]], [I[2], I[4], I[5]]])
+        P += b.mass * vc
+        Lm += np.cross(c, b.mass * vc) + R @ Il @ R.T @ om
+    return P, Lm
+
+
+def _tumble(kind, sim_dt, steps, gz):
+    cfg = quiet_cfg()
+    cfg.init_state.pos = [0.0, 0.0, 3.0]
+    cfg.sim.dt = sim_dt
+    cfg.sim.gravity = [0.0, 0.0, gz]
+    cfg.domain_rand.base_init_vel_range = dict(x=[0.3, 0.3], y=[-0.2, -0.2], z=[0.0, 0.0], roll=[0.8, 0.8], pitch=[-0.5, -0.5], yaw=[0.4, 0.4])
+    cfg.termination.fall_down = False
+    sim, model = _make(kind, cfg, 2)
+    sim.reset_all()
+    a = np.zeros((2, 12), np.float32)
+    sim.step(a)
+    P0, L0 = _total_momentum(sim, model)
+    for _ in range(steps):
+        sim.step(a)
+    P1, L1 = _total_momentum(sim, model)
+    assert sim.buf["reset"].sum() == 0
+    return P0, L0, P1, L1, sum(b.mass for b in model.bodies)
+
+
+@pytest.mark.parametrize("kind", ["oracle", "emu"])
+def test_momentum_conserved_without_gravity(kind):
+    """Free flight, g = 0, tumbling robot holding its pose with the PD loop (internal forces only): linear and angular
+    momentum are conserved; the residual is the first-order integration error and halves with the time step."""
+    P0, L0, P1, L1, mass = _tumble(kind, 0.005, 10, 0.0)
+    assert np.linalg.norm(P1 - P0) < 1.5e-3 * np.linalg.norm(P0)
+    assert np.linalg.norm(L1 - L0) < 2e-2 * np.linalg.norm(L0)
+    Ph0, Lh0, Ph1, Lh1, _ = _tumble(kind, 0.0025, 20, 0.0)
+    assert np.linalg.norm(Ph1 - Ph0) < 0.65 * np.linalg.norm(P1 - P0)
+    assert np.linalg.norm(Lh1 - Lh0) < 0.65 * np.linalg.norm(L1 - L0)
+
+
+@pytest.mark.parametrize("kind", ["oracle", "emu"])
+def test_free_fall_under_gravity(kind):
+    """dP_z = -m g t (to the integrator's first order); the horizontal leak of the semi-implicit Euler step is O(dt)."""
+    P0, L0, P1, L1, mass = _tumble(kind, 0.005, 10, -G)
+    t = 10 * 4 * 0.005
+    np.testing.assert_allclose(P1[2] - P0[2], -mass * G * t, rtol=2e-3)
+    Ph0, Lh0, Ph1, Lh1, _ = _tumble(kind, 0.0025, 20, -G)
+    assert np.linalg.norm((Ph1 - Ph0)[:2]) < 0.65 * np.linalg.norm((P1 - P0)[:2])
+    assert np.linalg.norm((P1 - P0)[:2]) < 0.04 * np.linalg.norm(P0[:2])
+
+
+@pytest.mark.parametrize("kind", ["oracle", "emu"])
+def test_static_stance_supports_weight(kind):
+    cfg = quiet_cfg()
+    cfg.init_state.pos = [0.0, 0.0, 0.40]
+    sim, model = _make(kind, cfg, 2)
+    sim.reset_all()
+    a = np.zeros((2, 12), np.float32)
+    for _ in range(100):
+        sim.step(a)
+    fz = sim.buf["contact_forces"][0, :, 2].sum()
+    mass = sum(b.mass for b in model.bodies)
+    assert abs(fz - mass * G) < 0.03 * mass * G, (fz, mass * G)
+    feet = sim.buf["contact_forces"][0, [4, 8, 12, 16], 2]
+    assert (feet > 20).all()                                                        # all four feet carry load
+    assert abs(sim.buf["root_states"][0, 9]) < 0.02                                 # at rest
+    np.testing.assert_allclose(sim.buf["contact_forces"][0, :, :2].sum(0), 0.0, atol=0.05 * mass * G)
+    # left/right symmetry of the settled pose
+    q = sim.buf["dof_state"][0, :, 0]
+    np.testing.assert_allclose(q[1:3], q[4:6], atol=0.02)
+
+
+@pytest.mark.parametrize("kind", ["oracle", "emu"])
+def test_limits_respected(kind):
+    cfg = quiet_cfg()
+    sim, model = _make(kind, cfg, 4)
+    sim.reset_all()
+    rs = np.random.RandomState(1)
+    for t in range(40):
+        sim.step((rs.normal(0, 6.0, (4, 12))).astype(np.float32))                   # violent actions
+        tau = sim.buf["torques"]
+        assert (np.abs(tau) <= np.array([44, 44, 55] * 4) + 1e-4).all()
+        qd = sim.buf["dof_state"][..., 1]
+        assert (np.abs(qd) <= np.array([20, 20, 15.89] * 4) + 1e-3).all()
+        q = sim.buf["dof_state"][..., 0]
+        lo = np.array([model.dof_pos_lower[j] for j in range(12)]); hi = np.array([model.dof_pos_upper[j] for j in range(12)])
+        assert (q > lo - 0.06).all() and (q < hi + 0.06).all()                      # soft: resolved at velocity level
+        assert np.isfinite(sim.buf["root_states"]).all()
+        np.testing.assert_allclose(np.linalg.norm(sim.buf["root_states"][:, 3:7], axis=1), 1.0, atol=1e-5)
