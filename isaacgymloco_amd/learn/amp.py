@@ -1,0 +1,230 @@
+"""Adversarial-motion-prior pieces of the AMP configuration (BASELINE config 4), PyTorch-ROCm.
+
+Restates, with the same public surface and numerics:
+  AMPLoader        rsl_rl/datasets/motion_loader.py:15-349  (mocap clips -> 30-dim expert transition pairs)
+  Normalizer       rsl_rl/utils/utils.py:78-130             (running mean/var, float64)
+  ReplayBuffer     rsl_rl/storage/replay_buffer.py:36-74    (ring buffer of policy transition pairs)
+  AMPDiscriminator rsl_rl/algorithms/amp_discriminator.py:9-72 (LSGAN discriminator, style reward, gradient penalty)
+Differences in mechanism (not in results): only the 30 feature columns of each pre-sampled frame are kept (the reference
+keeps all 49 and slices per minibatch, ML:315-330), blending is one vectorised gather per clip set, and the normaliser
+moments are accumulated on the device in float64 instead of round-tripping every minibatch through host numpy (HYBP:279-281).
+Host RNG draws (np.random) are made in the reference's order so that a seeded run samples the same transitions.
+"""
+import json
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch import autograd
+
+# 61-column mocap frame layout (ML:17-48)
+POS, ROT, JP, TOE, LV, AV, JV, TOEV = (0, 3), (3, 7), (7, 19), (19, 31), (31, 34), (34, 37), (37, 49), (49, 61)
+FEATURE_COLS = list(range(*JP)) + list(range(LV[0], JV[1]))      # joint pos (12) + base lin/ang vel (6) + joint vel (12) = 30
+
+
+def _reorder_pybullet_to_isaac(frames):
+    """Leg order FR,FL,RR,RL -> FL,FR,RL,RR for the four per-leg blocks (ML:134-164)."""
+    out = frames.copy()
+    for lo, hi in (JP, TOE, JV, TOEV):
+        fr, fl, rr, rl = np.split(frames[:, lo:hi], 4, axis=1)
+        out[:, lo:hi] = np.hstack([fl, fr, rl, rr])
+    return out
+
+
+def load_clip(path):
+    with open(path, "r") as f:
+        j = json.load(f)
+    return dict(frames=np.array(j["Frames"], dtype=np.float64), weight=float(j["MotionWeight"]), frame_duration=float(j["FrameDuration"]))
+
+
+def load_clip_bundle(npz_path):
+    """Clips stored as one .npz (frames_<i>, weight_<i>, frame_duration_<i>): the data fixture shipped with the tests."""
+    z = np.load(npz_path)
+    n = int(z["num_clips"])
+    return [dict(frames=z[f"frames_{i}"].astype(np.float64), weight=float(z[f"weight_{i}"]), frame_duration=float(z[f"frame_duration_{i}"])) for i in range(n)]
+
+
+class AMPLoader:
+    def __init__(self, device, time_between_frames, data_dir="", preload_transitions=False, num_preload_transitions=1000000,
+                 motion_files=(), clips=None):
+        self.device = device
+        self.time_between_frames = time_between_frames
+        if clips is None:
+            clips = []
+            for mf in motion_files:
+                if str(mf).endswith(".npz"):
+                    clips += load_clip_bundle(mf)
+                else:
+                    clips.append(load_clip(mf))
+        if not clips:
+            raise ValueError("AMPLoader needs at least one motion clip")
+        self.trajectories, weights, fdur, lens, nfr = [], [], [], [], []
+        for c in clips:
+            data = _reorder_pybullet_to_isaac(c["frames"])
+            self.trajectories.append(torch.tensor(data[:, FEATURE_COLS], dtype=torch.float32, device=device))
+            weights.append(c["weight"]); fdur.append(c["frame_duration"])
+            lens.append((data.shape[0] - 1) * c["frame_duration"]); nfr.append(float(data.shape[0]))
+        self.trajectory_idxs = list(range(len(clips)))
+        self.trajectory_weights = np.array(weights) / np.sum(weights)
+        self.trajectory_frame_durations, self.trajectory_lens, self.trajectory_num_frames = np.array(fdur), np.array(lens), np.array(nfr)
+        self.preload_transitions = preload_transitions
+        if preload_transitions:
+            idxs = self.weighted_traj_idx_sample_batch(num_preload_transitions)
+            times = self.traj_time_sample_batch(idxs)
+            self.preloaded_s = self.get_frame_at_time_batch(idxs, times)
+            self.preloaded_s_next = self.get_frame_at_time_batch(idxs, times + self.time_between_frames)
+
+    @property
+    def observation_dim(self):
+        return 30
+
+    @property
+    def num_motions(self):
+        return len(self.trajectories)
+
+    def weighted_traj_idx_sample_batch(self, size):          # ML:171-175
+        return np.random.choice(self.trajectory_idxs, size=size, p=self.trajectory_weights, replace=True)
+
+    def traj_time_sample_batch(self, traj_idxs):             # ML:183-187
+        subst = self.time_between_frames + self.trajectory_frame_durations[traj_idxs]
+        t = self.trajectory_lens[traj_idxs] * np.random.uniform(size=len(traj_idxs)) - subst
+        return np.maximum(np.zeros_like(t), t)
+
+    def get_frame_at_time_batch(self, traj_idxs, times):     # ML:231-255 (feature columns only)
+        p = times / self.trajectory_lens[traj_idxs]
+        n = self.trajectory_num_frames[traj_idxs]
+        lo, hi = np.floor(p * n).astype(np.int64), np.ceil(p * n).astype(np.int64)
+        start = torch.zeros(len(traj_idxs), 30, device=self.device)
+        end = torch.zeros(len(traj_idxs), 30, device=self.device)
+        for k in np.unique(traj_idxs):
+            m = torch.from_numpy(traj_idxs == k).to(self.device)
+            sel = traj_idxs == k
+            traj = self.trajectories[k]
+            start[m] = traj[torch.from_numpy(lo[sel]).to(self.device)]
+            end[m] = traj[torch.from_numpy(hi[sel]).to(self.device)]
+        blend = torch.tensor(p * n - lo, device=self.device, dtype=torch.float32).unsqueeze(-1)
+        return (1.0 - blend) * start + blend * end
+
+    def feed_forward_generator(self, num_mini_batch, mini_batch_size):   # ML:315-343
+        for _ in range(num_mini_batch):
+            if self.preload_transitions:
+                idxs = torch.from_numpy(np.random.choice(self.preloaded_s.shape[0], size=mini_batch_size)).to(self.device)
+                yield self.preloaded_s[idxs], self.preloaded_s_next[idxs]
+            else:
+                ti = self.weighted_traj_idx_sample_batch(mini_batch_size)
+                t = self.traj_time_sample_batch(ti)
+                yield self.get_frame_at_time_batch(ti, t), self.get_frame_at_time_batch(ti, t + self.time_between_frames)
+
+
+class Normalizer:
+    """Running mean / variance (parallel algorithm), float64, clip +-clip_obs (UT:78-130)."""
+
+    def __init__(self, input_dim, epsilon=1e-4, clip_obs=10.0, device="cpu"):
+        self._mean = torch.zeros(input_dim, dtype=torch.float64, device=device)
+        self._var = torch.ones(input_dim, dtype=torch.float64, device=device)
+        self._count = torch.tensor(1e-4, dtype=torch.float64, device=device)   # RunningMeanStd default epsilon (UT:79)
+        self.epsilon, self.clip_obs = epsilon, clip_obs
+        self.moment_sync = None     # data-parallel hook: callable(sum, sumsq, count) -> global triple
+
+    mean = property(lambda self: self._mean.cpu().numpy())
+    var = property(lambda self: self._var.cpu().numpy())
+    count = property(lambda self: float(self._count))
+
+    def to(self, device):
+        self._mean, self._var, self._count = self._mean.to(device), self._var.to(device), self._count.to(device)
+        return self
+
+    def normalize_torch(self, x, device=None):
+        mean = self._mean.to(dtype=torch.float32, device=x.device)
+        std = torch.sqrt((self._var + self.epsilon).to(dtype=torch.float32, device=x.device))
+        return torch.clamp((x - mean) / std, -self.clip_obs, self.clip_obs)
+
+    def normalize(self, x):
+        return np.clip((x - self.mean) / np.sqrt(self.var + self.epsilon), -self.clip_obs, self.clip_obs)
+
+    def update(self, arr):
+        a = torch.as_tensor(arr).to(device=self._mean.device)
+        n = torch.tensor(float(a.shape[0]), dtype=torch.float64, device=a.device)
+        if self.moment_sync is None:
+            # the reference feeds float32 arrays to np.mean / np.var (HYBP:280-281): batch moments are formed in the input
+            # precision, only the running state is float64
+            bmean, bvar = a.mean(dim=0).to(torch.float64), a.var(dim=0, unbiased=False).to(torch.float64)
+        else:
+            a = a.to(torch.float64)
+            s1, s2, n = self.moment_sync(a.sum(dim=0), (a * a).sum(dim=0), n)
+            bmean = s1 / n
+            bvar = s2 / n - bmean * bmean
+        delta = bmean - self._mean
+        tot = self._count + n
+        new_mean = self._mean + delta * n / tot
+        m2 = self._var * self._count + bvar * n + torch.square(delta) * self._count * n / (self._count + n)
+        self._mean, self._var, self._count = new_mean, m2 / (self._count + n), n + self._count
+
+
+class ReplayBuffer:
+    def __init__(self, obs_dim, buffer_size, device):
+        self.states = torch.zeros(buffer_size, obs_dim, device=device)
+        self.next_states = torch.zeros(buffer_size, obs_dim, device=device)
+        self.buffer_size, self.device = buffer_size, device
+        self.step = 0
+        self.num_samples = 0
+
+    def insert(self, states, next_states):                    # RB:52-68
+        n = states.shape[0]
+        end = self.step + n
+        if end > self.buffer_size:
+            head = self.buffer_size - self.step
+            self.states[self.step:] = states[:head]; self.next_states[self.step:] = next_states[:head]
+            self.states[:end - self.buffer_size] = states[head:]; self.next_states[:end - self.buffer_size] = next_states[head:]
+        else:
+            self.states[self.step:end] = states; self.next_states[self.step:end] = next_states
+        self.num_samples = min(self.buffer_size, max(end, self.num_samples))
+        self.step = (self.step + n) % self.buffer_size
+
+    def feed_forward_generator(self, num_mini_batch, mini_batch_size):   # RB:70-74
+        for _ in range(num_mini_batch):
+            idx = torch.from_numpy(np.random.choice(self.num_samples, size=mini_batch_size)).to(self.device)
+            yield self.states[idx], self.next_states[idx]
+
+
+class AMPDiscriminator(nn.Module):
+    def __init__(self, input_dim, amp_reward_coef, hidden_layer_sizes, device, task_reward_lerp=0.0):
+        super().__init__()
+        self.device, self.input_dim, self.amp_reward_coef, self.task_reward_lerp = device, input_dim, amp_reward_coef, task_reward_lerp
+        layers, d = [], input_dim
+        for h in hidden_layer_sizes:
+            layers += [nn.Linear(d, h), nn.ReLU()]
+            d = h
+        self.trunk = nn.Sequential(*layers).to(device)
+        self.amp_linear = nn.Linear(hidden_layer_sizes[-1], 1).to(device)
+        self.trunk.train(); self.amp_linear.train()
+
+    def forward(self, x):
+        return self.amp_linear(self.trunk(x))
+
+    def compute_grad_pen(self, expert_state, expert_next_state, lambda_=10):   # DISC:36-53
+        data = torch.cat([expert_state, expert_next_state], dim=-1)
+        data.requires_grad = True
+        disc = self.amp_linear(self.trunk(data))
+        grad = autograd.grad(outputs=disc, inputs=data, grad_outputs=torch.ones(disc.size(), device=disc.device),
+                             create_graph=True, retain_graph=True, only_inputs=True)[0]
+        return lambda_ * (grad.norm(2, dim=1) - 0).pow(2).mean()
+
+    def predict_amp_reward(self, state, next_state, task_reward, normalizer=None):   # DISC:55-72
+        with torch.no_grad():
+            self.eval()
+            if normalizer is not None:
+                state, next_state = normalizer.normalize_torch(state, self.device), normalizer.normalize_torch(next_state, self.device)
+            d = self.amp_linear(self.trunk(torch.cat([state, next_state], dim=-1)))
+            reward = self.amp_reward_coef * torch.clamp(1 - (1 / 4) * torch.square(d - 1), min=0)
+            if self.task_reward_lerp > 0:
+                reward = (1.0 - self.task_reward_lerp) * reward + self.task_reward_lerp * task_reward.unsqueeze(-1)
+            self.train()
+        return reward.squeeze(), d
+
+
+def default_motion_files():
+    """The Aliengo clip bundle shipped as a data fixture (7 clips selected by AGA:34-36)."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    return [os.path.join(os.path.dirname(os.path.dirname(here)), "tests", "golden", "mocap_aliengo.npz")]

@@ -18,7 +18,13 @@ def run_train_bench(env, cfg, args, dev, rank, world, barrier):
     task = args.task if args.task in C.TASKS else "aliengo"
     tc = train_cfg_dict(task)
     torch.manual_seed(1)   # identical initial policy on every rank (then broadcast anyway)
-    runner = HIMOnPolicyRunner(env, tc, log_dir=None, device=str(dev))
+    if C.TASKS[task][1]().runner_class_name == "HybridPolicyRunner":      # AMP configuration (AGA:297, AGA:329)
+        from .hybrid import HybridPolicyRunner
+        import numpy as np
+        np.random.seed(1 + rank)
+        runner = HybridPolicyRunner(env, tc, log_dir=None, device=str(dev))
+    else:
+        runner = HIMOnPolicyRunner(env, tc, log_dir=None, device=str(dev))
     T = runner.num_steps_per_env
     K, W = args.steps, args.warmup
     env.episode_length_buf = torch.randint_like(env.episode_length_buf, high=int(env.max_episode_length))
@@ -67,6 +73,6 @@ def run_train_bench(env, cfg, args, dev, rank, world, barrier):
              "collection_s_per_iteration": (elapsed - learn) / (K / T) if K >= T else None,
              "ppo_iteration_wall_s": elapsed / (K / T) if K >= T else None,
              "collection_env_steps_per_s": world * env.num_envs * K / max(elapsed - learn, 1e-9)}
-    workload = (f"{task}: HIMOnPolicyRunner loop = policy inference + LeggedRobot.step + storage for {T} steps/iteration, then GAE + "
+    workload = (f"{task}: {type(runner).__name__} loop = policy inference + LeggedRobot.step + storage for {T} steps/iteration, then GAE + "
                 f"HIMPPO.update (5 epochs x 4 minibatches), {env.num_envs} envs/GPU")
     return elapsed, extra, workload

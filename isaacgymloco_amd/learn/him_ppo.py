@@ -58,6 +58,15 @@ class DistCtx:
         v = v.to(torch.float32)
         return v[0], v[1], v[2]
 
+    def sum_triple_vec(self, a, b, c):
+        """element-wise sums over ranks of two vectors and a scalar (running-normaliser moments)"""
+        if not self.enabled:
+            return a, b, c
+        v = torch.cat((a.reshape(-1), b.reshape(-1), c.reshape(1))).to(torch.float64)
+        self.dist.all_reduce(v, op=self.dist.ReduceOp.SUM)
+        n = a.numel()
+        return v[:n].view_as(a), v[n:2 * n].view_as(b), v[2 * n]
+
     def broadcast_module(self, module):
         if not self.enabled:
             return

@@ -105,7 +105,9 @@ class HIMOnPolicyRunner:
                 collection_time = stop - start
                 start = stop
                 self.alg.compute_returns(critic_obs)
-            mean_value_loss, mean_surrogate_loss, mean_estimation_loss, mean_swap_loss = self.alg.update()
+            update_out = self.alg.update()      # HIMPPO: 4 values; HybridPPO: 8 (adds AMP loss, grad penalty, policy / expert prediction)
+            mean_value_loss, mean_surrogate_loss, mean_estimation_loss, mean_swap_loss = update_out[:4]
+            self.last_update = update_out
             if self.device != "cpu" and torch.cuda.is_available():
                 torch.cuda.synchronize()
             learn_time = time.time() - start

@@ -1,0 +1,115 @@
+"""Container-only: data bundle + golden vectors for the AMP path from the reference rsl_rl.
+  tests/golden/mocap_aliengo.npz  the 7 Aliengo mocap clips selected by AGA:34-36 (data: frames, weight, frame duration),
+                                  in the order the reference's glob returned them (that order feeds np.random.choice)
+  tests/golden/learner_amp.npz    AMPLoader pre-sampling, discriminator reward, Normalizer, ReplayBuffer, one HybridPPO.update()."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+import refenv  # noqa: E402
+
+refenv.install()
+import legged_gym.envs  # noqa: E402,F401
+from legged_gym.envs.aliengo import aliengo_amp_config  # noqa: E402
+from rsl_rl.algorithms import HybridPPO  # noqa: E402
+from rsl_rl.algorithms.amp_discriminator import AMPDiscriminator  # noqa: E402
+from rsl_rl.datasets.motion_loader import AMPLoader  # noqa: E402
+from rsl_rl.modules import HIMActorCritic  # noqa: E402
+from rsl_rl.storage.replay_buffer import ReplayBuffer  # noqa: E402
+from rsl_rl.utils.utils import Normalizer  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+ALG = dict(value_loss_coef=1.0, use_clipped_value_loss=True, clip_param=0.2, entropy_coef=0.01, num_learning_epochs=2,
+           num_mini_batches=2, learning_rate=1e-3, schedule="adaptive", gamma=0.99, lam=0.95, desired_kl=0.01, max_grad_norm=1.0,
+           amp_replay_buffer_size=64)
+
+
+def ck(module):
+    return {k: np.array([float(v.double().sum()), float(v.double().abs().sum())]) for k, v in module.state_dict().items()}
+
+
+def main():
+    files = list(aliengo_amp_config.MOTION_FILES)
+    bundle = {"num_clips": np.int64(len(files)), "names": np.array([os.path.basename(f) for f in files])}
+    for i, f in enumerate(files):
+        j = json.load(open(f))
+        bundle[f"frames_{i}"] = np.array(j["Frames"], dtype=np.float32)
+        bundle[f"weight_{i}"] = np.float64(j["MotionWeight"])
+        bundle[f"frame_duration_{i}"] = np.float64(j["FrameDuration"])
+    np.savez_compressed(os.path.join(GOLDEN, "mocap_aliengo.npz"), **bundle)
+
+    out = {}
+    np.random.seed(1)
+    loader = AMPLoader("cpu", time_between_frames=0.02, preload_transitions=True, num_preload_transitions=4000, motion_files=files)
+    cols = list(range(7, 19)) + list(range(31, 49))
+    out["pre_s"] = loader.preloaded_s[:, cols].numpy()
+    out["pre_s_next"] = loader.preloaded_s_next[:, cols].numpy()
+    gen = loader.feed_forward_generator(2, 16)
+    b0 = next(gen); b1 = next(gen)
+    out["ff_s"] = torch.stack((b0[0], b1[0])).numpy(); out["ff_s_next"] = torch.stack((b0[1], b1[1])).numpy()
+
+    g = torch.Generator().manual_seed(5)
+    nz = Normalizer(30)
+    x1, x2 = torch.randn(50, 30, generator=g) * 2 + 1, torch.randn(70, 30, generator=g) * 0.5 - 2
+    nz.update(x1.numpy()); nz.update(x2.numpy())
+    out["nz_x1"], out["nz_x2"], out["nz_mean"], out["nz_var"], out["nz_count"] = x1.numpy(), x2.numpy(), nz.mean, nz.var, np.float64(nz.count)
+    probe = torch.randn(9, 30, generator=g) * 3
+    out["nz_probe"], out["nz_probe_out"] = probe.numpy(), nz.normalize_torch(probe, "cpu").numpy()
+
+    torch.manual_seed(3)
+    disc = AMPDiscriminator(60, 0.5 * 0.02, [1024, 512], "cpu", 0.3)
+    s, ns, tr = torch.randn(12, 30, generator=g), torch.randn(12, 30, generator=g), torch.randn(12, generator=g)
+    r, d = disc.predict_amp_reward(s, ns, tr, normalizer=nz)
+    out["disc_s"], out["disc_ns"], out["disc_task"], out["disc_reward"], out["disc_d"] = s.numpy(), ns.numpy(), tr.numpy(), r.numpy(), d.numpy()
+    out["disc_gp"] = np.float64(disc.compute_grad_pen(s, ns, lambda_=10).item())
+
+    rb = ReplayBuffer(30, 20, "cpu")
+    chunks = [torch.randn(8, 30, generator=g) for _ in range(4)]
+    for c in chunks:
+        rb.insert(c, c + 1)
+    out["rb_chunks"] = torch.stack(chunks).numpy(); out["rb_states"] = rb.states.numpy(); out["rb_next"] = rb.next_states.numpy()
+    out["rb_step"], out["rb_num"] = np.int64(rb.step), np.int64(rb.num_samples)
+
+    # one HybridPPO rollout + update on synthetic data
+    N, T = 8, 6
+    torch.manual_seed(0)
+    ac = HIMActorCritic(270, 238, 45, 12, actor_hidden_dims=[512, 256, 128], critic_hidden_dims=[512, 256, 128], activation="elu", init_noise_std=1.0)
+    disc2 = AMPDiscriminator(60, 0.5 * 0.02, [1024, 512], "cpu", 0.3)
+    nz2 = Normalizer(30)
+    min_std = torch.tensor([0.05, 0.02, 0.05] * 4) * 1.5
+    alg = HybridPPO(ac, disc2, loader, nz2, device="cpu", min_std=min_std, **ALG)
+    alg.init_storage(N, T, [270], [238], [12])
+    obs_seq, crit_seq = torch.randn(T + 1, N, 270, generator=g), torch.randn(T + 1, N, 238, generator=g)
+    amp_seq = torch.randn(T + 1, N, 30, generator=g) * 0.5
+    rew_seq = torch.randn(T, N, generator=g)
+    done_seq = torch.rand(T, N, generator=g) < 0.2
+    torch.manual_seed(1)
+    np.random.seed(7)
+    with torch.inference_mode():
+        for t in range(T):
+            alg.act(obs_seq[t], crit_seq[t], amp_seq[t])
+            rew = alg.discriminator.predict_amp_reward(amp_seq[t], amp_seq[t + 1], rew_seq[t], normalizer=alg.amp_normalizer)[0]
+            alg.process_env_step(rew, done_seq[t], {"time_outs": done_seq[t] & False}, amp_seq[t + 1], crit_seq[t + 1])
+        alg.compute_returns(crit_seq[T])
+    torch.manual_seed(2)
+    res = alg.update()
+    out["hy_obs"], out["hy_crit"], out["hy_amp"], out["hy_rew"], out["hy_done"] = obs_seq.numpy(), crit_seq.numpy(), amp_seq.numpy(), rew_seq.numpy(), done_seq.numpy()
+    out["hy_losses"] = np.array(res, dtype=np.float64)
+    out["hy_lr"] = np.float64(alg.learning_rate)
+    out["hy_nz_mean"], out["hy_nz_var"] = nz2.mean, nz2.var
+    for k, v in ck(ac).items():
+        out["hy_ac/" + k] = v
+    for k, v in ck(disc2).items():
+        out["hy_disc/" + k] = v
+    np.savez_compressed(os.path.join(GOLDEN, "learner_amp.npz"), **out)
+    print("wrote bundle + learner_amp.npz", {k: os.path.getsize(os.path.join(GOLDEN, k)) // 1000 for k in ("mocap_aliengo.npz", "learner_amp.npz")}, "KB; losses", res)
+
+
+if __name__ == "__main__":
+    main()
