@@ -54,6 +54,20 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # fp32 GEMMs of the learner: use the hipBLASLt/rocBLAS solutions pre-selected by PyTorch TunableOp on gfx950
+    # (isaacgymloco_amd/learn/tunableop_gfx950.csv; LSIM_TUNE=1 re-tunes and rewrites it).  Must be set before torch loads.
+    tuned = os.path.join(ROOT, "isaacgymloco_amd", "learn", "tunableop_gfx950.csv")
+    if os.environ.get("LSIM_TUNE") == "1" or os.path.exists(tuned):
+        import shutil, tempfile
+        lr_ = int(os.environ.get("LOCAL_RANK", "0"))
+        tdir = tempfile.mkdtemp(prefix="lsim_tunableop_")
+        if os.path.exists(tuned):
+            shutil.copy(tuned, os.path.join(tdir, f"tuned{lr_}.csv"))   # TunableOp appends the device ordinal to the name
+        os.environ.setdefault("PYTORCH_TUNABLEOP_ENABLED", "1")
+        os.environ.setdefault("PYTORCH_TUNABLEOP_FILENAME", os.path.join(tdir, "tuned.csv"))
+        os.environ.setdefault("PYTORCH_TUNABLEOP_TUNING", "1" if os.environ.get("LSIM_TUNE") == "1" else "0")
+        os.environ.setdefault("PYTORCH_TUNABLEOP_MAX_TUNING_DURATION_MS", "100")
+        os.environ.setdefault("PYTORCH_TUNABLEOP_VERBOSE", "0")
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
@@ -141,6 +155,10 @@ def main():
             except Exception as e:  # the baseline is a reported extra, never the thing measured
                 out["cpu_baseline"] = {"value": None, "error": str(e)}
         print(json.dumps(out))
+    if os.environ.get("LSIM_TUNE") == "1" and rank == 0:   # keep the freshly tuned table (written at interpreter exit)
+        import atexit, shutil
+        src = os.environ["PYTORCH_TUNABLEOP_FILENAME"].replace(".csv", f"{local_rank}.csv")
+        atexit.register(lambda: os.path.exists(src) and shutil.copy(src, os.path.join(ROOT, "gpurun_out", "tunableop_new.csv")))
     if world > 1:
         dist.destroy_process_group()
 
