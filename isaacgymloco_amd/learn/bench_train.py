@@ -25,6 +25,8 @@ def run_train_bench(env, cfg, args, dev, rank, world, barrier):
         runner = HybridPolicyRunner(env, tc, log_dir=None, device=str(dev))
     else:
         runner = HIMOnPolicyRunner(env, tc, log_dir=None, device=str(dev))
+    import os
+    use_graphs = os.environ.get("LSIM_NO_GRAPHS") != "1" and runner.enable_graphs()
     T = runner.num_steps_per_env
     K, W = args.steps, args.warmup
     env.episode_length_buf = torch.randint_like(env.episode_length_buf, high=int(env.max_episode_length))
@@ -35,8 +37,12 @@ def run_train_bench(env, cfg, args, dev, rank, world, barrier):
 
     def one_step(timed):
         t0 = time.perf_counter()
-        with torch.inference_mode():
-            state["obs"], state["critic"], _, _, _ = runner._rollout_step(state["obs"], state["critic"])
+        if use_graphs:
+            runner.graphs.step()
+            state["critic"] = env.privileged_obs_buf
+        else:
+            with torch.inference_mode():
+                state["obs"], state["critic"], _, _, _ = runner._rollout_step(state["obs"], state["critic"])
         state["in_iter"] += 1
         if state["in_iter"] == T:
             if timed:
@@ -44,6 +50,8 @@ def run_train_bench(env, cfg, args, dev, rank, world, barrier):
             t1 = time.perf_counter()
             with torch.inference_mode():
                 runner.alg.compute_returns(state["critic"])
+            if use_graphs:
+                runner.graphs.end_iteration()
             runner.alg.update()
             state["in_iter"] = 0
             if timed:
@@ -72,7 +80,8 @@ def run_train_bench(env, cfg, args, dev, rank, world, barrier):
              "learn_s_per_update": learn / iters if state["iters"] else None,
              "collection_s_per_iteration": (elapsed - learn) / (K / T) if K >= T else None,
              "ppo_iteration_wall_s": elapsed / (K / T) if K >= T else None,
-             "collection_env_steps_per_s": world * env.num_envs * K / max(elapsed - learn, 1e-9)}
+             "collection_env_steps_per_s": world * env.num_envs * K / max(elapsed - learn, 1e-9),
+             "rollout_hip_graphs": bool(use_graphs)}
     workload = (f"{task}: {type(runner).__name__} loop = policy inference + LeggedRobot.step + storage for {T} steps/iteration, then GAE + "
                 f"HIMPPO.update (5 epochs x 4 minibatches), {env.num_envs} envs/GPU")
     return elapsed, extra, workload

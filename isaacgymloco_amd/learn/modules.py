@@ -121,7 +121,6 @@ class HIMActorCritic(nn.Module):
         self.critic = mlp([num_critic_obs, *critic_hidden_dims, 1], act)
         self.std = nn.Parameter(init_noise_std * torch.ones(num_actions))
         self.distribution = None
-        Normal.set_default_validate_args = False
 
     def reset(self, dones=None):
         pass
@@ -145,7 +144,9 @@ class HIMActorCritic(nn.Module):
 
     def update_distribution(self, obs_history):
         mean = self.actor(self._actor_input(obs_history))
-        self.distribution = Normal(mean, mean * 0.0 + self.std)
+        # validate_args=False: the reference intends this (HAC:103 assigns Normal.set_default_validate_args = False, a no-op);
+        # argument validation is a host sync per call and cannot be captured into a HIP graph
+        self.distribution = Normal(mean, mean * 0.0 + self.std, validate_args=False)
 
     def act(self, obs_history=None, **kwargs):
         self.update_distribution(obs_history)

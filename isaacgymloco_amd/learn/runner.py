@@ -41,7 +41,15 @@ class HIMOnPolicyRunner:
         self.tot_timesteps, self.tot_time, self.current_learning_iteration = 0, 0.0, 0
         self.fast = hasattr(env, "step_device") if fast is None else fast
         self.last_perf = {}
+        self.graphs = None
         env.reset()
+
+    def enable_graphs(self):
+        """Capture the rollout step into HIP graphs (graph_rollout.py).  Only for the plain HIM runner on a GPU env."""
+        if type(self) is HIMOnPolicyRunner and self.fast and str(self.device).startswith("cuda"):
+            from .graph_rollout import GraphedRollout
+            self.graphs = GraphedRollout(self)
+        return self.graphs is not None
 
     # ------------------------------------------------------------------ rollout
     def _rollout_step(self, obs, critic_obs):
@@ -87,7 +95,11 @@ class HIMOnPolicyRunner:
             fin = torch.zeros(3, device=self.device)   # finished episodes this iteration: count, sum reward, sum length
             with torch.inference_mode():
                 for _ in range(self.num_steps_per_env):
-                    obs, critic_obs, rewards, dones, infos = self._rollout_step(obs, critic_obs)
+                    if self.graphs is not None:
+                        self.graphs.step()
+                        obs, critic_obs, rewards, dones, infos = env.obs_buf, env.privileged_obs_buf, env.rew_buf, env.reset_buf, env.extras
+                    else:
+                        obs, critic_obs, rewards, dones, infos = self._rollout_step(obs, critic_obs)
                     if self.log_dir is not None:
                         cur_reward_sum += rewards
                         cur_episode_length += 1
@@ -105,6 +117,8 @@ class HIMOnPolicyRunner:
                 collection_time = stop - start
                 start = stop
                 self.alg.compute_returns(critic_obs)
+            if self.graphs is not None:
+                self.graphs.end_iteration()
             update_out = self.alg.update()      # HIMPPO: 4 values; HybridPPO: 8 (adds AMP loss, grad penalty, policy / expert prediction)
             mean_value_loss, mean_surrogate_loss, mean_estimation_loss, mean_swap_loss = update_out[:4]
             self.last_update = update_out
