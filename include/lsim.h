@@ -50,7 +50,7 @@ extern "C" {
 #define LSIM_NUM_AMP_OBS 30     /* LR:416 */
 #define LSIM_NUM_BASE_HEIGHT_PTS 63 /* 7 x 9, LR:1308-1312 */
 #define LSIM_MAX_COLLISION_POINTS 64
-#define LSIM_MAX_CONTACTS 16
+#define LSIM_MAX_CONTACTS 8
 #define LSIM_TERRAIN_LEVELS_MAX 32
 #define LSIM_TERRAIN_TYPES_MAX 32
 

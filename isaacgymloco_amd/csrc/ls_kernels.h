@@ -163,6 +163,7 @@ LS_WAVE_FN void ls_wave_step_a(const LsCtx& cx, const LsStepArgs& a, const int e
         LS_PHASE(ph_kinematics(sh, lane));
         LS_PHASE(ph_body_inertia(cx, sh, lane, sub == 0));
         LS_PHASE(ph_leg_composite(sh, lane));
+        LS_PHASE(ph_leg_schur(sh, lane));
         LS_PHASE(ph_base_assemble(sh, lane));
         LS_PHASE(ph_base_factor(sh, lane));
         LS_PHASE(ph_free_leg(sh, lane));
@@ -172,8 +173,13 @@ LS_WAVE_FN void ls_wave_step_a(const LsCtx& cx, const LsStepArgs& a, const int e
         LS_COLLECTIVE(wc_compact_contacts(sh, rg, lane), wc_compact_contacts(sh, L));
         LS_PHASE(ph_limits(cx, sh, lane));
         LS_PHASE(ph_rows(cx, sh, rg, lane, dt));
+#if defined(LS_EMU)
         LS_PHASE(ph_delassus(sh, rg, lane));
-        LS_COLLECTIVE(wc_pgs(sh, rg, lane, c.solver_iterations), wc_pgs(sh, L, c.solver_iterations));
+        wc_pgs(sh, L, c.solver_iterations);
+#else
+        wc_delassus_pgs(sh, rg, lane, c.solver_iterations);
+        __syncthreads();
+#endif
         LS_PHASE(ph_apply_impulses(sh, lane));
         LS_PHASE(ph_contact_forces(sh, lane, dt));
         LS_PHASE(ph_integrate(cx, sh, lane, dt));

@@ -128,14 +128,14 @@ LS_FN void chol6_solve(const float* L, float* b) {
     }
 }
 
-// ---- phase L: composite inertias / bias forces up each leg, leg mass block, its factor and Schur pieces (lane = leg)
+// ---- phase L1: composite inertias / bias forces up each leg -> F_k = Ic_k S_k (columns of Mbl), leg block Mll, h_l (lane = leg)
 LS_FN void ph_leg_composite(WaveShared& sh, int lane) {
     if (lane >= 4) return;
     float Ic[36];
     S6 fb = s6(v3(0, 0, 0), v3(0, 0, 0));
     for (int e = 0; e < 36; ++e) Ic[e] = 0.0f;
-    S6 F[3];
-    float h[3];
+    S6 Sk[3];
+    float Mll[6];
     for (int k = 3; k >= 0; --k) {
         int b = 1 + 4 * lane + k;
         const float* I6 = sh.u.I6[b];
@@ -143,37 +143,46 @@ LS_FN void ph_leg_composite(WaveShared& sh, int lane) {
         fb = fb + s6p(sh.Fb[b]);
         if (k < 3) {
             S6 S = s6p(sh.S[3 * lane + k]);
-            F[k] = m6v(Ic, S);
-            h[k] = dot(S, fb);
+            Sk[k] = S;
+            S6 F = m6v(Ic, S);                       // F_k = Ic_k S_k ; M_jk = S_j . F_k for ancestors j <= k
+            float Fm[6];
+            s6st(Fm, F);
+            for (int r = 0; r < 6; ++r) sh.Mbl[lane][3 * r + k] = Fm[r];
+            sh.hl[lane][k] = dot(S, fb);
+            if (k == 2) Mll[5] = dot(S, F);
+            else if (k == 1) { Mll[2] = dot(S, F); }
+            else Mll[0] = dot(S, F);
+            // off-diagonals need the ancestors' S, which are only known after the loop: keep F in LDS (Mbl) and finish below
         }
     }
-    S6 Sh = s6p(sh.S[3 * lane]), St = s6p(sh.S[3 * lane + 1]), Sc = s6p(sh.S[3 * lane + 2]);
-    float Mll[6] = {dot(Sh, F[0]), dot(Sh, F[1]), dot(St, F[1]), dot(Sh, F[2]), dot(St, F[2]), dot(Sc, F[2])};
+    s6st(sh.legF[lane], fb);
+    // off-diagonal entries M_ht = S_h.F_t, M_hc = S_h.F_c, M_tc = S_t.F_c from the stored columns
+    float Ft[6], Fc[6];
+    for (int r = 0; r < 6; ++r) { Ft[r] = sh.Mbl[lane][3 * r + 1]; Fc[r] = sh.Mbl[lane][3 * r + 2]; }
+    Mll[1] = dot(Sk[0], s6p(Ft));
+    Mll[3] = dot(Sk[0], s6p(Fc));
+    Mll[4] = dot(Sk[1], s6p(Fc));
     float L[6];
     chol3(Mll, L);
     for (int e = 0; e < 6; ++e) sh.Lll[lane][e] = L[e];
-    for (int e = 0; e < 36; ++e) sh.Ichip[lane][e] = Ic[e];
-    s6st(sh.legF[lane], fb);
-    for (int k = 0; k < 3; ++k) sh.hl[lane][k] = h[k];
-    float Fm[3][6];
-    for (int k = 0; k < 3; ++k) { s6st(Fm[k], F[k]); for (int r = 0; r < 6; ++r) sh.Mbl[lane][3 * r + k] = Fm[k][r]; }
-    // G = Mll^-1 Mlb^T (3x6): column c of Mlb^T is (F_h[c], F_t[c], F_c[c])
-    float G[18];
-    for (int c = 0; c < 6; ++c) {
-        float col[3] = {Fm[0][c], Fm[1][c], Fm[2][c]};
-        chol3_solve(L, col);
-        G[c] = col[0]; G[6 + c] = col[1]; G[12 + c] = col[2];
-    }
-    for (int e = 0; e < 18; ++e) sh.G[lane][e] = G[e];
-    for (int r = 0; r < 6; ++r)
-        for (int c = 0; c < 6; ++c) sh.A[lane][6 * r + c] = Fm[0][r] * G[c] + Fm[1][r] * G[6 + c] + Fm[2][r] * G[12 + c];
+}
+// ---- phase L2: G_l = Mll^-1 Mlb^T (3x6) from the stored columns (lane = 6 * leg + column)
+LS_FN void ph_leg_schur(WaveShared& sh, int lane) {
+    if (lane >= 24) return;
+    int l = lane / 6, c = lane - 6 * l;
+    float col[3] = {sh.Mbl[l][3 * c], sh.Mbl[l][3 * c + 1], sh.Mbl[l][3 * c + 2]};   // (F_h[c], F_t[c], F_c[c])
+    chol3_solve(sh.Lll[l], col);
+    sh.G[l][c] = col[0]; sh.G[l][6 + c] = col[1]; sh.G[l][12 + c] = col[2];
 }
 
-// ---- phase E: assemble the base Schur complement and total base bias force (lane = element)
+// ---- phase E: base Schur complement Sb = sum_b I6[b] - sum_l Mbl_l G_l and total base bias force (lane = element)
 LS_FN void ph_base_assemble(WaveShared& sh, int lane) {
     if (lane < 36) {
-        float s = sh.u.I6[0][lane];
-        for (int l = 0; l < 4; ++l) s += sh.Ichip[l][lane] - sh.A[l][lane];
+        float s = 0.0f;
+        for (int b = 0; b < LS_NB; ++b) s += sh.u.I6[b][lane];
+        int r = lane / 6, c = lane - 6 * r;
+        for (int l = 0; l < 4; ++l)
+            s -= sh.Mbl[l][3 * r] * sh.G[l][c] + sh.Mbl[l][3 * r + 1] * sh.G[l][6 + c] + sh.Mbl[l][3 * r + 2] * sh.G[l][12 + c];
         sh.Sb[lane] = s;
     } else if (lane < 42) {
         int k = lane - 36;
@@ -384,7 +393,8 @@ LS_FN void ph_rows(const LsCtx& cx, WaveShared& sh, LaneRegs& r, int lane, float
     r.brow = jv - vt;
 }
 
-// ---- phase R2: Delassus row W_i. = J_i Y^T (lane = row i)
+// ---- phase R2 (lane emulator only; the GPU fuses it into wc_delassus_pgs): Delassus row W_i. = J_i Y^T (lane = row i)
+#if defined(LS_EMU)
 LS_FN void ph_delassus(WaveShared& sh, LaneRegs& r, int lane) {
     if (lane >= sh.nrows) return;
     const int R = sh.nrows;
@@ -407,6 +417,7 @@ LS_FN void ph_delassus(WaveShared& sh, LaneRegs& r, int lane) {
     }
     r.wdiag = wd;
 }
+#endif
 
 // ---- wave collective: projected Gauss-Seidel sweep in impulse space
 //      w_i = b_i + sum_j W_ij lam_j is kept up to date by every lane; rows are relaxed in order r = 0..R-1.
@@ -431,18 +442,39 @@ static inline void wc_pgs(WaveShared& sh, LaneRegs* L, int iters) {
 LS_FN float ls_readlane(float v, int srclane) {  // srclane is wave-uniform
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), srclane));
 }
-LS_FN void wc_pgs(WaveShared& sh, LaneRegs& rg, int lane, int iters) {
+// GPU form: Delassus row and sweep fused so that the 36-entry row lives in registers only between here and the end of
+// the sweep (written unconditionally: no liveness across sub-steps); rows relaxed in order, impulse broadcast by readlane.
+LS_FN void wc_delassus_pgs(WaveShared& sh, const LaneRegs& rg, int lane, int iters) {
     const int R = sh.nrows;
     const bool act = lane < R;
+    const int leg = rg.row_leg;
+    const int lo = (act && leg >= 0) ? 6 + 3 * leg : 6;
+    const bool has_leg = act && leg >= 0;
+    const float jl0 = has_leg ? rg.Jl[0] : 0.0f, jl1 = has_leg ? rg.Jl[1] : 0.0f, jl2 = has_leg ? rg.Jl[2] : 0.0f;
+    float jb[6];
+    for (int k = 0; k < 6; ++k) jb[k] = act ? rg.Jb[k] : 0.0f;
+    float W[LS_MAXR];
+    float wd = 1.0f;
+#pragma unroll
+    for (int j = 0; j < LS_MAXR; ++j) {
+        float w = 0.0f;
+        if (j < R) {
+            const float* Y = sh.u.c.Y[j];
+            for (int k = 0; k < 6; ++k) w += jb[k] * Y[k];
+            w += jl0 * Y[lo] + jl1 * Y[lo + 1] + jl2 * Y[lo + 2];
+            if (j == lane) { w += 1e-6f; wd = w; }   // constraint-force mixing keeps the diagonal positive
+        }
+        W[j] = w;
+    }
     float lam = 0.0f, lam_n = 0.0f, w = act ? rg.brow : 0.0f;
-    const float inv_d = act ? 1.0f / rg.wdiag : 0.0f;
-    const int kind = rg.row_kind;
+    const float inv_d = act ? 1.0f / wd : 0.0f;
+    const int kind = act ? rg.row_kind : -1;
     const bool fric = (kind == 1 || kind == 2);
     const int nsrc = fric ? lane - kind : -1;   // row holding this contact's normal impulse
     const float mu = sh.mu;
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-        for (int r = 0; r < LS_MAXR; ++r) {   // fully unrolled: W[r] stays in a register, r is an immediate for readlane
+        for (int r = 0; r < LS_MAXR; ++r) {   // fully unrolled: W[r] is a register, r an immediate for readlane
             if (r < R) {
                 float nl = lam - w * inv_d;
                 if (fric) { float lim = mu * lam_n; nl = clampf(nl, -lim, lim); }
@@ -450,7 +482,7 @@ LS_FN void wc_pgs(WaveShared& sh, LaneRegs& rg, int lane, int iters) {
                 float delta = ls_readlane(nl - lam, r);
                 if (lane == r) lam = nl;
                 if (nsrc == r) lam_n += delta;      // friction lanes track their normal impulse without a shuffle
-                w += rg.W[r] * delta;
+                w += W[r] * delta;
             }
         }
     }

@@ -69,8 +69,6 @@ struct WaveShared {
             float dirs[LS_MAXR][3];
         } c;
     } u;
-    float Ichip[4][36];      // composite inertia of each leg subtree
-    float A[4][36];          // Mbl Mll^-1 Mlb
     float Mbl[4][18];        // 6x3: columns F_hip, F_thigh, F_calf
     float G[4][18];          // 3x6: Mll^-1 Mlb^T
     float Lll[4][6];         // Cholesky of the 3x3 leg block (l00,l10,l11,l20,l21,l22)
@@ -117,5 +115,7 @@ struct LaneRegs {
     int row_leg;             // leg whose dofs the row touches, -1 for the base body
     float Jb[6], Jl[3];
     float brow, wdiag;
-    float W[LS_MAXR];
+#if defined(LS_EMU)
+    float W[LS_MAXR];        // Delassus row (the GPU path keeps it local to wc_delassus_pgs)
+#endif
 };
