@@ -24,6 +24,15 @@ LS_FN V3 operator*(float s, V3 a) { return v3(a.x * s, a.y * s, a.z * s); }
 LS_FN float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 LS_FN V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 LS_FN float clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+// The library is built with -fno-hip-fp32-correctly-rounded-divide-sqrt (fast v_rcp/v_rsq based division in the dynamics);
+// quotients that feed an integer truncation of the reference (grid indices, LR:1343) must stay IEEE-exact.
+LS_FN float ls_div_exact(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __fdiv_rn(a, b);
+#else
+    return a / b;
+#endif
+}
 
 // row-major 3x3
 struct M3 {

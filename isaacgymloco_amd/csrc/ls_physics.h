@@ -470,19 +470,26 @@ LS_FN void wc_delassus_pgs(WaveShared& sh, const LaneRegs& rg, int lane, int ite
     const float inv_d = act ? 1.0f / wd : 0.0f;
     const int kind = act ? rg.row_kind : -1;
     const bool fric = (kind == 1 || kind == 2);
-    const int nsrc = fric ? lane - kind : -1;   // row holding this contact's normal impulse
-    const float mu = sh.mu;
+    // bounds without per-row lane masks: lo = -cf * lam_n, hi = cf * lam_n + hi_add  (normal / limit rows: [0, +inf))
+    const float cf = fric ? sh.mu : 0.0f;
+    const float hi_add = fric ? 0.0f : __builtin_inff();
+    const int ncr = 3 * sh.nc;                 // rows [0, ncr) are contact rows laid out (normal, t1, t2) per contact
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-        for (int r = 0; r < LS_MAXR; ++r) {   // fully unrolled: W[r] is a register, r an immediate for readlane
+        for (int r = 0; r < LS_MAXR; ++r) {   // fully unrolled: W[r] is a register, r an immediate for readlane / writelane
             if (r < R) {
-                float nl = lam - w * inv_d;
-                if (fric) { float lim = mu * lam_n; nl = clampf(nl, -lim, lim); }
-                else nl = fmaxf(nl, 0.0f);
-                float delta = ls_readlane(nl - lam, r);
-                if (lane == r) lam = nl;
-                if (nsrc == r) lam_n += delta;      // friction lanes track their normal impulse without a shuffle
-                w += W[r] * delta;
+                float t = cf * lam_n;
+                float nl = fmaf(-w, inv_d, lam);
+                nl = fminf(fmaxf(nl, -t), t + hi_add);
+                float d = nl - lam;
+                const int s_nl = __builtin_amdgcn_readlane(__float_as_int(nl), r);   // only lane r's candidate is the real one
+                const float s_d = ls_readlane(d, r);
+                lam = __int_as_float(__builtin_amdgcn_writelane(s_nl, r, __float_as_int(lam)));
+                if ((r % 3) == 0 && r + 2 < LS_MAXR && r < ncr) {   // a normal row: hand its impulse to its two friction rows
+                    lam_n = __int_as_float(__builtin_amdgcn_writelane(s_nl, r + 1, __float_as_int(lam_n)));
+                    lam_n = __int_as_float(__builtin_amdgcn_writelane(s_nl, r + 2, __float_as_int(lam_n)));
+                }
+                w = fmaf(W[r], s_d, w);
             }
         }
     }

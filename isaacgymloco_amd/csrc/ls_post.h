@@ -17,8 +17,8 @@ LS_FN float ls_sample_height_min3(const LsCtx& cx, float x, float y) {
 #pragma clang fp contract(off)
 #endif
     const lsim_config& c = cx.cfg;
-    float fx = (x + c.border_size) / c.horizontal_scale;
-    float fy = (y + c.border_size) / c.horizontal_scale;
+    float fx = ls_div_exact(x + c.border_size, c.horizontal_scale);
+    float fy = ls_div_exact(y + c.border_size, c.horizontal_scale);
     int px = (int)fx, py = (int)fy;
     px = px < 0 ? 0 : (px > c.grid_rows - 2 ? c.grid_rows - 2 : px);
     py = py < 0 ? 0 : (py > c.grid_cols - 2 ? c.grid_cols - 2 : py);
@@ -202,7 +202,7 @@ LS_FN float ls_foot_clearance_terrain(const LsCtx& cx, const WaveShared& sh, int
         else {
             float px = bs[0], py = bs[1], pz = bs[2];
             for (int s = 0; s < shifts; ++s) { px += c.border_size; py += c.border_size; pz += c.border_size; }
-            int ix = (int)(px / c.horizontal_scale), iy = (int)(py / c.horizontal_scale);
+            int ix = (int)ls_div_exact(px, c.horizontal_scale), iy = (int)ls_div_exact(py, c.horizontal_scale);
             ix = ix < 0 ? 0 : (ix > c.grid_rows - 2 ? c.grid_rows - 2 : ix);
             iy = iy < 0 ? 0 : (iy > c.grid_cols - 2 ? c.grid_cols - 2 : iy);
             const int16_t* g = LSB(cx, LSIM_BUF_HEIGHT_GRID, const int16_t);

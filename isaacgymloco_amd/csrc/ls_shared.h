@@ -54,13 +54,25 @@ struct WaveShared {
     float comd[3], pend[3];
     int delay;
     LsBodyLds body[LS_NB];
-    // ---- kinematics / dynamics of the current sub-step (world axes, positions relative to the base origin)
-    float R[LS_NB][9];
-    float p[LS_NB][3];
-    float S[12][6];          // motion subspace per dof
-    float V[LS_NB][6];       // body twists
-    float Ab[LS_NB][6];      // bias accelerations
-    float Fb[LS_NB][6];      // bias forces (per body, then leg totals in legF)
+    // ---- kinematics / dynamics of the current sub-step (world axes, positions relative to the base origin), overlaid
+    //      with the post-physics scratch that is only used once the last sub-step is over (keeps the block <= 10 KB so
+    //      that 16 robots per CU -- all 4096 of a 256-CU launch -- are resident at once)
+    union {
+        struct {
+            float R[LS_NB][9];
+            float p[LS_NB][3];
+            float S[12][6];          // motion subspace per dof
+            float V[LS_NB][6];       // body twists
+            float Ab[LS_NB][6];      // bias accelerations
+            float Fb[LS_NB][6];      // bias forces (per body, then leg totals in legF)
+        };
+        struct {
+            float heights[LSIM_NUM_HEIGHT_PTS];
+            float bh[LSIM_NUM_BASE_HEIGHT_PTS];
+            float cur[LSIM_NUM_PRIV_OBS];
+            float rewv[LSIM_NUM_REWARD_TERMS];
+        };
+    };
     float com0[3];           // base COM (world axes)
     union {
         float I6[LS_NB][36];                 // spatial inertias (dead after the composite pass)
@@ -95,11 +107,7 @@ struct WaveShared {
     float feet[4][6];        // world position / linear velocity of the feet (rows of rigid_body_states)
     float ranges[8];         // live command ranges [4][2]
     int eplen, do_reset, any_reset;
-    float heights[LSIM_NUM_HEIGHT_PTS];
-    float bh[LSIM_NUM_BASE_HEIGHT_PTS];
     float disturbance[3];
-    float cur[LSIM_NUM_PRIV_OBS];
-    float rewv[LSIM_NUM_REWARD_TERMS];
     int reset, timeout;
 };
 

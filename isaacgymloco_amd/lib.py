@@ -5,7 +5,8 @@ import os
 
 from . import abi
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "liblsim.so")
+# LSIM_LIB selects another build of the same HIP library (A/B experiments on kernel variants); never a fallback
+LIB_PATH = os.environ.get("LSIM_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "liblsim.so")
 _lib = None
 
 
