@@ -324,6 +324,10 @@ enum lsim_buffer_id {
     LSIM_BUF_STATS,              /* f32 [2,LSIM_STATS_SIZE] device-side per-step reductions, see below */
     LSIM_BUF_HEIGHT_GRID,        /* i16 [rows,cols] */
     LSIM_BUF_TERRAIN_ORIGINS,    /* f32 [levels,types,3] */
+    LSIM_BUF_TERRAIN_MESH,       /* i32 [rows,cols] per grid vertex of the reference's triangle mesh: bits 0-15 = height sample (int16);
+                                    bits 16-17 = dx+1, bits 18-19 = dy+1 (horizontal displacement of the vertex, in cells: the
+                                    slope_treshold vertical-wall correction, TER:72-75); bit 20 = some vertex of the 4x4 block around
+                                    cell (i,j) is displaced (contacts there use the exact triangle query) */
     LSIM_NUM_BUFFERS
 };
 

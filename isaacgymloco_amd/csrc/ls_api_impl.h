@@ -72,6 +72,42 @@ static int ls_upload(lsim_sim* s, int id, const std::vector<T>& v) {
     return lsbk_h2d(s->arena + s->offsets[id], v.data(), v.size() * sizeof(T));
 }
 
+// Vertex displacement of the reference's triangle mesh (isaacgym.terrain_utils.convert_heightfield_to_trimesh as called at
+// TER:72-75 with slope_treshold): where the height difference to a neighbour exceeds the threshold the LOWER vertex is moved
+// one cell towards the higher one, which turns the steep face into a vertical wall.  mesh_type heightfield: no correction.
+static std::vector<int32_t> ls_terrain_mesh(const lsim_config& c, const int16_t* hf) {
+    const int R = c.grid_rows, C = c.grid_cols;
+    std::vector<int32_t> out((size_t)R * C);
+    for (size_t k = 0; k < out.size(); ++k) out[k] = (int32_t)((uint32_t)(uint16_t)hf[k] | (5u << 16));
+    if (c.mesh_type != 2 || c.slope_threshold <= 0.0f) return out;
+    const float thr = c.slope_threshold * c.horizontal_scale / c.vertical_scale;
+    auto H = [&](int i, int j) { return (float)hf[(size_t)i * C + j]; };
+    std::vector<int8_t> dx((size_t)R * C, 0), dy((size_t)R * C, 0);
+    for (int i = 0; i < R; ++i)
+        for (int j = 0; j < C; ++j) {
+            int mx = 0, my = 0, mc = 0;
+            if (i + 1 < R && H(i + 1, j) - H(i, j) > thr) mx += 1;
+            if (i - 1 >= 0 && H(i - 1, j) - H(i, j) > thr) mx -= 1;
+            if (j + 1 < C && H(i, j + 1) - H(i, j) > thr) my += 1;
+            if (j - 1 >= 0 && H(i, j - 1) - H(i, j) > thr) my -= 1;
+            if (i + 1 < R && j + 1 < C && H(i + 1, j + 1) - H(i, j) > thr) mc += 1;
+            if (i - 1 >= 0 && j - 1 >= 0 && H(i - 1, j - 1) - H(i, j) > thr) mc -= 1;
+            dx[(size_t)i * C + j] = (int8_t)(mx + (mx == 0 ? mc : 0));
+            dy[(size_t)i * C + j] = (int8_t)(my + (my == 0 ? mc : 0));
+        }
+    for (int i = 0; i < R; ++i)
+        for (int j = 0; j < C; ++j) {
+            uint8_t f = (uint8_t)((dx[(size_t)i * C + j] + 1) | ((dy[(size_t)i * C + j] + 1) << 2));
+            bool any = false;
+            for (int a = i - 1; a <= i + 2 && !any; ++a)
+                for (int b = j - 1; b <= j + 2; ++b)
+                    if (a >= 0 && a < R && b >= 0 && b < C && (dx[(size_t)a * C + b] != 0 || dy[(size_t)a * C + b] != 0)) { any = true; break; }
+            if (any) f |= 16;
+            out[(size_t)i * C + j] = (int32_t)((uint32_t)(uint16_t)hf[(size_t)i * C + j] | ((uint32_t)f << 16));
+        }
+    return out;
+}
+
 extern "C" int LS_API(create)(const lsim_config* cfg, const lsim_robot_model* model, const int16_t* height_grid,
                               const float* terrain_origins, void* arena_dev, int device_id, lsim_sim** out) {
     if (!cfg || !model || !out) return LSIM_E_INVALID;
@@ -131,6 +167,8 @@ extern "C" int LS_API(create)(const lsim_config* cfg, const lsim_robot_model* mo
     bad |= ls_upload(s, LSIM_BUF_TERRAIN_LEVELS, lvl); bad |= ls_upload(s, LSIM_BUF_TERRAIN_TYPES, typ); bad |= ls_upload(s, LSIM_BUF_RESET, rst);
     bad |= ls_upload(s, LSIM_BUF_STATS, stats);
     if (c.mesh_type != 0) {
+        std::vector<int32_t> mesh = ls_terrain_mesh(c, height_grid);
+        bad |= ls_upload(s, LSIM_BUF_TERRAIN_MESH, mesh);
         bad |= lsbk_h2d(s->arena + s->offsets[LSIM_BUF_HEIGHT_GRID], height_grid, lsim_buffer_bytes(&c, LSIM_BUF_HEIGHT_GRID));
         bad |= lsbk_h2d(s->arena + s->offsets[LSIM_BUF_TERRAIN_ORIGINS], terrain_origins, lsim_buffer_bytes(&c, LSIM_BUF_TERRAIN_ORIGINS));
     }

@@ -272,16 +272,111 @@ LS_FN void ls_tangent_basis(V3 n, V3& t1, V3& t2) {
     t2 = cross(n, t1);
 }
 
+// closest point of triangle (a,b,c) to p (Ericson, Real-Time Collision Detection 5.1.5)
+LS_FN V3 ls_closest_on_triangle(V3 p, V3 a, V3 b, V3 c) {
+    V3 ab = b - a, ac = c - a, ap = p - a;
+    float d1 = dot(ab, ap), d2 = dot(ac, ap);
+    if (d1 <= 0.0f && d2 <= 0.0f) return a;
+    V3 bp = p - b;
+    float d3 = dot(ab, bp), d4 = dot(ac, bp);
+    if (d3 >= 0.0f && d4 <= d3) return b;
+    float vc = d1 * d4 - d3 * d2;
+    if (vc <= 0.0f && d1 >= 0.0f && d3 <= 0.0f) return a + ab * (d1 / fmaxf(d1 - d3, 1e-20f));
+    V3 cp = p - c;
+    float d5 = dot(ab, cp), d6 = dot(ac, cp);
+    if (d6 >= 0.0f && d5 <= d6) return c;
+    float vb = d5 * d2 - d1 * d6;
+    if (vb <= 0.0f && d2 >= 0.0f && d6 <= 0.0f) return a + ac * (d2 / fmaxf(d2 - d6, 1e-20f));
+    float va = d3 * d6 - d5 * d4;
+    if (va <= 0.0f && (d4 - d3) >= 0.0f && (d5 - d6) >= 0.0f) return b + (c - b) * ((d4 - d3) / fmaxf((d4 - d3) + (d5 - d6), 1e-20f));
+    float denom = 1.0f / fmaxf(va + vb + vc, 1e-20f);
+    return a + ab * (vb * denom) + ac * (vc * denom);
+}
+
+// world position of a vertex of the reference's triangle mesh from its packed word (LSIM_BUF_TERRAIN_MESH)
+LS_FN V3 ls_mesh_vertex(const lsim_config& c, int word, int a, int b) {
+    float dx = (float)(((word >> 16) & 3) - 1), dy = (float)(((word >> 18) & 3) - 1);
+    return v3(((float)a + dx) * c.horizontal_scale - c.border_size, ((float)b + dy) * c.horizontal_scale - c.border_size,
+              (float)(int16_t)(word & 0xFFFF) * c.vertical_scale);
+}
+
+// signed distance (negative inside the ground) and contact normal of a sphere centre against the terrain.
+//   fast path: plane of the grid triangle under the point (exact where no vertex of the 4x4 block is displaced);
+//   wall path: closest point over the triangles of the 3x3 cells around the point in the displaced mesh (TER:72-75).  Only
+//   features within reach = radius + contact_offset can make a contact, so cells whose bounding box (grown by reach in x/y,
+//   and in +z) excludes the centre are skipped, as are triangles whose plane lies more than reach below the centre.
+LS_FN void ls_terrain_contact(const LsCtx& cx, V3 cw, float radius, float& dist, V3& n) {
+    const lsim_config& c = cx.cfg;
+    if (c.mesh_type == 0) { dist = cw.z; n = v3(0, 0, 1); return; }
+    const int* mesh = (const int*)cx.buf[LSIM_BUF_TERRAIN_MESH];
+    const float hs = c.horizontal_scale, vs = c.vertical_scale;
+    float gx = (cw.x + c.border_size) / hs, gy = (cw.y + c.border_size) / hs;
+    float fi = clampf(floorf(gx), 0.0f, (float)(c.grid_rows - 2)), fj = clampf(floorf(gy), 0.0f, (float)(c.grid_cols - 2));
+    int i = (int)fi, j = (int)fj;
+    const int w00 = mesh[i * c.grid_cols + j];
+#if defined(LS_NO_WALLS)   // A/B experiments only
+    const bool walls = false;
+#else
+    const bool walls = (w00 & (1 << 20)) != 0;
+#endif
+    if (!walls) {
+        float h00 = (float)(int16_t)(w00 & 0xFFFF) * vs, h10 = (float)(int16_t)(mesh[(i + 1) * c.grid_cols + j] & 0xFFFF) * vs;
+        float h01 = (float)(int16_t)(mesh[i * c.grid_cols + j + 1] & 0xFFFF) * vs;
+        float h11 = (float)(int16_t)(mesh[(i + 1) * c.grid_cols + j + 1] & 0xFFFF) * vs;
+        float u = clampf(gx - fi, 0.0f, 1.0f), v = clampf(gy - fj, 0.0f, 1.0f);
+        float dhx, dhy, h;
+        if (u >= v) { dhx = h10 - h00; dhy = h11 - h10; h = h00 + u * dhx + v * dhy; }
+        else { dhx = h11 - h01; dhy = h01 - h00; h = h00 + v * dhy + u * dhx; }
+        float nx = -dhx / hs, ny = -dhy / hs, inv = 1.0f / sqrtf(nx * nx + ny * ny + 1.0f);
+        n = v3(nx * inv, ny * inv, inv);
+        dist = (cw.z - h) * inv;
+        return;
+    }
+    const float reach = radius + c.contact_offset;
+    float best = 1e30f;
+    V3 bq = v3(0, 0, 0), bn = v3(0, 0, 1);
+    for (int ci = i - 1; ci <= i + 1; ++ci)
+        for (int cj = j - 1; cj <= j + 1; ++cj) {
+            if (ci < 0 || cj < 0 || ci > c.grid_rows - 2 || cj > c.grid_cols - 2) continue;
+            const int* row = mesh + ci * c.grid_cols + cj;
+            V3 p00 = ls_mesh_vertex(c, row[0], ci, cj), p10 = ls_mesh_vertex(c, row[c.grid_cols], ci + 1, cj);
+            V3 p01 = ls_mesh_vertex(c, row[1], ci, cj + 1), p11 = ls_mesh_vertex(c, row[c.grid_cols + 1], ci + 1, cj + 1);
+            float xlo = fminf(fminf(p00.x, p10.x), fminf(p01.x, p11.x)), xhi = fmaxf(fmaxf(p00.x, p10.x), fmaxf(p01.x, p11.x));
+            float ylo = fminf(fminf(p00.y, p10.y), fminf(p01.y, p11.y)), yhi = fmaxf(fmaxf(p00.y, p10.y), fmaxf(p01.y, p11.y));
+            float zhi = fmaxf(fmaxf(p00.z, p10.z), fmaxf(p01.z, p11.z));
+            if (cw.x < xlo - reach || cw.x > xhi + reach || cw.y < ylo - reach || cw.y > yhi + reach || cw.z > zhi + reach) continue;
+            for (int t = 0; t < 2; ++t) {
+                V3 a = p00, b = t == 0 ? p11 : p10, cc = t == 0 ? p01 : p11;   // (ind0,ind3,ind1) and (ind0,ind2,ind3)
+                V3 nt = cross(b - a, cc - a);
+                float nl2 = dot(nt, nt);
+                if (nl2 < 1e-16f) continue;                                   // collapsed triangle
+                float nl = sqrtf(nl2);
+                if (dot(nt, cw - a) > reach * nl) continue;                   // plane out of reach below the centre
+                V3 q = ls_closest_on_triangle(cw, a, b, cc);
+                V3 dq = cw - q;
+                float d2 = dot(dq, dq);
+                if (d2 < best) { best = d2; bq = q; bn = nt * (1.0f / nl); }
+            }
+        }
+    if (best > 1e29f) { dist = 1.0f + radius; n = v3(0, 0, 1); return; }
+    float d = sqrtf(best);
+    V3 dq = cw - bq;
+    float side = dot(bn, dq);
+    if (side < -1e-6f) { dist = -d; n = bn; }                  // centre behind the face: inside the ground
+    else if (d > 1e-6f) { dist = d; n = dq * (1.0f / d); }
+    else { dist = 0.0f; n = bn; }
+}
+
 // ---- phase P: narrow phase, one collision point per lane
 LS_FN void ph_collide(const LsCtx& cx, WaveShared& sh, LaneRegs& r, int lane) {
     r.cp_active = 0;
     if (lane >= cx.model.num_collision_points) return;
     int b = r.cp_body;
     V3 pw = mul(m3p(sh.R[b]), v3p(r.cp_pos)) + v3p(sh.p[b]);
-    float h;
+    float d;
     V3 n;
-    ls_terrain_query(cx, sh.root[0] + pw.x, sh.root[1] + pw.y, h, n);
-    float dist = (sh.root[2] + pw.z - h) * n.z - r.cp_r;
+    ls_terrain_contact(cx, v3(sh.root[0] + pw.x, sh.root[1] + pw.y, sh.root[2] + pw.z), r.cp_r, d, n);
+    float dist = d - r.cp_r;
     if (dist < cx.cfg.contact_offset) {
         r.cp_active = 1;
         r.cp_dist = dist;
@@ -482,13 +577,14 @@ LS_FN void wc_delassus_pgs(WaveShared& sh, const LaneRegs& rg, int lane, int ite
                 float nl = fmaf(-w, inv_d, lam);
                 nl = fminf(fmaxf(nl, -t), t + hi_add);
                 float d = nl - lam;
-                const int s_nl = __builtin_amdgcn_readlane(__float_as_int(nl), r);   // only lane r's candidate is the real one
+                const float s_nl = ls_readlane(nl, r);       // only lane r's candidate is the real one
                 const float s_d = ls_readlane(d, r);
-                lam = __int_as_float(__builtin_amdgcn_writelane(s_nl, r, __float_as_int(lam)));
-                if ((r % 3) == 0 && r + 2 < LS_MAXR && r < ncr) {   // a normal row: hand its impulse to its two friction rows
-                    lam_n = __int_as_float(__builtin_amdgcn_writelane(s_nl, r + 1, __float_as_int(lam_n)));
-                    lam_n = __int_as_float(__builtin_amdgcn_writelane(s_nl, r + 2, __float_as_int(lam_n)));
-                }
+                int lid = lane;
+                asm volatile("" : "+v"(lid));                 // opaque copy: keeps the 36 (lane == r) masks from being hoisted
+                                                              // out of the iteration loop into (spilled) SGPR pairs
+                lam = (lid == r) ? s_nl : lam;
+                if ((r % 3) == 0 && r < ncr)                  // a normal row: hand its impulse to its two friction rows
+                    lam_n = ((unsigned)(lid - (r + 1)) < 2u) ? s_nl : lam_n;
                 w = fmaf(W[r], s_d, w);
             }
         }

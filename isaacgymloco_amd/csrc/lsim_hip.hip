@@ -27,7 +27,10 @@ __device__ __forceinline__ int ls_env_of_block(int b, int num_envs) {
     return (b & 7) * chunk + (b >> 3);
 }
 
-__global__ __launch_bounds__(64) void lsim_k_step_a(const LsCtx* __restrict__ ctx, LsStepArgs a) {
+// Kernel A is VALU-issue bound with ~45 % of wave cycles waiting on LDS/memory: 4 waves per SIMD (<= 128 VGPRs, a few dozen
+// spilled to scratch in the PGS sweep) beat 1-2 waves with everything in registers by 1.35x at N = 4096, where 4 waves/SIMD
+// is also exactly the whole batch resident at once (4096 waves / 1024 SIMDs; the 9.1 KB LDS struct allows 17 blocks per CU).
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void lsim_k_step_a(const LsCtx* __restrict__ ctx, LsStepArgs a) {
     __shared__ WaveShared sh;
     const int env = ls_env_of_block((int)blockIdx.x, ctx->cfg.num_envs);
     if (env >= ctx->cfg.num_envs) return;

@@ -29,7 +29,7 @@ typedef struct orc_sim {
 void orc_physics_substep(orc_sim* s, int e, const float tau[12], int apply_force);
 /* recompute rigid_body_states of env e from root/dof state (forward kinematics + velocities) */
 void orc_refresh_body_states(orc_sim* s, int e);
-/* terrain surface query used by the contact model: height and unit normal under world point (x,y) */
-void orc_terrain_query(const orc_sim* s, double x, double y, double* h, double n[3]);
+/* terrain contact query: signed distance of a world point to the (slope-corrected) terrain mesh, and the contact normal */
+void orc_terrain_contact(const orc_sim* s, const double cw[3], double radius, double* dist, double n[3]);
 
 #endif

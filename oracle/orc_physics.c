@@ -113,27 +113,133 @@ static void spatial_inertia(double mass, const double c[3], const double Ic[9], 
     }
 }
 
-/* triangulated height grid (diagonal (i,j)-(i+1,j+1), as isaacgym.terrain_utils.convert_heightfield_to_trimesh
- * orders its triangles); v1 contact surface: no vertical-wall correction (DESIGN.md "Terrain contact") */
-void orc_terrain_query(const orc_sim* s, double x, double y, double* h, double n[3]) {
+/* ---- terrain contact -----------------------------------------------------------------------------------------------
+ * The reference collides against the triangle mesh isaacgym.terrain_utils.convert_heightfield_to_trimesh builds from the
+ * height grid with slope_treshold (TER:72-75): per grid cell two triangles, diagonal (i,j)-(i+1,j+1); where the height step
+ * to a neighbour exceeds the threshold the LOWER vertex is moved one cell towards the higher one (vertical wall).
+ * orc_vertex_moves restates that published vertex rule; the query is an independent (double precision, projection +
+ * edge-distance) statement of "signed distance of a point to the displaced mesh". */
+static void orc_vertex_move(const orc_sim* s, int i, int j, int* mx_out, int* my_out) {
     const lsim_config* c = &s->cfg;
-    if (c->mesh_type == 0) { *h = 0; n[0] = n[1] = 0; n[2] = 1; return; }
+    const int16_t* g = ORC_I16(s, LSIM_BUF_HEIGHT_GRID);
+    const int R = c->grid_rows, C = c->grid_cols;
+    *mx_out = *my_out = 0;
+    if (c->mesh_type != 2 || c->slope_threshold <= 0.0f) return;
+    const double thr = (double)c->slope_threshold * c->horizontal_scale / c->vertical_scale;
+    double h = g[i * C + j];
+    int mx = 0, my = 0, mc = 0;
+    if (i + 1 < R && g[(i + 1) * C + j] - h > thr) mx += 1;
+    if (i >= 1 && g[(i - 1) * C + j] - h > thr) mx -= 1;
+    if (j + 1 < C && g[i * C + j + 1] - h > thr) my += 1;
+    if (j >= 1 && g[i * C + j - 1] - h > thr) my -= 1;
+    if (i + 1 < R && j + 1 < C && g[(i + 1) * C + j + 1] - h > thr) mc += 1;
+    if (i >= 1 && j >= 1 && g[(i - 1) * C + j - 1] - h > thr) mc -= 1;
+    *mx_out = mx + (mx == 0 ? mc : 0);
+    *my_out = my + (my == 0 ? mc : 0);
+}
+static void mesh_vertex(const orc_sim* s, int a, int b, double v[3]) {
+    const lsim_config* c = &s->cfg;
+    int mx, my;
+    orc_vertex_move(s, a, b, &mx, &my);
+    v[0] = (a + mx) * (double)c->horizontal_scale - c->border_size;
+    v[1] = (b + my) * (double)c->horizontal_scale - c->border_size;
+    v[2] = ORC_I16(s, LSIM_BUF_HEIGHT_GRID)[a * c->grid_cols + b] * (double)c->vertical_scale;
+}
+static double seg_closest(const double p[3], const double a[3], const double b[3], double q[3]) {
+    double ab[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, ap[3] = {p[0] - a[0], p[1] - a[1], p[2] - a[2]};
+    double l2 = v3dot(ab, ab), t = l2 > 0 ? v3dot(ap, ab) / l2 : 0.0;
+    if (t < 0) t = 0; if (t > 1) t = 1;
+    for (int k = 0; k < 3; ++k) q[k] = a[k] + t * ab[k];
+    double d[3] = {p[0] - q[0], p[1] - q[1], p[2] - q[2]};
+    return v3dot(d, d);
+}
+/* squared distance and closest point of a triangle; returns 0 for collapsed triangles */
+static int tri_closest(const double p[3], const double a[3], const double b[3], const double c[3], double q[3], double nrm[3], double* d2) {
+    double ab[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, ac[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]}, n[3];
+    v3cross(ab, ac, n);
+    double nl2 = v3dot(n, n);
+    if (nl2 < 1e-16) return 0;
+    double nl = sqrt(nl2);
+    for (int k = 0; k < 3; ++k) nrm[k] = n[k] / nl;
+    double ap[3] = {p[0] - a[0], p[1] - a[1], p[2] - a[2]};
+    double dist = v3dot(ap, nrm), proj[3];
+    for (int k = 0; k < 3; ++k) proj[k] = p[k] - dist * nrm[k];
+    /* barycentric test of the projection */
+    double v0[3] = {proj[0] - a[0], proj[1] - a[1], proj[2] - a[2]};
+    double d00 = v3dot(ab, ab), d01 = v3dot(ab, ac), d11 = v3dot(ac, ac), d20 = v3dot(v0, ab), d21 = v3dot(v0, ac);
+    double den = d00 * d11 - d01 * d01;
+    double v = (d11 * d20 - d01 * d21) / den, w = (d00 * d21 - d01 * d20) / den;
+    if (v >= 0 && w >= 0 && v + w <= 1) { memcpy(q, proj, sizeof(proj)); *d2 = dist * dist; return 1; }
+    double q1[3], q2[3], q3[3];
+    double e1 = seg_closest(p, a, b, q1), e2 = seg_closest(p, b, c, q2), e3 = seg_closest(p, c, a, q3);
+    if (e1 <= e2 && e1 <= e3) { memcpy(q, q1, sizeof(q1)); *d2 = e1; }
+    else if (e2 <= e3) { memcpy(q, q2, sizeof(q2)); *d2 = e2; }
+    else { memcpy(q, q3, sizeof(q3)); *d2 = e3; }
+    return 1;
+}
+static int cell_has_walls(const orc_sim* s, int i, int j) {
+    const lsim_config* c = &s->cfg;
+    for (int a = i - 1; a <= i + 2; ++a)
+        for (int b = j - 1; b <= j + 2; ++b) {
+            if (a < 0 || b < 0 || a >= c->grid_rows || b >= c->grid_cols) continue;
+            int mx, my;
+            orc_vertex_move(s, a, b, &mx, &my);
+            if (mx || my) return 1;
+        }
+    return 0;
+}
+/* signed distance of world point cw to the terrain surface (negative inside) and contact normal */
+void orc_terrain_contact(const orc_sim* s, const double cw[3], double radius, double* dist, double n[3]) {
+    const lsim_config* c = &s->cfg;
+    if (c->mesh_type == 0) { *dist = cw[2]; n[0] = n[1] = 0; n[2] = 1; return; }
     double hs = c->horizontal_scale, vs = c->vertical_scale;
-    double gx = (x + c->border_size) / hs, gy = (y + c->border_size) / hs;
+    double gx = (cw[0] + c->border_size) / hs, gy = (cw[1] + c->border_size) / hs;
     double fi = floor(gx), fj = floor(gy);
     if (fi < 0) fi = 0; if (fi > c->grid_rows - 2) fi = c->grid_rows - 2;
     if (fj < 0) fj = 0; if (fj > c->grid_cols - 2) fj = c->grid_cols - 2;
     int i = (int)fi, j = (int)fj;
-    double u = gx - fi, v = gy - fj;
-    if (u < 0) u = 0; if (u > 1) u = 1; if (v < 0) v = 0; if (v > 1) v = 1;
     const int16_t* g = ORC_I16(s, LSIM_BUF_HEIGHT_GRID);
     double h00 = g[i * c->grid_cols + j] * vs, h10 = g[(i + 1) * c->grid_cols + j] * vs;
     double h01 = g[i * c->grid_cols + j + 1] * vs, h11 = g[(i + 1) * c->grid_cols + j + 1] * vs;
-    double dhx, dhy;
-    if (u >= v) { dhx = h10 - h00; dhy = h11 - h10; *h = h00 + u * dhx + v * dhy; }
-    else { dhx = h11 - h01; dhy = h01 - h00; *h = h00 + v * dhy + u * dhx; }
-    double nx = -dhx / hs, ny = -dhy / hs, inv = 1.0 / sqrt(nx * nx + ny * ny + 1.0);
-    n[0] = nx * inv; n[1] = ny * inv; n[2] = inv;
+    if (!cell_has_walls(s, i, j)) { /* plane of the grid triangle under the point */
+        double u = gx - fi, v = gy - fj, h, dhx, dhy;
+        if (u < 0) u = 0; if (u > 1) u = 1; if (v < 0) v = 0; if (v > 1) v = 1;
+        if (u >= v) { dhx = h10 - h00; dhy = h11 - h10; h = h00 + u * dhx + v * dhy; }
+        else { dhx = h11 - h01; dhy = h01 - h00; h = h00 + v * dhy + u * dhx; }
+        double nx = -dhx / hs, ny = -dhy / hs, inv = 1.0 / sqrt(nx * nx + ny * ny + 1.0);
+        n[0] = nx * inv; n[1] = ny * inv; n[2] = inv;
+        *dist = (cw[2] - h) * inv;
+        return;
+    }
+    /* only features within reach = radius + contact_offset can make a contact: cells whose bounding box grown by reach (x, y, +z)
+     * excludes the centre are skipped, and triangles whose plane lies more than reach below the centre */
+    const double reach = radius + (double)c->contact_offset;
+    double best = 1e30, bq[3] = {0, 0, 0}, bn[3] = {0, 0, 1};
+    for (int ci = i - 1; ci <= i + 1; ++ci)
+        for (int cj = j - 1; cj <= j + 1; ++cj) {
+            if (ci < 0 || cj < 0 || ci > c->grid_rows - 2 || cj > c->grid_cols - 2) continue;
+            double p00[3], p10[3], p01[3], p11[3], q[3], nt[3], d2;
+            mesh_vertex(s, ci, cj, p00); mesh_vertex(s, ci + 1, cj, p10); mesh_vertex(s, ci, cj + 1, p01); mesh_vertex(s, ci + 1, cj + 1, p11);
+            int out = cw[2] > fmax(fmax(p00[2], p10[2]), fmax(p01[2], p11[2])) + reach;
+            for (int k = 0; k < 2; ++k) {
+                double lo = fmin(fmin(p00[k], p10[k]), fmin(p01[k], p11[k])), hi = fmax(fmax(p00[k], p10[k]), fmax(p01[k], p11[k]));
+                if (cw[k] < lo - reach || cw[k] > hi + reach) out = 1;
+            }
+            if (out) continue;
+            const double* tri[2][2] = {{p11, p01}, {p10, p11}};
+            for (int t = 0; t < 2; ++t) {
+                if (!tri_closest(cw, p00, tri[t][0], tri[t][1], q, nt, &d2)) continue;
+                double ap[3] = {cw[0] - p00[0], cw[1] - p00[1], cw[2] - p00[2]};
+                if (v3dot(nt, ap) > reach) continue;
+                if (d2 < best) { best = d2; memcpy(bq, q, sizeof(q)); memcpy(bn, nt, sizeof(nt)); }
+            }
+        }
+    if (best > 1e29) { *dist = 1.0 + radius; n[0] = n[1] = 0; n[2] = 1; return; }
+    double d = sqrt(best), dq[3] = {cw[0] - bq[0], cw[1] - bq[1], cw[2] - bq[2]};
+    double side = v3dot(bn, dq);
+    if (side < -1e-6) { *dist = -d; memcpy(n, bn, sizeof(bn)); }
+    else if (d > 1e-6) { *dist = d; for (int k = 0; k < 3; ++k) n[k] = dq[k] / d; }
+    else { *dist = 0; memcpy(n, bn, sizeof(bn)); }
 }
 
 static void tangent_basis(const double n[3], double t1[3], double t2[3]) {
@@ -314,9 +420,9 @@ void orc_physics_substep(orc_sim* s, int e, const float tau_f[12], int apply_for
         double pl[3] = {cp->pos[0], cp->pos[1], cp->pos[2]}, pw[3];
         m3v(X[cp->body].R, pl, pw);
         for (int k = 0; k < 3; ++k) pw[k] += X[cp->body].p[k];
-        double hh, n[3];
-        orc_terrain_query(s, p0[0] + pw[0], p0[1] + pw[1], &hh, n);
-        double dist = (p0[2] + pw[2] - hh) * n[2] - cp->radius;
+        double dsurf, n[3], cw[3] = {p0[0] + pw[0], p0[1] + pw[1], p0[2] + pw[2]};
+        orc_terrain_contact(s, cw, cp->radius, &dsurf, n);
+        double dist = dsurf - cp->radius;
         if (dist < c->contact_offset) {
             cbody[nc] = cp->body; cdist[nc] = dist;
             for (int k = 0; k < 3; ++k) { cn[nc][k] = n[k]; cpos[nc][k] = pw[k] - n[k] * cp->radius; }

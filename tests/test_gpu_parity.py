@@ -45,6 +45,63 @@ def test_hip_physics_matches_oracle(quiet):
         np.testing.assert_allclose(be.get("obs"), orc.buf["obs"], atol=5e-3, rtol=1e-3, err_msg=f"step {t}")
 
 
+def test_hip_stairs_wall_contacts_match_oracle():
+    """Stairs (slope-corrected mesh with vertical risers, TER:72-75): robots dropped all over the staircases.  States are
+    re-synchronised every step; float-vs-double decisions at triangle edges may differ for single env-steps, so the bar is
+    >= 97 % of env-steps with identical termination flag AND state within the fp32 tolerance."""
+    from hip_backend import HipBackend
+    N = 32
+    cfg = C.TASKS["aliengo_stairs"][0]()
+    cfg.terrain.terrain_proportions = [0, 0, 0, 0, 0.5, 0.5]
+    cfg.domain_rand.base_init_pos_range = dict(x=[-3.0, 3.0], y=[-3.0, 3.0], z=[0.0, 0.3])
+    orc, lc, model, ter = make_oracle(cfg, N, seed=3)
+    be = HipBackend(cfg, N, ter, seed=3)
+    mesh = be.get("terrain_mesh")
+    np.testing.assert_array_equal((mesh >> 16) & 0xFF, _flags_numpy(ter.heightsamples, cfg))
+    np.testing.assert_array_equal((mesh & 0xFFFF).astype(np.uint16).view(np.int16), ter.heightsamples)
+    orc.reset_all(); be.reset_all()
+    rs = np.random.RandomState(0)
+    ok = tot = 0
+    lateral = 0.0
+    for t in range(40):
+        a = rs.normal(0, 1, (N, 12)).astype(np.float32)
+        for k in ("root_states", "dof_state", "commands", "last_actions", "episode_length", "terrain_levels", "env_origins", "kp_factors",
+                  "kd_factors", "friction", "pending_force", "feet_air_time", "last_contacts", "episode_sums", "obs", "last_dof_vel"):
+            be.put(k, orc.buf[k])
+        orc.step(a); be.step(a)
+        same = be.get("reset") == orc.buf["reset"]          # a 1 N termination threshold on a chaotic contact force can flip
+        e_root = np.abs(be.get("root_states") - orc.buf["root_states"]).max(1)
+        e_dof = np.abs(be.get("dof_state") - orc.buf["dof_state"]).reshape(N, -1).max(1)
+        ok += int((same & (e_root < 2e-3) & (e_dof < 2e-2)).sum()); tot += N
+        feet = be.get("contact_forces")[:, [4, 8, 12, 16], :]
+        lat = np.linalg.norm(feet[..., :2], axis=-1)
+        if (lat > 5).any():
+            lateral = max(lateral, float((lat / (np.abs(feet[..., 2]) + 1e-6))[lat > 5].max()))
+    assert ok >= 0.97 * tot, (ok, tot)
+    assert lateral > 5.0, "risers must be able to produce mostly-horizontal foot forces (feet_stumble, LR:1589-1599)"
+
+
+def _flags_numpy(hf, cfg):
+    """numpy restatement of the vertex displacement rule (third implementation, for the flag buffer)"""
+    hf = hf.astype(np.float64)
+    R, Cc = hf.shape
+    thr = cfg.terrain.slope_treshold * cfg.terrain.horizontal_scale / cfg.terrain.vertical_scale
+    mx = np.zeros((R, Cc)); my = np.zeros((R, Cc)); mc = np.zeros((R, Cc))
+    mx[:R - 1, :] += hf[1:, :] - hf[:R - 1, :] > thr
+    mx[1:, :] -= hf[:R - 1, :] - hf[1:, :] > thr
+    my[:, :Cc - 1] += hf[:, 1:] - hf[:, :Cc - 1] > thr
+    my[:, 1:] -= hf[:, :Cc - 1] - hf[:, 1:] > thr
+    mc[:R - 1, :Cc - 1] += hf[1:, 1:] - hf[:R - 1, :Cc - 1] > thr
+    mc[1:, 1:] -= hf[:R - 1, :Cc - 1] - hf[1:, 1:] > thr
+    dx = (mx + mc * (mx == 0)).astype(np.int64); dy = (my + mc * (my == 0)).astype(np.int64)
+    moved = np.pad((dx != 0) | (dy != 0), ((1, 2), (1, 2)))
+    anyw = np.zeros((R, Cc), bool)
+    for a in range(4):
+        for b in range(4):
+            anyw |= moved[a:a + R, b:b + Cc]
+    return ((dx + 1) | ((dy + 1) << 2) | (anyw.astype(np.int64) << 4)).astype(np.uint8)
+
+
 def test_hip_full_size_invariants():
     """BASELINE size (N=4096): size-independent properties -- finite state, unit quaternions, torque and joint-velocity
     limits respected, standing robots carry their weight, reset bookkeeping consistent."""

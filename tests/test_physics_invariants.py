@@ -3,7 +3,7 @@ oracle and on the lane-emulated kernel sources.  These are NOT reference parity.
 import numpy as np
 import pytest
 
-from helpers import make_oracle, quiet_cfg, abi, LC, aliengo, T
+from helpers import C, make_oracle, quiet_cfg, abi, LC, aliengo, T
 
 G = 9.81
 
@@ -117,3 +117,32 @@ def test_limits_respected(kind):
         assert (q > lo - 0.06).all() and (q < hi + 0.06).all()                      # soft: resolved at velocity level
         assert np.isfinite(sim.buf["root_states"]).all()
         np.testing.assert_allclose(np.linalg.norm(sim.buf["root_states"][:, 3:7], axis=1), 1.0, atol=1e-5)
+
+
+def test_emu_stairs_wall_contacts_match_oracle():
+    """Stairs (slope-corrected mesh with vertical risers, TER:72-75), CPU leg of tests/test_gpu_parity.py's stairs test: the
+    lane-emulated kernel sources (fp32) against the oracle (fp64, independent triangle query), states re-synchronised every step."""
+    import emu_binding
+    N = 16
+    cfg = C.TASKS["aliengo_stairs"][0]()
+    cfg.terrain.terrain_proportions = [0, 0, 0, 0, 0.5, 0.5]
+    cfg.domain_rand.base_init_pos_range = dict(x=[-3.0, 3.0], y=[-3.0, 3.0], z=[0.0, 0.3])
+    orc, lc, model, ter = make_oracle(cfg, N, seed=3)
+    emu = emu_binding.EmuSim(lc, model, ter.heightsamples, ter.env_origins)
+    orc.reset_all(); emu.reset_all()
+    rs = np.random.RandomState(0)
+    ok = tot = walls = 0
+    for t in range(30):
+        a = rs.normal(0, 1, (N, 12)).astype(np.float32)
+        for k in ("root_states", "dof_state", "commands", "last_actions", "episode_length", "terrain_levels", "env_origins", "kp_factors",
+                  "kd_factors", "friction", "pending_force", "feet_air_time", "last_contacts", "episode_sums", "obs", "last_dof_vel"):
+            emu.buf[k][...] = orc.buf[k]
+        orc.step(a); emu.step(a)
+        same = emu.buf["reset"] == orc.buf["reset"]
+        e_root = np.abs(emu.buf["root_states"] - orc.buf["root_states"]).max(1)
+        e_dof = np.abs(emu.buf["dof_state"] - orc.buf["dof_state"]).reshape(N, -1).max(1)
+        ok += int((same & (e_root < 2e-3) & (e_dof < 2e-2)).sum()); tot += N
+        feet = orc.buf["contact_forces"][:, [4, 8, 12, 16], :]
+        walls += int((np.linalg.norm(feet[..., :2], axis=-1) > 2.0 * np.abs(feet[..., 2]) + 1.0).sum())
+    assert ok >= 0.97 * tot, (ok, tot)
+    assert walls > 0, "the scenario must exercise riser (mostly horizontal) foot contacts"
