@@ -137,13 +137,20 @@ def main():
     if rank == 0:
         value = world * N * K / elapsed
         achieved = ALGO_BYTES_PER_ENV_STEP * N / (ka * 1e-3) / 1e9 if ka == ka and ka > 0 else None
+        # HBM traffic per launch of kernel A comes from separate rocprofv3 --pmc passes of this same command (PMC counters cannot be
+        # read in-process); tools/pmc_summary.py writes the corrected figure, valid for the workload it was collected on
+        traffic, tpath = None, os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if tj.get("task") == args.task and tj.get("envs_per_gpu") == N:
+                traffic = tj["traffic_bytes_per_launch"]
         out = {
             "metric": "env-steps/sec (whole node)", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "task": args.task, "envs_per_gpu": N, "mode": mode, "parallelism": f"dp{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "kernel": "lsim_k_step_a", "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * N,
                          "kernel_avg_ms": ka,
                          "note": "latency/issue-bound at N=4096: compulsory traffic is ~28 MB per step (SURVEY.md 8d)"},

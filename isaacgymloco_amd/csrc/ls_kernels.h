@@ -19,9 +19,12 @@
 #define LS_ATOMIC_ADD(ptr, v) (*(ptr) += (v))
 #define LS_WAVE_FN static inline
 #else
-#define LS_LANES_PARAM LaneRegs& rg, const int lane
-#define LS_PHASE(call) do { call; __syncthreads(); } while (0)
-#define LS_COLLECTIVE(gpu_call, emu_call) do { gpu_call; __syncthreads(); } while (0)
+// Every phase re-derives its lane id from an opaque copy: the compiler then cannot hoist the dozens of per-phase lane
+// predicates and LDS addresses out of the sub-step loop (it did, and spilled ~50 VGPRs + 128 SGPRs to keep them alive).
+__device__ __forceinline__ int ls_opaque_lane(int l) { asm volatile("" : "+v"(l)); return l; }
+#define LS_LANES_PARAM LaneRegs& rg, const int lane0
+#define LS_PHASE(call) do { { const int lane = ls_opaque_lane(lane0); call; } __syncthreads(); } while (0)
+#define LS_COLLECTIVE(gpu_call, emu_call) do { { const int lane = ls_opaque_lane(lane0); gpu_call; } __syncthreads(); } while (0)
 #define LS_ATOMIC_ADD(ptr, v) atomicAdd((ptr), (v))
 #define LS_WAVE_FN __device__ __forceinline__
 #endif
@@ -65,11 +68,6 @@ LS_FN void ph_load_a(const LsCtx& cx, WaveShared& sh, LaneRegs& rg, int lane, in
         o.mass = b.mass;
         for (int k = 0; k < 3; ++k) { o.com[k] = b.com[k]; o.jpos[k] = b.joint_pos[k]; o.axis[k] = b.joint_axis[k]; }
         for (int k = 0; k < 6; ++k) o.inertia[k] = b.inertia[k];
-    }
-    if (lane < cx.model.num_collision_points) {
-        const lsim_collision_point& p = cx.model.points[lane];
-        rg.cp_pos[0] = p.pos[0]; rg.cp_pos[1] = p.pos[1]; rg.cp_pos[2] = p.pos[2];
-        rg.cp_r = p.radius; rg.cp_body = p.body;
     }
     rg.cp_active = 0;
     rg.row_kind = -1;
@@ -177,8 +175,7 @@ LS_WAVE_FN void ls_wave_step_a(const LsCtx& cx, const LsStepArgs& a, const int e
         LS_PHASE(ph_delassus(sh, rg, lane));
         wc_pgs(sh, L, c.solver_iterations);
 #else
-        wc_delassus_pgs(sh, rg, lane, c.solver_iterations);
-        __syncthreads();
+        LS_PHASE(wc_delassus_pgs(sh, rg, lane, c.solver_iterations));
 #endif
         LS_PHASE(ph_apply_impulses(sh, lane));
         LS_PHASE(ph_contact_forces(sh, lane, dt));

@@ -335,8 +335,11 @@ LS_FN void ls_terrain_contact(const LsCtx& cx, V3 cw, float radius, float& dist,
     const float reach = radius + c.contact_offset;
     float best = 1e30f;
     V3 bq = v3(0, 0, 0), bn = v3(0, 0, 1);
-    for (int ci = i - 1; ci <= i + 1; ++ci)
-        for (int cj = j - 1; cj <= j + 1; ++cj) {
+    // rolled on purpose: 18 inlined copies of the triangle query cost 24 KB of code and 160 VGPRs
+#pragma unroll 1
+    for (int cell = 0; cell < 9; ++cell) {
+        {
+            const int ci = i - 1 + cell / 3, cj = j - 1 + cell % 3;
             if (ci < 0 || cj < 0 || ci > c.grid_rows - 2 || cj > c.grid_cols - 2) continue;
             const int* row = mesh + ci * c.grid_cols + cj;
             V3 p00 = ls_mesh_vertex(c, row[0], ci, cj), p10 = ls_mesh_vertex(c, row[c.grid_cols], ci + 1, cj);
@@ -345,6 +348,7 @@ LS_FN void ls_terrain_contact(const LsCtx& cx, V3 cw, float radius, float& dist,
             float ylo = fminf(fminf(p00.y, p10.y), fminf(p01.y, p11.y)), yhi = fmaxf(fmaxf(p00.y, p10.y), fmaxf(p01.y, p11.y));
             float zhi = fmaxf(fmaxf(p00.z, p10.z), fmaxf(p01.z, p11.z));
             if (cw.x < xlo - reach || cw.x > xhi + reach || cw.y < ylo - reach || cw.y > yhi + reach || cw.z > zhi + reach) continue;
+#pragma unroll 1
             for (int t = 0; t < 2; ++t) {
                 V3 a = p00, b = t == 0 ? p11 : p10, cc = t == 0 ? p01 : p11;   // (ind0,ind3,ind1) and (ind0,ind2,ind3)
                 V3 nt = cross(b - a, cc - a);
@@ -358,6 +362,7 @@ LS_FN void ls_terrain_contact(const LsCtx& cx, V3 cw, float radius, float& dist,
                 if (d2 < best) { best = d2; bq = q; bn = nt * (1.0f / nl); }
             }
         }
+    }
     if (best > 1e29f) { dist = 1.0f + radius; n = v3(0, 0, 1); return; }
     float d = sqrtf(best);
     V3 dq = cw - bq;
@@ -371,17 +376,21 @@ LS_FN void ls_terrain_contact(const LsCtx& cx, V3 cw, float radius, float& dist,
 LS_FN void ph_collide(const LsCtx& cx, WaveShared& sh, LaneRegs& r, int lane) {
     r.cp_active = 0;
     if (lane >= cx.model.num_collision_points) return;
-    int b = r.cp_body;
-    V3 pw = mul(m3p(sh.R[b]), v3p(r.cp_pos)) + v3p(sh.p[b]);
+    // the point's constants are re-read from the (cache-resident) model every sub-step rather than held in registers
+    const lsim_collision_point& cp = cx.model.points[lane];
+    const int b = cp.body;
+    const float cp_r = cp.radius;
+    r.cp_body = b;
+    V3 pw = mul(m3p(sh.R[b]), v3(cp.pos[0], cp.pos[1], cp.pos[2])) + v3p(sh.p[b]);
     float d;
     V3 n;
-    ls_terrain_contact(cx, v3(sh.root[0] + pw.x, sh.root[1] + pw.y, sh.root[2] + pw.z), r.cp_r, d, n);
-    float dist = d - r.cp_r;
+    ls_terrain_contact(cx, v3(sh.root[0] + pw.x, sh.root[1] + pw.y, sh.root[2] + pw.z), cp_r, d, n);
+    float dist = d - cp_r;
     if (dist < cx.cfg.contact_offset) {
         r.cp_active = 1;
         r.cp_dist = dist;
         v3st(r.cp_n, n);
-        v3st(r.cp_x, pw - n * r.cp_r);
+        v3st(r.cp_x, pw - n * cp_r);
     }
 }
 

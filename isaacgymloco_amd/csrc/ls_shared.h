@@ -114,7 +114,6 @@ struct WaveShared {
 // lane-private state that survives phase boundaries (VGPRs on the GPU, an array element in tests/emu)
 struct LaneRegs {
     // collision point owned by this lane
-    float cp_pos[3], cp_r;
     int cp_body;
     int cp_active;
     float cp_dist, cp_n[3], cp_x[3];
