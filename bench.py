@@ -139,11 +139,14 @@ def main():
         achieved = ALGO_BYTES_PER_ENV_STEP * N / (ka * 1e-3) / 1e9 if ka == ka and ka > 0 else None
         # HBM traffic per launch of kernel A comes from separate rocprofv3 --pmc passes of this same command (PMC counters cannot be
         # read in-process); tools/pmc_summary.py writes the corrected figure, valid for the workload it was collected on
-        traffic, tpath = None, os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        traffic, valu_frac, tpath = None, None, os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
             if tj.get("task") == args.task and tj.get("envs_per_gpu") == N:
                 traffic = tj["traffic_bytes_per_launch"]
+                if tj.get("valu_wave_insts_per_launch") and achieved:
+                    # the kernel's real limiter: wave64 VALU instructions issue over 4 cycles on each of 1024 SIMDs (256 CUs x 4) at 2.4 GHz
+                    valu_frac = tj["valu_wave_insts_per_launch"] * 4.0 / (1024 * 2.4e9 * ka * 1e-3)
         out = {
             "metric": "env-steps/sec (whole node)", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -153,7 +156,9 @@ def main():
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "kernel": "lsim_k_step_a", "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * N,
                          "kernel_avg_ms": ka,
-                         "note": "latency/issue-bound at N=4096: compulsory traffic is ~28 MB per step (SURVEY.md 8d)"},
+                         "valu_issue_frac": valu_frac,
+                         "note": "VALU-issue bound, not HBM bound: 6.9 KB and ~17 k wave instructions per env-step (DESIGN.md, kernel A); "
+                                 "traffic and valu_issue_frac come from separate rocprofv3 --pmc passes (profiles/pmc_traffic.json)"},
         }
         out.update({k: v for k, v in extra.items() if k not in out})
         if world == 1 and not args.no_cpu_baseline:

@@ -23,8 +23,22 @@
 // predicates and LDS addresses out of the sub-step loop (it did, and spilled ~50 VGPRs + 128 SGPRs to keep them alive).
 __device__ __forceinline__ int ls_opaque_lane(int l) { asm volatile("" : "+v"(l)); return l; }
 #define LS_LANES_PARAM LaneRegs& rg, const int lane0
-#define LS_PHASE(call) do { { const int lane = ls_opaque_lane(lane0); call; } __syncthreads(); } while (0)
-#define LS_COLLECTIVE(gpu_call, emu_call) do { { const int lane = ls_opaque_lane(lane0); gpu_call; } __syncthreads(); } while (0)
+#if defined(LS_PHASE_TIMING)   // diagnostics build only (tools/phase_profile.py): shader-clock ticks per phase site, summed over waves
+__device__ unsigned long long g_ls_phase_ticks[64];
+__device__ unsigned long long g_ls_phase_calls[64];
+#define LS_TICK(site) do { if (lane0 == 0) { unsigned long long t_ = clock64(); ls_ticks[(site) & 63] += t_ - ls_t_prev; ls_calls[(site) & 63] += 1; \
+                                             ls_t_prev = t_; } } while (0)
+#define LS_TICK_INIT() __shared__ unsigned long long ls_ticks[64]; __shared__ unsigned int ls_calls[64]; \
+                       ls_ticks[lane0] = 0; ls_calls[lane0] = 0; __syncthreads(); unsigned long long ls_t_prev = clock64()
+#define LS_TICK_FLUSH() do { __syncthreads(); if (ls_calls[lane0]) { atomicAdd(&g_ls_phase_ticks[lane0], ls_ticks[lane0]); \
+                                                                      atomicAdd(&g_ls_phase_calls[lane0], (unsigned long long)ls_calls[lane0]); } } while (0)
+#else
+#define LS_TICK(site) do { } while (0)
+#define LS_TICK_INIT() do { } while (0)
+#define LS_TICK_FLUSH() do { } while (0)
+#endif
+#define LS_PHASE(call) do { { const int lane = ls_opaque_lane(lane0); call; } __syncthreads(); LS_TICK(__LINE__ - ls_line0); } while (0)
+#define LS_COLLECTIVE(gpu_call, emu_call) do { { const int lane = ls_opaque_lane(lane0); gpu_call; } __syncthreads(); LS_TICK(__LINE__ - ls_line0); } while (0)
 #define LS_ATOMIC_ADD(ptr, v) atomicAdd((ptr), (v))
 #define LS_WAVE_FN __device__ __forceinline__
 #endif
@@ -154,6 +168,8 @@ LS_WAVE_FN void ls_wave_step_a(const LsCtx& cx, const LsStepArgs& a, const int e
     const lsim_config& c = cx.cfg;
     const float dt = c.sim_dt;
     const bool skip = (a.flags & LSIM_STEP_SKIP_PHYSICS) != 0;
+    [[maybe_unused]] constexpr int ls_line0 = __LINE__;   // phase-site ids (LS_PHASE_TIMING builds) count lines from here
+    LS_TICK_INIT();
     LS_PHASE(ph_load_a(cx, sh, rg, lane, env, a));
     for (int sub = 0; sub < c.decimation; ++sub) {
         LS_PHASE(ph_torques(cx, sh, lane, env, sub));
@@ -198,6 +214,7 @@ LS_WAVE_FN void ls_wave_step_a(const LsCtx& cx, const LsStepArgs& a, const int e
     LS_PHASE(ph_reward_total(cx, sh, lane, env));
     LS_PHASE(if (sh.reset) ph_build_obs(cx, sh, lane, env, (uint32_t)a.step_counter, LSIM_RNG_TERM_NOISE, sh.cur));
     LS_PHASE(ph_term_outputs(cx, sh, lane, env, a));
+    LS_TICK_FLUSH();
 }
 
 // =============================================================================================== kernel B
@@ -393,6 +410,8 @@ LS_FN void ph_b_store_reset_all(const LsCtx& cx, WaveShared& sh, int lane, int e
 
 LS_WAVE_FN void ls_wave_step_b(const LsCtx& cx, const LsStepArgs& a, const int env, WaveShared& sh, LS_LANES_PARAM) {
     const lsim_config& c = cx.cfg;
+    [[maybe_unused]] constexpr int ls_line0 = __LINE__ - 48;   // kernel B's sites land above kernel A's (A uses 0..47)
+    LS_TICK_INIT();
     LS_PHASE(ph_load_b(cx, sh, lane, env, a));
     LS_PHASE(ph_b_housekeeping(cx, sh, lane, env, a); ph_b_terrain_curriculum(cx, sh, lane, env, a));
     LS_PHASE(ph_b_reset(cx, sh, lane, env, a));
@@ -404,4 +423,5 @@ LS_WAVE_FN void ls_wave_step_b(const LsCtx& cx, const LsStepArgs& a, const int e
     }
     LS_PHASE(ph_build_obs(cx, sh, lane, env, (uint32_t)a.step_counter, LSIM_RNG_OBS_NOISE, sh.cur); ph_b_stage_history(cx, sh, lane, env));
     LS_PHASE(ph_b_store(cx, sh, lane, env, a));
+    LS_TICK_FLUSH();
 }

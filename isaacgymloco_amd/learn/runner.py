@@ -44,6 +44,8 @@ class HIMOnPolicyRunner:
         self.graphs = None
         env.reset()
 
+    graphs = None   # GraphedRollout once enable_graphs() succeeded (subclasses with their own __init__ inherit the default)
+
     def enable_graphs(self):
         """Capture the rollout step into HIP graphs (graph_rollout.py).  Only for the plain HIM runner on a GPU env."""
         if type(self) is HIMOnPolicyRunner and self.fast and str(self.device).startswith("cuda"):

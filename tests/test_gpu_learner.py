@@ -59,3 +59,26 @@ def test_full_iteration_runs_and_learns_something():
     assert any(not torch.equal(before[k], after[k]) for k in before)
     assert all(torch.isfinite(v).all() for v in after.values())
     assert run.last_perf["fps"] > 0
+
+
+def test_amp_hybrid_runner_iteration_on_gpu():
+    """aliengo_amp: HybridPolicyRunner (policy + AMP discriminator, style reward from lsim's amp_obs buffers) for two iterations."""
+    import numpy as np
+    from isaacgymloco_amd.envs import config as C
+    from isaacgymloco_amd.envs.legged_robot import LeggedRobot
+    from isaacgymloco_amd.learn.bench_train import train_cfg_dict
+    from isaacgymloco_amd.learn.hybrid import HybridPolicyRunner
+    cfg = C.TASKS["aliengo_amp"][0]()
+    cfg.env.num_envs = 256
+    env = LeggedRobot(cfg, sim_device="cuda:0", seed=2, using_amp=True)
+    tc = train_cfg_dict("aliengo_amp")
+    tc["runner"]["num_steps_per_env"] = 8
+    torch.manual_seed(0); np.random.seed(0)
+    run = HybridPolicyRunner(env, tc, log_dir=None, device="cuda:0")
+    assert not run.enable_graphs()        # graph capture is only wired for the plain HIM runner
+    before = {k: v.clone() for k, v in run.alg.discriminator.state_dict().items()}
+    run.learn(2, init_at_random_ep_len=True)
+    after = run.alg.discriminator.state_dict()
+    assert any(not torch.equal(before[k], after[k]) for k in before)
+    assert all(torch.isfinite(v).all() for v in after.values())
+    assert all(torch.isfinite(v).all() for v in run.alg.actor_critic.state_dict().values())

@@ -1,0 +1,78 @@
+"""Per-phase shader-clock profile of kernels A and B (diagnostics; not part of the product build).
+
+Builds isaacgymloco_amd/csrc/variants/liblsim_phasetiming.so with -DLS_PHASE_TIMING (every LS_PHASE site adds its elapsed
+s_memtime ticks, lane 0 of each wave, to a device-side accumulator), runs the env-only loop and prints the mean ticks per wave
+per step for each phase site (source line of ls_kernels.h).  Run on the GPU box:  python tools/phase_profile.py [task] [N]
+The instrumentation itself costs ~10 % (MI355X_MICROARCH.md), so read the numbers as shares, not absolutes.
+"""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "isaacgymloco_amd", "csrc")
+OUT = os.path.join(CSRC, "variants", "liblsim_phasetiming.so")
+
+
+def build():
+    from isaacgymloco_amd.csrc import build as B
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    cmd = [os.environ.get("HIPCC", "hipcc")] + B.FLAGS + ["-DLS_PHASE_TIMING"] + [os.path.join(B.HERE, x) for x in B.SOURCES] + ["-o", OUT]
+    subprocess.check_call(cmd)
+    return OUT
+
+
+def sites():
+    """line number -> phase text for every LS_PHASE / LS_COLLECTIVE site of the two drivers"""
+    src = open(os.path.join(CSRC, "ls_kernels.h")).read().splitlines()
+    base = {}
+    out = {}
+    for i, l in enumerate(src, 1):
+        if "constexpr int ls_line0 = __LINE__" in l:
+            base[len(base)] = i - (48 if "- 48" in l else 0)
+    def base_for(i):
+        cands = [b for k, b in base.items() if (b if k == 0 else b + 48) <= i]
+        return cands[-1]
+    for i, l in enumerate(src, 1):
+        m = re.search(r"LS_(PHASE|COLLECTIVE)\((.*)\);", l)
+        if m and not l.lstrip().startswith("#") and base and i > min(base.values()):
+            out[(i - base_for(i)) & 63] = m.group(2)[:70]
+    return out
+
+
+if __name__ == "__main__":
+    sys.path.insert(0, ROOT)
+    if "--build-only" in sys.argv:
+        print(build()); sys.exit(0)
+    if not os.path.exists(OUT):
+        build()
+    os.environ["LSIM_LIB"] = OUT
+    import torch
+    from isaacgymloco_amd.envs import config as C
+    from isaacgymloco_amd.envs.legged_robot import LeggedRobot
+    task = sys.argv[1] if len(sys.argv) > 1 else "aliengo"
+    N = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+    cfg = C.TASKS[task][0]()
+    cfg.env.num_envs = N
+    env = LeggedRobot(cfg, sim_device="cuda:0", seed=1)
+    env.reset()
+    env.episode_length_buf = torch.randint_like(env.episode_length_buf, high=int(env.max_episode_length))
+    acts = [torch.randn(N, 12, device="cuda:0") for _ in range(16)]
+    L = ctypes.CDLL(OUT)
+    t = (ctypes.c_ulonglong * 64)(); c = (ctypes.c_ulonglong * 64)()
+    for i in range(50):
+        env.step_device(acts[i % 16])
+    L.lsim_debug_read_phase_ticks(t, c)
+    K = 200
+    for i in range(K):
+        env.step_device(acts[i % 16])
+    L.lsim_debug_read_phase_ticks(t, c)
+    names = sites()
+    tot_a = sum(t[s] for s in range(48)); tot_b = sum(t[s] for s in range(48, 64))
+    print(f"task {task} N {N}: mean ticks per wave per step: kernel A {tot_a / (K * N):.0f}, kernel B {tot_b / (K * N):.0f}")
+    for s in range(64):
+        if c[s]:
+            tot = tot_a if s < 48 else tot_b
+            print(f"site {s:2d} calls/step {c[s] / (K * N):4.1f} ticks/step {t[s] / (K * N):8.0f} {100.0 * t[s] / tot:5.1f}%  {names.get(s, '?')}")

@@ -64,7 +64,8 @@ def main(argv):
         k = next(x for x in kernels if kernel in x)
         f = acc[k]["FETCH_SIZE"]; w = acc[k]["WRITE_SIZE"]
         fetch_kb = f[0] / f[1]; write_kb = w[0] / w[1]
-        json.dump({"kernel": kernel, "task": task, "envs_per_gpu": envs, "fetch_size_kb_raw": fetch_kb, "write_size_kb_raw": write_kb,
+        vi = acc[k].get("SQ_INSTS_VALU")
+        json.dump({"kernel": kernel, "task": task, "envs_per_gpu": envs, "valu_wave_insts_per_launch": (vi[0] / vi[1]) if vi and vi[1] else None, "fetch_size_kb_raw": fetch_kb, "write_size_kb_raw": write_kb,
                    "traffic_bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0,
                    "correction": "FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B); WRITE_SIZE as reported",
                    "note": note}, open(traffic_json, "w"), indent=1)
