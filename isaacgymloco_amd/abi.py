@@ -97,6 +97,7 @@ NUM_BUFFERS = ENUMS["lsim_buffer_id"]["LSIM_NUM_BUFFERS"]
 RNG_TAGS = {k[len("LSIM_RNG_"):].lower(): v for k, v in ENUMS["lsim_rng_tag"].items()}
 
 DT_F32, DT_I64, DT_U8, DT_I32, DT_I16 = (DEFINES[k] for k in ("LSIM_DT_F32", "LSIM_DT_I64", "LSIM_DT_U8", "LSIM_DT_I32", "LSIM_DT_I16"))
+E_INVALID, E_NOMEM, E_HIP, E_UNSUPPORTED, E_ABI = (DEFINES[k] for k in ("LSIM_E_INVALID", "LSIM_E_NOMEM", "LSIM_E_HIP", "LSIM_E_UNSUPPORTED", "LSIM_E_ABI"))
 ABI_VERSION = DEFINES["LSIM_ABI_VERSION"]
 STEP_SKIP_PHYSICS = DEFINES["LSIM_STEP_SKIP_PHYSICS"]
 STEP_NO_RESET = DEFINES["LSIM_STEP_NO_RESET"]

@@ -18,6 +18,8 @@
 #define LS_COLLECTIVE(gpu_call, emu_call) do { emu_call; } while (0)
 #define LS_ATOMIC_ADD(ptr, v) (*(ptr) += (v))
 #define LS_WAVE_FN static inline
+#define LS_TICK_INIT() do { } while (0)
+#define LS_TICK_FLUSH() do { } while (0)
 #else
 // Every phase re-derives its lane id from an opaque copy: the compiler then cannot hoist the dozens of per-phase lane
 // predicates and LDS addresses out of the sub-step loop (it did, and spilled ~50 VGPRs + 128 SGPRs to keep them alive).

@@ -37,5 +37,7 @@ def make_oracle(cfg, num_envs, seed=1, terrain_seed=1, using_amp=False):
     ter = T.Terrain(cfg.terrain, num_envs, seed=terrain_seed)
     model = aliengo.build_model()
     lc = LC.make_lsim_config(cfg, num_envs=num_envs, terrain=ter, model=model, seed=seed, using_amp=using_amp)
+    if not hasattr(ter, "heightsamples"):      # mesh_type plane / none: no grid (TER:52-53)
+        ter.heightsamples = ter.env_origins = None
     sim = oracle.OracleSim(lc, model, ter.heightsamples, ter.env_origins)
     return sim, lc, model, ter

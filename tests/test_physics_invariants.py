@@ -146,3 +146,25 @@ def test_emu_stairs_wall_contacts_match_oracle():
         walls += int((np.linalg.norm(feet[..., :2], axis=-1) > 2.0 * np.abs(feet[..., 2]) + 1.0).sum())
     assert ok >= 0.97 * tot, (ok, tot)
     assert walls > 0, "the scenario must exercise riser (mostly horizontal) foot contacts"
+
+
+@pytest.mark.parametrize("N", [1, 13])
+def test_emu_plane_ground_ragged_sizes_match_oracle(N):
+    """mesh_type 'plane' (LR:1069-1078, no height grid, no terrain curriculum) at sizes that do not fill a block group."""
+    import emu_binding
+    cfg = C.TASKS["aliengo"][0]()
+    cfg.terrain.mesh_type = "plane"
+    cfg.terrain.measure_heights = True
+    orc, lc, model, ter = make_oracle(cfg, N, seed=11)
+    assert lc.mesh_type == 0 and lc.terrain_curriculum == 0
+    emu = emu_binding.EmuSim(lc, model, ter.heightsamples, ter.env_origins)
+    orc.reset_all(); emu.reset_all()
+    rs = np.random.RandomState(2)
+    for t in range(10):
+        a = rs.normal(0, 1, (N, 12)).astype(np.float32)
+        orc.step(a); emu.step(a)
+        np.testing.assert_array_equal(emu.buf["reset"], orc.buf["reset"], err_msg=f"step {t}")
+        np.testing.assert_allclose(emu.buf["root_states"], orc.buf["root_states"], atol=2e-3, rtol=1e-3, err_msg=f"step {t}")
+        np.testing.assert_allclose(emu.buf["obs"], orc.buf["obs"], atol=5e-3, rtol=1e-3, err_msg=f"step {t}")
+        np.testing.assert_allclose(emu.buf["rew"], orc.buf["rew"], atol=1e-3, rtol=1e-3, err_msg=f"step {t}")
+    assert np.all(emu.buf["measured_heights"] == 0.0)     # LR:1478-1479: zeros on a plane
