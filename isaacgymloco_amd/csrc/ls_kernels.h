@@ -179,6 +179,7 @@ LS_WAVE_FN void ls_wave_step_a(const LsCtx& cx, const LsStepArgs& a, const int e
         LS_PHASE(ph_kinematics(sh, lane));
         LS_PHASE(ph_body_inertia(cx, sh, lane, sub == 0));
         LS_PHASE(ph_leg_composite(sh, lane));
+        LS_PHASE(ph_leg_block(sh, lane));
         LS_PHASE(ph_leg_schur(sh, lane));
         LS_PHASE(ph_base_assemble(sh, lane));
         LS_PHASE(ph_base_factor(sh, lane));

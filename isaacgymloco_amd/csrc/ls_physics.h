@@ -128,50 +128,60 @@ LS_FN void chol6_solve(const float* L, float* b) {
     }
 }
 
-// ---- phase L1: composite inertias / bias forces up each leg -> F_k = Ic_k S_k (columns of Mbl), leg block Mll, h_l (lane = leg)
+// ---- phase L1a: composite inertias / bias forces up each leg, one matrix ROW per lane (lane = 6 * leg + row):
+//      F_k = Ic_k S_k (columns of Mbl) and the accumulated bias force at every level (parked in sh.G, which the Schur
+//      phase only writes afterwards).  M_jk = S_j . F_k for ancestors j <= k and h_k = S_k . f_k are 6-lane reductions:
+//      they are finished by ph_leg_block from LDS.
 LS_FN void ph_leg_composite(WaveShared& sh, int lane) {
-    if (lane >= 4) return;
-    float Ic[36];
-    S6 fb = s6(v3(0, 0, 0), v3(0, 0, 0));
-    for (int e = 0; e < 36; ++e) Ic[e] = 0.0f;
-    S6 Sk[3];
-    float Mll[6];
+    if (lane >= 24) return;
+    const int l = lane / 6, r = lane - 6 * l;
+    float Ic[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    float fb = 0.0f;
     for (int k = 3; k >= 0; --k) {
-        int b = 1 + 4 * lane + k;
-        const float* I6 = sh.u.I6[b];
-        for (int e = 0; e < 36; ++e) Ic[e] += I6[e];
-        fb = fb + s6p(sh.Fb[b]);
+        const int b = 1 + 4 * l + k;
+        const float* I6 = sh.u.I6[b] + 6 * r;
+        for (int c = 0; c < 6; ++c) Ic[c] += I6[c];
+        fb += sh.Fb[b][r];
         if (k < 3) {
-            S6 S = s6p(sh.S[3 * lane + k]);
-            Sk[k] = S;
-            S6 F = m6v(Ic, S);                       // F_k = Ic_k S_k ; M_jk = S_j . F_k for ancestors j <= k
-            float Fm[6];
-            s6st(Fm, F);
-            for (int r = 0; r < 6; ++r) sh.Mbl[lane][3 * r + k] = Fm[r];
-            sh.hl[lane][k] = dot(S, fb);
-            if (k == 2) Mll[5] = dot(S, F);
-            else if (k == 1) { Mll[2] = dot(S, F); }
-            else Mll[0] = dot(S, F);
-            // off-diagonals need the ancestors' S, which are only known after the loop: keep F in LDS (Mbl) and finish below
+            const float* S = sh.S[3 * l + k];
+            float f = 0.0f;
+            for (int c = 0; c < 6; ++c) f += Ic[c] * S[c];
+            sh.Mbl[l][3 * r + k] = f;
+            sh.G[l][6 * k + r] = fb;
         }
     }
-    s6st(sh.legF[lane], fb);
-    // off-diagonal entries M_ht = S_h.F_t, M_hc = S_h.F_c, M_tc = S_t.F_c from the stored columns
-    float Ft[6], Fc[6];
-    for (int r = 0; r < 6; ++r) { Ft[r] = sh.Mbl[lane][3 * r + 1]; Fc[r] = sh.Mbl[lane][3 * r + 2]; }
-    Mll[1] = dot(Sk[0], s6p(Ft));
-    Mll[3] = dot(Sk[0], s6p(Fc));
-    Mll[4] = dot(Sk[1], s6p(Fc));
-    float L[6];
-    chol3(Mll, L);
-    for (int e = 0; e < 6; ++e) sh.Lll[lane][e] = L[e];
+    sh.legF[l][r] = fb;
 }
-// ---- phase L2: G_l = Mll^-1 Mlb^T (3x6) from the stored columns (lane = 6 * leg + column)
+// ---- phase L1b: the 3x3 leg block M_ll (6 entries, parked in sh.lam until the Schur phase factors it) and h_l
+//      (lane = 9 * leg + entry; entries 0-5 = m00,m10,m11,m20,m21,m22, entries 6-8 = h_hip,h_thigh,h_calf)
+LS_FN void ph_leg_block(WaveShared& sh, int lane) {
+    if (lane >= 36) return;
+    const int l = lane / 9, e = lane - 9 * l;
+    if (e < 6) {
+        const int j = (e == 2 || e == 4) ? 1 : (e == 5 ? 2 : 0);           // ancestor (row of S)
+        const int k = (e == 0) ? 0 : (e <= 2 ? 1 : 2);                      // column F_k
+        const float* S = sh.S[3 * l + j];
+        float m = 0.0f;
+        for (int r = 0; r < 6; ++r) m += S[r] * sh.Mbl[l][3 * r + k];
+        sh.lam[6 * l + e] = m;
+    } else {
+        const int k = e - 6;
+        const float* S = sh.S[3 * l + k];
+        float h = 0.0f;
+        for (int r = 0; r < 6; ++r) h += S[r] * sh.G[l][6 * k + r];
+        sh.hl[l][k] = h;
+    }
+}
+// ---- phase L2: Cholesky of M_ll (every lane of the leg redundantly, lane c == 0 publishes it) and
+//      G_l = Mll^-1 Mlb^T (3x6) from the stored columns (lane = 6 * leg + column)
 LS_FN void ph_leg_schur(WaveShared& sh, int lane) {
     if (lane >= 24) return;
     int l = lane / 6, c = lane - 6 * l;
+    float L[6];
+    chol3(sh.lam + 6 * l, L);
+    if (c == 0) for (int e = 0; e < 6; ++e) sh.Lll[l][e] = L[e];
     float col[3] = {sh.Mbl[l][3 * c], sh.Mbl[l][3 * c + 1], sh.Mbl[l][3 * c + 2]};   // (F_h[c], F_t[c], F_c[c])
-    chol3_solve(sh.Lll[l], col);
+    chol3_solve(L, col);
     sh.G[l][c] = col[0]; sh.G[l][6 + c] = col[1]; sh.G[l][12 + c] = col[2];
 }
 
@@ -546,6 +556,47 @@ static inline void wc_pgs(WaveShared& sh, LaneRegs* L, int iters) {
 LS_FN float ls_readlane(float v, int srclane) {  // srclane is wave-uniform
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), srclane));
 }
+// v[lane_imm] = s  (v_writelane_b32 with an immediate lane: one instruction instead of a lane compare + select)
+template <int LANE> __device__ __forceinline__ void ls_writelane(float& v, float s) {
+    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(s), "n"(LANE));
+}
+// one Gauss-Seidel relaxation per row r = R0 .. LS_MAXR-1 (compile-time recursion: W[r] is a register, r an immediate).
+// Every lane evaluates its own candidate; only lane r's is real: readlane broadcasts it and its delta, lane r keeps it.
+template <int R0> __device__ __forceinline__ void ls_pgs_rows(int R, int ncr, const float (&W)[LS_MAXR], float cf, float hi_add, float inv_d,
+                                                             float& lam, float& lam_n, float& w) {
+    if constexpr (R0 < LS_MAXR) {
+        if (R0 < R) {
+            const float t = cf * lam_n, thi = fmaf(cf, lam_n, hi_add);
+            const float nl = __builtin_amdgcn_fmed3f(fmaf(-w, inv_d, lam), -t, thi);
+            const float d = nl - lam;
+            const float s_nl = ls_readlane(nl, R0), s_d = ls_readlane(d, R0);
+            ls_writelane<R0>(lam, s_nl);
+            if constexpr (R0 % 3 == 0 && R0 + 2 < 3 * LS_MAXC) {
+                if (R0 < ncr) {                      // a normal row: hand its impulse to its two friction rows
+                    ls_writelane<R0 + 1>(lam_n, s_nl);
+                    ls_writelane<R0 + 2>(lam_n, s_nl);
+                }
+            }
+            w = fmaf(W[R0], s_d, w);
+            ls_pgs_rows<R0 + 1>(R, ncr, W, cf, hi_add, inv_d, lam, lam_n, w);   // rows are contiguous: r >= R ends the sweep
+        }
+    }
+}
+// W[j] = J_lane . Y_j for rows j = J0 .. R-1 (compile-time recursion; rows are contiguous, so j >= R ends it with one branch)
+template <int J0> __device__ __forceinline__ void ls_delassus_rows(const WaveShared& sh, int R, int lane, int lo, const float (&jb)[6],
+                                                                  float jl0, float jl1, float jl2, float (&W)[LS_MAXR], float& wd) {
+    if constexpr (J0 < LS_MAXR) {
+        if (J0 < R) {
+            const float* Y = sh.u.c.Y[J0];
+            float w = 0.0f;
+            for (int k = 0; k < 6; ++k) w += jb[k] * Y[k];
+            w += jl0 * Y[lo] + jl1 * Y[lo + 1] + jl2 * Y[lo + 2];
+            if (J0 == lane) { w += 1e-6f; wd = w; }   // constraint-force mixing keeps the diagonal positive
+            W[J0] = w;
+            ls_delassus_rows<J0 + 1>(sh, R, lane, lo, jb, jl0, jl1, jl2, W, wd);
+        }
+    }
+}
 // GPU form: Delassus row and sweep fused so that the 36-entry row lives in registers only between here and the end of
 // the sweep (written unconditionally: no liveness across sub-steps); rows relaxed in order, impulse broadcast by readlane.
 LS_FN void wc_delassus_pgs(WaveShared& sh, const LaneRegs& rg, int lane, int iters) {
@@ -557,19 +608,9 @@ LS_FN void wc_delassus_pgs(WaveShared& sh, const LaneRegs& rg, int lane, int ite
     const float jl0 = has_leg ? rg.Jl[0] : 0.0f, jl1 = has_leg ? rg.Jl[1] : 0.0f, jl2 = has_leg ? rg.Jl[2] : 0.0f;
     float jb[6];
     for (int k = 0; k < 6; ++k) jb[k] = act ? rg.Jb[k] : 0.0f;
-    float W[LS_MAXR];
+    float W[LS_MAXR] = {};
     float wd = 1.0f;
-#pragma unroll
-    for (int j = 0; j < LS_MAXR; ++j) {
-        float w = 0.0f;
-        if (j < R) {
-            const float* Y = sh.u.c.Y[j];
-            for (int k = 0; k < 6; ++k) w += jb[k] * Y[k];
-            w += jl0 * Y[lo] + jl1 * Y[lo + 1] + jl2 * Y[lo + 2];
-            if (j == lane) { w += 1e-6f; wd = w; }   // constraint-force mixing keeps the diagonal positive
-        }
-        W[j] = w;
-    }
+    ls_delassus_rows<0>(sh, R, lane, lo, jb, jl0, jl1, jl2, W, wd);
     float lam = 0.0f, lam_n = 0.0f, w = act ? rg.brow : 0.0f;
     const float inv_d = act ? 1.0f / wd : 0.0f;
     const int kind = act ? rg.row_kind : -1;
@@ -578,26 +619,8 @@ LS_FN void wc_delassus_pgs(WaveShared& sh, const LaneRegs& rg, int lane, int ite
     const float cf = fric ? sh.mu : 0.0f;
     const float hi_add = fric ? 0.0f : __builtin_inff();
     const int ncr = 3 * sh.nc;                 // rows [0, ncr) are contact rows laid out (normal, t1, t2) per contact
-    for (int it = 0; it < iters; ++it) {
-#pragma unroll
-        for (int r = 0; r < LS_MAXR; ++r) {   // fully unrolled: W[r] is a register, r an immediate for readlane / writelane
-            if (r < R) {
-                float t = cf * lam_n;
-                float nl = fmaf(-w, inv_d, lam);
-                nl = fminf(fmaxf(nl, -t), t + hi_add);
-                float d = nl - lam;
-                const float s_nl = ls_readlane(nl, r);       // only lane r's candidate is the real one
-                const float s_d = ls_readlane(d, r);
-                int lid = lane;
-                asm volatile("" : "+v"(lid));                 // opaque copy: keeps the 36 (lane == r) masks from being hoisted
-                                                              // out of the iteration loop into (spilled) SGPR pairs
-                lam = (lid == r) ? s_nl : lam;
-                if ((r % 3) == 0 && r < ncr)                  // a normal row: hand its impulse to its two friction rows
-                    lam_n = ((unsigned)(lid - (r + 1)) < 2u) ? s_nl : lam_n;
-                w = fmaf(W[r], s_d, w);
-            }
-        }
-    }
+    for (int it = 0; it < iters; ++it)
+        ls_pgs_rows<0>(R, ncr, W, cf, hi_add, inv_d, lam, lam_n, w);
     if (act) sh.lam[lane] = lam;
 }
 #endif
