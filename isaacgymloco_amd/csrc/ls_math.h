@@ -66,8 +66,19 @@ LS_FN void R_to_quat(const M3& Rm, float* q) {
     else if (R[4] > R[8]) { float s = sqrtf(1.0f + R[4] - R[0] - R[8]) * 2; q[3] = (R[2] - R[6]) / s; q[0] = (R[1] + R[3]) / s; q[1] = 0.25f * s; q[2] = (R[5] + R[7]) / s; }
     else { float s = sqrtf(1.0f + R[8] - R[0] - R[4]) * 2; q[3] = (R[3] - R[1]) / s; q[0] = (R[2] + R[6]) / s; q[1] = (R[5] + R[7]) / s; q[2] = 0.25f * s; }
 }
+// joint angles are a few radians at most: the hardware v_sin_f32 / v_cos_f32 (abs error ~1e-6) replace ocml's ~60-instruction
+// range-reduced sinf / cosf on the device; the lane emulator and the oracle use libm
+LS_FN void ls_sincos_joint(float th, float& s, float& c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    s = __sinf(th); c = __cosf(th);
+#else
+    s = sinf(th); c = cosf(th);
+#endif
+}
 LS_FN M3 axis_angle_R(V3 a, float th) {
-    float c = cosf(th), s = sinf(th), t = 1 - c;
+    float c, s;
+    ls_sincos_joint(th, s, c);
+    float t = 1 - c;
     M3 R;
     R.m[0] = c + t * a.x * a.x; R.m[1] = t * a.x * a.y - s * a.z; R.m[2] = t * a.x * a.z + s * a.y;
     R.m[3] = t * a.x * a.y + s * a.z; R.m[4] = c + t * a.y * a.y; R.m[5] = t * a.y * a.z - s * a.x;
