@@ -202,9 +202,11 @@ LS_FN void ph_base_assemble(WaveShared& sh, int lane) {
     }
 }
 
-// ---- phase: Cholesky of the 6x6 Schur complement (lane 0), in place, lower factor row-major
+// ---- phase: Cholesky of the 6x6 Schur complement and its explicit inverse (lane = column of the inverse)
+//      Lanes 0-5 all run the factorisation (free in SIMT) and lane c then solves for column c of the inverse, so the two
+//      later users (free base acceleration, one solve per constraint row) do 36 FMAs instead of a 12-division substitution.
 LS_FN void ph_base_factor(WaveShared& sh, int lane) {
-    if (lane != 0) return;
+    if (lane >= 6) return;
     float A[36];
     for (int e = 0; e < 36; ++e) A[e] = sh.Sb[e];
     for (int j = 0; j < 6; ++j) {
@@ -218,7 +220,10 @@ LS_FN void ph_base_factor(WaveShared& sh, int lane) {
             A[6 * i + j] = v / d;
         }
     }
-    for (int e = 0; e < 36; ++e) sh.Sb[e] = A[e];
+    float col[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    for (int r = 0; r < 6; ++r) col[r] = (r == lane) ? 1.0f : 0.0f;
+    chol6_solve(A, col);
+    for (int r = 0; r < 6; ++r) sh.Sinv[6 * r + lane] = col[r];
 }
 
 // ---- free velocity: three small phases
@@ -229,16 +234,15 @@ LS_FN void ph_free_leg(WaveShared& sh, int lane) {  // lane = leg: y_l = Mll^-1 
     chol3_solve(sh.Lll[lane], y);
     for (int k = 0; k < 3; ++k) sh.yl[lane][k] = y[k];
 }
-LS_FN void ph_free_base(WaveShared& sh, int lane) {  // lane 0: a_b = Sb^-1 (-h_b - sum_l Mbl y_l)
-    if (lane != 0) return;
-    float rb[6];
+LS_FN void ph_free_base(WaveShared& sh, int lane) {  // lane = row of a_b = Sb^-1 (-h_b - sum_l Mbl y_l)
+    if (lane >= 6) return;
+    float a = 0.0f;
     for (int r = 0; r < 6; ++r) {
         float s = -sh.hb[r];
         for (int l = 0; l < 4; ++l) s -= sh.Mbl[l][3 * r] * sh.yl[l][0] + sh.Mbl[l][3 * r + 1] * sh.yl[l][1] + sh.Mbl[l][3 * r + 2] * sh.yl[l][2];
-        rb[r] = s;
+        a += sh.Sinv[6 * lane + r] * s;
     }
-    chol6_solve(sh.Sb, rb);
-    for (int r = 0; r < 6; ++r) sh.ab[r] = rb[r];
+    sh.ab[lane] = a;
 }
 LS_FN void ph_free_finish(WaveShared& sh, int lane, float dt) {  // lane = generalized velocity index
     if (lane >= LS_NV) return;
@@ -428,7 +432,25 @@ LS_FN void wc_compact_contacts(WaveShared& sh, LaneRegs& r, int lane) {
 }
 #endif
 
-// ---- phase: joint-limit rows (lane 0 builds the short ordered list)
+// ---- phase: joint-limit rows, the short ordered list of joints within 0.1 rad of a hard limit.
+//      GPU: lane = joint, ordered compaction by ballot; lane emulator: lane 0 walks the joints (same order, same result)
+#if !defined(LS_EMU)
+LS_FN void wc_limits(const LsCtx& cx, WaveShared& sh, int lane) {
+    bool has = false;
+    float gap = 0.0f, sgn = 0.0f;
+    if (lane < 12) {
+        float lo = sh.q[lane] - cx.model.dof_pos_lower[lane], hi = cx.model.dof_pos_upper[lane] - sh.q[lane];
+        if (lo < 0.1f) { has = true; gap = lo; sgn = 1.0f; }
+        else if (hi < 0.1f) { has = true; gap = hi; sgn = -1.0f; }
+    }
+    const unsigned long long m = __ballot(has);
+    if (has) {
+        const int rank = __popcll(m & ((1ull << lane) - 1ull));
+        sh.limdof[rank] = lane; sh.limgap[rank] = gap; sh.limsgn[rank] = sgn;
+    }
+    if (lane == 0) { const int n = __popcll(m); sh.nlim = n; sh.nrows = 3 * sh.nc + n; }
+}
+#endif
 LS_FN void ph_limits(const LsCtx& cx, WaveShared& sh, int lane) {
     if (lane != 0) return;
     int n = 0;
@@ -492,7 +514,15 @@ LS_FN void ph_rows(const LsCtx& cx, WaveShared& sh, LaneRegs& r, int lane, float
         chol3_solve(sh.Lll[leg], y);
         for (int k = 0; k < 6; ++k) rb[k] -= sh.Mbl[leg][3 * k] * y[0] + sh.Mbl[leg][3 * k + 1] * y[1] + sh.Mbl[leg][3 * k + 2] * y[2];
     }
-    chol6_solve(sh.Sb, rb);
+    {
+        float t[6];
+        for (int k = 0; k < 6; ++k) {
+            float s = 0.0f;
+            for (int cc = 0; cc < 6; ++cc) s += sh.Sinv[6 * k + cc] * rb[cc];
+            t[k] = s;
+        }
+        for (int k = 0; k < 6; ++k) rb[k] = t[k];
+    }
     float* Y = sh.u.c.Y[lane];
     for (int k = 0; k < 6; ++k) Y[k] = rb[k];
     for (int l = 0; l < 4; ++l)

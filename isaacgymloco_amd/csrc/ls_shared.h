@@ -87,7 +87,8 @@ struct WaveShared {
     float hl[4][3];
     float legF[4][6];
     float yl[4][3];
-    float Sb[36];            // Schur complement on the base, then its Cholesky factor (lower)
+    float Sb[36];            // Schur complement on the base
+    float Sinv[36];          // its inverse (symmetric), from the Cholesky factor: every later solve is a 6x6 mat-vec
     float hb[6], rb[6], ab[6];
     float vfree[LS_NV], vnew[LS_NV];
     // ---- contacts
