@@ -139,7 +139,9 @@ enum lsim_rng_tag {
     LSIM_RNG_INIT = 12,        /* LR:999-1028, 1232 idx 0..11 motor_strength, 12 kp, 13 kd, 14 motor factor,
                                   15 payload, 16..18 com, 19 friction bucket id, 20 terrain level;
                                   step word = 0xFFFFFFFF                                    */
-    LSIM_RNG_INIT_BUCKET = 13  /* LR:511            env word = bucket index, idx 0         */
+    LSIM_RNG_INIT_BUCKET = 13, /* LR:511            env word = bucket index, idx 0         */
+    LSIM_RNG_POLICY = 14       /* HIMP:94 (actor_critic.act sample), lsim_rollout_act: step word = draw counter,
+                                  block p gives the two Box-Muller pairs of actions 2p, 2p+1       */
 };
 
 /* ---- robot model: the URDF after Isaac Gym's fixed-joint collapse ----
@@ -408,6 +410,43 @@ const char* lsim_buffer_name(int buffer_id);
 
 const char* lsim_last_error(lsim_handle h);
 void lsim_destroy(lsim_handle h);
+
+/* ---- rollout-side fused kernels (SURVEY.md 8f "fused storage"): the elementwise / storage half of the on-policy rollout
+ * step.  The networks' GEMMs stay with the caller (PyTorch); these two calls replace the ~35 small torch kernels of
+ *   HIMPPO.act                (HIMP:90-103: sample a ~ N(mean, std), log-prob, keep mean/std/values/observations),
+ *   HIMPPO.process_env_step   (HIMP:105-118: next critic obs with the termination rows patched in, HIMR:119-121;
+ *                              time-out bootstrap  r += gamma * V * time_out),
+ *   HIMRolloutStorage.add_transitions (HST:92-106: eleven copies into the [T, N, .] storage at the step index).
+ * Stateless: every argument is a device pointer (or scalar) of the caller; `step_idx_dev` and `draw_counter_dev` live
+ * in device memory so that both calls can be captured in a HIP graph and replayed.  All pointers are fp32 unless noted. */
+typedef struct lsim_rollout_storage {
+    float* observations;                 /* [T, N, num_obs]       HST:60 */
+    float* privileged_observations;      /* [T, N, num_priv_obs]  HST:62 */
+    float* next_privileged_observations; /* [T, N, num_priv_obs]  HST:63 */
+    float* actions;                      /* [T, N, num_actions] */
+    float* values;                       /* [T, N, 1] */
+    float* actions_log_prob;             /* [T, N, 1] */
+    float* mu;                           /* [T, N, num_actions] */
+    float* sigma;                        /* [T, N, num_actions] */
+    float* rewards;                      /* [T, N, 1] */
+    uint8_t* dones;                      /* [T, N, 1] u8 */
+    int32_t num_steps, num_envs, num_obs, num_priv_obs, num_actions;   /* num_actions <= 32; row sizes even */
+} lsim_rollout_storage;
+
+/* actions_out[N, A] = mean + std * z with z ~ N(0,1) from Philox4x32-10 keyed (seed, rank), counter
+ * (env, *draw_counter_dev, LSIM_RNG_POLICY, pair index), Box-Muller; log-prob summed over the action dimension;
+ * writes storage row *step_idx_dev of observations, privileged_observations, actions, values, actions_log_prob, mu, sigma.
+ * mean [N, A], std [A] (the policy's std parameter), values [N, 1], obs [N, num_obs], priv_obs [N, num_priv_obs]. */
+int lsim_rollout_act(const lsim_rollout_storage* st, const int64_t* step_idx_dev, const int64_t* draw_counter_dev,
+                     const float* mean, const float* std, const float* values, const float* obs, const float* priv_obs,
+                     uint32_t seed, uint32_t rank, float* actions_out, void* stream);
+/* after lsim_step: writes storage row *step_idx_dev of next_privileged_observations (term_priv_obs rows where dones, else
+ * priv_obs), rewards (+ gamma * values * time_outs when time_outs != NULL), dones; then a second tiny kernel advances
+ * *step_idx_dev and *draw_counter_dev by one.  dones / time_outs are u8 [N]; values is the [N, 1] critic output kept
+ * from lsim_rollout_act's inputs. */
+int lsim_rollout_post(const lsim_rollout_storage* st, int64_t* step_idx_dev, int64_t* draw_counter_dev,
+                      const uint8_t* dones, const uint8_t* time_outs, const float* rewards, const float* values,
+                      const float* priv_obs, const float* term_priv_obs, float gamma, void* stream);
 
 #ifdef __cplusplus
 }

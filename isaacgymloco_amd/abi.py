@@ -68,7 +68,10 @@ def _parse(text):
             if not stmt:
                 continue
             ty, rest = stmt.split(" ", 1)
-            base = structs[ty] if ty in structs else _CTYPES[ty]
+            if ty.endswith("*"):                         # pointer members (device pointers) bind as void*
+                base = ctypes.c_void_p
+            else:
+                base = structs[ty] if ty in structs else _CTYPES[ty]
             for decl in rest.split(","):
                 decl = decl.strip()
                 dm = re.match(r"(\w+)((?:\[[^\]]+\])*)$", decl)
@@ -88,6 +91,7 @@ LsimConfig = STRUCTS["lsim_config"]
 LsimRobotModel = STRUCTS["lsim_robot_model"]
 LsimBody = STRUCTS["lsim_body"]
 LsimCollisionPoint = STRUCTS["lsim_collision_point"]
+LsimRolloutStorage = STRUCTS["lsim_rollout_storage"]
 
 REWARD_IDS = {k[len("LSIM_R_"):].lower(): v for k, v in ENUMS["lsim_reward_id"].items() if k.startswith("LSIM_R_")}
 NUM_REWARD_TERMS = ENUMS["lsim_reward_id"]["LSIM_NUM_REWARD_TERMS"]

@@ -1,19 +1,26 @@
-"""hipGraph-captured rollout step for HIMOnPolicyRunner (launch-bound inner loop -> two graph replays + one env launch).
+"""hipGraph-captured rollout step for HIMOnPolicyRunner: one graph replay + the simulator launch + one fused storage launch.
 
 The eager rollout step issues ~100 tiny torch kernels (policy / estimator / critic forward at batch N, Gaussian sampling,
 log-prob, the time-out bootstrap, eleven storage copies, HIMR:110-127 + HIMP:90-118 + HST:92-106).  At N = 4096 each takes
 a few microseconds on the GPU but ~10 us of host dispatch, so collection is host-bound (1.2 ms/step against 0.76 ms of GPU
-work).  Here the same torch ops are captured once into two HIP graphs that read the simulator's live buffers (static
-addresses inside the arena) and write the rollout storage at a device-resident step index:
+work).  Here
 
-    graph A:  act(obs, critic_obs) -> actions, values, log-prob, mu, sigma;   storage[idx] <- (obs, critic_obs, actions, ...)
-    env.step_device(actions)                                                  (HIP kernels A + B, not captured: per-call args)
-    graph B:  next_critic_obs = where(done, termination_obs, critic_obs);  reward += gamma * value * time_out;
-              storage[idx] <- (next_critic_obs, reward, done);  idx += 1
+    graph A :  the three networks' forward (torch GEMMs + ELU, captured once)  ->  mean, values
+               lsim_rollout_act   (HIP, include/lsim.h): a = mean + std * z, log-prob, storage[idx] <- (obs, critic_obs,
+                                   actions, values, log-prob, mu, sigma)                     -- captured in the same graph
+    env.step_device(actions)      (HIP kernels A + B, not captured: per-call arguments)
+    lsim_rollout_post (HIP)    :  storage[idx] <- (where(done, termination_obs, critic_obs), reward + gamma * value * time_out,
+                                   done);  idx += 1
 
-Numerics are the eager path's (same ops, same order); only the Philox offsets of the sampler differ.
+The storage index and the sampler's draw counter live in device memory, so nothing in the loop reads back to the host.
+The sampler is the library's counter-based Philox (keyed like the simulator by (seed, rank)), not torch's generator: the
+action distribution is the reference's N(mean, std); the draws are not torch's draws.
 """
+import ctypes
+
 import torch
+
+from .. import abi, lib
 
 
 class GraphedRollout:
@@ -21,46 +28,49 @@ class GraphedRollout:
         self.runner, self.env, self.alg = runner, runner.env, runner.alg
         self.storage = self.alg.storage
         self.dev = self.env.obs_buf.device
-        self.idx = torch.zeros(1, dtype=torch.long, device=self.dev)
-        self.one = torch.ones(1, dtype=torch.long, device=self.dev)
-        N = self.env.num_envs
-        self.actions = torch.zeros(N, self.env.num_actions, device=self.dev)
+        self._L = lib.load()
+        N, A = self.env.num_envs, self.env.num_actions
+        self.idx = torch.zeros(1, dtype=torch.long, device=self.dev)       # storage row of the current step (device resident)
+        self.draws = torch.zeros(1, dtype=torch.long, device=self.dev)     # Philox step word of the action sampler
+        self.actions = torch.zeros(N, A, device=self.dev)
         self.values = torch.zeros(N, 1, device=self.dev)
-        self.graph_a = self.graph_b = None
+        self.mean = torch.zeros(N, A, device=self.dev)
+        st, S = self.storage, abi.LsimRolloutStorage()
+        for name, t in (("observations", st.observations), ("privileged_observations", st.privileged_observations),
+                        ("next_privileged_observations", st.next_privileged_observations), ("actions", st.actions),
+                        ("values", st.values), ("actions_log_prob", st.actions_log_prob), ("mu", st.mu), ("sigma", st.sigma),
+                        ("rewards", st.rewards), ("dones", st.dones)):
+            assert t.is_contiguous() and t.device == self.dev
+            setattr(S, name, t.data_ptr())
+        assert st.dones.dtype == torch.uint8 and st.rewards.dtype == torch.float32
+        S.num_steps, S.num_envs = st.observations.shape[0], N
+        S.num_obs, S.num_priv_obs, S.num_actions = st.observations.shape[2], st.privileged_observations.shape[2], A
+        self._S = S
+        self._seed, self._rank = int(self.env.lcfg.seed), int(self.env.lcfg.rank)
+        self.graph_a = None
         self._capture()
 
-    # ---- the two halves of HIMR:110-127, written against static tensors -------------------------------------------
+    # ---- HIMP:90-103 written against static tensors; the elementwise tail is one HIP kernel --------------------------
     def _act(self):
-        env, ac, st, i = self.env, self.alg.actor_critic, self.storage, self.idx
-        obs, critic_obs = env.obs_buf, env.privileged_obs_buf
-        # ac.act(obs) without torch.normal(mean, std): that overload checks std >= 0 on the host (a sync, illegal while
-        # capturing); N(0,1) * std + mean is what it computes internally
-        ac.update_distribution(obs)
-        mean, std = ac.action_mean, ac.action_std
-        actions = torch.randn_like(mean) * std + mean
-        values = ac.evaluate(critic_obs)
-        logp = ac.get_actions_log_prob(actions)
-        self.actions.copy_(actions)
-        self.values.copy_(values)
-        st.observations.index_copy_(0, i, obs.unsqueeze(0))
-        st.privileged_observations.index_copy_(0, i, critic_obs.unsqueeze(0))
-        st.actions.index_copy_(0, i, actions.unsqueeze(0))
-        st.values.index_copy_(0, i, values.unsqueeze(0))
-        st.actions_log_prob.index_copy_(0, i, logp.view(1, -1, 1))
-        st.mu.index_copy_(0, i, ac.action_mean.unsqueeze(0))
-        st.sigma.index_copy_(0, i, ac.action_std.unsqueeze(0))
+        env, ac = self.env, self.alg.actor_critic
+        ac.update_distribution(env.obs_buf)
+        self.mean.copy_(ac.action_mean)
+        self.values.copy_(ac.evaluate(env.privileged_obs_buf))
+        s = torch.cuda.current_stream(self.dev).cuda_stream
+        lib.check(self._L.lsim_rollout_act(ctypes.byref(self._S), self.idx.data_ptr(), self.draws.data_ptr(), self.mean.data_ptr(),
+                                           ac.std.data_ptr(), self.values.data_ptr(), env.obs_buf.data_ptr(),
+                                           env.privileged_obs_buf.data_ptr(), self._seed, self._rank, self.actions.data_ptr(), s),
+                  what="lsim_rollout_act")
 
+    # ---- HIMR:119-121 + HIMP:105-118 + HST:92-106 ------------------------------------------------------------------------
     def _post(self):
-        env, st, i = self.env, self.storage, self.idx
-        dones = env.reset_buf
-        next_critic = torch.where(dones.unsqueeze(1), env.termination_privileged_obs_buf, env.privileged_obs_buf)
-        rewards = env.rew_buf.clone()
-        if "time_outs" in env.extras:   # HIMP:110-111
-            rewards += self.alg.gamma * torch.squeeze(self.values * env.extras["time_outs"].unsqueeze(1), 1)
-        st.next_privileged_observations.index_copy_(0, i, next_critic.unsqueeze(0))
-        st.rewards.index_copy_(0, i, rewards.view(1, -1, 1))
-        st.dones.index_copy_(0, i, dones.view(1, -1, 1).to(torch.uint8))
-        i.add_(self.one)
+        env = self.env
+        to = env.extras.get("time_outs")
+        s = torch.cuda.current_stream(self.dev).cuda_stream
+        lib.check(self._L.lsim_rollout_post(ctypes.byref(self._S), self.idx.data_ptr(), self.draws.data_ptr(), env.reset_buf.data_ptr(),
+                                            to.data_ptr() if to is not None else None, env.rew_buf.data_ptr(), self.values.data_ptr(),
+                                            env.privileged_obs_buf.data_ptr(), env.termination_privileged_obs_buf.data_ptr(),
+                                            float(self.alg.gamma), s), what="lsim_rollout_post")
 
     def _capture(self):
         s = torch.cuda.Stream(device=self.dev)
@@ -72,20 +82,17 @@ class GraphedRollout:
             self.idx.zero_()
         torch.cuda.current_stream(self.dev).wait_stream(s)
         torch.cuda.synchronize(self.dev)
-        self.graph_a, self.graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.no_grad():
-            with torch.cuda.graph(self.graph_a):
-                self._act()
-            with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool()):
-                self._post()
+        self.graph_a = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph_a):
+            self._act()
         self.idx.zero_()
         self.storage.step = 0
 
     def step(self):
-        """one rollout step: graph A, simulator step, graph B"""
+        """one rollout step: graph A (networks + fused sample/store), simulator step, fused post-step store"""
         self.graph_a.replay()
         self.env.step_device(self.actions)
-        self.graph_b.replay()
+        self._post()
         self.storage.step += 1
 
     def end_iteration(self):

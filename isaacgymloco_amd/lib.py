@@ -40,6 +40,9 @@ def load():
     L.lsim_last_error.restype = ctypes.c_char_p
     L.lsim_reward_name.restype = ctypes.c_char_p
     L.lsim_buffer_name.restype = ctypes.c_char_p
+    f32 = ctypes.c_float
+    L.lsim_rollout_act.argtypes = [ctypes.POINTER(abi.LsimRolloutStorage), vp, vp, vp, vp, vp, vp, vp, u32, u32, vp, vp]
+    L.lsim_rollout_post.argtypes = [ctypes.POINTER(abi.LsimRolloutStorage), vp, vp, vp, vp, vp, vp, vp, vp, f32, vp]
     L.lsim_destroy.argtypes = [vp]
     L.lsim_destroy.restype = None
     _lib = L

@@ -82,3 +82,69 @@ def test_amp_hybrid_runner_iteration_on_gpu():
     assert any(not torch.equal(before[k], after[k]) for k in before)
     assert all(torch.isfinite(v).all() for v in after.values())
     assert all(torch.isfinite(v).all() for v in run.alg.actor_critic.state_dict().values())
+
+
+def test_fused_rollout_kernels_match_torch():
+    """lsim_rollout_act / lsim_rollout_post (include/lsim.h) against the torch ops they replace (HIMP:90-118, HST:92-106):
+    fp32 tolerance 1e-5 on log-prob / bootstrap, exact copies, N(0,1) statistics and (seed, counter) determinism of the sampler."""
+    import ctypes
+    from torch.distributions import Normal
+    from isaacgymloco_amd import abi, lib
+    L = lib.load()
+    dev = "cuda:0"
+    T, N, A, O, P = 3, 1000, 12, 270, 238
+    g = torch.Generator(device=dev).manual_seed(0)
+    rnd = lambda *s: torch.randn(*s, device=dev, generator=g)
+    st = {k: torch.zeros(T, N, d, device=dev) for k, d in (("observations", O), ("privileged_observations", P),
+          ("next_privileged_observations", P), ("actions", A), ("values", 1), ("actions_log_prob", 1), ("mu", A), ("sigma", A), ("rewards", 1))}
+    st["dones"] = torch.zeros(T, N, 1, device=dev, dtype=torch.uint8)
+    S = abi.LsimRolloutStorage()
+    for k, t in st.items():
+        setattr(S, k, t.data_ptr())
+    S.num_steps, S.num_envs, S.num_obs, S.num_priv_obs, S.num_actions = T, N, O, P, A
+    idx = torch.ones(1, dtype=torch.long, device=dev)              # write row 1
+    draws = torch.full((1,), 7, dtype=torch.long, device=dev)
+    mean, std, values = rnd(N, A), torch.rand(A, device=dev, generator=g) + 0.3, rnd(N, 1)
+    obs, priv, term = rnd(N, O), rnd(N, P), rnd(N, P)
+    acts = torch.zeros(N, A, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    call = lambda out: L.lsim_rollout_act(ctypes.byref(S), idx.data_ptr(), draws.data_ptr(), mean.data_ptr(), std.data_ptr(), values.data_ptr(),
+                                          obs.data_ptr(), priv.data_ptr(), 5, 0, out.data_ptr(), s)
+    assert call(acts) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(st["observations"][1], obs) and torch.equal(st["privileged_observations"][1], priv)
+    assert torch.equal(st["actions"][1], acts) and torch.equal(st["mu"][1], mean) and torch.equal(st["values"][1], values)
+    assert torch.equal(st["sigma"][1], std.expand(N, A))
+    assert st["observations"][0].abs().sum() == 0 and st["observations"][2].abs().sum() == 0
+    ref_lp = Normal(mean, std.expand(N, A)).log_prob(acts).sum(-1, keepdim=True)
+    torch.testing.assert_close(st["actions_log_prob"][1], ref_lp, rtol=1e-5, atol=1e-5)
+    z = ((acts - mean) / std).flatten()
+    assert abs(float(z.mean())) < 0.03 and abs(float(z.var()) - 1.0) < 0.05 and float(z.abs().max()) < 6.0
+    assert abs(float((z[:-1] * z[1:]).mean())) < 0.03          # neighbouring draws (the two halves of a Box-Muller pair) uncorrelated
+    again = torch.zeros_like(acts)
+    assert call(again) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(again, acts)                             # same (seed, rank, counter) -> same draws
+    # ---- post
+    dones = torch.rand(N, device=dev, generator=g) < 0.3
+    touts = dones & (torch.rand(N, device=dev, generator=g) < 0.5)
+    rew = rnd(N)
+    assert L.lsim_rollout_post(ctypes.byref(S), idx.data_ptr(), draws.data_ptr(), dones.data_ptr(), touts.data_ptr(), rew.data_ptr(), values.data_ptr(),
+                               priv.data_ptr(), term.data_ptr(), ctypes.c_float(0.99), s) == 0
+    torch.cuda.synchronize()
+    assert int(idx) == 2 and int(draws) == 8
+    assert torch.equal(st["next_privileged_observations"][1], torch.where(dones.unsqueeze(1), term, priv))
+    assert torch.equal(st["dones"][1, :, 0], dones.to(torch.uint8))
+    torch.testing.assert_close(st["rewards"][1, :, 0], rew + 0.99 * values[:, 0] * touts.float(), rtol=1e-6, atol=1e-6)
+    other = torch.zeros_like(acts)
+    assert call(other) == 0                                     # counter advanced -> fresh draws, now into row 2
+    torch.cuda.synchronize()
+    assert not torch.equal(other, acts) and torch.equal(st["actions"][2], other)
+    # a full storage must not be written past its end (HST:93-94 raises in the reference)
+    idx.fill_(T)
+    before = st["actions"].clone()
+    assert call(other) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(st["actions"], before)
+    assert L.lsim_rollout_act(None, idx.data_ptr(), draws.data_ptr(), mean.data_ptr(), std.data_ptr(), values.data_ptr(), obs.data_ptr(),
+                              priv.data_ptr(), 5, 0, acts.data_ptr(), s) == abi.E_INVALID
