@@ -447,6 +447,12 @@ int lsim_rollout_act(const lsim_rollout_storage* st, const int64_t* step_idx_dev
 int lsim_rollout_post(const lsim_rollout_storage* st, int64_t* step_idx_dev, int64_t* draw_counter_dev,
                       const uint8_t* dones, const uint8_t* time_outs, const float* rewards, const float* values,
                       const float* priv_obs, const float* term_priv_obs, float gamma, void* stream);
+/* GAE(lambda) reverse sweep of HIMRolloutStorage.compute_returns (HST:113-123), one thread per env over the T stored steps:
+ *   delta = r_t + (1 - done_t) * gamma * V_{t+1} - V_t;   A_t = delta + (1 - done_t) * gamma * lam * A_{t+1};   returns_t = A_t + V_t
+ * with V_T = last_values [N, 1].  Writes returns [T, N, 1] and the raw advantages returns - values [T, N, 1]; the batch
+ * normalisation of HST:126-127 (a global mean / std, reduced over ranks when data parallel) stays with the caller. */
+int lsim_rollout_gae(const lsim_rollout_storage* st, const float* last_values, float gamma, float lam,
+                     float* returns, float* advantages, void* stream);
 
 #ifdef __cplusplus
 }

@@ -113,3 +113,29 @@ extern "C" int lsim_rollout_post(const lsim_rollout_storage* st, int64_t* step_i
     hipLaunchKernelGGL(lsim_k_rollout_advance, dim3(1), dim3(1), 0, (hipStream_t)stream, step_idx_dev, draw_counter_dev);
     return hipGetLastError() == hipSuccess ? LSIM_OK : LSIM_E_HIP;
 }
+
+__global__ __launch_bounds__(256) void lsim_k_rollout_gae(lsim_rollout_storage st, const float* last_values, float gamma, float lam,
+                                                           float* returns, float* advantages) {
+    const int env = blockIdx.x * 256 + threadIdx.x;
+    if (env >= st.num_envs) return;
+    float nxt = last_values[env], adv = 0.0f;
+    for (int t = st.num_steps - 1; t >= 0; --t) {
+        const size_t row = (size_t)t * st.num_envs + env;
+        const float nd = 1.0f - (float)st.dones[row], v = st.values[row];
+        const float delta = st.rewards[row] + nd * gamma * nxt - v;
+        adv = delta + nd * gamma * lam * adv;
+        returns[row] = adv + v;
+        advantages[row] = (adv + v) - v;      // HST:126: returns - values, as the reference forms it
+        nxt = v;
+    }
+}
+
+extern "C" int lsim_rollout_gae(const lsim_rollout_storage* st, const float* last_values, float gamma, float lam,
+                                float* returns, float* advantages, void* stream) {
+    int rc = ls_rollout_check(st);
+    if (rc != LSIM_OK) return rc;
+    if (!last_values || !returns || !advantages) return LSIM_E_INVALID;
+    hipLaunchKernelGGL(lsim_k_rollout_gae, dim3((st->num_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, *st, last_values, gamma, lam,
+                       returns, advantages);
+    return hipGetLastError() == hipSuccess ? LSIM_OK : LSIM_E_HIP;
+}

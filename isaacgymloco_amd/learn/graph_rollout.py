@@ -20,7 +20,7 @@ import ctypes
 
 import torch
 
-from .. import abi, lib
+from .. import lib
 
 
 class GraphedRollout:
@@ -35,17 +35,7 @@ class GraphedRollout:
         self.actions = torch.zeros(N, A, device=self.dev)
         self.values = torch.zeros(N, 1, device=self.dev)
         self.mean = torch.zeros(N, A, device=self.dev)
-        st, S = self.storage, abi.LsimRolloutStorage()
-        for name, t in (("observations", st.observations), ("privileged_observations", st.privileged_observations),
-                        ("next_privileged_observations", st.next_privileged_observations), ("actions", st.actions),
-                        ("values", st.values), ("actions_log_prob", st.actions_log_prob), ("mu", st.mu), ("sigma", st.sigma),
-                        ("rewards", st.rewards), ("dones", st.dones)):
-            assert t.is_contiguous() and t.device == self.dev
-            setattr(S, name, t.data_ptr())
-        assert st.dones.dtype == torch.uint8 and st.rewards.dtype == torch.float32
-        S.num_steps, S.num_envs = st.observations.shape[0], N
-        S.num_obs, S.num_priv_obs, S.num_actions = st.observations.shape[2], st.privileged_observations.shape[2], A
-        self._S = S
+        self._S = self.storage.c_struct()
         self._seed, self._rank = int(self.env.lcfg.seed), int(self.env.lcfg.rank)
         self.graph_a = None
         self._capture()

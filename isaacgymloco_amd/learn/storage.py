@@ -60,18 +60,45 @@ class HIMRolloutStorage:
     def clear(self):
         self.step = 0
 
+    def c_struct(self):
+        """lsim_rollout_storage (include/lsim.h) over this storage's device tensors, for the fused HIP rollout kernels"""
+        from .. import abi
+        if getattr(self, "_c_struct", None) is None:
+            S = abi.LsimRolloutStorage()
+            for name in ("observations", "privileged_observations", "next_privileged_observations", "actions", "values",
+                         "actions_log_prob", "mu", "sigma", "rewards", "dones"):
+                t = getattr(self, name)
+                assert t is not None and t.is_cuda and t.is_contiguous(), name
+                setattr(S, name, t.data_ptr())
+            assert self.dones.dtype == torch.uint8 and self.rewards.dtype == torch.float32
+            S.num_steps, S.num_envs = self.num_transitions_per_env, self.num_envs
+            S.num_obs, S.num_priv_obs = self.observations.shape[2], self.privileged_observations.shape[2]
+            S.num_actions = self.actions.shape[2]
+            self._c_struct = S
+        return self._c_struct
+
     def compute_returns(self, last_values, gamma, lam):
         """GAE(lambda) reverse sweep (HST:113-123) and advantage normalisation over the whole batch (HST:126-127)."""
         T = self.num_transitions_per_env
-        not_done = 1.0 - self.dones.float()
-        adv = torch.zeros_like(last_values)
-        nxt = last_values
-        for s in range(T - 1, -1, -1):
-            delta = self.rewards[s] + not_done[s] * gamma * nxt - self.values[s]
-            adv = delta + not_done[s] * gamma * lam * adv
-            self.returns[s] = adv + self.values[s]
-            nxt = self.values[s]
-        a = self.returns - self.values
+        if self.values.is_cuda and self.privileged_observations is not None:
+            # one HIP launch (one thread per env walks the T steps) instead of ~8 torch kernels per step
+            import ctypes
+            from .. import lib
+            a = torch.empty_like(self.returns)
+            lv = last_values.detach().contiguous()
+            lib.check(lib.load().lsim_rollout_gae(ctypes.byref(self.c_struct()), lv.data_ptr(), float(gamma), float(lam),
+                                                  self.returns.data_ptr(), a.data_ptr(),
+                                                  torch.cuda.current_stream(self.values.device).cuda_stream), what="lsim_rollout_gae")
+        else:
+            not_done = 1.0 - self.dones.float()
+            adv = torch.zeros_like(last_values)
+            nxt = last_values
+            for s in range(T - 1, -1, -1):
+                delta = self.rewards[s] + not_done[s] * gamma * nxt - self.values[s]
+                adv = delta + not_done[s] * gamma * lam * adv
+                self.returns[s] = adv + self.values[s]
+                nxt = self.values[s]
+            a = self.returns - self.values
         if self.advantage_sync is None:
             self.advantages = (a - a.mean()) / (a.std() + 1e-8)
         else:   # global statistics over all ranks (unbiased std, like Tensor.std())

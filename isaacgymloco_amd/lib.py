@@ -43,6 +43,7 @@ def load():
     f32 = ctypes.c_float
     L.lsim_rollout_act.argtypes = [ctypes.POINTER(abi.LsimRolloutStorage), vp, vp, vp, vp, vp, vp, vp, u32, u32, vp, vp]
     L.lsim_rollout_post.argtypes = [ctypes.POINTER(abi.LsimRolloutStorage), vp, vp, vp, vp, vp, vp, vp, vp, f32, vp]
+    L.lsim_rollout_gae.argtypes = [ctypes.POINTER(abi.LsimRolloutStorage), vp, f32, f32, vp, vp, vp]
     L.lsim_destroy.argtypes = [vp]
     L.lsim_destroy.restype = None
     _lib = L

@@ -148,3 +148,22 @@ def test_fused_rollout_kernels_match_torch():
     assert torch.equal(st["actions"], before)
     assert L.lsim_rollout_act(None, idx.data_ptr(), draws.data_ptr(), mean.data_ptr(), std.data_ptr(), values.data_ptr(), obs.data_ptr(),
                               priv.data_ptr(), 5, 0, acts.data_ptr(), s) == abi.E_INVALID
+
+
+def test_fused_gae_matches_torch_sweep():
+    """lsim_rollout_gae against the reference's reverse sweep (HST:113-127) as written in storage.compute_returns' torch branch"""
+    from isaacgymloco_amd.learn.storage import HIMRolloutStorage
+    T, N = 24, 777
+    g = torch.Generator().manual_seed(3)
+    gpu = HIMRolloutStorage(N, T, [270], [238], [12], device="cuda:0")
+    cpu = HIMRolloutStorage(N, T, [270], [238], [12], device="cpu")
+    for name in ("rewards", "values"):
+        v = torch.randn(T, N, 1, generator=g)
+        getattr(cpu, name).copy_(v); getattr(gpu, name).copy_(v)
+    d = (torch.rand(T, N, 1, generator=g) < 0.05).to(torch.uint8)
+    cpu.dones.copy_(d); gpu.dones.copy_(d)
+    last = torch.randn(N, 1, generator=g)
+    cpu.compute_returns(last, 0.99, 0.95)
+    gpu.compute_returns(last.to("cuda:0"), 0.99, 0.95)
+    torch.testing.assert_close(gpu.returns.cpu(), cpu.returns, rtol=2e-6, atol=2e-6)
+    torch.testing.assert_close(gpu.advantages.cpu(), cpu.advantages, rtol=1e-5, atol=1e-5)
