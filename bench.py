@@ -24,23 +24,15 @@ HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s spec
 
 
 def cpu_baseline(task, sample_envs=64, budget_s=12.0):
-    """Time the CPU oracle (build's scalar C twin of the same step; kind='port') on the host cores of this box."""
-    import numpy as np
-    from helpers import C, make_oracle
-    cfg = C.TASKS[task][0]()
-    orc, lc, model, ter = make_oracle(cfg, sample_envs, seed=1)
-    orc.reset_all()
-    rs = np.random.RandomState(0)
-    acts = rs.normal(0, 1, (sample_envs, 12)).astype(np.float32)
-    orc.step(acts)
-    t0 = time.perf_counter()
-    n = 0
-    while time.perf_counter() - t0 < budget_s:
-        orc.step(acts)
-        n += 1
-    dt = time.perf_counter() - t0
-    return {"value": sample_envs * n / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "sample": f"{n} steps x {sample_envs} envs of the same task on 1 host core ({os.cpu_count()} present), CPU oracle (scalar C, fp64 physics)"}
+    """Time the CPU oracle (build's scalar C twin of the same step; kind='port') on the host cores of this box: a child process
+    (oracle/cpu_bench.py, no GPU, no torch) runs one oracle instance per core for a bounded sample and reports the aggregate."""
+    import subprocess
+    procs = min(len(os.sched_getaffinity(0)), 64)          # bounded: 64 workers x 64 envs is plenty to show the per-core rate
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_bench.py"), "--task", task, "--envs", str(sample_envs),
+                          "--seconds", str(budget_s), "--procs", str(procs)], capture_output=True, text=True, timeout=600)
+    if out.returncode != 0:
+        raise RuntimeError(out.stderr[-400:])
+    return json.loads(out.stdout.strip().splitlines()[-1])
 
 
 def main():
@@ -73,11 +65,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)   # RCCL; the rank's GPU is bound before the first collective
 
     from isaacgymloco_amd.envs import config as C
     from isaacgymloco_amd.envs.legged_robot import LeggedRobot
@@ -160,6 +152,19 @@ def main():
                          "note": "VALU-issue bound, not HBM bound: 6.9 KB and ~17 k wave instructions per env-step (DESIGN.md, kernel A); "
                                  "traffic and valu_issue_frac come from separate rocprofv3 --pmc passes (profiles/pmc_traffic.json)"},
         }
+        # measured device-memory copy rate on this box (quote the datasheet peak AND a measurement): 1 GiB fp32 copy
+        try:
+            xs = torch.empty(1 << 28, device=dev); ys = torch.empty_like(xs)
+            ys.copy_(xs); torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                ys.copy_(xs)
+            e1.record(); torch.cuda.synchronize(dev)
+            out["roofline"]["measured_copy_gbs"] = 5 * 2 * xs.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            del xs, ys
+        except Exception:
+            out["roofline"]["measured_copy_gbs"] = None
         out.update({k: v for k, v in extra.items() if k not in out})
         if world == 1 and not args.no_cpu_baseline:
             try:

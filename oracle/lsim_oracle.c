@@ -752,6 +752,7 @@ int orc_create(const lsim_config* cfg, const lsim_robot_model* model, const int1
     if (c->mesh_type != 0) {
         if (!grid || !origins) return LSIM_E_INVALID;
         memcpy(s->buf[LSIM_BUF_HEIGHT_GRID], grid, lsim_buffer_bytes(c, LSIM_BUF_HEIGHT_GRID));
+        orc_build_mesh_cache(s);
         memcpy(s->buf[LSIM_BUF_TERRAIN_ORIGINS], origins, lsim_buffer_bytes(c, LSIM_BUF_TERRAIN_ORIGINS));
     }
     for (int i = 0; i < 4; ++i) for (int k = 0; k < 2; ++k) s->command_ranges[i][k] = (double)c->command_ranges[i][k];
@@ -860,5 +861,6 @@ int orc_get_command_ranges(orc_sim* s, double out[8]) { memcpy(out, s->command_r
 void orc_destroy(orc_sim* s) {
     if (!s) return;
     for (int id = 0; id < LSIM_NUM_BUFFERS; ++id) free(s->buf[id]);
+    free(s->vmove); free(s->cell_walls);
     free(s);
 }

@@ -16,6 +16,8 @@ typedef struct orc_sim {
     int active_terms[LSIM_NUM_REWARD_TERMS];  /* alphabetical, termination excluded (LR:1050-1055) */
     int num_active;
     char err[256];
+    int8_t* vmove;              /* [rows*cols][2] horizontal displacement of each mesh vertex (orc_build_mesh_cache) */
+    uint8_t* cell_walls;        /* [rows*cols] 1 where a displaced vertex lies in the 4x4 vertex block around the cell */
 } orc_sim;
 
 #define ORC_F(s, id) ((float*)(s)->buf[id])
@@ -31,5 +33,7 @@ void orc_physics_substep(orc_sim* s, int e, const float tau[12], int apply_force
 void orc_refresh_body_states(orc_sim* s, int e);
 /* terrain contact query: signed distance of a world point to the (slope-corrected) terrain mesh, and the contact normal */
 void orc_terrain_contact(const orc_sim* s, const double cw[3], double radius, double* dist, double n[3]);
+/* tabulate the vertex displacement rule once per terrain (called by orc_create after the grid is in place) */
+void orc_build_mesh_cache(orc_sim* s);
 
 #endif

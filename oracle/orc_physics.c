@@ -19,6 +19,7 @@
  */
 #include <math.h>
 #include <string.h>
+#include <stdlib.h>
 
 #include "orc_internal.h"
 
@@ -137,10 +138,33 @@ static void orc_vertex_move(const orc_sim* s, int i, int j, int* mx_out, int* my
     *mx_out = mx + (mx == 0 ? mc : 0);
     *my_out = my + (my == 0 ? mc : 0);
 }
+void orc_build_mesh_cache(orc_sim* s) {
+    const lsim_config* c = &s->cfg;
+    if (c->mesh_type == 0 || c->grid_rows <= 0) return;
+    const int R = c->grid_rows, C = c->grid_cols;
+    s->vmove = (int8_t*)calloc((size_t)R * C, 2);
+    s->cell_walls = (uint8_t*)calloc((size_t)R * C, 1);
+    for (int i = 0; i < R; ++i)
+        for (int j = 0; j < C; ++j) {
+            int mx, my;
+            orc_vertex_move(s, i, j, &mx, &my);
+            s->vmove[2 * ((size_t)i * C + j)] = (int8_t)mx;
+            s->vmove[2 * ((size_t)i * C + j) + 1] = (int8_t)my;
+        }
+    for (int i = 0; i < R; ++i)
+        for (int j = 0; j < C; ++j) {
+            int any = 0;
+            for (int a = i - 1; a <= i + 2 && !any; ++a)
+                for (int b = j - 1; b <= j + 2; ++b) {
+                    if (a < 0 || b < 0 || a >= R || b >= C) continue;
+                    if (s->vmove[2 * ((size_t)a * C + b)] || s->vmove[2 * ((size_t)a * C + b) + 1]) { any = 1; break; }
+                }
+            s->cell_walls[(size_t)i * C + j] = (uint8_t)any;
+        }
+}
 static void mesh_vertex(const orc_sim* s, int a, int b, double v[3]) {
     const lsim_config* c = &s->cfg;
-    int mx, my;
-    orc_vertex_move(s, a, b, &mx, &my);
+    int mx = s->vmove[2 * ((size_t)a * c->grid_cols + b)], my = s->vmove[2 * ((size_t)a * c->grid_cols + b) + 1];
     v[0] = (a + mx) * (double)c->horizontal_scale - c->border_size;
     v[1] = (b + my) * (double)c->horizontal_scale - c->border_size;
     v[2] = ORC_I16(s, LSIM_BUF_HEIGHT_GRID)[a * c->grid_cols + b] * (double)c->vertical_scale;
@@ -177,17 +201,7 @@ static int tri_closest(const double p[3], const double a[3], const double b[3], 
     else { memcpy(q, q3, sizeof(q3)); *d2 = e3; }
     return 1;
 }
-static int cell_has_walls(const orc_sim* s, int i, int j) {
-    const lsim_config* c = &s->cfg;
-    for (int a = i - 1; a <= i + 2; ++a)
-        for (int b = j - 1; b <= j + 2; ++b) {
-            if (a < 0 || b < 0 || a >= c->grid_rows || b >= c->grid_cols) continue;
-            int mx, my;
-            orc_vertex_move(s, a, b, &mx, &my);
-            if (mx || my) return 1;
-        }
-    return 0;
-}
+static int cell_has_walls(const orc_sim* s, int i, int j) { return s->cell_walls[(size_t)i * s->cfg.grid_cols + j]; }
 /* signed distance of world point cw to the terrain surface (negative inside) and contact normal */
 void orc_terrain_contact(const orc_sim* s, const double cw[3], double radius, double* dist, double n[3]) {
     const lsim_config* c = &s->cfg;
