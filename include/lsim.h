@@ -454,6 +454,17 @@ int lsim_rollout_post(const lsim_rollout_storage* st, int64_t* step_idx_dev, int
 int lsim_rollout_gae(const lsim_rollout_storage* st, const float* last_values, float gamma, float lam,
                      float* returns, float* advantages, void* stream);
 
+/* ---- learner-side kernel: weight / bias gradient of a small Linear layer over a tall minibatch,
+ *   dw[n, k] = sum_b g[b, n] * x[b, k],   db[n] = sum_b g[b, n]      (torch.nn.Linear backward: grad_weight = g^T x, grad_bias = g.sum(0))
+ * for ceil(n_out / 16) * ceil(k_in / 16) <= 32 (each <= 8): the heads and narrow layers of HAC:66-95 / HES:36-54 / DISC:18-25, whose
+ * K = 102 400 reductions BLAS runs at a few percent of peak.  x [batch, k_in] with row stride ldx, g [batch, n_out] with row stride ldg
+ * (floats), dw [n_out, k_in] and db [n_out] (db may be NULL) contiguous.  `workspace` is a caller-allocated device buffer of at least
+ * lsim_linear_wgrad_workspace() bytes holding the per-wave partial results (summed in a fixed order: deterministic).
+ * Returns LSIM_E_UNSUPPORTED for larger layers (use BLAS). */
+int lsim_linear_wgrad_workspace(long batch, int k_in, int n_out, size_t* bytes, int* num_waves);
+int lsim_linear_wgrad(const float* x, int64_t ldx, const float* g, int64_t ldg, int64_t batch, int k_in, int n_out,
+                      float* dw, float* db, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,70 @@
+"""nn.Linear whose backward uses the library's tall-skinny weight-gradient kernel (include/lsim.h, lsim_linear_wgrad) for the
+learner's narrow layers on the GPU.
+
+Forward and grad_input are the usual BLAS calls.  grad_weight = g^T x and grad_bias = g.sum(0) over a 102 400-row minibatch are
+K = 102 400 reductions into a tiny output; rocBLAS/hipBLASLt run them at a few percent of peak (48-270 us per layer, and torch's
+column sum needs 260 us for 19 columns), the MFMA kernel in csrc/ls_learn.h reads x and g once (10-40 us).  Same parameters,
+same state_dict keys, same initialisation as nn.Linear (it IS an nn.Linear); results differ from BLAS by fp32 summation order.
+"""
+import ctypes
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+_MIN_BATCH = 4096
+_workspaces = {}
+
+
+def _eligible(batch, k_in, n_out):
+    nt, kt = (n_out + 15) // 16, (k_in + 15) // 16
+    return batch >= _MIN_BATCH and nt <= 8 and kt <= 8 and nt * kt <= 32
+
+
+def linear_wgrad(x, g, want_bias=True):
+    """(g^T x, g.sum(0)) for 2-D fp32 CUDA tensors through lsim_linear_wgrad"""
+    from .. import lib
+    L = lib.load()
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    if g.stride(1) != 1:
+        g = g.contiguous()
+    batch, k_in = x.shape
+    n_out = g.shape[1]
+    need, waves = ctypes.c_size_t(), ctypes.c_int()
+    lib.check(L.lsim_linear_wgrad_workspace(batch, k_in, n_out, ctypes.byref(need), ctypes.byref(waves)), what="lsim_linear_wgrad_workspace")
+    ws = _workspaces.get(x.device)
+    if ws is None or ws.numel() < need.value:
+        ws = torch.empty(max(need.value, 1 << 20), dtype=torch.uint8, device=x.device)
+        _workspaces[x.device] = ws
+    dw = torch.empty(n_out, k_in, device=x.device, dtype=torch.float32)
+    db = torch.empty(n_out, device=x.device, dtype=torch.float32) if want_bias else None
+    lib.check(L.lsim_linear_wgrad(x.data_ptr(), x.stride(0), g.data_ptr(), g.stride(0), batch, k_in, n_out, dw.data_ptr(),
+                                  db.data_ptr() if want_bias else None, ws.data_ptr(), ws.numel(),
+                                  torch.cuda.current_stream(x.device).cuda_stream), what="lsim_linear_wgrad")
+    return dw, db
+
+
+class _SkinnyLinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        gx = g @ weight if ctx.needs_input_grad[0] else None
+        dw = db = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw, db = linear_wgrad(x, g, want_bias=ctx.has_bias)
+        return gx, dw, db
+
+
+class SkinnyLinear(nn.Linear):
+    def forward(self, x):
+        if (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and torch.is_grad_enabled() and self.weight.requires_grad
+                and _eligible(x.shape[0], self.in_features, self.out_features)):
+            return _SkinnyLinearFn.apply(x, self.weight, self.bias)
+        return F.linear(x, self.weight, self.bias)

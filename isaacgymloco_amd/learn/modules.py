@@ -10,6 +10,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.distributions import Normal
 
+from .fused_linear import SkinnyLinear
+
 _ACTIVATIONS = {"elu": nn.ELU, "selu": nn.SELU, "relu": nn.ReLU, "crelu": nn.ReLU, "silu": nn.SiLU,
                 "lrelu": nn.LeakyReLU, "tanh": nn.Tanh, "sigmoid": nn.Sigmoid}
 
@@ -24,7 +26,7 @@ def mlp(sizes, activation, last_activation=False):
     """Linear(sizes[0], sizes[1]) -> act -> ... -> Linear(sizes[-2], sizes[-1]) [-> act]"""
     layers = []
     for i in range(len(sizes) - 1):
-        layers.append(nn.Linear(sizes[i], sizes[i + 1]))
+        layers.append(SkinnyLinear(sizes[i], sizes[i + 1]))   # an nn.Linear; narrow layers get the HIP weight-gradient kernel on the GPU
         if i < len(sizes) - 2 or last_activation:
             layers.append(activation)
     return nn.Sequential(*layers)

@@ -167,3 +167,39 @@ def test_fused_gae_matches_torch_sweep():
     gpu.compute_returns(last.to("cuda:0"), 0.99, 0.95)
     torch.testing.assert_close(gpu.returns.cpu(), cpu.returns, rtol=2e-6, atol=2e-6)
     torch.testing.assert_close(gpu.advantages.cpu(), cpu.advantages, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("k_in,n_out", [(128, 12), (128, 1), (64, 19), (45, 128), (64, 16), (128, 64), (16, 32), (7, 3)])
+def test_linear_wgrad_kernel_matches_blas(k_in, n_out):
+    """lsim_linear_wgrad (MFMA, csrc/ls_learn.h) against g^T x and g.sum(0) in fp64; strided x (a column slice, like the
+    estimator's next_obs = critic_obs[:, 3:48]) and a ragged batch that does not fill the last wave."""
+    from isaacgymloco_amd.learn.fused_linear import linear_wgrad
+    g_ = torch.Generator(device="cuda:0").manual_seed(k_in * 131 + n_out)
+    B = 102400 - 37
+    big = torch.randn(B, k_in + 5, device="cuda:0", generator=g_)
+    x = big[:, 3:3 + k_in]
+    g = torch.randn(B, n_out, device="cuda:0", generator=g_)
+    dw, db = linear_wgrad(x, g)
+    ref_w = (g.double().t() @ x.double())
+    ref_b = g.double().sum(0)
+    scale = (B ** 0.5)
+    assert float((dw.double() - ref_w).abs().max()) < 2e-5 * scale       # fp32 accumulation over 1e5 terms of O(1)
+    assert float((db.double() - ref_b).abs().max()) < 2e-5 * scale
+    dw2, db2 = linear_wgrad(x, g)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)                   # fixed reduction order
+
+
+def test_skinny_linear_trains_like_nn_linear():
+    """SkinnyLinear is an nn.Linear (same init stream, same keys); its GPU backward matches torch's within fp32 summation error"""
+    import torch.nn as nn
+    from isaacgymloco_amd.learn.fused_linear import SkinnyLinear
+    torch.manual_seed(0); a = nn.Linear(128, 12).to("cuda:0")
+    torch.manual_seed(0); b = SkinnyLinear(128, 12).to("cuda:0")
+    assert torch.equal(a.weight, b.weight) and list(a.state_dict()) == list(b.state_dict())
+    x = torch.randn(8192, 128, device="cuda:0", requires_grad=True)
+    x2 = x.detach().clone().requires_grad_(True)
+    (a(x).tanh().sum()).backward()
+    (b(x2).tanh().sum()).backward()
+    torch.testing.assert_close(b.weight.grad, a.weight.grad, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(b.bias.grad, a.bias.grad, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(x2.grad, x.grad, rtol=1e-5, atol=1e-6)
