@@ -1,0 +1,60 @@
+"""Learnability check (not a benchmark): train aliengo (flat-ish terrain mix of the task config, 4096 envs) for a number of PPO
+iterations with the build's runner and record mean episode reward / length / tracking reward per iteration.
+usage: python tools/train_probe.py [iterations] [out.json]"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import shutil, tempfile
+tdir = tempfile.mkdtemp(prefix="lsim_tunableop_")
+shutil.copy(os.path.join(ROOT, "isaacgymloco_amd", "learn", "tunableop_gfx950.csv"), os.path.join(tdir, "tuned0.csv"))
+os.environ.setdefault("PYTORCH_TUNABLEOP_ENABLED", "1")
+os.environ.setdefault("PYTORCH_TUNABLEOP_FILENAME", os.path.join(tdir, "tuned.csv"))
+os.environ.setdefault("PYTORCH_TUNABLEOP_TUNING", "0")
+import torch
+from isaacgymloco_amd.envs import config as C
+from isaacgymloco_amd.envs.legged_robot import LeggedRobot
+from isaacgymloco_amd.learn.bench_train import train_cfg_dict
+from isaacgymloco_amd.learn.runner import HIMOnPolicyRunner
+
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "gpurun_out", "train_curve.json")
+task = sys.argv[3] if len(sys.argv) > 3 else "aliengo"
+cfg = C.TASKS[task][0]()
+env = LeggedRobot(cfg, sim_device="cuda:0", seed=1)
+torch.manual_seed(1)
+runner = HIMOnPolicyRunner(env, train_cfg_dict(task), log_dir=None, device="cuda:0")
+runner.enable_graphs()
+runner.alg.actor_critic.train()
+env.episode_length_buf = torch.randint_like(env.episode_length_buf, high=int(env.max_episode_length))
+N, T = env.num_envs, runner.num_steps_per_env
+cur_r = torch.zeros(N, device="cuda:0"); cur_l = torch.zeros(N, device="cuda:0")
+curve = []
+t_start = time.time()
+for it in range(iters):
+    fin = torch.zeros(3, device="cuda:0")
+    track = torch.zeros(1, device="cuda:0")
+    with torch.inference_mode():
+        for _ in range(T):
+            runner.graphs.step()
+            d = env.reset_buf.float()
+            cur_r += env.rew_buf; cur_l += 1
+            fin += torch.stack((d.sum(), (cur_r * d).sum(), (cur_l * d).sum()))
+            cur_r *= 1 - d; cur_l *= 1 - d
+            track += env.rew_buf.mean()
+        runner.alg.compute_returns(env.privileged_obs_buf)
+    runner.graphs.end_iteration()
+    vl, sl, el, swl = runner.alg.update()[:4]
+    f = fin.tolist()
+    rec = dict(it=it, mean_step_reward=float(track) / T, finished=f[0], mean_ep_reward=f[1] / max(f[0], 1), mean_ep_len=f[2] / max(f[0], 1),
+               value_loss=vl, surrogate_loss=sl, est_loss=el, swap_loss=swl, lr=runner.alg.learning_rate,
+               action_std=float(runner.alg.actor_critic.std.mean()), terrain_level=float(env.terrain_levels.float().mean()),
+               wall_s=time.time() - t_start)
+    curve.append(rec)
+    if it % 10 == 0 or it == iters - 1:
+        print(json.dumps(rec), flush=True)
+os.makedirs(os.path.dirname(out), exist_ok=True)
+json.dump(dict(task=task, num_envs=N, steps_per_iteration=T, curve=curve), open(out, "w"))
