@@ -21,6 +21,7 @@ __global__ __launch_bounds__(64 * LS_WGRAD_WAVES_PER_BLOCK) void lsim_k_linear_w
     const int lane = threadIdx.x & 63, wave = blockIdx.x * LS_WGRAD_WAVES_PER_BLOCK + (threadIdx.x >> 6);
     const int sub = lane >> 4, col = lane & 15;
     const long b0 = (long)wave * rows_per_wave;
+    if (b0 >= batch) return;                      // padding waves of the last block own no partial slot
     long b1 = b0 + rows_per_wave;
     if (b1 > batch) b1 = batch;
     ls_v4f acc[NT][KT];
@@ -99,9 +100,131 @@ __global__ __launch_bounds__(256) void lsim_k_wgrad_reduce(const float* __restri
     }
 }
 
-#define LS_WGRAD_MAX_TILES 32
+// ---- larger layers: the output is cut into 64 (n) x 128 (k) tiles, one wave per (tile, batch slice), 32 MFMA accumulators.
+// Operand loads are 16-byte vectors: lane (sub, col) reads g[row][n_base + 4 col .. +3] and x[row][k_base + 64 q + 4 col .. +3], so
+// MFMA tile j of a 4-tile group holds the outputs n = n_base + 4 i + j (a permutation of the outputs inside the group that is
+// undone when the accumulators are written).  The next step's operands are loaded before the current step's 32 MFMAs issue
+// (register double buffer), two waves per SIMD.  VX / VG: the operand's rows are 16-byte aligned (ld % 4 == 0); otherwise scalars.
+// VEC: 2 = 16-byte vector load (rows 16-byte aligned), 1 = two 8-byte loads (rows 8-byte aligned, e.g. ld = 238 or 270), 0 = scalars
+// FULL: the four columns are inside the matrix (interior tile): no column tests, no branches -- the row test becomes a select on a
+// clamped row, so that all operand loads of a step issue back to back and overlap.
+template <int VEC, bool FULL>
+__device__ __forceinline__ void ls_wgrad_load4(const float* __restrict__ p, long ld, long row, bool row_ok, long safe_row, int c0, int cmax, float (&v)[4]) {
+    if (FULL) {
+        const float* q = p + (row_ok ? row : safe_row) * ld + c0;
+        float t0, t1, t2, t3;
+        if (VEC == 2) { const float4 t = *(const float4*)q; t0 = t.x; t1 = t.y; t2 = t.z; t3 = t.w; }
+        else if (VEC == 1) { const float2 ta = *(const float2*)q, tb = *(const float2*)(q + 2); t0 = ta.x; t1 = ta.y; t2 = tb.x; t3 = tb.y; }
+        else { t0 = q[0]; t1 = q[1]; t2 = q[2]; t3 = q[3]; }
+        v[0] = row_ok ? t0 : 0.0f; v[1] = row_ok ? t1 : 0.0f; v[2] = row_ok ? t2 : 0.0f; v[3] = row_ok ? t3 : 0.0f;
+        return;
+    }
+    v[0] = v[1] = v[2] = v[3] = 0.0f;
+    if (!row_ok || c0 >= cmax) return;
+    const float* q = p + row * ld + c0;
+    if (VEC == 2 && c0 + 3 < cmax) {
+        const float4 t = *(const float4*)q;
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else if (VEC == 1 && c0 + 3 < cmax) {
+        const float2 t0 = *(const float2*)q, t1 = *(const float2*)(q + 2);
+        v[0] = t0.x; v[1] = t0.y; v[2] = t1.x; v[3] = t1.y;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (c0 + j < cmax) v[j] = q[j];
+    }
+}
 
-typedef void (*ls_wgrad_fn)(const float*, long, const float*, long, long, int, int, long, float*, float*);
+// the batch loop of one (tile, slice): operands of the current step and of the next two are in registers (prefetch distance 2:
+// ~2 x 1024 MFMA cycles per wave, two waves per SIMD)
+template <int VX, int VG, int KG, bool FULL>
+__device__ __forceinline__ void ls_wgrad_tile_loop(const float* __restrict__ x, long ldx, const float* __restrict__ g, long ldg, long b0, long b1,
+                                                   int n_base, int k_base, int n_out, int k_in, int sub, int col,
+                                                   ls_v4f (&acc)[4][4 * KG], float (&dbacc)[4]) {
+    float a0[4], x0[KG][4], a1[4], x1[KG][4], a2[4], x2[KG][4];
+#define LS_LOAD_STEP(ROW, A, X) do { const long row_ = (ROW); const bool ok_ = row_ < b1;                                    \
+        ls_wgrad_load4<VG, FULL>(g, ldg, row_, ok_, b0, n_base + 4 * col, n_out, A);                                          \
+        ls_wgrad_load4<VX, FULL>(x, ldx, row_, ok_, b0, k_base + 4 * col, k_in, X[0]);                                        \
+        if (KG > 1) ls_wgrad_load4<VX, FULL>(x, ldx, row_, ok_, b0, k_base + 64 + 4 * col, k_in, X[KG - 1]); } while (0)
+    LS_LOAD_STEP(b0 + sub, a0, x0);
+    LS_LOAD_STEP(b0 + 4 + sub, a1, x1);
+    for (long b = b0; b < b1; b += 4) {
+        LS_LOAD_STEP(b + 8 + sub, a2, x2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            dbacc[j] += a0[j];
+#pragma unroll
+            for (int kt = 0; kt < 4 * KG; ++kt)
+                acc[j][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], x0[kt >> 2][kt & 3], acc[j][kt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a0[j] = a1[j]; a1[j] = a2[j];
+#pragma unroll
+            for (int q = 0; q < KG; ++q) { x0[q][j] = x1[q][j]; x1[q][j] = x2[q][j]; }
+        }
+    }
+#undef LS_LOAD_STEP
+}
+
+// KG: 64-wide k groups per tile (1 for k_in <= 64, else 2)
+template <int VX, int VG, int KG>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void lsim_k_linear_wgrad_tiled(const float* __restrict__ x, long ldx, const float* __restrict__ g, long ldg, long batch, int k_in, int n_out,
+                               int k_blocks, int tiles, int slices, long rows_per_slice, float* __restrict__ part_dw, float* __restrict__ part_db) {
+    const int lane = threadIdx.x & 63;
+    const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long slice = wave / tiles;
+    if (slice >= slices) return;
+    const int tile = (int)(wave - slice * tiles);
+    const int nb = tile / k_blocks, kb = tile - nb * k_blocks;
+    const int n_base = nb * 64, k_base = kb * 64 * KG;
+    const int sub = lane >> 4, col = lane & 15;
+    const long b0 = slice * rows_per_slice;
+    long b1 = b0 + rows_per_slice;
+    if (b1 > batch) b1 = batch;
+    ls_v4f acc[4][4 * KG];
+    float dbacc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int kt = 0; kt < 4 * KG; ++kt) acc[j][kt] = (ls_v4f){0.0f, 0.0f, 0.0f, 0.0f};
+    const bool full = (n_base + 64 <= n_out) && (k_base + 64 * KG <= k_in);      // wave-uniform: interior tile
+    if (full) ls_wgrad_tile_loop<VX, VG, KG, true>(x, ldx, g, ldg, b0, b1, n_base, k_base, n_out, k_in, sub, col, acc, dbacc);
+    else ls_wgrad_tile_loop<VX, VG, KG, false>(x, ldx, g, ldg, b0, b1, n_base, k_base, n_out, k_in, sub, col, acc, dbacc);
+    // accumulator (j, kt)[r] of lane (sub, col) is the output n = n_base + 4 (4 sub + r) + j, k = k_base + 64 (kt / 4) + 4 col + kt % 4
+    float* pw = part_dw + (size_t)slice * n_out * k_in;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n_base + 4 * (4 * sub + r) + j;
+            if (n >= n_out) continue;
+#pragma unroll
+            for (int q = 0; q < KG; ++q) {
+                const int k = k_base + 64 * q + 4 * col;
+                if (k >= k_in) continue;
+                float* dst = pw + (size_t)n * k_in + k;
+                if ((k_in & 3) == 0) {      // k + 3 < k_in and 16-byte aligned
+                    *(float4*)dst = make_float4(acc[j][4 * q][r], acc[j][4 * q + 1][r], acc[j][4 * q + 2][r], acc[j][4 * q + 3][r]);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) if (k + c < k_in) dst[c] = acc[j][4 * q + c][r];
+                }
+            }
+        }
+    if (part_db && kb == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v = dbacc[j];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            const int n = n_base + 4 * col + j;
+            if (sub == 0 && n < n_out) part_db[(size_t)slice * n_out + n] = v;
+        }
+    }
+}
+
+#define LS_WGRAD_MAX_TILES 32
 
 template <int NT, int KT> static void ls_wgrad_launch(const float* x, long ldx, const float* g, long ldg, long batch, int k_in, int n_out,
                                                       long rows_per_wave, int blocks, float* pdw, float* pdb, hipStream_t s) {
@@ -119,44 +242,90 @@ template <int NT> static int ls_wgrad_dispatch_k(int kt, const float* x, long ld
     }
 }
 
-extern "C" int lsim_linear_wgrad_workspace(long batch, int k_in, int n_out, size_t* bytes, int* num_waves) {
-    if (!bytes || !num_waves || batch <= 0 || k_in <= 0 || n_out <= 0) return LSIM_E_INVALID;
+// launch plan shared by the workspace query and the call
+struct LsWgradPlan {
+    int small;            // 1: whole output in one wave's accumulators (lsim_k_linear_wgrad), 0: 64 x 128 tiles
+    int partials;         // number of partial results per output element
+    long rows;            // batch rows per partial
+    int n_blocks, k_blocks;
+};
+static int ls_wgrad_plan(long batch, int k_in, int n_out, LsWgradPlan* p) {
+    // above ~40 k outputs (512 -> 256, 238 -> 512) hipBLASLt's 85 TFLOP/s macro-tile kernels are as fast or faster: leave those to BLAS
+    if (batch <= 0 || k_in <= 0 || n_out <= 0 || (long)k_in * n_out > 40000) return LSIM_E_UNSUPPORTED;
     const int nt = (n_out + 15) / 16, kt = (k_in + 15) / 16;
-    if (nt > 8 || kt > 8 || nt * kt > LS_WGRAD_MAX_TILES) return LSIM_E_UNSUPPORTED;
-    long waves = 1024;                                   // one wave per SIMD of the 256-CU part
-    long rpw = ((batch + waves - 1) / waves + 3) & ~3L;  // multiple of the 4 rows one MFMA consumes
-    if (rpw < 16) rpw = 16;
-    waves = (batch + rpw - 1) / rpw;
-    waves = (waves + LS_WGRAD_WAVES_PER_BLOCK - 1) / LS_WGRAD_WAVES_PER_BLOCK * LS_WGRAD_WAVES_PER_BLOCK;
-    *num_waves = (int)waves;
-    *bytes = (size_t)waves * ((size_t)n_out * k_in + n_out) * sizeof(float);
+    if (nt <= 8 && kt <= 8 && nt * kt <= LS_WGRAD_MAX_TILES && (long)n_out * k_in <= 4096) {
+        p->small = 1;
+        long rpw = ((batch + 1023) / 1024 + 3) & ~3L;      // one wave per SIMD of the 256-CU part; 4 rows per MFMA
+        if (rpw < 16) rpw = 16;
+        p->rows = rpw;
+        p->partials = (int)((batch + rpw - 1) / rpw);
+        p->n_blocks = p->k_blocks = 1;
+        return LSIM_OK;
+    }
+    p->small = 0;
+    p->n_blocks = (n_out + 63) / 64;
+    p->k_blocks = k_in <= 64 ? 1 : (k_in + 127) / 128;     // 64-wide k tile for the narrow inputs, 128-wide otherwise
+    const int tiles = p->n_blocks * p->k_blocks;
+    long slices = 2048 / tiles;                             // two waves per SIMD
+    const long cap = (32L << 20) / ((long)n_out * k_in * 4); // keep the partial results (written once, read once) under 32 MB
+    if (slices > cap) slices = cap;
+    if (slices < 1) slices = 1;
+    long rps = ((batch + slices - 1) / slices + 3) & ~3L;
+    if (rps < 64) rps = 64;
+    p->rows = rps;
+    p->partials = (int)((batch + rps - 1) / rps);
+    return LSIM_OK;
+}
+
+extern "C" int lsim_linear_wgrad_workspace(long batch, int k_in, int n_out, size_t* bytes, int* num_partials) {
+    if (!bytes || !num_partials) return LSIM_E_INVALID;
+    LsWgradPlan p;
+    int rc = ls_wgrad_plan(batch, k_in, n_out, &p);
+    if (rc != LSIM_OK) return rc;
+    *num_partials = p.partials;
+    *bytes = (size_t)p.partials * ((size_t)n_out * k_in + n_out) * sizeof(float);
     return LSIM_OK;
 }
 
 extern "C" int lsim_linear_wgrad(const float* x, int64_t ldx, const float* g, int64_t ldg, int64_t batch, int k_in, int n_out,
                                  float* dw, float* db, void* workspace, size_t workspace_bytes, void* stream) {
     if (!x || !g || !dw || !workspace) return LSIM_E_INVALID;
-    size_t need; int waves;
-    int rc = lsim_linear_wgrad_workspace(batch, k_in, n_out, &need, &waves);
+    LsWgradPlan p;
+    int rc = ls_wgrad_plan(batch, k_in, n_out, &p);
     if (rc != LSIM_OK) return rc;
+    const size_t need = (size_t)p.partials * ((size_t)n_out * k_in + n_out) * sizeof(float);
     if (workspace_bytes < need || ldx < k_in || ldg < n_out) return LSIM_E_INVALID;
-    const int nt = (n_out + 15) / 16, kt = (k_in + 15) / 16;
-    long rpw = ((batch + 1023) / 1024 + 3) & ~3L;
-    if (rpw < 16) rpw = 16;
     float* pdw = (float*)workspace;
-    float* pdb = db ? pdw + (size_t)waves * n_out * k_in : nullptr;
+    float* pdb = db ? pdw + (size_t)p.partials * n_out * k_in : nullptr;
     hipStream_t s = (hipStream_t)stream;
-    const int blocks = waves / LS_WGRAD_WAVES_PER_BLOCK;
-    int bad = 1;
-    switch (nt) {
-#define LS_N(NT) case NT: bad = ls_wgrad_dispatch_k<NT>(kt, x, ldx, g, ldg, batch, k_in, n_out, rpw, blocks, pdw, pdb, s); break;
-        LS_N(1) LS_N(2) LS_N(3) LS_N(4) LS_N(5) LS_N(6) LS_N(7) LS_N(8)
+    if (p.small) {
+        const int nt = (n_out + 15) / 16, kt = (k_in + 15) / 16;
+        const int blocks = (p.partials + LS_WGRAD_WAVES_PER_BLOCK - 1) / LS_WGRAD_WAVES_PER_BLOCK;
+        int bad = 1;
+        switch (nt) {
+#define LS_N(NT) case NT: bad = ls_wgrad_dispatch_k<NT>(kt, x, ldx, g, ldg, batch, k_in, n_out, p.rows, blocks, pdw, pdb, s); break;
+            LS_N(1) LS_N(2) LS_N(3) LS_N(4) LS_N(5) LS_N(6) LS_N(7) LS_N(8)
 #undef LS_N
-        default: break;
+            default: break;
+        }
+        if (bad) return LSIM_E_UNSUPPORTED;
+    } else {
+        const int tiles = p.n_blocks * p.k_blocks;
+        const long waves = (long)tiles * p.partials;
+        const int blocks = (int)((waves + 3) / 4);
+        const int vx = ((ldx % 4 == 0) && (((uintptr_t)x & 15) == 0)) ? 2 : (((ldx % 2 == 0) && (((uintptr_t)x & 7) == 0)) ? 1 : 0);
+        const int vg = ((ldg % 4 == 0) && (((uintptr_t)g & 15) == 0)) ? 2 : 0;
+        const int kg = k_in <= 64 ? 1 : 2;
+#define LS_T(VX, VG, KG) hipLaunchKernelGGL((lsim_k_linear_wgrad_tiled<VX, VG, KG>), dim3(blocks), dim3(256), 0, s, x, (long)ldx, g, (long)ldg, (long)batch, \
+                                            k_in, n_out, p.k_blocks, tiles, p.partials, p.rows, pdw, pdb)
+#define LS_TK(VX, VG) do { if (kg == 1) LS_T(VX, VG, 1); else LS_T(VX, VG, 2); } while (0)
+        if (vg == 2) { if (vx == 2) LS_TK(2, 2); else if (vx == 1) LS_TK(1, 2); else LS_TK(0, 2); }
+        else         { if (vx == 2) LS_TK(2, 0); else if (vx == 1) LS_TK(1, 0); else LS_TK(0, 0); }
+#undef LS_TK
+#undef LS_T
     }
-    if (bad) return LSIM_E_UNSUPPORTED;
     const int count = n_out * k_in;
-    hipLaunchKernelGGL(lsim_k_wgrad_reduce, dim3((count + 15) / 16), dim3(256), 0, s, pdw, waves, count, dw);
-    if (db) hipLaunchKernelGGL(lsim_k_wgrad_reduce, dim3((n_out + 15) / 16), dim3(256), 0, s, pdb, waves, n_out, db);
+    hipLaunchKernelGGL(lsim_k_wgrad_reduce, dim3((count + 15) / 16), dim3(256), 0, s, pdw, p.partials, count, dw);
+    if (db) hipLaunchKernelGGL(lsim_k_wgrad_reduce, dim3((n_out + 15) / 16), dim3(256), 0, s, pdb, p.partials, n_out, db);
     return hipGetLastError() == hipSuccess ? LSIM_OK : LSIM_E_HIP;
 }

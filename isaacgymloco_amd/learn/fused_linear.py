@@ -2,8 +2,8 @@
 learner's narrow layers on the GPU.
 
 Forward and grad_input are the usual BLAS calls.  grad_weight = g^T x and grad_bias = g.sum(0) over a 102 400-row minibatch are
-K = 102 400 reductions into a tiny output; rocBLAS/hipBLASLt run them at a few percent of peak (48-270 us per layer, and torch's
-column sum needs 260 us for 19 columns), the MFMA kernel in csrc/ls_learn.h reads x and g once (10-40 us).  Same parameters,
+K = 102 400 reductions into a small output; rocBLAS/hipBLASLt run them at 1-55 % of the fp32 MFMA peak (and torch's column sum
+needs 260 us for 19 columns); the MFMA kernels in csrc/ls_learn.h read x and g once per 64 x 128 output tile.  Same parameters,
 same state_dict keys, same initialisation as nn.Linear (it IS an nn.Linear); results differ from BLAS by fp32 summation order.
 """
 import ctypes
@@ -14,11 +14,21 @@ import torch.nn.functional as F
 
 _MIN_BATCH = 4096
 _workspaces = {}
+_plans = {}
 
 
 def _eligible(batch, k_in, n_out):
-    nt, kt = (n_out + 15) // 16, (k_in + 15) // 16
-    return batch >= _MIN_BATCH and nt <= 8 and kt <= 8 and nt * kt <= 32
+    """the library decides (lsim_linear_wgrad_workspace returns LSIM_E_UNSUPPORTED for shapes it leaves to BLAS)"""
+    if batch < _MIN_BATCH:
+        return False
+    key = (batch, k_in, n_out)
+    ok = _plans.get(key)
+    if ok is None:
+        from .. import lib
+        need, parts = ctypes.c_size_t(), ctypes.c_int()
+        ok = lib.load().lsim_linear_wgrad_workspace(batch, k_in, n_out, ctypes.byref(need), ctypes.byref(parts)) == 0
+        _plans[key] = ok
+    return ok
 
 
 def linear_wgrad(x, g, want_bias=True):

@@ -1,16 +1,18 @@
-"""GPU probe: lsim_linear_wgrad vs BLAS (g.t() @ x, g.sum(0)) timing for the learner's narrow layers."""
-import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+"""GPU probe: lsim_linear_wgrad vs BLAS (g.t() @ x, g.sum(0)) for one layer shape; run under rocprofv3 --kernel-trace and read the
+kernel durations (host timing is launch-bound for the small shapes).  usage: python3 tools/wgrad_probe.py K_IN N_OUT [tuned]"""
+import os, sys, shutil, tempfile
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+if len(sys.argv) > 3:
+    tdir = tempfile.mkdtemp(prefix="lsim_tunableop_")
+    shutil.copy(os.path.join(ROOT, "isaacgymloco_amd", "learn", "tunableop_gfx950.csv"), os.path.join(tdir, "tuned0.csv"))
+    os.environ["PYTORCH_TUNABLEOP_ENABLED"] = "1"; os.environ["PYTORCH_TUNABLEOP_FILENAME"] = os.path.join(tdir, "tuned.csv"); os.environ["PYTORCH_TUNABLEOP_TUNING"] = "0"
 import torch
 from isaacgymloco_amd.learn.fused_linear import linear_wgrad
 B = 102400
-def bench(f, n=30):
-    for _ in range(3): f()
-    torch.cuda.synchronize(); t = time.perf_counter()
-    for _ in range(n): f()
-    torch.cuda.synchronize(); return (time.perf_counter() - t) / n
-for k, n in [(128, 12), (128, 1), (64, 19), (45, 128), (64, 16), (128, 64), (16, 32)]:
-    x = torch.randn(B, k, device="cuda"); g = torch.randn(B, n, device="cuda")
-    t_blas = bench(lambda: (g.t() @ x, g.sum(0)))
-    t_hip = bench(lambda: linear_wgrad(x, g))
-    print(f"{k:4d}->{n:4d}  BLAS dW+db {t_blas * 1e6:7.1f} us   lsim_linear_wgrad {t_hip * 1e6:7.1f} us")
+k, n = int(sys.argv[1]), int(sys.argv[2])
+x = torch.randn(B, k, device="cuda"); g = torch.randn(B, n, device="cuda")
+for _ in range(12):
+    a = g.t() @ x; b = g.sum(0)
+    c, d = linear_wgrad(x, g)
+torch.cuda.synchronize()
