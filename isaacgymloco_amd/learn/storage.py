@@ -125,7 +125,10 @@ class HIMRolloutStorage:
             critic = next_critic = obs
         fields = (obs, critic, self.actions.flatten(0, 1), next_critic, self.values.flatten(0, 1), self.advantages.flatten(0, 1),
                   self.returns.flatten(0, 1), self.actions_log_prob.flatten(0, 1), self.mu.flatten(0, 1), self.sigma.flatten(0, 1))
+        # The reference draws ONE permutation and reuses it for every epoch (HST:140, HST:159-164), so minibatch i holds the same
+        # rows in all epochs: gather the whole batch through the permutation once and hand out contiguous slices, instead of
+        # re-gathering ~800 floats per sample for each of the epochs x minibatches (same values, 1/num_epochs of the gather traffic).
+        shuffled = tuple(f[perm] for f in fields)
         for _ in range(num_epochs):
             for i in range(num_mini_batches):
-                idx = perm[i * mb:(i + 1) * mb]
-                yield tuple(f[idx] for f in fields)
+                yield tuple(f[i * mb:(i + 1) * mb] for f in shuffled)
