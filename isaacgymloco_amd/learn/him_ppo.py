@@ -135,6 +135,7 @@ class HIMPPO:
         last_est = last_swap = None
         for (obs, critic_obs, actions, next_critic_obs, target_values, advantages, returns, old_logp, old_mu, old_sigma) in \
                 self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs):
+            ac.estimator.prime(obs)        # one encoder forward serves the policy features and the estimator loss below
             ac.act(obs)
             logp = ac.get_actions_log_prob(actions)
             value = ac.evaluate(critic_obs)

@@ -55,6 +55,7 @@ class HybridPPO(HIMPPO):
                    self.amp_storage.feed_forward_generator(n_updates, mb), self.amp_data.feed_forward_generator(n_updates, mb))
         for sample, (pol_s, pol_ns), (exp_s_raw, exp_ns_raw) in gens:
             obs, critic_obs, actions, next_critic_obs, target_values, advantages, returns, old_logp, old_mu, old_sigma = sample
+            ac.estimator.prime(obs)        # one encoder forward serves the policy features and the estimator loss below
             ac.act(obs)
             logp = ac.get_actions_log_prob(actions)
             value = ac.evaluate(critic_obs)

@@ -64,9 +64,22 @@ class HIMEstimator(nn.Module):
         self.learning_rate = learning_rate
         self.optimizer = torch.optim.Adam(self.parameters(), lr=learning_rate)
         self.grad_sync = None   # set by the data-parallel runner: callable(list_of_params) averaging .grad over ranks
+        self._primed = None     # (obs_history tensor, encoder output with autograd graph) shared by encode() and losses()
+
+    def prime(self, obs_history):
+        """Run the encoder ONCE for a minibatch, with autograd, and let both consumers of that minibatch use it: the policy's
+        no-grad input features (HAC:136-141) and the estimator's own loss (HES:76-108).  The reference runs the same forward
+        twice with unchanged weights; the values are identical."""
+        self._primed = (obs_history, self.encoder(obs_history.detach()))
+
+    def _encoder_out(self, obs_history, want_grad):
+        if self._primed is not None and self._primed[0] is obs_history:
+            out = self._primed[1]
+            return out if want_grad else out.detach()
+        return self.encoder(obs_history if want_grad else obs_history.detach())
 
     def encode(self, obs_history):
-        out = self.encoder(obs_history.detach())
+        out = self._encoder_out(obs_history, want_grad=False)
         return out[..., :3], F.normalize(out[..., 3:], dim=-1, p=2)
 
     def forward(self, obs_history):
@@ -80,7 +93,7 @@ class HIMEstimator(nn.Module):
         n = self.num_one_step_obs
         vel = next_critic_obs[:, n:n + 3].detach()
         next_obs = next_critic_obs.detach()[:, 3:n + 3]
-        out = self.encoder(obs_history)
+        out = self._encoder_out(obs_history, want_grad=True)
         pred_vel, z_s = out[..., :3], F.normalize(out[..., 3:], dim=-1, p=2)
         z_t = F.normalize(self.target(next_obs), dim=-1, p=2)
         with torch.no_grad():
@@ -100,6 +113,7 @@ class HIMEstimator(nn.Module):
             for g in self.optimizer.param_groups:
                 g["lr"] = lr
         est, swap = self.losses(obs_history, next_critic_obs)
+        self._primed = None
         self.optimizer.zero_grad()
         (est + swap).backward()
         if self.grad_sync is not None:
