@@ -1,0 +1,27 @@
+"""Copy the judged summaries of one tools/gpu_round.sh run (gpurun_out/<tag>/) into profiles/ under round-prefixed names.
+usage: python tools/publish_profiles.py r01e r01"""
+import csv
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag, rnd = sys.argv[1], sys.argv[2]
+O, P = os.path.join(ROOT, "gpurun_out", tag), os.path.join(ROOT, "profiles")
+for src, dst in (("bench_default", "bench_default_train"), ("bench_env", "bench_env_only"), ("bench_aliengo_stairs", "bench_aliengo_stairs"),
+                 ("bench_aliengo_amp", "bench_aliengo_amp"), ("bench_env_N262144", "bench_env_only_N262144"), ("bench_env_N64", "bench_env_only_N64")):
+    f = os.path.join(O, src + ".json")
+    if os.path.exists(f) and open(f).read().lstrip().startswith("{"):
+        shutil.copy(f, os.path.join(P, f"{rnd}_{dst}.json"))
+    else:
+        print("missing / invalid:", f)
+shutil.copy(os.path.join(O, "pmc_env_N4096.csv"), os.path.join(P, f"{rnd}_pmc_env_only_N4096.csv"))
+shutil.copy(os.path.join(O, "pmc_traffic.json"), os.path.join(P, "pmc_traffic.json"))
+for src, dst in (("prof_env/env_kernel_stats.csv", "kernel_stats_env_only"), ("prof_train/train_kernel_stats.csv", "kernel_stats_train")):
+    rows = list(csv.reader(open(os.path.join(O, src))))
+    with open(os.path.join(P, f"{rnd}_{dst}.csv"), "w", newline="") as fh:
+        w = csv.writer(fh)
+        for r in rows:
+            r[0] = r[0][:160]     # torch's templated kernel names run to kilobytes
+            w.writerow(r)
+print("published", tag, "->", P)
