@@ -145,24 +145,28 @@ __device__ __forceinline__ void ls_wgrad_tile_loop(const float* __restrict__ x, 
         ls_wgrad_load4<VG, FULL>(g, ldg, row_, ok_, b0, n_base + 4 * col, n_out, A);                                          \
         ls_wgrad_load4<VX, FULL>(x, ldx, row_, ok_, b0, k_base + 4 * col, k_in, X[0]);                                        \
         if (KG > 1) ls_wgrad_load4<VX, FULL>(x, ldx, row_, ok_, b0, k_base + 64 + 4 * col, k_in, X[KG - 1]); } while (0)
-    LS_LOAD_STEP(b0 + sub, a0, x0);
-    LS_LOAD_STEP(b0 + 4 + sub, a1, x1);
+#define LS_MFMA_STEP(A, X) do {                                                                                              \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                      \
+            dbacc[j] += A[j];                                                                                                \
+            _Pragma("unroll") for (int kt = 0; kt < 4 * KG; ++kt)                                                            \
+                acc[j][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[j], X[kt >> 2][kt & 3], acc[j][kt], 0, 0, 0);            \
+        } } while (0)
+    // a0/x0 = operands of the current step, a1/x1 of the next, a2/x2 in flight for the one after.  The rotation copies sit at the
+    // TOP of the iteration, so the s_waitcnt they need covers loads issued a whole iteration (32 MFMAs) earlier, and the loads
+    // issued below stay in flight across this iteration's MFMAs.  Rows past the slice load zeros.
+    LS_LOAD_STEP(b0 + sub, a1, x1);
+    LS_LOAD_STEP(b0 + 4 + sub, a2, x2);
     for (long b = b0; b < b1; b += 4) {
-        LS_LOAD_STEP(b + 8 + sub, a2, x2);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            dbacc[j] += a0[j];
-#pragma unroll
-            for (int kt = 0; kt < 4 * KG; ++kt)
-                acc[j][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], x0[kt >> 2][kt & 3], acc[j][kt], 0, 0, 0);
-        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             a0[j] = a1[j]; a1[j] = a2[j];
 #pragma unroll
             for (int q = 0; q < KG; ++q) { x0[q][j] = x1[q][j]; x1[q][j] = x2[q][j]; }
         }
+        LS_LOAD_STEP(b + 8 + sub, a2, x2);
+        LS_MFMA_STEP(a0, x0);
     }
+#undef LS_MFMA_STEP
 #undef LS_LOAD_STEP
 }
 
@@ -172,7 +176,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void lsim_k_linear_wgrad_tiled(const float* __restrict__ x, long ldx, const float* __restrict__ g, long ldg, long batch, int k_in, int n_out,
                                int k_blocks, int tiles, int slices, long rows_per_slice, float* __restrict__ part_dw, float* __restrict__ part_db) {
     const int lane = threadIdx.x & 63;
-    const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long wave = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: scalar loop control
     const long slice = wave / tiles;
     if (slice >= slices) return;
     const int tile = (int)(wave - slice * tiles);
