@@ -465,6 +465,15 @@ int lsim_linear_wgrad_workspace(long batch, int k_in, int n_out, size_t* bytes, 
 int lsim_linear_wgrad(const float* x, int64_t ldx, const float* g, int64_t ldg, int64_t batch, int k_in, int n_out,
                       float* dw, float* db, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Sinkhorn-Knopp assignment of the estimator's prototype scores (HIMEstimator.sinkhorn, HES:119-133; no gradient flows through it):
+ *   Q = exp(scores / eps)^T;  Q /= sum(Q);  iters x { Q /= rowsum; Q /= K; Q /= colsum; Q /= B };  out = (Q * B)^T
+ * scores [batch, K] with row stride lds (floats), K <= 64, out [batch, K] contiguous.  Computed as E * u[k] * v[b] with 2 * iters + 1
+ * small launches instead of ~26 passes over the matrix; `workspace` holds E and the per-block partial sums
+ * (lsim_sinkhorn_workspace() bytes); sums are formed in a fixed order (deterministic). */
+int lsim_sinkhorn_workspace(long batch, int K, size_t* bytes);
+int lsim_sinkhorn(const float* scores, int64_t lds, int64_t batch, int K, float eps, int iters, float* out,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

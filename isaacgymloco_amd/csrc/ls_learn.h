@@ -333,3 +333,83 @@ extern "C" int lsim_linear_wgrad(const float* x, int64_t ldx, const float* g, in
     if (db) hipLaunchKernelGGL(lsim_k_wgrad_reduce, dim3((n_out + 15) / 16), dim3(256), 0, s, pdb, p.partials, n_out, db);
     return hipGetLastError() == hipSuccess ? LSIM_OK : LSIM_E_HIP;
 }
+
+// ---- Sinkhorn-Knopp assignment of HIMEstimator (HES:119-133): Q = exp(scores / eps)^T, then `iters` x {rows sum to 1/K, columns
+// sum to 1/B}, returned as (Q * B)^T.  Every step of the reference only rescales rows (one factor per prototype) or columns (one
+// factor per sample), so Q[k, b] = E[b, k] * u[k] * v[b] with E = exp(scores / eps) throughout (the initial division by the total
+// sum cancels in the first row normalisation).  Instead of ~26 torch kernels over the (K, B) matrix per call:
+//   pass 0: E, per-block partial column sums of E                     -> u[k] = 1 / (K * sum_b E[b, k])
+//   pass i: v[b] = 1 / (B * sum_k E[b, k] u[k]); partial column sums of E * v   -> u[k] = 1 / (K * sum_b E[b, k] v[b])
+//   last  : out[b, k] = B * E[b, k] * u[k] * v[b]
+// K <= 64 (one lane per prototype); a block owns LS_SK_ROWS consecutive samples; partial sums are added in a fixed order.
+#define LS_SK_ROWS 256
+
+__global__ __launch_bounds__(256) void lsim_k_sinkhorn_pass(const float* __restrict__ scores, long lds, long batch, int K, float inv_eps,
+                                                            const float* __restrict__ u /* NULL in pass 0 */, float* __restrict__ E,
+                                                            float* __restrict__ part /* [blocks][K] or NULL */, float* __restrict__ out /* last pass */) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long r0 = (long)blockIdx.x * LS_SK_ROWS;
+    const float uk = (u && lane < K) ? u[lane] : 0.0f;
+    float colsum = 0.0f;
+    for (int i = w; i < LS_SK_ROWS; i += 4) {           // one wave per row, lane = prototype
+        const long b = r0 + i;
+        if (b >= batch) break;
+        float e = 0.0f;
+        if (lane < K) {
+            if (!u) { e = expf(scores[b * lds + lane] * inv_eps); E[b * K + lane] = e; }
+            else e = E[b * K + lane];
+        }
+        if (!u) { colsum += e; continue; }
+        float t = e * uk;
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+        const float v = 1.0f / ((float)batch * t);
+        if (out) { if (lane < K) out[b * K + lane] = (float)batch * e * uk * v; }
+        else colsum += e * v;
+    }
+    if (!part) return;
+    red[w][lane] = colsum;
+    __syncthreads();
+    if (w == 0 && lane < K) part[(size_t)blockIdx.x * K + lane] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
+__global__ __launch_bounds__(64) void lsim_k_sinkhorn_scale(const float* __restrict__ part, int blocks, int K, float* __restrict__ u) {
+    const int k = threadIdx.x;
+    if (k >= K) return;
+    float s0 = 0.0f, s1 = 0.0f;
+    int i = 0;
+    for (; i + 1 < blocks; i += 2) { s0 += part[(size_t)i * K + k]; s1 += part[(size_t)(i + 1) * K + k]; }
+    if (i < blocks) s0 += part[(size_t)i * K + k];
+    u[k] = 1.0f / ((float)K * (s0 + s1));
+}
+
+extern "C" int lsim_sinkhorn_workspace(long batch, int K, size_t* bytes) {
+    if (!bytes || batch <= 0 || K <= 0 || K > 64) return LSIM_E_INVALID;
+    const long blocks = (batch + LS_SK_ROWS - 1) / LS_SK_ROWS;
+    *bytes = ((size_t)batch * K + (size_t)blocks * K + 64) * sizeof(float);
+    return LSIM_OK;
+}
+
+extern "C" int lsim_sinkhorn(const float* scores, int64_t lds, int64_t batch, int K, float eps, int iters, float* out,
+                             void* workspace, size_t workspace_bytes, void* stream) {
+    size_t need;
+    int rc = lsim_sinkhorn_workspace(batch, K, &need);
+    if (rc != LSIM_OK) return rc;
+    if (!scores || !out || !workspace || workspace_bytes < need || iters < 1 || lds < K || eps <= 0.0f) return LSIM_E_INVALID;
+    const int blocks = (int)((batch + LS_SK_ROWS - 1) / LS_SK_ROWS);
+    float* E = (float*)workspace;
+    float* part = E + (size_t)batch * K;
+    float* u = part + (size_t)blocks * K;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(lsim_k_sinkhorn_pass, dim3(blocks), dim3(256), 0, s, scores, (long)lds, (long)batch, K, 1.0f / eps, (const float*)nullptr, E, part,
+                       (float*)nullptr);
+    hipLaunchKernelGGL(lsim_k_sinkhorn_scale, dim3(1), dim3(64), 0, s, part, blocks, K, u);
+    for (int it = 1; it < iters; ++it) {
+        hipLaunchKernelGGL(lsim_k_sinkhorn_pass, dim3(blocks), dim3(256), 0, s, scores, (long)lds, (long)batch, K, 1.0f / eps, (const float*)u, E, part,
+                           (float*)nullptr);
+        hipLaunchKernelGGL(lsim_k_sinkhorn_scale, dim3(1), dim3(64), 0, s, part, blocks, K, u);
+    }
+    hipLaunchKernelGGL(lsim_k_sinkhorn_pass, dim3(blocks), dim3(256), 0, s, scores, (long)lds, (long)batch, K, 1.0f / eps, (const float*)u, E,
+                       (float*)nullptr, out);
+    return hipGetLastError() == hipSuccess ? LSIM_OK : LSIM_E_HIP;
+}

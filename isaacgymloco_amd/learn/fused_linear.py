@@ -78,3 +78,22 @@ class SkinnyLinear(nn.Linear):
                 and _eligible(x.shape[0], self.in_features, self.out_features)):
             return _SkinnyLinearFn.apply(x, self.weight, self.bias)
         return F.linear(x, self.weight, self.bias)
+
+
+def sinkhorn_hip(scores, eps, iters):
+    """HIMEstimator's Sinkhorn-Knopp assignment through lsim_sinkhorn (same arithmetic as modules.sinkhorn, factored as E * u[k] * v[b])"""
+    from .. import lib
+    L = lib.load()
+    if scores.stride(1) != 1:
+        scores = scores.contiguous()
+    B, K = scores.shape
+    need = ctypes.c_size_t()
+    lib.check(L.lsim_sinkhorn_workspace(B, K, ctypes.byref(need)), what="lsim_sinkhorn_workspace")
+    ws = _workspaces.get(("sinkhorn", scores.device))
+    if ws is None or ws.numel() < need.value:
+        ws = torch.empty(need.value, dtype=torch.uint8, device=scores.device)
+        _workspaces[("sinkhorn", scores.device)] = ws
+    out = torch.empty(B, K, device=scores.device, dtype=torch.float32)
+    lib.check(L.lsim_sinkhorn(scores.data_ptr(), scores.stride(0), B, K, float(eps), int(iters), out.data_ptr(), ws.data_ptr(), ws.numel(),
+                              torch.cuda.current_stream(scores.device).cuda_stream), what="lsim_sinkhorn")
+    return out

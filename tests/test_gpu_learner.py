@@ -204,3 +204,24 @@ def test_skinny_linear_trains_like_nn_linear():
     torch.testing.assert_close(b.weight.grad, a.weight.grad, rtol=1e-4, atol=1e-3)
     torch.testing.assert_close(b.bias.grad, a.bias.grad, rtol=1e-4, atol=1e-3)
     torch.testing.assert_close(x2.grad, x.grad, rtol=1e-5, atol=1e-6)
+
+
+def test_fused_sinkhorn_matches_torch():
+    """lsim_sinkhorn against the torch statement of HES:119-133 (modules.sinkhorn's small-batch branch), fp32 tolerance 1e-4 relative"""
+    from isaacgymloco_amd.learn import modules as M
+    g = torch.Generator(device="cuda:0").manual_seed(5)
+    for B, K in ((102400, 32), (5000, 7)):
+        z = torch.nn.functional.normalize(torch.randn(B, 16, device="cuda:0", generator=g), dim=-1)
+        proto = torch.nn.functional.normalize(torch.randn(K, 16, device="cuda:0", generator=g), dim=-1)
+        scores = z @ proto.T                                   # cosine similarities in [-1, 1], as in HES:96-97
+        got = M.sinkhorn(scores)                               # HIP path (B >= 4096)
+        Q = torch.exp(scores.double() / 0.05).T                # the reference arithmetic in fp64
+        Kk, Bb = Q.shape
+        Q /= Q.sum()
+        for _ in range(3):
+            Q /= Q.sum(dim=1, keepdim=True); Q /= Kk
+            Q /= Q.sum(dim=0, keepdim=True); Q /= Bb
+        ref = (Q * Bb).T
+        torch.testing.assert_close(got.double(), ref, rtol=1e-4, atol=1e-7)
+        torch.testing.assert_close(got.sum(1), torch.ones(B, device="cuda:0"), rtol=1e-4, atol=1e-5)   # columns of Q*B sum to one
+        assert torch.equal(got, M.sinkhorn(scores))            # deterministic

@@ -20,6 +20,24 @@ from isaacgymloco_amd.learn.bench_train import train_cfg_dict
 from isaacgymloco_amd.learn.runner import HIMOnPolicyRunner
 
 n_upd = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+if "--torch-sinkhorn" in sys.argv:      # A/B: force the torch statement of the Sinkhorn step
+    import isaacgymloco_amd.learn.fused_linear as FL
+    FL.sinkhorn_hip = None
+    import isaacgymloco_amd.learn.modules as M
+    _orig = M.sinkhorn
+    def _torch_sinkhorn(scores, eps=0.05, iters=3):
+        with torch.no_grad():
+            Q = torch.exp(scores / eps).T
+            K, B = Q.shape
+            Q /= Q.sum()
+            for _ in range(iters):
+                Q /= Q.sum(dim=1, keepdim=True); Q /= K
+                Q /= Q.sum(dim=0, keepdim=True); Q /= B
+            return (Q * B).T
+    M.sinkhorn = _torch_sinkhorn
+if "--nn-linear" in sys.argv:           # A/B: plain nn.Linear backward (BLAS wgrad)
+    import isaacgymloco_amd.learn.fused_linear as FL
+    FL._eligible = lambda *a: False
 cfg = C.TASKS["aliengo"][0]()
 env = LeggedRobot(cfg, sim_device="cuda:0", seed=1)
 torch.manual_seed(1)
