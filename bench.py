@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--task", default="aliengo")
     ap.add_argument("--mode", default="auto", choices=["auto", "env", "train"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mixed-robots", action="store_true",
+                    help="BASELINE config 5: the upper half of the ranks simulate Go1 instead of --task's robot (one shared policy; not reference-comparable)")
     args = ap.parse_args()
 
     # fp32 GEMMs of the learner: use the hipBLASLt/rocBLAS solutions pre-selected by PyTorch TunableOp on gfx950
@@ -82,6 +84,8 @@ def main():
     if mode == "auto":
         mode = "train" if have_learner else "env"
 
+    if args.mixed_robots and world > 1 and rank >= world // 2:
+        args.task = "go1"           # same observation / action layout, different model table and gains (envs/config.py GO1_OVERRIDES)
     cfg = C.TASKS[args.task][0]()
     cfg.env.num_envs = args.envs
     env = LeggedRobot(cfg, sim_device=f"cuda:{local_rank}", seed=1, rank=rank, using_amp=(args.task == "aliengo_amp"))

@@ -241,7 +241,33 @@ def aliengo_amp_cfg_ppo():
     return ConfigNode(_build(LEGGED_ROBOT_PPO_DEFAULTS, ALIENGO_PPO_OVERRIDES, ALIENGO_AMP_PPO_OVERRIDES))
 
 
+# ----------------------------------------------------------------------------- Go1 on the Aliengo task (BASELINE config 5's second robot)
+# The reference registers a "go1" task (envs/__init__.py:52) whose config predates its own LeggedRobot (it lacks the
+# dof_init_pos_ratio_range / base_init_*_range / termination keys LR:699-812 read) and does not run.  This task is therefore the
+# Aliengo task -- same observations, actions, reward set, curricula -- with the robot-specific values of the reference's
+# Go1RoughCfg (go1_config.py: init_state, control, asset, base_height_target) and the Go1 model table (robots/tables/go1.json).
+# NOT reference-comparable.
+GO1_OVERRIDES = {
+    "init_state": dict(pos=[0.0, 0.0, 0.42], default_joint_angles=_leaf(
+        FL_hip_joint=0.1, RL_hip_joint=0.1, FR_hip_joint=-0.1, RR_hip_joint=-0.1,
+        FL_thigh_joint=0.8, RL_thigh_joint=1.0, FR_thigh_joint=0.8, RR_thigh_joint=1.0,
+        FL_calf_joint=-1.5, RL_calf_joint=-1.5, FR_calf_joint=-1.5, RR_calf_joint=-1.5)),
+    "control": dict(stiffness=_leaf(joint=40.0), damping=_leaf(joint=1.0), action_scale=0.25),
+    "asset": dict(file="{LEGGED_GYM_ROOT_DIR}/resources/robots/go1/urdf/go1.urdf", name="go1", flip_visual_attachments=False),
+    "rewards": dict(base_height_target=0.3, foot_height_target_base=-0.2),
+}
+
+
+def go1_cfg():
+    return ConfigNode(_build(LEGGED_ROBOT_DEFAULTS, ALIENGO_OVERRIDES, GO1_OVERRIDES))
+
+
+def go1_cfg_ppo():
+    return ConfigNode(_build(LEGGED_ROBOT_PPO_DEFAULTS, ALIENGO_PPO_OVERRIDES, {"runner": dict(experiment_name="flat_go1")}))
+
+
 TASKS = {
+    "go1": (go1_cfg, go1_cfg_ppo),
     "aliengo": (aliengo_cfg, aliengo_cfg_ppo),
     "aliengo_stairs": (aliengo_stairs_cfg, aliengo_stairs_cfg_ppo),
     "aliengo_amp": (aliengo_amp_cfg, aliengo_amp_cfg_ppo),

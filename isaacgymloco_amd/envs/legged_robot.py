@@ -19,6 +19,21 @@ import torch
 
 from .. import abi, lib
 from ..robots import aliengo
+
+
+def build_robot_model(asset):
+    """lsim_robot_model for cfg.asset (LR:1135-1219): the hand-checked Aliengo table, a URDF file if `asset.file` resolves to one, or a
+    stored table of robots/tables/ (go1, a1) chosen by `asset.name`."""
+    import os
+    from ..robots import urdf
+    pats = dict(penalize_contacts_on=tuple(asset.penalize_contacts_on), terminate_after_contacts_on=tuple(asset.terminate_after_contacts_on),
+                foot_name=asset.foot_name)
+    if asset.name == "aliengo":
+        return aliengo.build_model(pats["penalize_contacts_on"], pats["terminate_after_contacts_on"], pats["foot_name"])
+    path = str(asset.file).replace("{LEGGED_GYM_ROOT_DIR}", os.environ.get("LEGGED_GYM_ROOT_DIR", ""))
+    if path and os.path.isfile(path):
+        return urdf.build_model(path, **pats)[0]
+    return urdf.build_model_from_table(asset.name, **pats)[0]
 from . import lsim_config as LC
 from .terrain import Terrain
 
@@ -49,7 +64,7 @@ class LeggedRobot:
         self.history_length = int(self.num_obs / self.num_one_step_obs)
         self.num_dof = self.num_dofs = 12
         self.num_bodies = 17
-        self.dof_names = list(aliengo.DOF_NAMES)
+        self.dof_names = list(aliengo.DOF_NAMES)      # FL, FR, RL, RR x (hip, thigh, calf): the same for every supported quadruped
         # _parse_cfg (LR:1252-1263)
         self.dt = cfg.control.decimation * cfg.sim.dt
         self.obs_scales = cfg.normalization.obs_scales
@@ -61,7 +76,7 @@ class LeggedRobot:
         dev = torch.device(sim_device)
         self._dev_index = dev.index if dev.index is not None else torch.cuda.current_device()
         self.terrain = terrain if terrain is not None else Terrain(cfg.terrain, self.num_envs, seed=seed if terrain_seed is None else terrain_seed)
-        self.model = aliengo.build_model(tuple(cfg.asset.penalize_contacts_on), tuple(cfg.asset.terminate_after_contacts_on), cfg.asset.foot_name)
+        self.model = build_robot_model(cfg.asset)
         self.lcfg = LC.make_lsim_config(cfg, num_envs=self.num_envs, terrain=self.terrain, model=self.model, seed=seed, rank=rank, using_amp=using_amp)
 
         nbytes = ctypes.c_size_t()

@@ -9,13 +9,16 @@ their parents and keeps the feet (dont_collapse, URDF:517): 17 bodies, 12 DoF
 tests/test_model.py re-derives it from the reference URDF when that file is available.
 
 Collision geometry is represented as sphere-swept points per body
-(DESIGN.md "Collision shapes"): box corners / edge samples with radius 0, capsule end
-spheres, foot sphere.  Priority order = order in the table (overflow beyond
-LSIM_MAX_CONTACTS contacts is dropped from the end): feet, base, calves, thighs, hips.
+(DESIGN.md 4.6), derived from the URDF's collision primitives by the shared rules of
+robots/common.py: box corners / edge samples with radius 0, spheres along the limb boxes,
+capsule end spheres, one sphere per rotor disc, foot sphere -- 64 points.  Priority order =
+order in the table (contacts beyond LSIM_MAX_CONTACTS are dropped from the end): feet,
+base, calves, thighs, hips.  robots/urdf.py builds the same table from the URDF file itself.
 """
 import numpy as np
 
 from .. import abi
+from .common import collision_points as _points_from_prims, merge, rpy_matrix
 
 LEGS = ("FL", "FR", "RL", "RR")  # Isaac Gym DoF/body order (LR:1143-1145)
 _SX = {"FL": 1.0, "FR": 1.0, "RL": -1.0, "RR": -1.0}   # front / rear
@@ -45,7 +48,6 @@ LIMITS = dict(hip=(-0.873, 1.047, 20.0, 44.0), thigh=(-0.524, 3.927, 20.0, 44.0)
 # collision primitives (URDF <collision>): trunk box, hip cylinder (-> capsule, AGC:131), thigh/calf boxes, foot sphere
 TRUNK_BOX = (0.647, 0.15, 0.112)
 HIP_CYL = dict(radius=0.046, length=0.0418, at=(0.0, 0.083, 0.0))       # axis along y
-CALF_ROTOR_CYL = dict(radius=0.035, at=(0.0, -0.0997, 0.0))              # on the thigh link, axis along y
 THIGH_BOX = (0.25, 0.0374, 0.043)   # long axis along -z of the link, centred at z = -0.125
 CALF_BOX = (0.25, 0.0208, 0.016)
 FOOT_RADIUS = 0.0265
@@ -68,17 +70,6 @@ def _mirror(part, sx, sy):
         a = part["at"]
         out["at"] = (a[0] * sx, a[1] * sy, a[2])
     return out
-
-
-def merge(parts):
-    """Rigidly merge [(mass, com(3), inertia-about-com 3x3)] -> same triple (parallel-axis theorem)."""
-    m = sum(p[0] for p in parts)
-    c = sum(p[0] * np.asarray(p[1], dtype=np.float64) for p in parts) / m
-    I = np.zeros((3, 3))
-    for pm, pc, pI in parts:
-        d = np.asarray(pc, dtype=np.float64) - c
-        I += pI + pm * (np.dot(d, d) * np.eye(3) - np.outer(d, d))
-    return m, c, I
 
 
 def _hip_signs(leg):
@@ -116,34 +107,37 @@ def body_table():
     return bodies
 
 
-def collision_points():
-    """[(body, (x,y,z), radius)] in priority order."""
-    pts = []
-    for l in range(4):                                   # feet
-        pts.append((4 + 4 * l, (0.0, 0.0, 0.0), FOOT_RADIUS))
-    hx, hy, hz = (0.5 * v for v in TRUNK_BOX)            # trunk box: 8 corners + mid points of the 4 long edges
-    for sx in (1, -1):
-        for sy in (1, -1):
-            for sz in (-1, 1):
-                pts.append((0, (sx * hx, sy * hy, sz * hz), 0.0))
-    for sy in (1, -1):
-        for sz in (-1, 1):
-            pts.append((0, (0.0, sy * hy, sz * hz), 0.0))
-    rc = 0.5 * min(CALF_BOX[1], CALF_BOX[2])
-    for l in range(4):                                   # calf: 3 spheres along the shank (the foot sphere covers the tip)
-        for z in (0.0, -CALF_BOX[0] / 3, -2 * CALF_BOX[0] / 3):
-            pts.append((3 + 4 * l, (0.0, 0.0, z), rc))
-    rt = 0.5 * min(THIGH_BOX[1], THIGH_BOX[2])
-    for l in range(4):                                   # thigh: 4 spheres along the link
-        for z in (0.0, -THIGH_BOX[0] / 3, -2 * THIGH_BOX[0] / 3, -THIGH_BOX[0]):
-            pts.append((2 + 4 * l, (0.0, 0.0, z), rt))
-    for l, leg in enumerate(LEGS):                       # hip capsule end spheres
+ROTOR_DISC = dict(radius=0.035, length=0.02)   # hip / thigh / calf rotor housings (URDF <collision> cylinders of the *_rotor links)
+_RX90, _RY90 = (np.pi / 2, 0.0, 0.0), (0.0, np.pi / 2, 0.0)   # cylinder axis along y / box long axis along z
+
+
+def _prims():
+    """Collision primitives per body after the fixed-joint collapse, in the order Isaac Gym meets them in the URDF (the link's own
+    shape first, then the merged children in URDF joint order: FR, FL, RR, RL): [(kind, dims, position, rotation)] per body."""
+    cyl = lambda d, at, rpy: ("cylinder", np.array([d["radius"], d["length"]]), np.array(at, dtype=np.float64), rpy_matrix(rpy))
+    box = lambda size, at: ("box", np.array(size, dtype=np.float64), np.array(at, dtype=np.float64), rpy_matrix(_RY90))
+    out = [[] for _ in range(17)]
+    out[0].append(("box", np.array(TRUNK_BOX), np.zeros(3), np.eye(3)))
+    for leg in ("FR", "FL", "RR", "RL"):
+        r = _mirror(HIP_ROTOR, _SX[leg], _SY[leg])
+        out[0].append(cyl(ROTOR_DISC, r["at"], _RY90))
+    for l, leg in enumerate(LEGS):
         sy = _SY[leg]
-        for dy in (-0.5 * HIP_CYL["length"], 0.5 * HIP_CYL["length"]):
-            pts.append((1 + 4 * l, (0.0, HIP_CYL["at"][1] * sy + dy, 0.0), HIP_CYL["radius"]))
-    for l, leg in enumerate(LEGS):                       # calf-rotor capsule on the thigh
-        pts.append((2 + 4 * l, (0.0, CALF_ROTOR_CYL["at"][1] * _SY[leg], 0.0), CALF_ROTOR_CYL["radius"]))
-    return pts
+        out[1 + 4 * l].append(cyl(HIP_CYL, (0.0, HIP_CYL["at"][1] * sy, 0.0), _RX90))
+        out[1 + 4 * l].append(cyl(ROTOR_DISC, (0.0, THIGH_ROTOR["at"][1] * sy, 0.0), _RX90))
+        out[2 + 4 * l].append(box(THIGH_BOX, (0.0, 0.0, -0.5 * THIGH_BOX[0])))
+        out[2 + 4 * l].append(cyl(ROTOR_DISC, (0.0, CALF_ROTOR["at"][1] * sy, 0.0), _RX90))
+        out[3 + 4 * l].append(box(CALF_BOX, (0.0, 0.0, -0.5 * CALF_BOX[0])))
+        out[4 + 4 * l].append(("sphere", np.array([FOOT_RADIUS]), np.zeros(3), np.eye(3)))
+    return out
+
+
+def collision_points():
+    """[(body, (x,y,z), radius)] in priority order, from the URDF's collision primitives by the rules of robots/common.py"""
+    bodies = body_table()
+    for b, prims in zip(bodies, _prims()):
+        b["prims"] = prims
+    return _points_from_prims(bodies, "foot")
 
 
 def build_model(penalize_contacts_on=("thigh", "calf", "base"), terminate_after_contacts_on=("base",), foot_name="foot"):

@@ -194,3 +194,22 @@ def test_hip_api_rejects_bad_arguments():
     env.reset()
     obs, _, _, _ = env.step_device(torch.zeros(8, 12, device="cuda:0"))
     assert torch.isfinite(obs).all()
+
+
+def test_hip_go1_matches_oracle():
+    """second robot (task "go1", model table robots/tables/go1.json): HIP vs oracle with full physics and random actions"""
+    from hip_backend import HipBackend
+    N = 16
+    cfg = C.TASKS["go1"][0]()
+    cfg.terrain.terrain_proportions = [1.0, 0.0, 0.0, 0.0]
+    orc, lc, model, ter = make_oracle(cfg, N, seed=5)
+    be = HipBackend(cfg, N, ter, seed=5)
+    orc.reset_all(); be.reset_all()
+    rs = np.random.RandomState(0)
+    for t in range(12):
+        a = rs.normal(0, 1, (N, 12)).astype(np.float32)
+        orc.step(a); be.step(a)
+        np.testing.assert_array_equal(be.get("reset"), orc.buf["reset"], err_msg=f"step {t}")
+        np.testing.assert_allclose(be.get("root_states"), orc.buf["root_states"], atol=2e-3, rtol=1e-3, err_msg=f"step {t}")
+        np.testing.assert_allclose(be.get("dof_state"), orc.buf["dof_state"], atol=5e-3, rtol=1e-3, err_msg=f"step {t}")
+        np.testing.assert_allclose(be.get("obs"), orc.buf["obs"], atol=5e-3, rtol=1e-3, err_msg=f"step {t}")

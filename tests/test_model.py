@@ -20,7 +20,7 @@ def test_masses_and_topology():
     assert [m.bodies[i].dof for i in range(17)] == [-1, 0, 1, 2, -1, 3, 4, 5, -1, 6, 7, 8, -1, 9, 10, 11, -1]
     assert list(m.feet_bodies) == [4, 8, 12, 16]
     assert m.termination_body_mask == 1 and bin(m.penalised_body_mask).count("1") == 9
-    assert m.num_collision_points == 56
+    assert m.num_collision_points == 64       # every URDF collision primitive incl. the rotor housings (robots/common.py rules)
 
 
 @pytest.mark.skipif(not os.path.exists(URDF), reason="reference checkout not present")
@@ -46,3 +46,31 @@ def test_table_matches_reference_urdf():
         assert np.sign(float(th.get("ixy"))) == np.sign(aliengo._mirror(aliengo.THIGH, 1.0, aliengo._SY[leg])["inertia"][1])
     trunk = float(links["trunk"].find("inertial").find("mass").get("value"))
     assert abs(bodies[0]["mass"] - (trunk + 0.001 + 4 * 0.146)) < 1e-9
+
+
+def test_stored_tables_build_and_aliengo_table_equals_hand_table():
+    """robots/tables/*.json (written by tools/gen_robot_tables.py through the URDF loader) build valid models; the Aliengo one is
+    byte-identical to the hand-checked table of robots/aliengo.py"""
+    from isaacgymloco_amd.robots import urdf
+    m, names, dofs = urdf.build_model_from_table("aliengo")
+    assert bytes(m) == bytes(aliengo.build_model())
+    assert dofs == aliengo.DOF_NAMES and names == aliengo.BODY_NAMES
+    for robot, mass in (("go1", 11.31), ("a1", 12.454)):
+        g, gn, gd = urdf.build_model_from_table(robot)
+        assert abs(sum(g.bodies[i].mass for i in range(17)) - mass) < 5e-3
+        assert gd == aliengo.DOF_NAMES and list(g.feet_bodies) == [4, 8, 12, 16]
+        assert 40 <= g.num_collision_points <= 64 and g.termination_body_mask == 1
+        assert all(g.dof_pos_lower[j] < g.dof_pos_upper[j] for j in range(12))
+
+
+@pytest.mark.skipif(not os.path.exists(URDF), reason="reference checkout not present")
+def test_urdf_loader_reproduces_tables():
+    """the generic loader (fixed-joint collapse, Isaac ordering, collision rules) on the reference's URDFs == the shipped tables"""
+    import json
+    from isaacgymloco_amd.robots import urdf
+    m, _, _ = urdf.build_model(URDF)
+    assert bytes(m) == bytes(aliengo.build_model())
+    for robot in ("go1", "a1"):
+        a, _, _ = urdf.build_model(URDF.replace("aliengo", robot))
+        b, _, _ = urdf.build_model_from_table(robot)
+        assert bytes(a) == bytes(b)

@@ -168,3 +168,24 @@ def test_emu_plane_ground_ragged_sizes_match_oracle(N):
         np.testing.assert_allclose(emu.buf["obs"], orc.buf["obs"], atol=5e-3, rtol=1e-3, err_msg=f"step {t}")
         np.testing.assert_allclose(emu.buf["rew"], orc.buf["rew"], atol=1e-3, rtol=1e-3, err_msg=f"step {t}")
     assert np.all(emu.buf["measured_heights"] == 0.0)     # LR:1478-1479: zeros on a plane
+
+
+def test_go1_table_emu_matches_oracle_and_stands():
+    """second robot (robots/tables/go1.json, task "go1"): the lane-emulated kernels agree with the oracle, and a zero-action robot dropped
+    from its init height settles on its feet (total foot force ~ m g, no termination)"""
+    import emu_binding
+    cfg = quiet_cfg("go1")
+    orc, lc, model, ter = make_oracle(cfg, 4, seed=2)
+    mass = sum(model.bodies[i].mass for i in range(17))
+    assert abs(mass - 11.31) < 5e-3
+    emu = emu_binding.EmuSim(lc, model, ter.heightsamples, ter.env_origins)
+    orc.reset_all(); emu.reset_all()
+    a = np.zeros((4, 12), np.float32)
+    for t in range(60):
+        orc.step(a); emu.step(a)
+        np.testing.assert_array_equal(emu.buf["reset"], orc.buf["reset"], err_msg=f"step {t}")
+        np.testing.assert_allclose(emu.buf["root_states"], orc.buf["root_states"], atol=3e-3, rtol=1e-3, err_msg=f"step {t}")
+    assert orc.buf["reset"].sum() == 0
+    fz = orc.buf["contact_forces"][:, [4, 8, 12, 16], 2].sum(1)
+    np.testing.assert_allclose(fz, mass * G, rtol=0.05)
+    assert np.all(orc.buf["root_states"][:, 2] > 0.2) and np.all(orc.buf["root_states"][:, 2] < 0.45)
