@@ -161,3 +161,19 @@ class HybridPolicyRunner(HIMOnPolicyRunner):
     def learn(self, num_learning_iterations, init_at_random_ep_len=False):
         self._amp_obs = None
         return super().learn(num_learning_iterations, init_at_random_ep_len)
+
+    # the reference's HybridPolicyRunner.save (HYBR:334-345) drops the discriminator and the AMP normaliser: a resumed run restarts them
+    def _extra_checkpoint_state(self):
+        out = super()._extra_checkpoint_state()
+        nz = self.alg.amp_normalizer
+        out["discriminator_state_dict"] = self.alg.discriminator.state_dict()
+        out["amp_normalizer"] = {"mean": nz._mean.cpu(), "var": nz._var.cpu(), "count": nz._count.cpu()}
+        return out
+
+    def _load_extra_checkpoint_state(self, d):
+        super()._load_extra_checkpoint_state(d)
+        if "discriminator_state_dict" in d:
+            self.alg.discriminator.load_state_dict(d["discriminator_state_dict"])
+        if "amp_normalizer" in d:
+            nz, st = self.alg.amp_normalizer, d["amp_normalizer"]
+            nz._mean, nz._var, nz._count = st["mean"].to(nz._mean.device), st["var"].to(nz._var.device), st["count"].to(nz._count.device)

@@ -210,17 +210,36 @@ class HIMOnPolicyRunner:
         if self.dist_ctx.enabled and self.dist_ctx.dist.get_rank() != 0:
             return
         os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
-        torch.save({"model_state_dict": self.alg.actor_critic.state_dict(), "optimizer_state_dict": self.alg.optimizer.state_dict(),
-                    "estimator_optimizer_state_dict": self.alg.actor_critic.estimator.optimizer.state_dict(),
-                    "iter": self.current_learning_iteration, "infos": infos}, path)
+        d = {"model_state_dict": self.alg.actor_critic.state_dict(), "optimizer_state_dict": self.alg.optimizer.state_dict(),
+             "estimator_optimizer_state_dict": self.alg.actor_critic.estimator.optimizer.state_dict(),
+             "iter": self.current_learning_iteration, "infos": infos}            # the reference's keys (HIMR:233-240): play.py loads these
+        d.update(self._extra_checkpoint_state())                                 # ... plus what it forgets; extra keys are ignored by its load()
+        torch.save(d, path)
+
+    def _extra_checkpoint_state(self):
+        out = {"learning_rate": self.alg.learning_rate}
+        if hasattr(self.env, "state_dict"):
+            out["env_state_dict"] = self.env.state_dict()
+        if self.graphs is not None:
+            out["rollout_draw_counter"] = int(self.graphs.draws.item())
+        return out
+
+    def _load_extra_checkpoint_state(self, d):
+        if "learning_rate" in d:
+            self.alg.learning_rate = d["learning_rate"]
+        if "env_state_dict" in d and hasattr(self.env, "load_state_dict"):
+            self.env.load_state_dict(d["env_state_dict"])
+        if "rollout_draw_counter" in d and self.graphs is not None:
+            self.graphs.draws.fill_(d["rollout_draw_counter"])
 
     def load(self, path, load_optimizer=True):
-        d = torch.load(path, map_location=self.device)
+        d = torch.load(path, map_location=self.device, weights_only=False)   # holds optimizer state and plain-python extras
         self.alg.actor_critic.load_state_dict(d["model_state_dict"])
         if load_optimizer:
             self.alg.optimizer.load_state_dict(d["optimizer_state_dict"])
             self.alg.actor_critic.estimator.optimizer.load_state_dict(d["estimator_optimizer_state_dict"])
         self.current_learning_iteration = d["iter"]
+        self._load_extra_checkpoint_state(d)
         return d["infos"]
 
     def get_inference_policy(self, device=None):

@@ -225,3 +225,25 @@ def test_fused_sinkhorn_matches_torch():
         torch.testing.assert_close(got.double(), ref, rtol=1e-4, atol=1e-7)
         torch.testing.assert_close(got.sum(1), torch.ones(B, device="cuda:0"), rtol=1e-4, atol=1e-5)   # columns of Q*B sum to one
         assert torch.equal(got, M.sinkhorn(scores))            # deterministic
+
+
+def test_checkpoint_round_trip_restores_env_curricula(tmp_path):
+    """save() writes the reference's keys plus the simulator-side state the reference forgets; load() restores both"""
+    env, run = _make(seed=4)
+    run.enable_graphs()
+    run.learn(2, init_at_random_ep_len=True)
+    env.terrain_levels.fill_(3)
+    path = str(tmp_path / "model_2.pt")
+    run.save(path)
+    d = torch.load(path, map_location="cpu", weights_only=False)
+    assert {"model_state_dict", "optimizer_state_dict", "estimator_optimizer_state_dict", "iter", "infos"} <= set(d)     # HIMR:233-240
+    st = env.state_dict()
+    env2, run2 = _make(seed=9)
+    run2.enable_graphs()
+    run2.load(path)
+    st2 = env2.state_dict()
+    assert st2["step_counter"] == st["step_counter"] and torch.equal(st2["terrain_levels"], st["terrain_levels"])
+    assert torch.equal(st2["command_ranges"], st["command_ranges"]) and int(run2.graphs.draws) == int(run.graphs.draws)
+    for k, v in run.alg.actor_critic.state_dict().items():
+        assert torch.equal(v, run2.alg.actor_critic.state_dict()[k])
+    run2.learn(1)                                           # and training continues from there
