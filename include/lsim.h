@@ -454,6 +454,27 @@ int lsim_rollout_post(const lsim_rollout_storage* st, int64_t* step_idx_dev, int
 int lsim_rollout_gae(const lsim_rollout_storage* st, const float* last_values, float gamma, float lam,
                      float* returns, float* advantages, void* stream);
 
+/* ---- fused rollout-time forward of the HIM policy (HAC:136-163, HES:64-68, HIMP:90-96): estimator encoder
+ * (observation history -> 3 velocity + latent), L2-normalised latent, actor on [one-step obs, velocity, latent], critic on the
+ * privileged observation -- 11 Linear layers with ELU between them -- in one launch, MFMA fp32, activations in LDS.
+ * Weights are passed PADDED: weight [n_pad][k_pad] row-major and bias [n_pad], both dimensions multiples of 16, zero filled beyond
+ * [n_out][k_in], 16-byte aligned (the caller packs torch's nn.Linear parameters once per policy update).
+ * mean_out [num_envs, num_actions], values_out [num_envs, 1].  LSIM_E_UNSUPPORTED for other topologies / sizes (hidden widths > 512,
+ * inputs > 272): run the networks in the host framework then. */
+typedef struct lsim_mlp_layer {
+    const float* weight;      /* [n_pad][k_pad] */
+    const float* bias;        /* [n_pad] */
+    int32_t k_pad, n_pad, k_in, n_out;
+} lsim_mlp_layer;
+typedef struct lsim_him_policy {
+    lsim_mlp_layer encoder[3];   /* HES:36-45  history -> ... -> 3 + latent (no activation after the last layer) */
+    lsim_mlp_layer actor[4];     /* HAC:66-80  one_step_obs + 3 + latent -> ... -> num_actions */
+    lsim_mlp_layer critic[4];    /* HAC:82-95  privileged obs -> ... -> 1 */
+    int32_t num_obs, num_priv_obs, num_one_step_obs, num_actions;
+} lsim_him_policy;
+int lsim_policy_forward(const lsim_him_policy* p, const float* obs, const float* priv_obs, int64_t num_envs, float* mean_out,
+                        float* values_out, void* stream);
+
 /* ---- learner-side kernel: weight / bias gradient of a small Linear layer over a tall minibatch,
  *   dw[n, k] = sum_b g[b, n] * x[b, k],   db[n] = sum_b g[b, n]      (torch.nn.Linear backward: grad_weight = g^T x, grad_bias = g.sum(0))
  * for ceil(n_out / 16) * ceil(k_in / 16) <= 32 (each <= 8): the heads and narrow layers of HAC:66-95 / HES:36-54 / DISC:18-25, whose

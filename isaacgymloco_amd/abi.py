@@ -67,6 +67,8 @@ def _parse(text):
             stmt = " ".join(stmt.split())
             if not stmt:
                 continue
+            if stmt.startswith("const "):
+                stmt = stmt[len("const "):]
             ty, rest = stmt.split(" ", 1)
             if ty.endswith("*"):                         # pointer members (device pointers) bind as void*
                 base = ctypes.c_void_p
@@ -92,6 +94,8 @@ LsimRobotModel = STRUCTS["lsim_robot_model"]
 LsimBody = STRUCTS["lsim_body"]
 LsimCollisionPoint = STRUCTS["lsim_collision_point"]
 LsimRolloutStorage = STRUCTS["lsim_rollout_storage"]
+LsimMlpLayer = STRUCTS["lsim_mlp_layer"]
+LsimHimPolicy = STRUCTS["lsim_him_policy"]
 
 REWARD_IDS = {k[len("LSIM_R_"):].lower(): v for k, v in ENUMS["lsim_reward_id"].items() if k.startswith("LSIM_R_")}
 NUM_REWARD_TERMS = ENUMS["lsim_reward_id"]["LSIM_NUM_REWARD_TERMS"]

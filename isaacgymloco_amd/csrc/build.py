@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 LIB = os.path.join(HERE, "liblsim.so")
 SOURCES = ["lsim_hip.hip"]
-HEADERS = ["ls_math.h", "ls_shared.h", "ls_physics.h", "ls_post.h", "ls_kernels.h", "ls_api_impl.h", "ls_rollout.h", "ls_learn.h"]
+HEADERS = ["ls_math.h", "ls_shared.h", "ls_physics.h", "ls_post.h", "ls_kernels.h", "ls_api_impl.h", "ls_rollout.h", "ls_learn.h", "ls_policy.h"]
 # -fno-hip-fp32-correctly-rounded-divide-sqrt: the dynamics is VALU-issue bound and ~150 divisions per sub-step cost ~12
 # instructions each when IEEE-rounded; quotients that must be exact use ls_div_exact (ls_math.h)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-pass-failed",

@@ -21,6 +21,7 @@ static void lsbk_prof_free(lsim_sim* s);
 #include "ls_kernels.h"
 #include "ls_rollout.h"
 #include "ls_learn.h"
+#include "ls_policy.h"
 
 // Each XCD (8 per chip, block b is dispatched to XCD b % 8) works on one contiguous slice of the env range, so a
 // robot's state lines stay in one XCD's L2 and neighbouring robots do not false-share lines across XCD L2s.

@@ -5,9 +5,9 @@ log-prob, the time-out bootstrap, eleven storage copies, HIMR:110-127 + HIMP:90-
 a few microseconds on the GPU but ~10 us of host dispatch, so collection is host-bound (1.2 ms/step against 0.76 ms of GPU
 work).  Here
 
-    graph A :  the three networks' forward (torch GEMMs + ELU, captured once)  ->  mean, values
-               lsim_rollout_act   (HIP, include/lsim.h): a = mean + std * z, log-prob, storage[idx] <- (obs, critic_obs,
-                                   actions, values, log-prob, mu, sigma)                     -- captured in the same graph
+    lsim_policy_forward (HIP)  :  encoder + normalise + actor + critic in one MFMA kernel (learn/fused_policy.py)  ->  mean, values
+                                  [other network topologies: torch's forward, captured once in a HIP graph]
+    lsim_rollout_act   (HIP)   :  a = mean + std * z, log-prob, storage[idx] <- (obs, critic_obs, actions, values, log-prob, mu, sigma)
     env.step_device(actions)      (HIP kernels A + B, not captured: per-call arguments)
     lsim_rollout_post (HIP)    :  storage[idx] <- (where(done, termination_obs, critic_obs), reward + gamma * value * time_out,
                                    done);  idx += 1
@@ -38,14 +38,22 @@ class GraphedRollout:
         self._S = self.storage.c_struct()
         self._seed, self._rank = int(self.env.lcfg.seed), int(self.env.lcfg.rank)
         self.graph_a = None
-        self._capture()
+        # preferred: the library's fused policy kernel (11 Linear + 8 ELU + glue in one launch); otherwise capture torch's forward
+        from .fused_policy import PackedHimPolicy
+        self.packed = PackedHimPolicy(self.alg.actor_critic) if PackedHimPolicy.supported(self.alg.actor_critic) else None
+        if self.packed is None:
+            self._capture()
+        self.storage.step = 0
 
     # ---- HIMP:90-103 written against static tensors; the elementwise tail is one HIP kernel --------------------------
     def _act(self):
         env, ac = self.env, self.alg.actor_critic
-        ac.update_distribution(env.obs_buf)
-        self.mean.copy_(ac.action_mean)
-        self.values.copy_(ac.evaluate(env.privileged_obs_buf))
+        if self.packed is not None:
+            self.packed.forward(env.obs_buf, env.privileged_obs_buf, self.mean, self.values)
+        else:
+            ac.update_distribution(env.obs_buf)
+            self.mean.copy_(ac.action_mean)
+            self.values.copy_(ac.evaluate(env.privileged_obs_buf))
         s = torch.cuda.current_stream(self.dev).cuda_stream
         lib.check(self._L.lsim_rollout_act(ctypes.byref(self._S), self.idx.data_ptr(), self.draws.data_ptr(), self.mean.data_ptr(),
                                            ac.std.data_ptr(), self.values.data_ptr(), env.obs_buf.data_ptr(),
@@ -79,12 +87,17 @@ class GraphedRollout:
         self.storage.step = 0
 
     def step(self):
-        """one rollout step: graph A (networks + fused sample/store), simulator step, fused post-step store"""
-        self.graph_a.replay()
+        """one rollout step: networks + fused sample/store (two launches, or one graph replay), simulator step, fused post-step store"""
+        if self.packed is not None:
+            self._act()
+        else:
+            self.graph_a.replay()
         self.env.step_device(self.actions)
         self._post()
         self.storage.step += 1
 
     def end_iteration(self):
-        """after compute_returns/update (which call storage.clear()): rewind the device-side step index"""
+        """after compute_returns/update (which call storage.clear()): rewind the device-side step index, pick up the new weights"""
         self.idx.zero_()
+        if self.packed is not None:
+            self.packed.refresh()

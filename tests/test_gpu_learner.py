@@ -247,3 +247,33 @@ def test_checkpoint_round_trip_restores_env_curricula(tmp_path):
     for k, v in run.alg.actor_critic.state_dict().items():
         assert torch.equal(v, run2.alg.actor_critic.state_dict()[k])
     run2.learn(1)                                           # and training continues from there
+
+
+@pytest.mark.parametrize("N", [4096, 37])
+def test_fused_policy_forward_matches_torch(N):
+    """lsim_policy_forward (one MFMA kernel: encoder, normalise, actor, critic) against HIMActorCritic's own forward (HAC:136-163);
+    fp32 tolerance 2e-5 relative to the output scale; ragged batch that does not fill the last 16-row block"""
+    from isaacgymloco_amd.learn.modules import HIMActorCritic
+    from isaacgymloco_amd.learn.fused_policy import PackedHimPolicy
+    torch.manual_seed(3)
+    ac = HIMActorCritic(270, 238, 45, 12).to("cuda:0")
+    with torch.no_grad():
+        for p in ac.parameters():
+            p.add_(0.05 * torch.randn_like(p))          # move away from the init's symmetry
+    assert PackedHimPolicy.supported(ac)
+    pk = PackedHimPolicy(ac)
+    obs, priv = 2.0 * torch.randn(N, 270, device="cuda:0"), 2.0 * torch.randn(N, 238, device="cuda:0")
+    mean, val = torch.empty(N, 12, device="cuda:0"), torch.empty(N, 1, device="cuda:0")
+    pk.forward(obs, priv, mean, val)
+    with torch.no_grad():
+        ac.update_distribution(obs)
+        ref_mean, ref_val = ac.action_mean, ac.evaluate(priv)
+    torch.testing.assert_close(mean, ref_mean, rtol=2e-4, atol=2e-5 * float(ref_mean.abs().max()))
+    torch.testing.assert_close(val, ref_val, rtol=2e-4, atol=2e-5 * float(ref_val.abs().max()))
+    with torch.no_grad():                                # refresh() after a parameter change
+        ac.actor[0].weight.mul_(1.5)
+    pk.refresh()
+    pk.forward(obs, priv, mean, val)
+    with torch.no_grad():
+        ac.update_distribution(obs)
+    torch.testing.assert_close(mean, ac.action_mean, rtol=2e-4, atol=2e-5 * float(ac.action_mean.abs().max()))
