@@ -227,4 +227,4 @@ class AMPDiscriminator(nn.Module):
 def default_motion_files():
     """The Aliengo clip bundle shipped as a data fixture (7 clips selected by AGA:34-36)."""
     here = os.path.dirname(os.path.abspath(__file__))
-    return [os.path.join(os.path.dirname(os.path.dirname(here)), "tests", "golden", "mocap_aliengo.npz")]
+    return [os.path.join(os.path.dirname(here), "data", "mocap_aliengo.npz")]

@@ -61,12 +61,13 @@ class GraphedRollout:
                   what="lsim_rollout_act")
 
     # ---- HIMR:119-121 + HIMP:105-118 + HST:92-106 ------------------------------------------------------------------------
-    def _post(self):
+    def _post(self, rewards=None):
         env = self.env
         to = env.extras.get("time_outs")
+        rewards = env.rew_buf if rewards is None else rewards
         s = torch.cuda.current_stream(self.dev).cuda_stream
         lib.check(self._L.lsim_rollout_post(ctypes.byref(self._S), self.idx.data_ptr(), self.draws.data_ptr(), env.reset_buf.data_ptr(),
-                                            to.data_ptr() if to is not None else None, env.rew_buf.data_ptr(), self.values.data_ptr(),
+                                            to.data_ptr() if to is not None else None, rewards.data_ptr(), self.values.data_ptr(),
                                             env.privileged_obs_buf.data_ptr(), env.termination_privileged_obs_buf.data_ptr(),
                                             float(self.alg.gamma), s), what="lsim_rollout_post")
 
@@ -101,3 +102,30 @@ class GraphedRollout:
         self.idx.zero_()
         if self.packed is not None:
             self.packed.refresh()
+
+
+class HybridFusedRollout(GraphedRollout):
+    """The same device-side rollout step for HybridPolicyRunner (AMP, HYBR:118-152): between the simulator step and the storage write
+    the task reward is blended with the discriminator's style reward on (amp_obs, next_amp_obs) -- terminal AMP states patched in for
+    resetting envs (HYBR:136-140) -- and the pair goes into the AMP replay buffer (HYBP:121-124).  Those pieces stay torch ops."""
+
+    def __init__(self, runner):
+        super().__init__(runner)
+        self._amp_obs = self.env.get_amp_observations().clone()
+        self.rewards = torch.zeros(self.env.num_envs, device=self.dev)
+
+    def step(self):
+        env, alg = self.env, self.alg
+        amp_obs = self._amp_obs
+        if self.packed is not None:
+            self._act()
+        else:
+            self.graph_a.replay()
+        env.step_device(self.actions)
+        next_amp = env.get_amp_observations().clone()
+        next_with_term = torch.where(env.reset_buf.unsqueeze(1), env.terminal_amp_states_buf, next_amp)
+        self.rewards.copy_(alg.discriminator.predict_amp_reward(amp_obs, next_with_term, env.rew_buf, normalizer=alg.amp_normalizer)[0])
+        alg.amp_storage.insert(amp_obs, next_with_term)
+        self._post(self.rewards)
+        self._amp_obs = next_amp
+        self.storage.step += 1

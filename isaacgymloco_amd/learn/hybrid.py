@@ -162,6 +162,10 @@ class HybridPolicyRunner(HIMOnPolicyRunner):
         self._amp_obs = None
         return super().learn(num_learning_iterations, init_at_random_ep_len)
 
+    def _make_fused_rollout(self):
+        from .graph_rollout import HybridFusedRollout
+        return HybridFusedRollout(self)
+
     # the reference's HybridPolicyRunner.save (HYBR:334-345) drops the discriminator and the AMP normaliser: a resumed run restarts them
     def _extra_checkpoint_state(self):
         out = super()._extra_checkpoint_state()

@@ -47,11 +47,15 @@ class HIMOnPolicyRunner:
     graphs = None   # GraphedRollout once enable_graphs() succeeded (subclasses with their own __init__ inherit the default)
 
     def enable_graphs(self):
-        """Capture the rollout step into HIP graphs (graph_rollout.py).  Only for the plain HIM runner on a GPU env."""
-        if type(self) is HIMOnPolicyRunner and self.fast and str(self.device).startswith("cuda"):
-            from .graph_rollout import GraphedRollout
-            self.graphs = GraphedRollout(self)
+        """Switch the rollout step to the fused device path (graph_rollout.py): HIP kernels for the policy forward, sampling and
+        storage writes, no host round trips.  Needs the build's GPU environment (step_device)."""
+        if self.fast and str(self.device).startswith("cuda"):
+            self.graphs = self._make_fused_rollout()
         return self.graphs is not None
+
+    def _make_fused_rollout(self):
+        from .graph_rollout import GraphedRollout
+        return GraphedRollout(self) if type(self) is HIMOnPolicyRunner else None
 
     # ------------------------------------------------------------------ rollout
     def _rollout_step(self, obs, critic_obs):

@@ -11,7 +11,7 @@ from isaacgymloco_amd.learn.hybrid import HybridPPO
 from isaacgymloco_amd.learn.modules import HIMActorCritic
 
 FX = os.path.join(ROOT, "tests", "golden", "learner_amp.npz")
-BUNDLE = os.path.join(ROOT, "tests", "golden", "mocap_aliengo.npz")
+BUNDLE = os.path.join(ROOT, "isaacgymloco_amd", "data", "mocap_aliengo.npz")
 ALG = dict(value_loss_coef=1.0, use_clipped_value_loss=True, clip_param=0.2, entropy_coef=0.01, num_learning_epochs=2,
            num_mini_batches=2, learning_rate=1e-3, schedule="adaptive", gamma=0.99, lam=0.95, desired_kl=0.01, max_grad_norm=1.0,
            amp_replay_buffer_size=64)

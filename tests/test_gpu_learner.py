@@ -75,9 +75,14 @@ def test_amp_hybrid_runner_iteration_on_gpu():
     tc["runner"]["num_steps_per_env"] = 8
     torch.manual_seed(0); np.random.seed(0)
     run = HybridPolicyRunner(env, tc, log_dir=None, device="cuda:0")
-    assert not run.enable_graphs()        # graph capture is only wired for the plain HIM runner
     before = {k: v.clone() for k, v in run.alg.discriminator.state_dict().items()}
-    run.learn(2, init_at_random_ep_len=True)
+    run.learn(1, init_at_random_ep_len=True)              # eager rollout (reference call order)
+    assert run.enable_graphs()                            # fused device-side rollout incl. style reward + replay insert
+    n0 = run.alg.amp_storage.num_samples
+    run.learn(2)
+    assert run.alg.amp_storage.num_samples > n0
+    st = run.alg.storage
+    assert torch.isfinite(st.rewards).all() and float(st.rewards.abs().sum()) > 0
     after = run.alg.discriminator.state_dict()
     assert any(not torch.equal(before[k], after[k]) for k in before)
     assert all(torch.isfinite(v).all() for v in after.values())

@@ -1,5 +1,5 @@
 """Container-only: data bundle + golden vectors for the AMP path from the reference rsl_rl.
-  tests/golden/mocap_aliengo.npz  the 7 Aliengo mocap clips selected by AGA:34-36 (data: frames, weight, frame duration),
+  isaacgymloco_amd/data/mocap_aliengo.npz  the 7 Aliengo mocap clips selected by AGA:34-36 (data: frames, weight, frame duration),
                                   in the order the reference's glob returned them (that order feeds np.random.choice)
   tests/golden/learner_amp.npz    AMPLoader pre-sampling, discriminator reward, Normalizer, ReplayBuffer, one HybridPPO.update()."""
 import json
@@ -42,7 +42,7 @@ def main():
         bundle[f"frames_{i}"] = np.array(j["Frames"], dtype=np.float32)
         bundle[f"weight_{i}"] = np.float64(j["MotionWeight"])
         bundle[f"frame_duration_{i}"] = np.float64(j["FrameDuration"])
-    np.savez_compressed(os.path.join(GOLDEN, "mocap_aliengo.npz"), **bundle)
+    np.savez_compressed(os.path.join(ROOT, "isaacgymloco_amd", "data", "mocap_aliengo.npz"), **bundle)
 
     out = {}
     np.random.seed(1)
@@ -108,7 +108,7 @@ def main():
     for k, v in ck(disc2).items():
         out["hy_disc/" + k] = v
     np.savez_compressed(os.path.join(GOLDEN, "learner_amp.npz"), **out)
-    print("wrote bundle + learner_amp.npz", {k: os.path.getsize(os.path.join(GOLDEN, k)) // 1000 for k in ("mocap_aliengo.npz", "learner_amp.npz")}, "KB; losses", res)
+    print("wrote bundle + learner_amp.npz", {k: os.path.getsize(os.path.join(GOLDEN, k)) // 1000 for k in ("learner_amp.npz",)}, "KB; losses", res)
 
 
 if __name__ == "__main__":
