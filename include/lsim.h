@@ -486,6 +486,18 @@ int lsim_linear_wgrad_workspace(long batch, int k_in, int n_out, size_t* bytes, 
 int lsim_linear_wgrad(const float* x, int64_t ldx, const float* g, int64_t ldg, int64_t batch, int k_in, int n_out,
                       float* dw, float* db, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Clipped-PPO loss of HIMPPO.update (HIMP:136-176), forward AND backward in one pass: per-sample Gaussian log-prob, ratio, clipped
+ * surrogate, clipped value loss, entropy bonus, and the KL estimate of the adaptive learning-rate rule (HIMP:144-156).
+ *   out5 = { mean surrogate, mean value loss, mean entropy, mean KL, total = surrogate + value_loss_coef * value - entropy_coef * entropy }
+ *   grad_mu [B, A], grad_sigma [B, A], grad_value [B] = d total / d (mu, sigma, value), torch's sub-gradient conventions.
+ * mu, sigma, actions, old_mu, old_sigma [B, A]; value, old_logp, advantages, returns, target_values [B], all contiguous fp32.
+ * target_values may be NULL when use_clipped_value_loss == 0.  workspace: lsim_ppo_loss_workspace() bytes; deterministic. */
+int lsim_ppo_loss_workspace(long batch, size_t* bytes);
+int lsim_ppo_loss(const float* mu, const float* sigma, const float* value, const float* actions, const float* old_logp, const float* advantages,
+                  const float* returns, const float* target_values, const float* old_mu, const float* old_sigma, int64_t batch, int num_actions,
+                  float clip_param, float value_loss_coef, float entropy_coef, int use_clipped_value_loss,
+                  float* out5, float* grad_mu, float* grad_sigma, float* grad_value, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Sinkhorn-Knopp assignment of the estimator's prototype scores (HIMEstimator.sinkhorn, HES:119-133; no gradient flows through it):
  *   Q = exp(scores / eps)^T;  Q /= sum(Q);  iters x { Q /= rowsum; Q /= K; Q /= colsum; Q /= B };  out = (Q * B)^T
  * scores [batch, K] with row stride lds (floats), K <= 64, out [batch, K] contiguous.  Computed as E * u[k] * v[b] with 2 * iters + 1

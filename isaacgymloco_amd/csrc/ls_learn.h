@@ -413,3 +413,125 @@ extern "C" int lsim_sinkhorn(const float* scores, int64_t lds, int64_t batch, in
                        (float*)nullptr, out);
     return hipGetLastError() == hipSuccess ? LSIM_OK : LSIM_E_HIP;
 }
+
+// ---- clipped-PPO loss of HIMPPO.update (HIMP:136-176), forward and backward in one pass over the minibatch.
+//   logp_b   = sum_j -(a - mu)^2 / (2 sigma^2) - log sigma - log sqrt(2 pi)            ratio_b = exp(logp_b - old_logp_b)
+//   surrogate = mean_b max(-A_b ratio_b, -A_b clamp(ratio_b, 1 - eps, 1 + eps))
+//   value     = mean_b max((v - R)^2, (tv + clamp(v - tv, -eps, eps) - R)^2)            (or mean (R - v)^2 without clipping)
+//   entropy   = mean_b sum_j (0.5 + 0.5 log(2 pi) + log sigma)
+//   kl        = mean_b sum_j log(sigma / old_sigma + 1e-5) + (old_sigma^2 + (old_mu - mu)^2) / (2 sigma^2) - 0.5      (no gradient)
+//   loss      = surrogate + c_v value - c_e entropy
+// and d loss / d mu [B, A], d loss / d sigma [B, A], d loss / d v [B] with torch's sub-gradient conventions (maximum: ties split evenly,
+// clamp: gradient passes on the closed interval).  One thread per sample; block partial sums are added in a fixed order by a second
+// launch.  Replaces ~90 small torch kernels per minibatch (log-prob, entropy, KL, ratio, clamps, maxima, means and their backward).
+struct LsPpoLossArgs {
+    const float* mu; const float* sigma; const float* value;                 // [B, A], [B, A], [B]
+    const float* actions; const float* old_logp; const float* adv; const float* returns; const float* target_values;
+    const float* old_mu; const float* old_sigma;
+    float* g_mu; float* g_sigma; float* g_value;                             // gradients of the total loss (for grad_output = 1)
+    float* partial;                                                          // [blocks][4]: surrogate, value, entropy, kl sums
+    long batch; int A;
+    float clip, value_coef, entropy_coef; int clipped_value;
+};
+
+__global__ __launch_bounds__(256) void lsim_k_ppo_loss(LsPpoLossArgs a) {
+    __shared__ float red[4][4];
+    const long b = (long)blockIdx.x * 256 + threadIdx.x;
+    float s_sur = 0.0f, s_val = 0.0f, s_ent = 0.0f, s_kl = 0.0f;
+    if (b < a.batch) {
+        const int A = a.A;
+        const float invB = 1.0f / (float)a.batch;
+        const float* mu = a.mu + b * A; const float* sg = a.sigma + b * A; const float* ac = a.actions + b * A;
+        const float* omu = a.old_mu + b * A; const float* osg = a.old_sigma + b * A;
+        float logp = 0.0f, ent = 0.0f, kl = 0.0f;
+        for (int j = 0; j < A; ++j) {
+            const float s = sg[j], d = ac[j] - mu[j], ls = logf(s);
+            logp += -(d * d) / (2.0f * s * s) - ls - 0.9189385332046727f;
+            ent += 1.4189385332046727f + ls;
+            const float dm = omu[j] - mu[j];
+            kl += logf(s / osg[j] + 1.0e-5f) + (osg[j] * osg[j] + dm * dm) / (2.0f * s * s) - 0.5f;
+        }
+        const float adv = a.adv[b];
+        const float ratio = expf(logp - a.old_logp[b]);
+        const float lo = 1.0f - a.clip, hi = 1.0f + a.clip;
+        const float rc = fminf(fmaxf(ratio, lo), hi);
+        const float s1 = -adv * ratio, s2 = -adv * rc;
+        s_sur = fmaxf(s1, s2);
+        // d surrogate / d ratio: branch 1 always differentiable; branch 2 only where the clamp passes (closed interval); ties split evenly
+        const float in_range = (ratio >= lo && ratio <= hi) ? 1.0f : 0.0f;
+        const float w1 = s1 > s2 ? 1.0f : (s1 == s2 ? 0.5f : 0.0f), w2 = 1.0f - w1;
+        const float dS_dlogp = invB * (-adv) * (w1 + w2 * in_range) * ratio;
+        // value loss
+        const float v = a.value[b], R = a.returns[b];
+        float dV_dv;
+        if (a.clipped_value) {
+            const float tv = a.target_values[b], dv = v - tv;
+            const float vc = tv + fminf(fmaxf(dv, -a.clip), a.clip);
+            const float l1 = (v - R) * (v - R), l2 = (vc - R) * (vc - R);
+            s_val = fmaxf(l1, l2);
+            const float pass = (dv >= -a.clip && dv <= a.clip) ? 1.0f : 0.0f;
+            const float u1 = l1 > l2 ? 1.0f : (l1 == l2 ? 0.5f : 0.0f), u2 = 1.0f - u1;
+            dV_dv = invB * (u1 * 2.0f * (v - R) + u2 * 2.0f * (vc - R) * pass);
+        } else {
+            s_val = (R - v) * (R - v);
+            dV_dv = invB * 2.0f * (v - R);
+        }
+        a.g_value[b] = a.value_coef * dV_dv;
+        for (int j = 0; j < A; ++j) {
+            const float s = sg[j], d = ac[j] - mu[j];
+            a.g_mu[b * A + j] = dS_dlogp * d / (s * s);
+            a.g_sigma[b * A + j] = dS_dlogp * (d * d / (s * s * s) - 1.0f / s) - a.entropy_coef * invB / s;
+        }
+        s_ent = ent; s_kl = kl;
+    }
+    // block sums in a fixed order: wave shuffle tree, then the four waves
+    float v4[4] = {s_sur, s_val, s_ent, s_kl};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float x = v4[k];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) a.partial[(size_t)blockIdx.x * 4 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// out[0..3] = means of surrogate, value, entropy, kl; out[4] = total loss
+__global__ __launch_bounds__(64) void lsim_k_ppo_loss_finish(const float* __restrict__ partial, int blocks, long batch, float value_coef, float entropy_coef,
+                                                             float* __restrict__ out) {
+    const int k = threadIdx.x & 3, part = threadIdx.x >> 2;      // 16 interleaved partial sums per quantity
+    float s = 0.0f;
+    for (int i = part; i < blocks; i += 16) s += partial[(size_t)i * 4 + k];
+    for (int off = 32; off >= 4; off >>= 1) s += __shfl_down(s, off, 64);
+    __shared__ float m[4];
+    if (threadIdx.x < 4) { m[k] = s / (float)batch; }
+    __syncthreads();
+    if (threadIdx.x < 4) out[k] = m[k];
+    if (threadIdx.x == 0) out[4] = m[0] + value_coef * m[1] - entropy_coef * m[2];
+}
+
+extern "C" int lsim_ppo_loss_workspace(long batch, size_t* bytes) {
+    if (!bytes || batch <= 0) return LSIM_E_INVALID;
+    *bytes = (size_t)((batch + 255) / 256) * 4 * sizeof(float);
+    return LSIM_OK;
+}
+
+extern "C" int lsim_ppo_loss(const float* mu, const float* sigma, const float* value, const float* actions, const float* old_logp, const float* advantages,
+                             const float* returns, const float* target_values, const float* old_mu, const float* old_sigma, int64_t batch, int num_actions,
+                             float clip_param, float value_loss_coef, float entropy_coef, int use_clipped_value_loss,
+                             float* out5, float* grad_mu, float* grad_sigma, float* grad_value, void* workspace, size_t workspace_bytes, void* stream) {
+    size_t need;
+    if (lsim_ppo_loss_workspace(batch, &need) != LSIM_OK) return LSIM_E_INVALID;
+    if (!mu || !sigma || !value || !actions || !old_logp || !advantages || !returns || !old_mu || !old_sigma || !out5 || !grad_mu || !grad_sigma ||
+        !grad_value || !workspace || workspace_bytes < need || num_actions <= 0 || (use_clipped_value_loss && !target_values)) return LSIM_E_INVALID;
+    LsPpoLossArgs a;
+    a.mu = mu; a.sigma = sigma; a.value = value; a.actions = actions; a.old_logp = old_logp; a.adv = advantages; a.returns = returns;
+    a.target_values = target_values; a.old_mu = old_mu; a.old_sigma = old_sigma; a.g_mu = grad_mu; a.g_sigma = grad_sigma; a.g_value = grad_value;
+    a.partial = (float*)workspace; a.batch = batch; a.A = num_actions; a.clip = clip_param; a.value_coef = value_loss_coef;
+    a.entropy_coef = entropy_coef; a.clipped_value = use_clipped_value_loss;
+    const int blocks = (int)((batch + 255) / 256);
+    hipLaunchKernelGGL(lsim_k_ppo_loss, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(lsim_k_ppo_loss_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)workspace, blocks, (long)batch, value_loss_coef,
+                       entropy_coef, out5);
+    return hipGetLastError() == hipSuccess ? LSIM_OK : LSIM_E_HIP;
+}

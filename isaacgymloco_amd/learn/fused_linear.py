@@ -97,3 +97,41 @@ def sinkhorn_hip(scores, eps, iters):
     lib.check(L.lsim_sinkhorn(scores.data_ptr(), scores.stride(0), B, K, float(eps), int(iters), out.data_ptr(), ws.data_ptr(), ws.numel(),
                               torch.cuda.current_stream(scores.device).cuda_stream), what="lsim_sinkhorn")
     return out
+
+
+class _PpoLossFn(torch.autograd.Function):
+    """clipped-PPO loss through lsim_ppo_loss: forward and the three input gradients come from the same pass"""
+
+    @staticmethod
+    def forward(ctx, mu, sigma, value, actions, old_logp, adv, returns, target_values, old_mu, old_sigma, clip, vcoef, ecoef, clipped):
+        from .. import lib
+        L = lib.load()
+        c = lambda t: t.detach().contiguous()
+        mu_, sg_, v_ = c(mu), c(sigma), c(value).reshape(-1)
+        B, A = mu_.shape
+        need = ctypes.c_size_t()
+        lib.check(L.lsim_ppo_loss_workspace(B, ctypes.byref(need)), what="lsim_ppo_loss_workspace")
+        ws = torch.empty(need.value, dtype=torch.uint8, device=mu.device)
+        out = torch.empty(5, device=mu.device)
+        g_mu, g_sg, g_v = torch.empty_like(mu_), torch.empty_like(sg_), torch.empty_like(v_)
+        args = [c(t).reshape(B, -1) if t is not None else None for t in (actions, old_logp, adv, returns, target_values, old_mu, old_sigma)]
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        lib.check(L.lsim_ppo_loss(mu_.data_ptr(), sg_.data_ptr(), v_.data_ptr(), ptr(args[0]), ptr(args[1]), ptr(args[2]), ptr(args[3]), ptr(args[4]),
+                                  ptr(args[5]), ptr(args[6]), B, A, float(clip), float(vcoef), float(ecoef), int(bool(clipped)), out.data_ptr(),
+                                  g_mu.data_ptr(), g_sg.data_ptr(), g_v.data_ptr(), ws.data_ptr(), ws.numel(),
+                                  torch.cuda.current_stream(mu.device).cuda_stream), what="lsim_ppo_loss")
+        ctx.save_for_backward(g_mu, g_sg, g_v)
+        ctx.value_shape = value.shape
+        stats = out[:4]
+        ctx.mark_non_differentiable(stats)
+        return out[4], stats
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_stats):
+        g_mu, g_sg, g_v = ctx.saved_tensors
+        return (g_loss * g_mu, g_loss * g_sg, (g_loss * g_v).reshape(ctx.value_shape)) + (None,) * 11
+
+
+def ppo_loss_hip(mu, sigma, value, actions, old_logp, adv, returns, target_values, old_mu, old_sigma, clip, vcoef, ecoef, clipped):
+    """-> (total loss with autograd to mu / sigma / value, stats = [surrogate, value loss, entropy, kl] means, detached)"""
+    return _PpoLossFn.apply(mu, sigma, value, actions, old_logp, adv, returns, target_values, old_mu, old_sigma, clip, vcoef, ecoef, clipped)

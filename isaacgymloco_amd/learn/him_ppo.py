@@ -115,10 +115,11 @@ class HIMPPO:
         last_values = self.actor_critic.evaluate(last_critic_obs).detach()
         self.storage.compute_returns(last_values, self.gamma, self.lam)
 
-    def _adapt_lr(self, mu, sigma, old_mu, old_sigma):
+    def _adapt_lr(self, mu, sigma, old_mu, old_sigma, kl_mean=None):
         with torch.inference_mode():
-            kl = torch.sum(torch.log(sigma / old_sigma + 1.0e-5) + (torch.square(old_sigma) + torch.square(old_mu - mu)) / (2.0 * torch.square(sigma)) - 0.5, dim=-1)
-            kl_mean = torch.mean(kl)
+            if kl_mean is None:
+                kl = torch.sum(torch.log(sigma / old_sigma + 1.0e-5) + (torch.square(old_sigma) + torch.square(old_mu - mu)) / (2.0 * torch.square(sigma)) - 0.5, dim=-1)
+                kl_mean = torch.mean(kl)
             if self.dist_ctx is not None:
                 kl_mean = self.dist_ctx.average_scalar(kl_mean)
             kl_mean = kl_mean.item()
@@ -129,6 +130,26 @@ class HIMPPO:
         for g in self.optimizer.param_groups:
             g["lr"] = self.learning_rate
 
+    def _ppo_loss(self, ac, mu, sigma, value, actions, old_logp, advantages, returns, target_values, old_mu, old_sigma):
+        """(total loss, surrogate, value loss, KL mean or None) of HIMP:136-176.  On the GPU one HIP kernel (lsim_ppo_loss: forward, backward
+        and the KL estimate of the adaptive-lr rule in a single pass); elsewhere the reference's torch statement."""
+        if mu.is_cuda and mu.dtype == torch.float32:
+            from .fused_linear import ppo_loss_hip
+            loss, st = ppo_loss_hip(mu, sigma, value, actions, old_logp, advantages, returns, target_values, old_mu, old_sigma, self.clip_param,
+                                    self.value_loss_coef, self.entropy_coef, self.use_clipped_value_loss)
+            return loss, st[0], st[1], st[3]
+        logp = ac.get_actions_log_prob(actions)
+        entropy = ac.entropy
+        adv = torch.squeeze(advantages)
+        ratio = torch.exp(logp - torch.squeeze(old_logp))
+        surrogate_loss = torch.max(-adv * ratio, -adv * torch.clamp(ratio, 1.0 - self.clip_param, 1.0 + self.clip_param)).mean()
+        if self.use_clipped_value_loss:
+            clipped = target_values + (value - target_values).clamp(-self.clip_param, self.clip_param)
+            value_loss = torch.max((value - returns).pow(2), (clipped - returns).pow(2)).mean()
+        else:
+            value_loss = (returns - value).pow(2).mean()
+        return surrogate_loss + self.value_loss_coef * value_loss - self.entropy_coef * entropy.mean(), surrogate_loss, value_loss, None
+
     def update(self):
         ac = self.actor_critic
         sums = torch.zeros(4, device=self.device)
@@ -137,21 +158,13 @@ class HIMPPO:
                 self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs):
             ac.estimator.prime(obs)        # one encoder forward serves the policy features and the estimator loss below
             ac.act(obs)
-            logp = ac.get_actions_log_prob(actions)
             value = ac.evaluate(critic_obs)
-            mu, sigma, entropy = ac.action_mean, ac.action_std, ac.entropy
+            mu, sigma = ac.action_mean, ac.action_std
+            loss, surrogate_loss, value_loss, kl_mean = self._ppo_loss(ac, mu, sigma, value, actions, old_logp, advantages, returns, target_values,
+                                                                       old_mu, old_sigma)
             if self.desired_kl is not None and self.schedule == "adaptive":
-                self._adapt_lr(mu, sigma, old_mu, old_sigma)
+                self._adapt_lr(mu, sigma, old_mu, old_sigma, kl_mean)
             est, swap = ac.estimator.update(obs, next_critic_obs, lr=self.learning_rate)
-            adv = torch.squeeze(advantages)
-            ratio = torch.exp(logp - torch.squeeze(old_logp))
-            surrogate_loss = torch.max(-adv * ratio, -adv * torch.clamp(ratio, 1.0 - self.clip_param, 1.0 + self.clip_param)).mean()
-            if self.use_clipped_value_loss:
-                clipped = target_values + (value - target_values).clamp(-self.clip_param, self.clip_param)
-                value_loss = torch.max((value - returns).pow(2), (clipped - returns).pow(2)).mean()
-            else:
-                value_loss = (returns - value).pow(2).mean()
-            loss = surrogate_loss + self.value_loss_coef * value_loss - self.entropy_coef * entropy.mean()
             self.optimizer.zero_grad()
             loss.backward()
             if self.dist_ctx is not None:

@@ -57,20 +57,13 @@ class HybridPPO(HIMPPO):
             obs, critic_obs, actions, next_critic_obs, target_values, advantages, returns, old_logp, old_mu, old_sigma = sample
             ac.estimator.prime(obs)        # one encoder forward serves the policy features and the estimator loss below
             ac.act(obs)
-            logp = ac.get_actions_log_prob(actions)
             value = ac.evaluate(critic_obs)
-            mu, sigma, entropy = ac.action_mean, ac.action_std, ac.entropy
+            mu, sigma = ac.action_mean, ac.action_std
+            ppo_loss, surrogate_loss, value_loss, kl_mean = self._ppo_loss(ac, mu, sigma, value, actions, old_logp, advantages, returns, target_values,
+                                                                           old_mu, old_sigma)
             if self.desired_kl is not None and self.schedule == "adaptive":
-                self._adapt_lr(mu, sigma, old_mu, old_sigma)
+                self._adapt_lr(mu, sigma, old_mu, old_sigma, kl_mean)
             est, swap = ac.estimator.update(obs, next_critic_obs, lr=self.learning_rate)
-            adv = torch.squeeze(advantages)
-            ratio = torch.exp(logp - torch.squeeze(old_logp))
-            surrogate_loss = torch.max(-adv * ratio, -adv * torch.clamp(ratio, 1.0 - self.clip_param, 1.0 + self.clip_param)).mean()
-            if self.use_clipped_value_loss:
-                clipped = target_values + (value - target_values).clamp(-self.clip_param, self.clip_param)
-                value_loss = torch.max((value - returns).pow(2), (clipped - returns).pow(2)).mean()
-            else:
-                value_loss = (returns - value).pow(2).mean()
             exp_s, exp_ns = exp_s_raw, exp_ns_raw
             if self.amp_normalizer is not None:
                 with torch.no_grad():
@@ -81,7 +74,7 @@ class HybridPPO(HIMPPO):
             amp_loss = 0.5 * (torch.nn.functional.mse_loss(expert_d, torch.ones_like(expert_d)) +
                               torch.nn.functional.mse_loss(policy_d, -torch.ones_like(policy_d)))
             grad_pen = disc.compute_grad_pen(exp_s_raw, exp_ns_raw, lambda_=10)     # on the un-normalised expert pair (HYBP:262-263)
-            loss = surrogate_loss + self.value_loss_coef * value_loss - self.entropy_coef * entropy.mean() + amp_loss + grad_pen
+            loss = ppo_loss + amp_loss + grad_pen
             self.optimizer.zero_grad()
             loss.backward()
             if self.dist_ctx is not None:

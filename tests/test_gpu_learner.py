@@ -282,3 +282,67 @@ def test_fused_policy_forward_matches_torch(N):
     with torch.no_grad():
         ac.update_distribution(obs)
     torch.testing.assert_close(mean, ac.action_mean, rtol=2e-4, atol=2e-5 * float(ac.action_mean.abs().max()))
+
+
+@pytest.mark.parametrize("clipped", [True, False])
+def test_fused_ppo_loss_matches_torch_autograd(clipped):
+    """lsim_ppo_loss (forward + backward + KL in one pass) against the torch statement of HIMP:136-176 and its autograd gradients"""
+    from torch.distributions import Normal
+    from isaacgymloco_amd.learn.fused_linear import ppo_loss_hip
+    g = torch.Generator(device="cuda:0").manual_seed(11)
+    B, A, clip, cv, ce = 20000, 12, 0.2, 1.0, 0.01
+    rnd = lambda *s: torch.randn(*s, device="cuda:0", generator=g)
+    mu = (0.5 * rnd(B, A)).requires_grad_(True)
+    std = (0.5 + torch.rand(A, device="cuda:0", generator=g)).requires_grad_(True)
+    value = rnd(B, 1).requires_grad_(True)
+    old_mu, old_sigma = mu.detach() + 0.1 * rnd(B, A), (std.detach() * (1 + 0.1 * rnd(A).clamp(-2, 2))).expand(B, A).contiguous()
+    actions = old_mu + old_sigma * rnd(B, A)
+    old_logp = Normal(old_mu, old_sigma).log_prob(actions).sum(-1, keepdim=True)
+    adv, returns, tv = rnd(B, 1), rnd(B, 1), value.detach() + 0.3 * rnd(B, 1)
+
+    def torch_loss(mu, std, value):
+        sigma = mu * 0.0 + std
+        dist = Normal(mu, sigma)
+        logp, ent = dist.log_prob(actions).sum(-1), dist.entropy().sum(-1)
+        a = adv.squeeze()
+        ratio = torch.exp(logp - old_logp.squeeze())
+        sur = torch.max(-a * ratio, -a * torch.clamp(ratio, 1 - clip, 1 + clip)).mean()
+        if clipped:
+            vc = tv + (value - tv).clamp(-clip, clip)
+            vl = torch.max((value - returns).pow(2), (vc - returns).pow(2)).mean()
+        else:
+            vl = (returns - value).pow(2).mean()
+        kl = torch.sum(torch.log(sigma / old_sigma + 1e-5) + (old_sigma ** 2 + (old_mu - mu) ** 2) / (2 * sigma ** 2) - 0.5, -1).mean()
+        return sur + cv * vl - ce * ent.mean(), sur, vl, ent.mean(), kl
+
+    ref = torch_loss(mu, std, value)
+    ref[0].backward()
+    ref_g = (mu.grad.clone(), std.grad.clone(), value.grad.clone())
+    for t in (mu, std, value):
+        t.grad = None
+    sigma = mu * 0.0 + std
+    loss, st = ppo_loss_hip(mu, sigma, value, actions, old_logp, adv, returns, tv, old_mu, old_sigma, clip, cv, ce, clipped)
+    loss.backward()
+    torch.testing.assert_close(loss, ref[0], rtol=2e-5, atol=2e-6)
+    for got, want in zip(st, ref[1:]):
+        torch.testing.assert_close(got, want.detach(), rtol=2e-5, atol=2e-6)
+    # the loss is piecewise: a sample whose ratio (or value error) sits within fp32 rounding of a clip boundary may take the other
+    # branch in the two implementations, so those few rows are compared on the loss only
+    with torch.no_grad():
+        sg = (mu * 0.0 + std)
+        ratio = torch.exp(Normal(mu, sg).log_prob(actions).sum(-1) - old_logp.squeeze())
+        near = ((ratio - (1 - clip)).abs() < 1e-4) | ((ratio - (1 + clip)).abs() < 1e-4)
+        if clipped:
+            dv = (value - tv).squeeze()
+            vc = tv + (value - tv).clamp(-clip, clip)
+            l_gap = ((value - returns) ** 2 - (vc - returns) ** 2).squeeze().abs()
+            near |= ((dv.abs() - clip).abs() < 1e-4) | ((l_gap < 1e-5) & (dv.abs() > clip))     # exact ties (unclipped rows) agree
+    keep = ~near
+    assert int(near.sum()) < 0.01 * B
+    scale = float(ref_g[0].abs().max())
+    torch.testing.assert_close(mu.grad[keep], ref_g[0][keep], rtol=1e-4, atol=1e-5 * scale)
+    torch.testing.assert_close(value.grad[keep], ref_g[2][keep], rtol=1e-4, atol=1e-5 * float(ref_g[2].abs().max()))
+    if int(near.sum()) == 0:
+        torch.testing.assert_close(std.grad, ref_g[1], rtol=2e-4, atol=1e-5 * float(ref_g[1].abs().max()))
+    else:   # std's gradient sums over the batch: bound the contribution of the excluded rows
+        torch.testing.assert_close(std.grad, ref_g[1], rtol=1e-2, atol=float(near.sum()) * scale)
