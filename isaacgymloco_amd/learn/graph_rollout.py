@@ -43,6 +43,7 @@ class GraphedRollout:
         self.packed = PackedHimPolicy(self.alg.actor_critic) if PackedHimPolicy.supported(self.alg.actor_critic) else None
         if self.packed is None:
             self._capture()
+        self._weights_stale = True
         self.storage.step = 0
 
     # ---- HIMP:90-103 written against static tensors; the elementwise tail is one HIP kernel --------------------------
@@ -89,6 +90,7 @@ class GraphedRollout:
 
     def step(self):
         """one rollout step: networks + fused sample/store (two launches, or one graph replay), simulator step, fused post-step store"""
+        self._sync_weights()
         if self.packed is not None:
             self._act()
         else:
@@ -97,11 +99,16 @@ class GraphedRollout:
         self._post()
         self.storage.step += 1
 
-    def end_iteration(self):
-        """after compute_returns/update (which call storage.clear()): rewind the device-side step index, pick up the new weights"""
-        self.idx.zero_()
-        if self.packed is not None:
+    def _sync_weights(self):
+        if self._weights_stale and self.packed is not None:
             self.packed.refresh()
+        self._weights_stale = False
+
+    def end_iteration(self):
+        """after compute_returns (callers rewind before or after update()): rewind the device-side step index.  The packed weights of
+        the fused policy kernel are re-copied lazily at the first step of the next rollout, i.e. always AFTER the optimiser steps."""
+        self.idx.zero_()
+        self._weights_stale = True
 
 
 class HybridFusedRollout(GraphedRollout):
@@ -117,6 +124,7 @@ class HybridFusedRollout(GraphedRollout):
     def step(self):
         env, alg = self.env, self.alg
         amp_obs = self._amp_obs
+        self._sync_weights()
         if self.packed is not None:
             self._act()
         else:

@@ -346,3 +346,17 @@ def test_fused_ppo_loss_matches_torch_autograd(clipped):
         torch.testing.assert_close(std.grad, ref_g[1], rtol=2e-4, atol=1e-5 * float(ref_g[1].abs().max()))
     else:   # std's gradient sums over the batch: bound the contribution of the excluded rows
         torch.testing.assert_close(std.grad, ref_g[1], rtol=1e-2, atol=float(near.sum()) * scale)
+
+
+def test_fused_rollout_uses_the_updated_policy():
+    """after update() the next rollout must act with the NEW weights (the fused policy kernel reads packed copies of them)"""
+    env, run = _make(seed=6)
+    assert run.enable_graphs() and run.graphs.packed is not None
+    run.learn(2, init_at_random_ep_len=True)
+    ac = run.alg.actor_critic
+    run.graphs.step()
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        ac.update_distribution(run.alg.storage.observations[0])
+        want = ac.action_mean
+    torch.testing.assert_close(run.alg.storage.mu[0], want, rtol=2e-4, atol=2e-5 * float(want.abs().max()))
