@@ -342,7 +342,7 @@ extern "C" int lsim_linear_wgrad(const float* x, int64_t ldx, const float* g, in
 //   pass i: v[b] = 1 / (B * sum_k E[b, k] u[k]); partial column sums of E * v   -> u[k] = 1 / (K * sum_b E[b, k] v[b])
 //   last  : out[b, k] = B * E[b, k] * u[k] * v[b]
 // K <= 64 (one lane per prototype); a block owns LS_SK_ROWS consecutive samples; partial sums are added in a fixed order.
-#define LS_SK_ROWS 256
+#define LS_SK_ROWS 64            // 16 rows per wave: ~1600 blocks for a 102 400-row minibatch keep every SIMD several waves deep
 
 __global__ __launch_bounds__(256) void lsim_k_sinkhorn_pass(const float* __restrict__ scores, long lds, long batch, int K, float inv_eps,
                                                             const float* __restrict__ u /* NULL in pass 0 */, float* __restrict__ E,
@@ -373,14 +373,24 @@ __global__ __launch_bounds__(256) void lsim_k_sinkhorn_pass(const float* __restr
     if (w == 0 && lane < K) part[(size_t)blockIdx.x * K + lane] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
-__global__ __launch_bounds__(64) void lsim_k_sinkhorn_scale(const float* __restrict__ part, int blocks, int K, float* __restrict__ u) {
-    const int k = threadIdx.x;
-    if (k >= K) return;
+// u[k] = 1 / (K * sum over blocks of part[block][k]); 16 interleaved slices per prototype, combined in LDS in a fixed order
+__global__ __launch_bounds__(1024) void lsim_k_sinkhorn_scale(const float* __restrict__ part, int blocks, int K, float* __restrict__ u) {
+    __shared__ float red[16][64];
+    const int k = threadIdx.x & 63, sl = threadIdx.x >> 6;
     float s0 = 0.0f, s1 = 0.0f;
-    int i = 0;
-    for (; i + 1 < blocks; i += 2) { s0 += part[(size_t)i * K + k]; s1 += part[(size_t)(i + 1) * K + k]; }
-    if (i < blocks) s0 += part[(size_t)i * K + k];
-    u[k] = 1.0f / ((float)K * (s0 + s1));
+    if (k < K) {
+        int i = sl;
+        for (; i + 16 < blocks; i += 32) { s0 += part[(size_t)i * K + k]; s1 += part[(size_t)(i + 16) * K + k]; }
+        if (i < blocks) s0 += part[(size_t)i * K + k];
+    }
+    red[sl][k] = s0 + s1;
+    __syncthreads();
+    if (sl == 0 && k < K) {
+        float t = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t += red[j][k];
+        u[k] = 1.0f / ((float)K * t);
+    }
 }
 
 extern "C" int lsim_sinkhorn_workspace(long batch, int K, size_t* bytes) {
@@ -403,11 +413,11 @@ extern "C" int lsim_sinkhorn(const float* scores, int64_t lds, int64_t batch, in
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(lsim_k_sinkhorn_pass, dim3(blocks), dim3(256), 0, s, scores, (long)lds, (long)batch, K, 1.0f / eps, (const float*)nullptr, E, part,
                        (float*)nullptr);
-    hipLaunchKernelGGL(lsim_k_sinkhorn_scale, dim3(1), dim3(64), 0, s, part, blocks, K, u);
+    hipLaunchKernelGGL(lsim_k_sinkhorn_scale, dim3(1), dim3(1024), 0, s, part, blocks, K, u);
     for (int it = 1; it < iters; ++it) {
         hipLaunchKernelGGL(lsim_k_sinkhorn_pass, dim3(blocks), dim3(256), 0, s, scores, (long)lds, (long)batch, K, 1.0f / eps, (const float*)u, E, part,
                            (float*)nullptr);
-        hipLaunchKernelGGL(lsim_k_sinkhorn_scale, dim3(1), dim3(64), 0, s, part, blocks, K, u);
+        hipLaunchKernelGGL(lsim_k_sinkhorn_scale, dim3(1), dim3(1024), 0, s, part, blocks, K, u);
     }
     hipLaunchKernelGGL(lsim_k_sinkhorn_pass, dim3(blocks), dim3(256), 0, s, scores, (long)lds, (long)batch, K, 1.0f / eps, (const float*)u, E,
                        (float*)nullptr, out);

@@ -169,10 +169,12 @@ extern "C" int lsim_policy_forward(const lsim_him_policy* p, const float* obs, c
     if (p->critic[3].n_out != 1 || p->critic[0].k_pad > LS_POL_MAX_IN) bad = 1;
     if (bad) return LSIM_E_UNSUPPORTED;
     const size_t lds = (size_t)LS_POL_ROWS * (2 * (LS_POL_MAX_IN + LS_POL_PAD) + (LS_POL_MAX_HIDDEN + LS_POL_PAD)) * sizeof(float);
-    static size_t configured = 0;
-    if (lds > configured) {
+    static size_t configured[64] = {0};          // per device: the attribute belongs to the device's copy of the kernel
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LSIM_E_HIP;
+    if (lds > configured[dev]) {
         if (hipFuncSetAttribute((const void*)lsim_k_policy_forward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return LSIM_E_HIP;
-        configured = lds;
+        configured[dev] = lds;
     }
     const int blocks = (int)((num_envs + LS_POL_ROWS - 1) / LS_POL_ROWS);
     hipLaunchKernelGGL(lsim_k_policy_forward, dim3(blocks, 2), dim3(64 * LS_POL_WAVES), lds, (hipStream_t)stream, *p, obs, priv_obs, (long)num_envs, mean_out, values_out);
