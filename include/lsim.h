@@ -498,6 +498,11 @@ int lsim_ppo_loss(const float* mu, const float* sigma, const float* value, const
                   float clip_param, float value_loss_coef, float entropy_coef, int use_clipped_value_loss,
                   float* out5, float* grad_mu, float* grad_sigma, float* grad_value, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Adaptive learning rate of HIMPPO (HIMP:144-156) evaluated on the device: *lr_dev /= factor when *kl_mean_dev > 2 desired_kl,
+ * *= factor when 0 < *kl_mean_dev < desired_kl / 2, clamped to [lr_min, lr_max].  Both scalars live in device memory (the optimisers read
+ * the same lr tensor), so the reference's per-minibatch host read-back of the KL estimate is not needed. */
+int lsim_adaptive_lr(const float* kl_mean_dev, float desired_kl, float lr_min, float lr_max, float factor, float* lr_dev, void* stream);
+
 /* Sinkhorn-Knopp assignment of the estimator's prototype scores (HIMEstimator.sinkhorn, HES:119-133; no gradient flows through it):
  *   Q = exp(scores / eps)^T;  Q /= sum(Q);  iters x { Q /= rowsum; Q /= K; Q /= colsum; Q /= B };  out = (Q * B)^T
  * scores [batch, K] with row stride lds (floats), K <= 64, out [batch, K] contiguous.  Computed as E * u[k] * v[b] with 2 * iters + 1

@@ -545,3 +545,20 @@ extern "C" int lsim_ppo_loss(const float* mu, const float* sigma, const float* v
                        entropy_coef, out5);
     return hipGetLastError() == hipSuccess ? LSIM_OK : LSIM_E_HIP;
 }
+
+// ---- adaptive learning rate of HIMPPO (HIMP:144-156) on the device: lr /= 1.5 when the KL estimate exceeds twice the target, lr *= 1.5
+// when it is below half of it (and positive), clamped to [lr_min, lr_max].  Keeps the rule out of the host so that the per-minibatch
+// .item() of the reference (a pipeline drain, ~4 % of the update) disappears; the optimisers read the same device scalar.
+__global__ void lsim_k_adaptive_lr(const float* __restrict__ kl_mean, float desired_kl, float lr_min, float lr_max, float factor, float* __restrict__ lr) {
+    const float k = *kl_mean;
+    float l = *lr;
+    if (k > 2.0f * desired_kl) l = fmaxf(lr_min, l / factor);
+    else if (k < 0.5f * desired_kl && k > 0.0f) l = fminf(lr_max, l * factor);
+    *lr = l;
+}
+
+extern "C" int lsim_adaptive_lr(const float* kl_mean_dev, float desired_kl, float lr_min, float lr_max, float factor, float* lr_dev, void* stream) {
+    if (!kl_mean_dev || !lr_dev || desired_kl <= 0.0f || factor <= 1.0f || lr_min <= 0.0f || lr_max < lr_min) return LSIM_E_INVALID;
+    hipLaunchKernelGGL(lsim_k_adaptive_lr, dim3(1), dim3(1), 0, (hipStream_t)stream, kl_mean_dev, desired_kl, lr_min, lr_max, factor, lr_dev);
+    return hipGetLastError() == hipSuccess ? LSIM_OK : LSIM_E_HIP;
+}

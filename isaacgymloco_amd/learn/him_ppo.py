@@ -76,9 +76,44 @@ class HIMPPO:
         self.value_loss_coef, self.entropy_coef, self.gamma, self.lam = value_loss_coef, entropy_coef, gamma, lam
         self.max_grad_norm, self.use_clipped_value_loss = max_grad_norm, use_clipped_value_loss
         self.dist_ctx = dist_ctx
+        self._lr_t = None      # device-resident learning rate (enable_device_lr)
         if dist_ctx is not None and dist_ctx.enabled:
             dist_ctx.broadcast_module(self.actor_critic)
             self.actor_critic.estimator.grad_sync = dist_ctx.average_grads
+
+    def enable_device_lr(self):
+        """GPU fast path of the optimiser side (same update rule, HIMP:144-156 / HIMP:181-184): the learning rate becomes a device scalar that
+        the adaptive-KL rule rewrites with one tiny kernel (lsim_adaptive_lr) instead of a host read-back per minibatch, and both Adam
+        optimisers become torch's single-kernel (`fused=True`) implementation reading that scalar.  Together 10 % of the update."""
+        dev = next(self.actor_critic.parameters()).device
+        if dev.type != "cuda" or self._lr_t is not None:
+            return self._lr_t is not None
+        self._lr_t = torch.tensor(float(self.learning_rate), device=dev, dtype=torch.float32)
+
+        def rebuild(opt):
+            keep = ("params", "weight_decay", "betas", "eps", "amsgrad", "maximize", "name")
+            new = torch.optim.Adam([{k: v for k, v in g.items() if k in keep} for g in opt.param_groups], lr=self._lr_t, fused=True)
+            if opt.state:
+                new.load_state_dict(opt.state_dict())
+            for g in new.param_groups:
+                g["lr"] = self._lr_t
+            return new
+        self.optimizer = rebuild(self.optimizer)
+        est = self.actor_critic.estimator
+        est.optimizer = rebuild(est.optimizer)
+        return True
+
+    def _relink_lr(self):
+        """optimizer.load_state_dict() restores plain float learning rates: point the groups at the device scalar again"""
+        if self._lr_t is not None:
+            for opt in (self.optimizer, self.actor_critic.estimator.optimizer):
+                for g in opt.param_groups:
+                    g["lr"] = self._lr_t
+
+    def _set_learning_rate(self, lr):
+        self.learning_rate = float(lr)
+        if self._lr_t is not None:
+            self._lr_t.fill_(float(lr))
 
     def init_storage(self, num_envs, num_transitions_per_env, actor_obs_shape, critic_obs_shape, action_shape):
         self.storage = HIMRolloutStorage(num_envs, num_transitions_per_env, actor_obs_shape, critic_obs_shape, action_shape, self.device)
@@ -116,6 +151,15 @@ class HIMPPO:
         self.storage.compute_returns(last_values, self.gamma, self.lam)
 
     def _adapt_lr(self, mu, sigma, old_mu, old_sigma, kl_mean=None):
+        if self._lr_t is not None and kl_mean is not None:        # device path: no host round trip
+            import ctypes as _ct
+            from .. import lib
+            if self.dist_ctx is not None and self.dist_ctx.enabled:
+                kl_mean = self.dist_ctx.average_scalar(kl_mean)
+            kl_mean = kl_mean.detach().reshape(1).contiguous()
+            lib.check(lib.load().lsim_adaptive_lr(kl_mean.data_ptr(), float(self.desired_kl), 1e-5, 1e-2, 1.5, self._lr_t.data_ptr(),
+                                                  torch.cuda.current_stream(self._lr_t.device).cuda_stream), what="lsim_adaptive_lr")
+            return
         with torch.inference_mode():
             if kl_mean is None:
                 kl = torch.sum(torch.log(sigma / old_sigma + 1.0e-5) + (torch.square(old_sigma) + torch.square(old_mu - mu)) / (2.0 * torch.square(sigma)) - 0.5, dim=-1)
@@ -164,7 +208,7 @@ class HIMPPO:
                                                                        old_mu, old_sigma)
             if self.desired_kl is not None and self.schedule == "adaptive":
                 self._adapt_lr(mu, sigma, old_mu, old_sigma, kl_mean)
-            est, swap = ac.estimator.update(obs, next_critic_obs, lr=self.learning_rate)
+            est, swap = ac.estimator.update(obs, next_critic_obs, lr=None if self._lr_t is not None else self.learning_rate)
             self.optimizer.zero_grad()
             loss.backward()
             if self.dist_ctx is not None:
@@ -174,6 +218,8 @@ class HIMPPO:
             sums += torch.stack((value_loss.detach(), surrogate_loss.detach(), est, swap))
             last_est, last_swap = est, swap
         n = self.num_learning_epochs * self.num_mini_batches
+        if self._lr_t is not None:
+            self.learning_rate = float(self._lr_t)       # one read-back per update (logging, checkpoints)
         sums = (sums / n).tolist()
         self.storage.clear()
         # the reference returns the LAST minibatch's estimator losses in slots 3 and 4 (HIMP:198)

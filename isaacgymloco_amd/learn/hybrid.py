@@ -63,7 +63,7 @@ class HybridPPO(HIMPPO):
                                                                            old_mu, old_sigma)
             if self.desired_kl is not None and self.schedule == "adaptive":
                 self._adapt_lr(mu, sigma, old_mu, old_sigma, kl_mean)
-            est, swap = ac.estimator.update(obs, next_critic_obs, lr=self.learning_rate)
+            est, swap = ac.estimator.update(obs, next_critic_obs, lr=None if self._lr_t is not None else self.learning_rate)
             exp_s, exp_ns = exp_s_raw, exp_ns_raw
             if self.amp_normalizer is not None:
                 with torch.no_grad():
@@ -88,6 +88,8 @@ class HybridPPO(HIMPPO):
                 self.amp_normalizer.update(exp_s)
             sums += torch.stack((value_loss.detach(), surrogate_loss.detach(), amp_loss.detach(), grad_pen.detach(),
                                  policy_d.mean().detach(), expert_d.mean().detach()))
+        if self._lr_t is not None:
+            self.learning_rate = float(self._lr_t)
         s = (sums / n_updates).tolist()
         self.storage.clear()
         return s[0], s[1], float(est), float(swap), s[2], s[3], s[4], s[5]

@@ -51,6 +51,8 @@ class HIMOnPolicyRunner:
         storage writes, no host round trips.  Needs the build's GPU environment (step_device)."""
         if self.fast and str(self.device).startswith("cuda"):
             self.graphs = self._make_fused_rollout()
+            if self.graphs is not None:
+                self.alg.enable_device_lr()
         return self.graphs is not None
 
     def _make_fused_rollout(self):
@@ -230,7 +232,7 @@ class HIMOnPolicyRunner:
 
     def _load_extra_checkpoint_state(self, d):
         if "learning_rate" in d:
-            self.alg.learning_rate = d["learning_rate"]
+            self.alg._set_learning_rate(d["learning_rate"])
         if "env_state_dict" in d and hasattr(self.env, "load_state_dict"):
             self.env.load_state_dict(d["env_state_dict"])
         if "rollout_draw_counter" in d and self.graphs is not None:
@@ -242,6 +244,7 @@ class HIMOnPolicyRunner:
         if load_optimizer:
             self.alg.optimizer.load_state_dict(d["optimizer_state_dict"])
             self.alg.actor_critic.estimator.optimizer.load_state_dict(d["estimator_optimizer_state_dict"])
+            self.alg._relink_lr()
         self.current_learning_iteration = d["iter"]
         self._load_extra_checkpoint_state(d)
         return d["infos"]

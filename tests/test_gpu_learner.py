@@ -360,3 +360,25 @@ def test_fused_rollout_uses_the_updated_policy():
         ac.update_distribution(run.alg.storage.observations[0])
         want = ac.action_mean
     torch.testing.assert_close(run.alg.storage.mu[0], want, rtol=2e-4, atol=2e-5 * float(want.abs().max()))
+
+
+def test_device_lr_and_fused_adam_match_the_host_rule():
+    """enable_device_lr(): lsim_adaptive_lr + fused Adam reading a device scalar give the same learning-rate trajectory and (to fp32
+    rounding of a different Adam kernel) the same parameters as the reference-style host rule with .item() per minibatch"""
+    env_a, run_a = _make(seed=8)
+    env_b, run_b = _make(seed=8)
+    assert run_a.enable_graphs() and run_a.alg._lr_t is not None
+    run_b.alg.enable_device_lr = lambda: False
+    assert run_b.enable_graphs() and run_b.alg._lr_t is None
+    run_b.alg.actor_critic.load_state_dict(run_a.alg.actor_critic.state_dict())
+    for it in range(3):
+        torch.manual_seed(100 + it); run_a.learn(1)
+        torch.manual_seed(100 + it); run_b.learn(1)
+        assert abs(run_a.alg.learning_rate - run_b.alg.learning_rate) <= 1e-6 * run_b.alg.learning_rate, it
+    pa, pb = run_a.alg.actor_critic.state_dict(), run_b.alg.actor_critic.state_dict()
+    for k in pa:
+        torch.testing.assert_close(pa[k], pb[k], rtol=5e-3, atol=5e-4, msg=k)
+    path = "/tmp/lsim_ckpt_lr.pt"
+    run_a.save(path); run_a.load(path)
+    assert all(g["lr"] is run_a.alg._lr_t for g in run_a.alg.optimizer.param_groups)
+    run_a.learn(1)

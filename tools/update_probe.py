@@ -35,6 +35,9 @@ if "--torch-sinkhorn" in sys.argv:      # A/B: force the torch statement of the 
                 Q /= Q.sum(dim=0, keepdim=True); Q /= B
             return (Q * B).T
     M.sinkhorn = _torch_sinkhorn
+if "--no-lr-sync" in sys.argv:        # A/B: what the per-minibatch .item() of the adaptive-lr rule costs (lr simply stays fixed)
+    import isaacgymloco_amd.learn.him_ppo as HP
+    HP.HIMPPO._adapt_lr = lambda self, *a, **k: None
 if "--nn-linear" in sys.argv:           # A/B: plain nn.Linear backward (BLAS wgrad)
     import isaacgymloco_amd.learn.fused_linear as FL
     FL._eligible = lambda *a: False
@@ -44,6 +47,11 @@ torch.manual_seed(1)
 runner = HIMOnPolicyRunner(env, train_cfg_dict("aliengo"), log_dir=None, device="cuda:0")
 runner.enable_graphs()
 runner.alg.actor_critic.train()
+if "--fused-adam" in sys.argv:          # A/B: torch's single-kernel Adam instead of the foreach implementation
+    alg = runner.alg
+    alg.optimizer = torch.optim.Adam(alg.actor_critic.parameters(), lr=alg.learning_rate, fused=True)
+    est = alg.actor_critic.estimator
+    est.optimizer = torch.optim.Adam(est.parameters(), lr=est.learning_rate, fused=True)
 for it in range(n_upd + 1):
     for _ in range(runner.num_steps_per_env):
         runner.graphs.step()
