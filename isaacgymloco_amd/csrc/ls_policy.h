@@ -167,6 +167,9 @@ extern "C" int lsim_policy_forward(const lsim_him_policy* p, const float* obs, c
     k = p->num_priv_obs;
     for (int l = 0; l < 4; ++l) { bad |= ls_pol_check_layer(&p->critic[l], k); k = p->critic[l].n_out; }
     if (p->critic[3].n_out != 1 || p->critic[0].k_pad > LS_POL_MAX_IN) bad = 1;
+    // layers whose output lands in LDS buffer B (row stride LS_POL_MAX_IN + pad): second and last layer of each network
+    if (p->encoder[1].n_pad > LS_POL_MAX_IN || p->actor[1].n_pad > LS_POL_MAX_IN || p->actor[3].n_pad > LS_POL_MAX_IN ||
+        p->critic[1].n_pad > LS_POL_MAX_IN || p->critic[3].n_pad > LS_POL_MAX_IN) bad = 1;
     if (bad) return LSIM_E_UNSUPPORTED;
     const size_t lds = (size_t)LS_POL_ROWS * (2 * (LS_POL_MAX_IN + LS_POL_PAD) + (LS_POL_MAX_HIDDEN + LS_POL_PAD)) * sizeof(float);
     static size_t configured[64] = {0};          // per device: the attribute belongs to the device's copy of the kernel

@@ -28,7 +28,8 @@ class PackedHimPolicy:
         if enc is None or act is None or cri is None or (len(enc), len(act), len(cri)) != (3, 4, 4):
             return False
         wide = max(l.out_features for l in enc + act + cri)
-        return wide <= 512 and ac.num_actor_obs <= 272 and cri[0].in_features <= 272 and ac.num_actions <= 16 and next(ac.parameters()).is_cuda
+        second = max(enc[1].out_features, act[1].out_features, cri[1].out_features)     # these land in the narrower LDS buffer
+        return wide <= 512 and second <= 272 and ac.num_actor_obs <= 272 and cri[0].in_features <= 272 and ac.num_actions <= 16 and next(ac.parameters()).is_cuda
 
     def __init__(self, ac):
         assert self.supported(ac)
