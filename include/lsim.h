@@ -266,7 +266,8 @@ typedef struct lsim_config {
     int32_t solver_iterations;
     float contact_offset, max_depenetration_velocity, erp, contact_slop;
     int32_t using_amp;              /* LRC:36: step() also produces terminal AMP states */
-    int32_t reserved[8];
+    float max_linear_velocity, max_angular_velocity;   /* asset options LRC:229-230 (1000 / 1000): PhysX clamps body velocities there */
+    int32_t reserved[6];
 } lsim_config;
 
 /* ---- device buffers.  Shapes are per handle (N = num_envs); dtype codes below. ---- */

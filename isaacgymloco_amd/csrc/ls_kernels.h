@@ -188,7 +188,7 @@ LS_WAVE_FN void ls_wave_step_a(const LsCtx& cx, const LsStepArgs& a, const int e
         LS_PHASE(ph_free_finish(sh, lane, dt));
         LS_PHASE(ph_collide(cx, sh, rg, lane));
         LS_COLLECTIVE(wc_compact_contacts(sh, rg, lane), wc_compact_contacts(sh, L));
-        LS_COLLECTIVE(wc_limits(cx, sh, lane), LS_PHASE(ph_limits(cx, sh, lane)));
+        LS_COLLECTIVE(wc_limits(cx, sh, lane, dt), LS_PHASE(ph_limits(cx, sh, lane, dt)));
         LS_PHASE(ph_rows(cx, sh, rg, lane, dt));
 #if defined(LS_EMU)
         LS_PHASE(ph_delassus(sh, rg, lane));

@@ -432,32 +432,47 @@ LS_FN void wc_compact_contacts(WaveShared& sh, LaneRegs& r, int lane) {
 }
 #endif
 
-// ---- phase: joint-limit rows, the short ordered list of joints within 0.1 rad of a hard limit.
+// ---- phase: joint position AND velocity limits as ONE two-sided ("boxed") row per joint: L <= qd_j <= U with
+//      [L, U] = [-vmax, vmax]  cut by  qd >= -gap_lo / dt (within 0.1 rad of the lower stop)  /  qd <= gap_hi / dt (upper stop); a
+//      penetrated stop pushes back with erp, capped at 1 rad/s.  A joint needs its row when the free velocity violates a bound or
+//      comes within LS_LIMIT_MARGIN of the velocity limit of it; because the limit impulses of one joint move its neighbours on the same leg by
+//      tens of rad/s, all three joints of a leg get rows as soon as one of them needs one.  [Clamping the joint velocity after the
+//      solve instead leaves the reaction of a saturated motor torque on the base and spins up a robot in free flight.]
 //      GPU: lane = joint, ordered compaction by ballot; lane emulator: lane 0 walks the joints (same order, same result)
+#define LS_LIMIT_MARGIN 0.2f    // a joint "needs" its row when the free velocity is within this fraction of vmax of a bound (or beyond it)
+LS_FN bool ls_joint_limit_bounds(const LsCtx& cx, const WaveShared& sh, int j, float dt, float& Lb, float& Ub) {
+    const float lo = sh.q[j] - cx.model.dof_pos_lower[j], hi = cx.model.dof_pos_upper[j] - sh.q[j];
+    const float vmax = cx.model.dof_vel_limit[j], vf = sh.vfree[6 + j];
+    Lb = -vmax; Ub = vmax;
+    if (lo < 0.1f) Lb = fmaxf(Lb, lo >= 0.0f ? -lo / dt : fminf(1.0f, cx.cfg.erp * (-lo) / dt));
+    if (hi < 0.1f) Ub = fminf(Ub, hi >= 0.0f ? hi / dt : -fminf(1.0f, cx.cfg.erp * (-hi) / dt));
+    if (Ub < Lb) Ub = Lb;                                   // both stops violated at once cannot happen; keep the box well formed
+    return fminf(vf - Lb, Ub - vf) < LS_LIMIT_MARGIN * vmax;
+}
 #if !defined(LS_EMU)
-LS_FN void wc_limits(const LsCtx& cx, WaveShared& sh, int lane) {
-    bool has = false;
-    float gap = 0.0f, sgn = 0.0f;
-    if (lane < 12) {
-        float lo = sh.q[lane] - cx.model.dof_pos_lower[lane], hi = cx.model.dof_pos_upper[lane] - sh.q[lane];
-        if (lo < 0.1f) { has = true; gap = lo; sgn = 1.0f; }
-        else if (hi < 0.1f) { has = true; gap = hi; sgn = -1.0f; }
-    }
+LS_FN void wc_limits(const LsCtx& cx, WaveShared& sh, int lane, float dt) {
+    bool need = false;
+    float Lb = 0.0f, Ub = 0.0f;
+    if (lane < 12) need = ls_joint_limit_bounds(cx, sh, lane, dt, Lb, Ub);
+    const unsigned long long mneed = __ballot(need);
+    const bool has = lane < 12 && ((mneed >> (3 * (lane / 3))) & 7ull) != 0ull;     // any joint of this leg
     const unsigned long long m = __ballot(has);
     if (has) {
         const int rank = __popcll(m & ((1ull << lane) - 1ull));
-        sh.limdof[rank] = lane; sh.limgap[rank] = gap; sh.limsgn[rank] = sgn;
+        sh.limdof[rank] = lane; sh.limvt[rank] = Lb; sh.limrng[rank] = Ub - Lb;
     }
     if (lane == 0) { const int n = __popcll(m); sh.nlim = n; sh.nrows = 3 * sh.nc + n; }
 }
 #endif
-LS_FN void ph_limits(const LsCtx& cx, WaveShared& sh, int lane) {
+LS_FN void ph_limits(const LsCtx& cx, WaveShared& sh, int lane, float dt) {
     if (lane != 0) return;
     int n = 0;
-    for (int j = 0; j < 12; ++j) {
-        float lo = sh.q[j] - cx.model.dof_pos_lower[j], hi = cx.model.dof_pos_upper[j] - sh.q[j];
-        if (lo < 0.1f) { sh.limdof[n] = j; sh.limgap[n] = lo; sh.limsgn[n] = 1.0f; ++n; }
-        else if (hi < 0.1f) { sh.limdof[n] = j; sh.limgap[n] = hi; sh.limsgn[n] = -1.0f; ++n; }
+    for (int leg = 0; leg < 4; ++leg) {
+        float Lb[3], Ub[3];
+        bool any = false;
+        for (int k = 0; k < 3; ++k) any = ls_joint_limit_bounds(cx, sh, 3 * leg + k, dt, Lb[k], Ub[k]) || any;
+        if (!any) continue;
+        for (int k = 0; k < 3; ++k) { sh.limdof[n] = 3 * leg + k; sh.limvt[n] = Lb[k]; sh.limrng[n] = Ub[k] - Lb[k]; ++n; }
     }
     sh.nlim = n;
     sh.nrows = 3 * sh.nc + n;
@@ -466,9 +481,10 @@ LS_FN void ph_limits(const LsCtx& cx, WaveShared& sh, int lane) {
 // ---- phase R1: constraint row Jacobian, Y = M^-1 J^T (structured solve), right-hand side (lane = row)
 LS_FN void ph_rows(const LsCtx& cx, WaveShared& sh, LaneRegs& r, int lane, float dt) {
     r.row_kind = -1;
+    r.row_rng = __builtin_inff();
     if (lane >= sh.nrows) return;
     const lsim_config& c = cx.cfg;
-    float vt;
+    float vt, rng = __builtin_inff();     // rng: width of a two-sided row's velocity interval (joint limits), +inf for one-sided rows
     int leg;
     float Jb[6] = {0, 0, 0, 0, 0, 0}, Jl[3] = {0, 0, 0};
     V3 d = v3(0, 0, 0);
@@ -497,9 +513,9 @@ LS_FN void ph_rows(const LsCtx& cx, WaveShared& sh, LaneRegs& r, int lane, float
         int i = lane - 3 * sh.nc;
         int j = sh.limdof[i];
         leg = j / 3;
-        Jl[j - 3 * leg] = sh.limsgn[i];
-        float gap = sh.limgap[i];
-        vt = gap >= 0.0f ? -gap / dt : fminf(1.0f, c.erp * (-gap) / dt);
+        Jl[j - 3 * leg] = 1.0f;
+        vt = sh.limvt[i];                 // lower velocity bound; the row is two-sided: the upper bound is limrng above it
+        rng = sh.limrng[i];
         r.row_kind = 3;
     }
     r.row_leg = leg;
@@ -535,6 +551,7 @@ LS_FN void ph_rows(const LsCtx& cx, WaveShared& sh, LaneRegs& r, int lane, float
     for (int k = 0; k < 6; ++k) jv += Jb[k] * sh.vfree[k];
     if (leg >= 0) for (int k = 0; k < 3; ++k) jv += Jl[k] * sh.vfree[6 + 3 * leg + k];
     r.brow = jv - vt;
+    r.row_rng = rng;
 }
 
 // ---- phase R2 (lane emulator only; the GPU fuses it into wc_delassus_pgs): Delassus row W_i. = J_i Y^T (lane = row i)
@@ -574,7 +591,8 @@ static inline void wc_pgs(WaveShared& sh, LaneRegs* L, int iters) {
         for (int r = 0; r < R; ++r) {
             float nl = lam[r] - w[r] / L[r].wdiag;
             int kind = L[r].row_kind;
-            if (kind == 0 || kind == 3) nl = fmaxf(nl, 0.0f);
+            if (kind == 0) nl = fmaxf(nl, 0.0f);
+            else if (kind == 3) nl = fmaxf(nl, 0.0f) + fminf(nl + L[r].row_rng / L[r].wdiag, 0.0f);   // boxed: lower bound pushes up, upper bound down
             else { float lim = sh.mu * lam[r - kind]; nl = clampf(nl, -lim, lim); }
             float delta = nl - lam[r];
             lam[r] = nl;
@@ -592,12 +610,14 @@ template <int LANE> __device__ __forceinline__ void ls_writelane(float& v, float
 }
 // one Gauss-Seidel relaxation per row r = R0 .. LS_MAXR-1 (compile-time recursion: W[r] is a register, r an immediate).
 // Every lane evaluates its own candidate; only lane r's is real: readlane broadcasts it and its delta, lane r keeps it.
-template <int R0> __device__ __forceinline__ void ls_pgs_rows(int R, int ncr, const float (&W)[LS_MAXR], float cf, float hi_add, float inv_d,
+template <int R0> __device__ __forceinline__ void ls_pgs_rows(int R, int ncr, const float (&W)[LS_MAXR], float cf, float hi_add, float inv_d, float rng_d,
                                                              float& lam, float& lam_n, float& w) {
     if constexpr (R0 < LS_MAXR) {
         if (R0 < R) {
             const float t = cf * lam_n, thi = fmaf(cf, lam_n, hi_add);
-            const float nl = __builtin_amdgcn_fmed3f(fmaf(-w, inv_d, lam), -t, thi);
+            const float raw = fmaf(-w, inv_d, lam);
+            // one-sided rows: clamp into [-t, thi]; two-sided (joint limit) rows add the push-down of the upper bound: min(raw + range / d, 0)
+            const float nl = __builtin_amdgcn_fmed3f(raw, -t, thi) + fminf(raw + rng_d, 0.0f);
             const float d = nl - lam;
             const float s_nl = ls_readlane(nl, R0), s_d = ls_readlane(d, R0);
             ls_writelane<R0>(lam, s_nl);
@@ -608,7 +628,7 @@ template <int R0> __device__ __forceinline__ void ls_pgs_rows(int R, int ncr, co
                 }
             }
             w = fmaf(W[R0], s_d, w);
-            ls_pgs_rows<R0 + 1>(R, ncr, W, cf, hi_add, inv_d, lam, lam_n, w);   // rows are contiguous: r >= R ends the sweep
+            ls_pgs_rows<R0 + 1>(R, ncr, W, cf, hi_add, inv_d, rng_d, lam, lam_n, w);   // rows are contiguous: r >= R ends the sweep
         }
     }
 }
@@ -649,8 +669,9 @@ LS_FN void wc_delassus_pgs(WaveShared& sh, const LaneRegs& rg, int lane, int ite
     const float cf = fric ? sh.mu : 0.0f;
     const float hi_add = fric ? 0.0f : __builtin_inff();
     const int ncr = 3 * sh.nc;                 // rows [0, ncr) are contact rows laid out (normal, t1, t2) per contact
+    const float rng_d = act ? rg.row_rng * inv_d : __builtin_inff();     // +inf for one-sided rows: the extra term vanishes
     for (int it = 0; it < iters; ++it)
-        ls_pgs_rows<0>(R, ncr, W, cf, hi_add, inv_d, lam, lam_n, w);
+        ls_pgs_rows<0>(R, ncr, W, cf, hi_add, inv_d, rng_d, lam, lam_n, w);
     if (act) sh.lam[lane] = lam;
 }
 #endif
@@ -676,12 +697,17 @@ LS_FN void ph_contact_forces(WaveShared& sh, int lane, float dt) {
 // ---- phase: integrate (lanes 0-11 joints, lane 12 base)
 LS_FN void ph_integrate(const LsCtx& cx, WaveShared& sh, int lane, float dt) {
     if (lane < 12) {
-        float lim = cx.model.dof_vel_limit[lane];
+        float lim = 1.5f * cx.model.dof_vel_limit[lane];     // the limit itself is a constraint row; this only bounds solver residue
         float v = clampf(sh.vnew[6 + lane], -lim, lim);
         sh.q[lane] += dt * v;
         sh.qd[lane] = v;
     } else if (lane == 12) {
         V3 w = v3p(sh.vnew), vl = v3p(sh.vnew + 3);
+        {   // body velocity caps of the asset options (LRC:229-230; PhysX clamps there too): a safety net, never reached by a sane robot
+            const float wn = sqrtf(dot(w, w)), ln = sqrtf(dot(vl, vl));
+            if (cx.cfg.max_angular_velocity > 0.0f && wn > cx.cfg.max_angular_velocity) w = w * (cx.cfg.max_angular_velocity / wn);
+            if (cx.cfg.max_linear_velocity > 0.0f && ln > cx.cfg.max_linear_velocity) vl = vl * (cx.cfg.max_linear_velocity / ln);
+        }
         V3 dp = vl * dt;
         V3 vo = vl + cross(w, dp);   // velocity of the base origin after it moved by dp
         float* q = sh.root + 3;

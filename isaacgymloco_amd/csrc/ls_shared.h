@@ -96,7 +96,7 @@ struct WaveShared {
     int cbody[LS_MAXC];
     float cpos[LS_MAXC][3], cn[LS_MAXC][3], cdist[LS_MAXC];
     int limdof[12];
-    float limgap[12], limsgn[12];
+    float limvt[12], limrng[12];     // lower velocity bound and width of the admissible interval of each joint-limit row
     int nlim;
     float lam[LS_MAXR];
     float cf[LS_NB][3];
@@ -123,6 +123,7 @@ struct LaneRegs {
     int row_leg;             // leg whose dofs the row touches, -1 for the base body
     float Jb[6], Jl[3];
     float brow, wdiag;
+    float row_rng;           // width of a two-sided row's interval (+inf: one-sided)
 #if defined(LS_EMU)
     float W[LS_MAXR];        // Delassus row (the GPU path keeps it local to wc_delassus_pgs)
 #endif

@@ -180,4 +180,6 @@ def make_lsim_config(cfg, num_envs=None, terrain=None, model=None, seed=1, rank=
     c.erp = SOLVER_DEFAULTS["erp"]
     c.contact_slop = SOLVER_DEFAULTS["contact_slop"]
     c.using_amp = int(bool(using_amp))
+    c.max_linear_velocity = cfg.asset.max_linear_velocity
+    c.max_angular_velocity = cfg.asset.max_angular_velocity
     return c

@@ -468,13 +468,33 @@ void orc_physics_substep(orc_sim* s, int e, const float tau_f[12], int apply_for
             ++R;
         }
     }
-    for (int j = 0; j < 12; ++j) { /* joint limits */
-        double lo = q[j] - m->dof_pos_lower[j], hi = m->dof_pos_upper[j] - q[j];
-        double gap, sgn;
-        if (lo < 0.1) { gap = lo; sgn = 1; } else if (hi < 0.1) { gap = hi; sgn = -1; } else continue;
+    static const double LIMIT_MARGIN = 0.2;   /* same constant as LS_LIMIT_MARGIN of the kernels */
+    double lim_L[12], lim_U[12], rrng[MAXR];
+    int lim_need[12];
+    for (int j = 0; j < 12; ++j) {
+        /* joint position AND velocity limits as ONE row per joint: the admissible velocity interval is
+         *   [L, U] = [-vmax, vmax]  intersected with  v >= -gap_lo/dt (near the lower stop)  /  v <= gap_hi/dt (near the upper stop),
+         * penetrated stops push back with erp, capped at 1 rad/s.  Clamping the joint velocity after the solve
+         * instead (as this code once did) leaves the reaction of the saturated motor torque on the base and pumps angular momentum into a
+         * robot in free flight. */
+        double lo = q[j] - m->dof_pos_lower[j], hi = m->dof_pos_upper[j] - q[j], vmax = m->dof_vel_limit[j], vf = vfree[6 + j];
+        double Lb = -vmax, Ub = vmax;
+        if (lo < 0.1) Lb = fmax(Lb, lo >= 0 ? -lo / dt : fmin(1.0, c->erp * (-lo) / dt));
+        if (hi < 0.1) Ub = fmin(Ub, hi >= 0 ? hi / dt : -fmin(1.0, c->erp * (-hi) / dt));
+        if (Ub < Lb) Ub = Lb;
+        lim_L[j] = Lb; lim_U[j] = Ub;
+        lim_need[j] = fmin(vf - Lb, Ub - vf) < LIMIT_MARGIN * vmax;
+    }
+    for (int j = 0; j < 12; ++j) {
+        /* a two-sided row L <= qd_j <= U for every joint of a leg on which some joint violates a bound or comes within half the velocity
+         * limit of it (limit impulses of one joint move its neighbours on the leg by tens of rad/s) */
+        int leg = j / 3;
+        if (!(lim_need[3 * leg] || lim_need[3 * leg + 1] || lim_need[3 * leg + 2])) continue;
+        double sgn = 1;
         memset(J[R], 0, sizeof(J[R]));
         J[R][6 + j] = sgn;
-        vt[R] = gap >= 0 ? -gap / dt : fmin(1.0, c->erp * (-gap) / dt);
+        vt[R] = lim_L[j];
+        rrng[R] = lim_U[j] - lim_L[j];
         rkind[R] = 3; rcontact[R] = -1;
         dirs[R][0] = dirs[R][1] = dirs[R][2] = 0;
         ++R;
@@ -495,7 +515,8 @@ void orc_physics_substep(orc_sim* s, int e, const float tau_f[12], int apply_for
             double w = b[r];
             for (int q2 = 0; q2 < R; ++q2) w += W[r][q2] * lam[q2];
             double nl = lam[r] - w / W[r][r];
-            if (rkind[r] == 0 || rkind[r] == 3) { if (nl < 0) nl = 0; }
+            if (rkind[r] == 0) { if (nl < 0) nl = 0; }
+            else if (rkind[r] == 3) { double up = nl + rrng[r] / W[r][r]; nl = (nl > 0 ? nl : 0) + (up < 0 ? up : 0); }   /* two-sided */
             else { double lim = mu * lam[r - rkind[r]]; if (nl > lim) nl = lim; if (nl < -lim) nl = -lim; }
             lam[r] = nl;
         }
@@ -508,8 +529,13 @@ void orc_physics_substep(orc_sim* s, int e, const float tau_f[12], int apply_for
     for (int r = 0; r < R; ++r) if (rcontact[r] >= 0) for (int k = 0; k < 3; ++k) cf[cbody[rcontact[r]]][k] += lam[r] * dirs[r][k] / dt;
     for (int i = 0; i < NB; ++i) for (int k = 0; k < 3; ++k) cfo[3 * i + k] = (float)cf[i][k];
     /* 10. integrate */
+    {   /* body velocity caps of the asset options (LRC:229-230; PhysX clamps there too): a safety net, never reached by a sane robot */
+        double wn = sqrt(vn[0] * vn[0] + vn[1] * vn[1] + vn[2] * vn[2]), ln = sqrt(vn[3] * vn[3] + vn[4] * vn[4] + vn[5] * vn[5]);
+        if (c->max_angular_velocity > 0 && wn > c->max_angular_velocity) for (int k = 0; k < 3; ++k) vn[k] *= c->max_angular_velocity / wn;
+        if (c->max_linear_velocity > 0 && ln > c->max_linear_velocity) for (int k = 3; k < 6; ++k) vn[k] *= c->max_linear_velocity / ln;
+    }
     for (int j = 0; j < 12; ++j) {
-        double lim = m->dof_vel_limit[j];
+        double lim = 1.5 * m->dof_vel_limit[j];   /* the limit itself is a constraint row (step 7); this only bounds solver residue */
         if (vn[6 + j] > lim) vn[6 + j] = lim;
         if (vn[6 + j] < -lim) vn[6 + j] = -lim;
         q[j] += dt * vn[6 + j];

@@ -213,3 +213,25 @@ def test_hip_go1_matches_oracle():
         np.testing.assert_allclose(be.get("root_states"), orc.buf["root_states"], atol=2e-3, rtol=1e-3, err_msg=f"step {t}")
         np.testing.assert_allclose(be.get("dof_state"), orc.buf["dof_state"], atol=5e-3, rtol=1e-3, err_msg=f"step {t}")
         np.testing.assert_allclose(be.get("obs"), orc.buf["obs"], atol=5e-3, rtol=1e-3, err_msg=f"step {t}")
+
+
+@pytest.mark.parametrize("task", ["aliengo_amp", "aliengo_stairs"])
+def test_hip_soak_states_stay_bounded(task):
+    """600 steps of rough N(0,1)..3 N(0,1) actions at N = 1024, incl. the AMP task whose config has no termination block (fallen robots
+    keep simulating): nothing non-finite, no robot launched (a joint-velocity clamp once pumped momentum into airborne robots until
+    velocities reached 1e4 m/s and the AMP task produced NaN)."""
+    import torch
+    from isaacgymloco_amd.envs.legged_robot import LeggedRobot
+    cfg = C.TASKS[task][0]()
+    cfg.env.num_envs = 1024
+    env = LeggedRobot(cfg, sim_device="cuda:0", seed=3, using_amp=(task == "aliengo_amp"))
+    env.reset()
+    g = torch.Generator(device="cuda:0").manual_seed(0)
+    zmax = torch.zeros((), device="cuda:0"); vmax = torch.zeros((), device="cuda:0")
+    for i in range(600):
+        obs, priv, rew, done = env.step_device(torch.randn(1024, 12, device="cuda:0", generator=g) * (1.0 if i % 200 < 150 else 3.0))
+        zmax = torch.maximum(zmax, env.root_states[:, 2].abs().max())
+        vmax = torch.maximum(vmax, env.root_states[:, 7:13].abs().max())
+    for t in (obs, priv, rew, env.root_states, env.dof_state, env.contact_forces):
+        assert torch.isfinite(t).all()
+    assert float(zmax) < 4.0 and float(vmax) < 60.0, (float(zmax), float(vmax))
