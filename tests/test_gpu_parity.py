@@ -235,3 +235,60 @@ def test_hip_soak_states_stay_bounded(task):
     for t in (obs, priv, rew, env.root_states, env.dof_state, env.contact_forces):
         assert torch.isfinite(t).all()
     assert float(zmax) < 4.0 and float(vmax) < 60.0, (float(zmax), float(vmax))
+
+
+def test_hip_handles_are_independent_and_stream_ordered():
+    """C-ABI hardening: (1) two handles in one process do not share state -- interleaving their steps gives each the trajectory it has
+    alone; (2) work is ordered on whatever HIP stream the caller passes, not on the default stream; (3) a library-owned arena
+    (arena_dev = NULL, the non-PyTorch host case) produces the same buffers as a caller-owned one."""
+    import ctypes
+    import torch
+    from isaacgymloco_amd import lib
+    from isaacgymloco_amd.envs.legged_robot import LeggedRobot
+
+    def make(seed):
+        cfg = C.TASKS["aliengo"][0]()
+        cfg.env.num_envs = 40
+        e = LeggedRobot(cfg, sim_device="cuda:0", seed=seed)
+        e.reset()
+        return e
+    g = torch.Generator(device="cuda:0").manual_seed(1)
+    acts = [torch.randn(40, 12, device="cuda:0", generator=g) for _ in range(12)]
+    solo = make(21)
+    ref = []
+    for a in acts:
+        ref.append(solo.step_device(a)[0].clone())
+    a_env, b_env = make(21), make(22)                       # same seed as `solo`, plus a second simulator in between
+    side = torch.cuda.Stream()
+    got = []
+    for a in acts:
+        b_env.step_device(a * 2.0)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                       # non-default stream for handle A
+            got.append(a_env.step_device(a)[0].clone())
+        torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    for r, o in zip(ref, got):
+        assert torch.equal(r, o)
+    # ---- library-owned arena through the raw C-ABI
+    L = lib.load()
+    h = ctypes.c_void_p()
+    grid = np.ascontiguousarray(solo.terrain.heightsamples, dtype=np.int16)
+    orig = np.ascontiguousarray(solo.terrain.env_origins, dtype=np.float32)
+    lib.check(L.lsim_create(ctypes.byref(solo.lcfg), ctypes.byref(solo.model), grid.ctypes.data, orig.ctypes.data, None, 0, ctypes.byref(h)),
+              what="lsim_create(NULL arena)")
+    lib.check(L.lsim_reset_all(h, None), h, "lsim_reset_all")
+    zero = torch.zeros(40, 12, device="cuda:0")
+    lib.check(L.lsim_step(h, ctypes.c_void_p(zero.data_ptr()), None), h, "lsim_step")     # LeggedRobot.reset() = reset_all + one zero-action step
+    for a in acts[:3]:
+        lib.check(L.lsim_step(h, ctypes.c_void_p(a.data_ptr()), None), h, "lsim_step")
+    torch.cuda.synchronize()
+    ptr, shape, nd, dt = ctypes.c_void_p(), (ctypes.c_int64 * 4)(), ctypes.c_int(), ctypes.c_int()
+    lib.check(L.lsim_get_buffer(h, abi.BUFFER_IDS["obs"], ctypes.byref(ptr), shape, ctypes.byref(nd), ctypes.byref(dt)), h, "lsim_get_buffer")
+    host = np.empty((shape[0], shape[1]), np.float32)
+    import torch.cuda
+    tmp = torch.empty(shape[0], shape[1], device="cuda:0")
+    ctypes.CDLL("libamdhip64.so").hipMemcpy(ctypes.c_void_p(tmp.data_ptr()), ptr, ctypes.c_size_t(host.nbytes), 3)   # device to device
+    torch.cuda.synchronize()
+    assert torch.equal(tmp, ref[2])
+    L.lsim_destroy(h)
