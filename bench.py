@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--task", default="aliengo")
     ap.add_argument("--mode", default="auto", choices=["auto", "env", "train"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--actions", default="normal", choices=["normal", "zeros"],
+                    help="env mode action source (SURVEY.md 8d): N(0,1) = an untrained policy (init_noise_std 1), or zeros = standing robots")
     ap.add_argument("--mixed-robots", action="store_true",
                     help="BASELINE config 5: the upper half of the ranks simulate Go1 instead of --task's robot (one shared policy; not reference-comparable)")
     args = ap.parse_args()
@@ -103,6 +105,8 @@ def main():
         env.episode_length_buf = torch.randint_like(env.episode_length_buf, high=int(env.max_episode_length))
         g = torch.Generator(device=dev).manual_seed(1 + rank)
         acts = [torch.randn(N, 12, device=dev, generator=g) for _ in range(16)]   # untrained policy: N(0,1) (init_noise_std=1, AGC:299)
+        if args.actions == "zeros":
+            acts = [torch.zeros(N, 12, device=dev)] * 16
         for i in range(W):
             env.step_device(acts[i % 16])
         env._L.lsim_set_profiling(env._h, K)
@@ -119,7 +123,8 @@ def main():
         ka = sum(ms_a[i] for i in range(n.value)) / max(n.value, 1)
         kb = sum(ms_b[i] for i in range(n.value)) / max(n.value, 1)
         extra = {"kernel_a_ms": ka, "kernel_b_ms": kb}
-        workload = f"{args.task}: LeggedRobot.step() back-to-back, N(0,1) actions, {N} envs/GPU (no policy/learner in the loop)"
+        workload = (f"{args.task}: LeggedRobot.step() back-to-back, {'N(0,1)' if args.actions == 'normal' else 'zero'} actions, {N} envs/GPU "
+                    "(no policy/learner in the loop)")
     else:
         from isaacgymloco_amd.learn.bench_train import run_train_bench
         elapsed, extra, workload = run_train_bench(env, cfg, args, dev, rank, world, barrier)

@@ -10,6 +10,7 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')
 timeout 900 python bench.py > $O/bench_default.log 2>&1; tail -1 $O/bench_default.log > $O/bench_default.json
 timeout 600 python bench.py --mode env --steps 500 --warmup 50 > $O/bench_env.log 2>&1; tail -1 $O/bench_env.log > $O/bench_env.json
 timeout 900 python bench.py --mode env --envs 262144 --steps 50 --warmup 10 --no-cpu-baseline > $O/bench_env_N262144.log 2>&1; tail -1 $O/bench_env_N262144.log > $O/bench_env_N262144.json
+timeout 300 python bench.py --mode env --actions zeros --steps 500 --warmup 50 --no-cpu-baseline > $O/bench_env_zero_actions.log 2>&1; tail -1 $O/bench_env_zero_actions.log > $O/bench_env_zero_actions.json
 timeout 300 python bench.py --mode env --envs 64 --steps 500 --warmup 50 --no-cpu-baseline > $O/bench_env_N64.log 2>&1; tail -1 $O/bench_env_N64.log > $O/bench_env_N64.json
 for t in aliengo_stairs aliengo_amp; do timeout 900 python bench.py --task $t --no-cpu-baseline > $O/bench_$t.log 2>&1; tail -1 $O/bench_$t.log > $O/bench_$t.json; done
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_env -o env -- python3 bench.py --mode env --steps 100 --warmup 20 --no-cpu-baseline > $O/prof_env.log 2>&1

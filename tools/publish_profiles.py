@@ -9,7 +9,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, rnd = sys.argv[1], sys.argv[2]
 O, P = os.path.join(ROOT, "gpurun_out", tag), os.path.join(ROOT, "profiles")
 for src, dst in (("bench_default", "bench_default_train"), ("bench_env", "bench_env_only"), ("bench_aliengo_stairs", "bench_aliengo_stairs"),
-                 ("bench_aliengo_amp", "bench_aliengo_amp"), ("bench_env_N262144", "bench_env_only_N262144"), ("bench_env_N64", "bench_env_only_N64")):
+                 ("bench_aliengo_amp", "bench_aliengo_amp"), ("bench_env_N262144", "bench_env_only_N262144"), ("bench_env_N64", "bench_env_only_N64"),
+                 ("bench_env_zero_actions", "bench_env_only_zero_actions")):
     f = os.path.join(O, src + ".json")
     if os.path.exists(f) and open(f).read().lstrip().startswith("{"):
         shutil.copy(f, os.path.join(P, f"{rnd}_{dst}.json"))
