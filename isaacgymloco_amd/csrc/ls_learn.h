@@ -175,17 +175,23 @@ template <int VX, int VG, int KG>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void lsim_k_linear_wgrad_tiled(const float* __restrict__ x, long ldx, const float* __restrict__ g, long ldg, long batch, int k_in, int n_out,
                                int k_blocks, int tiles, int slices, long rows_per_slice, float* __restrict__ part_dw, float* __restrict__ part_db) {
+    // one BLOCK per (output tile, batch slice): its four waves split the slice's rows four ways and add their accumulators in LDS at the
+    // end, so there is one partial result per block but four times as many waves in flight (two per SIMD: one wave's operand loads,
+    // register rotation and waits hide behind the other's MFMAs)
     const int lane = threadIdx.x & 63;
-    const long wave = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: scalar loop control
-    const long slice = wave / tiles;
-    if (slice >= slices) return;
-    const int tile = (int)(wave - slice * tiles);
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));                                // wave-uniform: scalar loop control
+    const long slice = (long)blockIdx.x / tiles;
+    const int tile = (int)((long)blockIdx.x - slice * tiles);
     const int nb = tile / k_blocks, kb = tile - nb * k_blocks;
     const int n_base = nb * 64, k_base = kb * 64 * KG;
     const int sub = lane >> 4, col = lane & 15;
-    const long b0 = slice * rows_per_slice;
-    long b1 = b0 + rows_per_slice;
-    if (b1 > batch) b1 = batch;
+    const long s0 = slice * rows_per_slice;
+    long s1 = s0 + rows_per_slice;
+    if (s1 > batch) s1 = batch;
+    const long quarter = (((s1 - s0) + 3) / 4 + 3) & ~3L;          // rows per wave, a multiple of the 4 rows one MFMA step consumes
+    long b0 = s0 + wv * quarter, b1 = b0 + quarter;
+    if (b0 > s1) b0 = s1;
+    if (b1 > s1) b1 = s1;
     ls_v4f acc[4][4 * KG];
     float dbacc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -195,6 +201,29 @@ void lsim_k_linear_wgrad_tiled(const float* __restrict__ x, long ldx, const floa
     const bool full = (n_base + 64 <= n_out) && (k_base + 64 * KG <= k_in);      // wave-uniform: interior tile
     if (full) ls_wgrad_tile_loop<VX, VG, KG, true>(x, ldx, g, ldg, b0, b1, n_base, k_base, n_out, k_in, sub, col, acc, dbacc);
     else ls_wgrad_tile_loop<VX, VG, KG, false>(x, ldx, g, ldg, b0, b1, n_base, k_base, n_out, k_in, sub, col, acc, dbacc);
+    // block reduction: wave 0 stores its accumulators to LDS (lane-major, 16-byte vectors: no bank conflicts), waves 1-3 add theirs in
+    // turn; wave 3 ends up with the block's sums and writes the partial tile
+    __shared__ float4 red[4 * 4 * KG][64];
+    __shared__ float redb[4][64];
+    for (int turn = 0; turn < 4; ++turn) {
+        if (wv == turn) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int kt = 0; kt < 4 * KG; ++kt) {
+                    float4 v = make_float4(acc[j][kt][0], acc[j][kt][1], acc[j][kt][2], acc[j][kt][3]);
+                    if (turn > 0) { const float4 o = red[j * 4 * KG + kt][lane]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                    if (turn < 3) red[j * 4 * KG + kt][lane] = v;
+                    else { acc[j][kt][0] = v.x; acc[j][kt][1] = v.y; acc[j][kt][2] = v.z; acc[j][kt][3] = v.w; }
+                }
+                float d = dbacc[j];
+                if (turn > 0) d += redb[j][lane];
+                if (turn < 3) redb[j][lane] = d; else dbacc[j] = d;
+            }
+        }
+        __syncthreads();
+    }
+    if (wv != 3) return;
     // accumulator (j, kt)[r] of lane (sub, col) is the output n = n_base + 4 (4 sub + r) + j, k = k_base + 64 (kt / 4) + 4 col + kt % 4
     float* pw = part_dw + (size_t)slice * n_out * k_in;
 #pragma unroll
@@ -254,8 +283,10 @@ struct LsWgradPlan {
     int n_blocks, k_blocks;
 };
 static int ls_wgrad_plan(long batch, int k_in, int n_out, LsWgradPlan* p) {
-    // above ~40 k outputs (512 -> 256, 238 -> 512) hipBLASLt's 85 TFLOP/s macro-tile kernels are as fast or faster: leave those to BLAS
-    if (batch <= 0 || k_in <= 0 || n_out <= 0 || (long)k_in * n_out > 40000) return LSIM_E_UNSUPPORTED;
+    // measured against TunableOp-selected hipBLASLt (tools/wgrad_sweep.sh): the block-cooperative tiled kernel wins up to 512 -> 256
+    // (295 vs 363 us) when the operand rows are 16-byte aligned; with unaligned rows (k_in % 4 != 0: 238 -> 512) it only ties above ~40 k outputs
+    const long count = (long)k_in * n_out;
+    if (batch <= 0 || k_in <= 0 || n_out <= 0 || count > 140000 || ((k_in & 3) != 0 && count > 40000)) return LSIM_E_UNSUPPORTED;
     const int nt = (n_out + 15) / 16, kt = (k_in + 15) / 16;
     if (nt <= 8 && kt <= 8 && nt * kt <= LS_WGRAD_MAX_TILES && (long)n_out * k_in <= 4096) {
         p->small = 1;
@@ -270,11 +301,11 @@ static int ls_wgrad_plan(long batch, int k_in, int n_out, LsWgradPlan* p) {
     p->n_blocks = (n_out + 63) / 64;
     p->k_blocks = k_in <= 64 ? 1 : (k_in + 127) / 128;     // 64-wide k tile for the narrow inputs, 128-wide otherwise
     const int tiles = p->n_blocks * p->k_blocks;
-    long slices = 2048 / tiles;                             // two waves per SIMD
+    long slices = 512 / tiles;                              // 4 waves per block: tiles * slices * 4 = 2048 waves, two per SIMD
     const long cap = (32L << 20) / ((long)n_out * k_in * 4); // keep the partial results (written once, read once) under 32 MB
     if (slices > cap) slices = cap;
     if (slices < 1) slices = 1;
-    long rps = ((batch + slices - 1) / slices + 3) & ~3L;
+    long rps = ((batch + slices - 1) / slices + 15) & ~15L;  // each of the block's four waves takes a quarter, in steps of 4 rows
     if (rps < 64) rps = 64;
     p->rows = rps;
     p->partials = (int)((batch + rps - 1) / rps);
@@ -315,8 +346,7 @@ extern "C" int lsim_linear_wgrad(const float* x, int64_t ldx, const float* g, in
         if (bad) return LSIM_E_UNSUPPORTED;
     } else {
         const int tiles = p.n_blocks * p.k_blocks;
-        const long waves = (long)tiles * p.partials;
-        const int blocks = (int)((waves + 3) / 4);
+        const int blocks = tiles * p.partials;               // one block of four waves per (tile, slice)
         const int vx = ((ldx % 4 == 0) && (((uintptr_t)x & 15) == 0)) ? 2 : (((ldx % 2 == 0) && (((uintptr_t)x & 7) == 0)) ? 1 : 0);
         const int vg = ((ldg % 4 == 0) && (((uintptr_t)g & 15) == 0)) ? 2 : 0;
         const int kg = k_in <= 64 ? 1 : 2;

@@ -175,7 +175,7 @@ def test_fused_gae_matches_torch_sweep():
 
 
 @pytest.mark.parametrize("k_in,n_out", [(128, 12), (128, 1), (64, 19), (45, 128), (64, 16), (128, 64), (16, 32), (7, 3),
-                                        (64, 512), (256, 128), (270, 128), (130, 70), (250, 150)])
+                                        (64, 512), (256, 128), (270, 128), (130, 70), (250, 150), (512, 256)])
 def test_linear_wgrad_kernel_matches_blas(k_in, n_out):
     """lsim_linear_wgrad (MFMA, csrc/ls_learn.h) against g^T x and g.sum(0) in fp64; strided x (a column slice, like the
     estimator's next_obs = critic_obs[:, 3:48]) and a ragged batch that does not fill the last wave."""

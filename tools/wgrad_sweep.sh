@@ -1,7 +1,7 @@
 #!/bin/bash
 # per-shape kernel durations of BLAS vs lsim_linear_wgrad (rocprofv3 kernel trace); usage: bash tools/wgrad_sweep.sh
 export TMPDIR=/tmp
-for shape in "128 12" "128 1" "64 19" "45 128" "64 16" "16 32" "128 64" "64 512" "256 128" "270 128"; do
+for shape in "128 12" "128 1" "64 19" "45 128" "64 16" "16 32" "128 64" "64 512" "256 128" "270 128" "238 512" "512 256"; do
   rm -rf /tmp/wgs; timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/wgs -o w -- python3 tools/wgrad_probe.py $shape tuned > /dev/null 2>&1
   python3 - "$shape" <<'PY'
 import csv, sys
