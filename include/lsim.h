@@ -487,6 +487,14 @@ int lsim_linear_wgrad_workspace(long batch, int k_in, int n_out, size_t* bytes, 
 int lsim_linear_wgrad(const float* x, int64_t ldx, const float* g, int64_t ldg, int64_t batch, int k_in, int n_out,
                       float* dw, float* db, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Backward of a Linear layer followed by ELU (y = x W^T + b, z = elu(y), alpha = 1) given the gradient of z: the gradient of the
+ * pre-activation  grad_pre = grad_out * (z > 0 ? 1 : z + 1)  (torch's elu_backward on the saved OUTPUT) is formed on the fly as the MFMA
+ * operand of the weight-gradient kernel and written once -- [batch, n_out] contiguous -- for the caller's input-gradient GEMM
+ * (grad_pre @ W); dw / db as lsim_linear_wgrad.  One pass over grad_out and z instead of elu_backward + column sum + wgrad.
+ * Same workspace as lsim_linear_wgrad; LSIM_E_UNSUPPORTED for shapes lsim_linear_wgrad handles in its single-wave form (<= 4096 outputs). */
+int lsim_linear_elu_wgrad(const float* x, int64_t ldx, const float* grad_out, int64_t ldg, const float* elu_out, int64_t ldz, int64_t batch,
+                          int k_in, int n_out, float* dw, float* db, float* grad_pre, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Clipped-PPO loss of HIMPPO.update (HIMP:136-176), forward AND backward in one pass: per-sample Gaussian log-prob, ratio, clipped
  * surrogate, clipped value loss, entropy bonus, and the KL estimate of the adaptive learning-rate rule (HIMP:144-156).
  *   out5 = { mean surrogate, mean value loss, mean entropy, mean KL, total = surrogate + value_loss_coef * value - entropy_coef * entropy }

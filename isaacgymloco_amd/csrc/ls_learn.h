@@ -136,13 +136,18 @@ __device__ __forceinline__ void ls_wgrad_load4(const float* __restrict__ p, long
 
 // the batch loop of one (tile, slice): operands of the current step and of the next two are in registers (prefetch distance 2:
 // ~2 x 1024 MFMA cycles per wave, two waves per SIMD)
-template <int VX, int VG, int KG, bool FULL>
-__device__ __forceinline__ void ls_wgrad_tile_loop(const float* __restrict__ x, long ldx, const float* __restrict__ g, long ldg, long b0, long b1,
+// FZ: the A operand is formed on the fly as g_z * elu'(z) from the incoming gradient g_z and the saved ELU OUTPUT z (torch's
+// elu_backward with is_result: z > 0 ? 1 : z + alpha, alpha = 1), and the waves of k-block 0 also write it out (g_y, the gradient of
+// the pre-activation, which the caller's input-gradient GEMM needs): the separate elu_backward pass over [B, N] disappears.
+template <int VX, int VG, int KG, bool FULL, bool FZ>
+__device__ __forceinline__ void ls_wgrad_tile_loop(const float* __restrict__ x, long ldx, const float* __restrict__ g, long ldg,
+                                                   const float* __restrict__ z, long ldz, float* __restrict__ gy, bool write_gy, long b0, long b1,
                                                    int n_base, int k_base, int n_out, int k_in, int sub, int col,
                                                    ls_v4f (&acc)[4][4 * KG], float (&dbacc)[4]) {
-    float a0[4], x0[KG][4], a1[4], x1[KG][4], a2[4], x2[KG][4];
-#define LS_LOAD_STEP(ROW, A, X) do { const long row_ = (ROW); const bool ok_ = row_ < b1;                                    \
+    float a0[4], x0[KG][4], a1[4], x1[KG][4], a2[4], x2[KG][4], z1[4], z2[4];
+#define LS_LOAD_STEP(ROW, A, Z, X) do { const long row_ = (ROW); const bool ok_ = row_ < b1;                                 \
         ls_wgrad_load4<VG, FULL>(g, ldg, row_, ok_, b0, n_base + 4 * col, n_out, A);                                          \
+        if (FZ) ls_wgrad_load4<VG, FULL>(z, ldz, row_, ok_, b0, n_base + 4 * col, n_out, Z);                                  \
         ls_wgrad_load4<VX, FULL>(x, ldx, row_, ok_, b0, k_base + 4 * col, k_in, X[0]);                                        \
         if (KG > 1) ls_wgrad_load4<VX, FULL>(x, ldx, row_, ok_, b0, k_base + 64 + 4 * col, k_in, X[KG - 1]); } while (0)
 #define LS_MFMA_STEP(A, X) do {                                                                                              \
@@ -154,16 +159,27 @@ __device__ __forceinline__ void ls_wgrad_tile_loop(const float* __restrict__ x, 
     // a0/x0 = operands of the current step, a1/x1 of the next, a2/x2 in flight for the one after.  The rotation copies sit at the
     // TOP of the iteration, so the s_waitcnt they need covers loads issued a whole iteration (32 MFMAs) earlier, and the loads
     // issued below stay in flight across this iteration's MFMAs.  Rows past the slice load zeros.
-    LS_LOAD_STEP(b0 + sub, a1, x1);
-    LS_LOAD_STEP(b0 + 4 + sub, a2, x2);
+    LS_LOAD_STEP(b0 + sub, a1, z1, x1);
+    LS_LOAD_STEP(b0 + 4 + sub, a2, z2, x2);
     for (long b = b0; b < b1; b += 4) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            a0[j] = a1[j]; a1[j] = a2[j];
+            a0[j] = FZ ? a1[j] * (z1[j] > 0.0f ? 1.0f : z1[j] + 1.0f) : a1[j];
+            a1[j] = a2[j];
+            if (FZ) z1[j] = z2[j];
 #pragma unroll
             for (int q = 0; q < KG; ++q) { x0[q][j] = x1[q][j]; x1[q][j] = x2[q][j]; }
         }
-        LS_LOAD_STEP(b + 8 + sub, a2, x2);
+        if (FZ && write_gy) {
+            const long row = b + sub;
+            const int n = n_base + 4 * col;
+            if (row < b1 && n < n_out) {
+                float* dst = gy + row * (long)n_out + n;
+                if (FULL && (n_out & 3) == 0) *(float4*)dst = make_float4(a0[0], a0[1], a0[2], a0[3]);
+                else { for (int j = 0; j < 4; ++j) if (n + j < n_out) dst[j] = a0[j]; }
+            }
+        }
+        LS_LOAD_STEP(b + 8 + sub, a2, z2, x2);
         LS_MFMA_STEP(a0, x0);
     }
 #undef LS_MFMA_STEP
@@ -171,9 +187,10 @@ __device__ __forceinline__ void ls_wgrad_tile_loop(const float* __restrict__ x, 
 }
 
 // KG: 64-wide k groups per tile (1 for k_in <= 64, else 2)
-template <int VX, int VG, int KG>
+template <int VX, int VG, int KG, bool FZ>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void lsim_k_linear_wgrad_tiled(const float* __restrict__ x, long ldx, const float* __restrict__ g, long ldg, long batch, int k_in, int n_out,
+void lsim_k_linear_wgrad_tiled(const float* __restrict__ x, long ldx, const float* __restrict__ g, long ldg, const float* __restrict__ z, long ldz,
+                               float* __restrict__ gy, long batch, int k_in, int n_out,
                                int k_blocks, int tiles, int slices, long rows_per_slice, float* __restrict__ part_dw, float* __restrict__ part_db) {
     // one BLOCK per (output tile, batch slice): its four waves split the slice's rows four ways and add their accumulators in LDS at the
     // end, so there is one partial result per block but four times as many waves in flight (two per SIMD: one wave's operand loads,
@@ -199,8 +216,8 @@ void lsim_k_linear_wgrad_tiled(const float* __restrict__ x, long ldx, const floa
 #pragma unroll
         for (int kt = 0; kt < 4 * KG; ++kt) acc[j][kt] = (ls_v4f){0.0f, 0.0f, 0.0f, 0.0f};
     const bool full = (n_base + 64 <= n_out) && (k_base + 64 * KG <= k_in);      // wave-uniform: interior tile
-    if (full) ls_wgrad_tile_loop<VX, VG, KG, true>(x, ldx, g, ldg, b0, b1, n_base, k_base, n_out, k_in, sub, col, acc, dbacc);
-    else ls_wgrad_tile_loop<VX, VG, KG, false>(x, ldx, g, ldg, b0, b1, n_base, k_base, n_out, k_in, sub, col, acc, dbacc);
+    if (full) ls_wgrad_tile_loop<VX, VG, KG, true, FZ>(x, ldx, g, ldg, z, ldz, gy, kb == 0, b0, b1, n_base, k_base, n_out, k_in, sub, col, acc, dbacc);
+    else ls_wgrad_tile_loop<VX, VG, KG, false, FZ>(x, ldx, g, ldg, z, ldz, gy, kb == 0, b0, b1, n_base, k_base, n_out, k_in, sub, col, acc, dbacc);
     // block reduction: wave 0 stores its accumulators to LDS (lane-major, 16-byte vectors: no bank conflicts), waves 1-3 add theirs in
     // turn; wave 3 ends up with the block's sums and writes the partial tile
     __shared__ float4 red[4 * 4 * KG][64];
@@ -322,14 +339,16 @@ extern "C" int lsim_linear_wgrad_workspace(long batch, int k_in, int n_out, size
     return LSIM_OK;
 }
 
-extern "C" int lsim_linear_wgrad(const float* x, int64_t ldx, const float* g, int64_t ldg, int64_t batch, int k_in, int n_out,
-                                 float* dw, float* db, void* workspace, size_t workspace_bytes, void* stream) {
+static int ls_linear_wgrad_impl(const float* x, int64_t ldx, const float* g, int64_t ldg, const float* z, int64_t ldz, float* gy, int64_t batch,
+                                int k_in, int n_out, float* dw, float* db, void* workspace, size_t workspace_bytes, void* stream) {
     if (!x || !g || !dw || !workspace) return LSIM_E_INVALID;
     LsWgradPlan p;
     int rc = ls_wgrad_plan(batch, k_in, n_out, &p);
     if (rc != LSIM_OK) return rc;
     const size_t need = (size_t)p.partials * ((size_t)n_out * k_in + n_out) * sizeof(float);
     if (workspace_bytes < need || ldx < k_in || ldg < n_out) return LSIM_E_INVALID;
+    const bool fz = z != nullptr;
+    if (fz && (p.small || !gy || ldz < n_out)) return p.small ? LSIM_E_UNSUPPORTED : LSIM_E_INVALID;
     float* pdw = (float*)workspace;
     float* pdb = db ? pdw + (size_t)p.partials * n_out * k_in : nullptr;
     hipStream_t s = (hipStream_t)stream;
@@ -348,20 +367,34 @@ extern "C" int lsim_linear_wgrad(const float* x, int64_t ldx, const float* g, in
         const int tiles = p.n_blocks * p.k_blocks;
         const int blocks = tiles * p.partials;               // one block of four waves per (tile, slice)
         const int vx = ((ldx % 4 == 0) && (((uintptr_t)x & 15) == 0)) ? 2 : (((ldx % 2 == 0) && (((uintptr_t)x & 7) == 0)) ? 1 : 0);
-        const int vg = ((ldg % 4 == 0) && (((uintptr_t)g & 15) == 0)) ? 2 : 0;
+        int vg = ((ldg % 4 == 0) && (((uintptr_t)g & 15) == 0)) ? 2 : 0;
+        if (fz && !((ldz % 4 == 0) && (((uintptr_t)z & 15) == 0))) vg = 0;
         const int kg = k_in <= 64 ? 1 : 2;
-#define LS_T(VX, VG, KG) hipLaunchKernelGGL((lsim_k_linear_wgrad_tiled<VX, VG, KG>), dim3(blocks), dim3(256), 0, s, x, (long)ldx, g, (long)ldg, (long)batch, \
-                                            k_in, n_out, p.k_blocks, tiles, p.partials, p.rows, pdw, pdb)
-#define LS_TK(VX, VG) do { if (kg == 1) LS_T(VX, VG, 1); else LS_T(VX, VG, 2); } while (0)
+#define LS_T(VX, VG, KG, FZ) hipLaunchKernelGGL((lsim_k_linear_wgrad_tiled<VX, VG, KG, FZ>), dim3(blocks), dim3(256), 0, s, x, (long)ldx, g, (long)ldg, z, (long)ldz, \
+                                                gy, (long)batch, k_in, n_out, p.k_blocks, tiles, p.partials, p.rows, pdw, pdb)
+#define LS_TZ(VX, VG, KG) do { if (fz) LS_T(VX, VG, KG, true); else LS_T(VX, VG, KG, false); } while (0)
+#define LS_TK(VX, VG) do { if (kg == 1) LS_TZ(VX, VG, 1); else LS_TZ(VX, VG, 2); } while (0)
         if (vg == 2) { if (vx == 2) LS_TK(2, 2); else if (vx == 1) LS_TK(1, 2); else LS_TK(0, 2); }
         else         { if (vx == 2) LS_TK(2, 0); else if (vx == 1) LS_TK(1, 0); else LS_TK(0, 0); }
 #undef LS_TK
+#undef LS_TZ
 #undef LS_T
     }
     const int count = n_out * k_in;
     hipLaunchKernelGGL(lsim_k_wgrad_reduce, dim3((count + 15) / 16), dim3(256), 0, s, pdw, p.partials, count, dw);
     if (db) hipLaunchKernelGGL(lsim_k_wgrad_reduce, dim3((n_out + 15) / 16), dim3(256), 0, s, pdb, p.partials, n_out, db);
     return hipGetLastError() == hipSuccess ? LSIM_OK : LSIM_E_HIP;
+}
+
+extern "C" int lsim_linear_wgrad(const float* x, int64_t ldx, const float* g, int64_t ldg, int64_t batch, int k_in, int n_out,
+                                 float* dw, float* db, void* workspace, size_t workspace_bytes, void* stream) {
+    return ls_linear_wgrad_impl(x, ldx, g, ldg, nullptr, 0, nullptr, batch, k_in, n_out, dw, db, workspace, workspace_bytes, stream);
+}
+
+extern "C" int lsim_linear_elu_wgrad(const float* x, int64_t ldx, const float* grad_out, int64_t ldg, const float* elu_out, int64_t ldz, int64_t batch,
+                                     int k_in, int n_out, float* dw, float* db, float* grad_pre, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!elu_out || !grad_pre) return LSIM_E_INVALID;
+    return ls_linear_wgrad_impl(x, ldx, grad_out, ldg, elu_out, ldz, grad_pre, batch, k_in, n_out, dw, db, workspace, workspace_bytes, stream);
 }
 
 // ---- Sinkhorn-Knopp assignment of HIMEstimator (HES:119-133): Q = exp(scores / eps)^T, then `iters` x {rows sum to 1/K, columns

@@ -72,6 +72,69 @@ class _SkinnyLinearFn(torch.autograd.Function):
         return gx, dw, db
 
 
+def _eligible_fused_elu(batch, k_in, n_out):
+    """Linear + ELU pairs whose weight gradient runs in the library's tiled kernel (more than 4096 outputs, see ls_learn.h)"""
+    return _eligible(batch, k_in, n_out) and k_in * n_out > 4096
+
+
+class _LinearEluFn(torch.autograd.Function):
+    """z = elu(x W^T + b) whose backward runs ONE fused pass (lsim_linear_elu_wgrad): grad_pre = g * elu'(z) formed on the fly as the
+    MFMA operand of the weight-gradient kernel (and written once), then the usual BLAS input gradient grad_pre @ W."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        z = F.elu(F.linear(x, weight, bias))
+        ctx.save_for_backward(x, weight, z)
+        ctx.has_bias = bias is not None
+        return z
+
+    @staticmethod
+    def backward(ctx, g):
+        from .. import lib
+        x, weight, z = ctx.saved_tensors
+        L = lib.load()
+        if x.stride(1) != 1:
+            x = x.contiguous()
+        g = g.contiguous()
+        batch, k_in = x.shape
+        n_out = weight.shape[0]
+        need, parts = ctypes.c_size_t(), ctypes.c_int()
+        lib.check(L.lsim_linear_wgrad_workspace(batch, k_in, n_out, ctypes.byref(need), ctypes.byref(parts)), what="lsim_linear_wgrad_workspace")
+        ws = _workspaces.get(x.device)
+        if ws is None or ws.numel() < need.value:
+            ws = torch.empty(max(need.value, 1 << 20), dtype=torch.uint8, device=x.device)
+            _workspaces[x.device] = ws
+        dw = torch.empty(n_out, k_in, device=x.device, dtype=torch.float32)
+        db = torch.empty(n_out, device=x.device, dtype=torch.float32) if ctx.has_bias else None
+        g_pre = torch.empty(batch, n_out, device=x.device, dtype=torch.float32)
+        lib.check(L.lsim_linear_elu_wgrad(x.data_ptr(), x.stride(0), g.data_ptr(), g.stride(0), z.data_ptr(), z.stride(0), batch, k_in, n_out,
+                                          dw.data_ptr(), db.data_ptr() if db is not None else None, g_pre.data_ptr(), ws.data_ptr(), ws.numel(),
+                                          torch.cuda.current_stream(x.device).cuda_stream), what="lsim_linear_elu_wgrad")
+        gx = g_pre @ weight if ctx.needs_input_grad[0] else None
+        return gx, dw, db
+
+
+class HimMLP(nn.Sequential):
+    """nn.Sequential of Linear / ELU modules (same children, same state_dict keys) that runs eligible (Linear, ELU) pairs through
+    _LinearEluFn on the GPU when gradients are needed; everything else exactly as nn.Sequential."""
+
+    def forward(self, x):
+        mods = list(self)
+        i = 0
+        fuse = x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and torch.is_grad_enabled()
+        while i < len(mods):
+            m = mods[i]
+            nxt = mods[i + 1] if i + 1 < len(mods) else None
+            if (fuse and isinstance(m, nn.Linear) and m.weight.requires_grad and isinstance(nxt, nn.ELU) and nxt.alpha == 1.0 and not nxt.inplace
+                    and _eligible_fused_elu(x.shape[0], m.in_features, m.out_features)):
+                x = _LinearEluFn.apply(x, m.weight, m.bias)
+                i += 2
+            else:
+                x = m(x)
+                i += 1
+        return x
+
+
 class SkinnyLinear(nn.Linear):
     def forward(self, x):
         if (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and torch.is_grad_enabled() and self.weight.requires_grad

@@ -10,7 +10,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.distributions import Normal
 
-from .fused_linear import SkinnyLinear
+from .fused_linear import HimMLP, SkinnyLinear
 
 _ACTIVATIONS = {"elu": nn.ELU, "selu": nn.SELU, "relu": nn.ReLU, "crelu": nn.ReLU, "silu": nn.SiLU,
                 "lrelu": nn.LeakyReLU, "tanh": nn.Tanh, "sigmoid": nn.Sigmoid}
@@ -29,7 +29,7 @@ def mlp(sizes, activation, last_activation=False):
         layers.append(SkinnyLinear(sizes[i], sizes[i + 1]))   # an nn.Linear; narrow layers get the HIP weight-gradient kernel on the GPU
         if i < len(sizes) - 2 or last_activation:
             layers.append(activation)
-    return nn.Sequential(*layers)
+    return HimMLP(*layers)      # an nn.Sequential; fuses (Linear, ELU) backward passes on the GPU (fused_linear.py)
 
 
 @torch.no_grad()

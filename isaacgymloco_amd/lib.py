@@ -52,6 +52,7 @@ def load():
     L.lsim_ppo_loss_workspace.argtypes = [ctypes.c_long, ctypes.POINTER(ctypes.c_size_t)]
     L.lsim_ppo_loss.argtypes = [vp] * 10 + [i64, i32, f32, f32, f32, i32, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
     L.lsim_adaptive_lr.argtypes = [vp, f32, f32, f32, f32, vp, vp]
+    L.lsim_linear_elu_wgrad.argtypes = [vp, i64, vp, i64, vp, i64, i64, i32, i32, vp, vp, vp, vp, ctypes.c_size_t, vp]
     L.lsim_destroy.argtypes = [vp]
     L.lsim_destroy.restype = None
     _lib = L

@@ -382,3 +382,25 @@ def test_device_lr_and_fused_adam_match_the_host_rule():
     run_a.save(path); run_a.load(path)
     assert all(g["lr"] is run_a.alg._lr_t for g in run_a.alg.optimizer.param_groups)
     run_a.learn(1)
+
+
+@pytest.mark.parametrize("k_in,n_out", [(64, 512), (512, 256), (256, 128), (270, 128), (45, 128), (128, 64)])
+def test_fused_linear_elu_backward_matches_torch(k_in, n_out):
+    """_LinearEluFn (lsim_linear_elu_wgrad: elu_backward folded into the weight-gradient kernel) against nn.Linear + nn.ELU autograd"""
+    import torch.nn as nn
+    from isaacgymloco_amd.learn.fused_linear import HimMLP
+    torch.manual_seed(k_in + n_out)
+    B = 20480 + 12
+    ref = nn.Sequential(nn.Linear(k_in, n_out), nn.ELU(), nn.Linear(n_out, 5)).to("cuda:0")
+    fus = HimMLP(nn.Linear(k_in, n_out), nn.ELU(), nn.Linear(n_out, 5)).to("cuda:0")
+    fus.load_state_dict(ref.state_dict())
+    big = torch.randn(B, k_in + 3, device="cuda:0")
+    xa = big[:, 1:1 + k_in].clone().requires_grad_(True) if k_in % 2 else big[:, :k_in].clone().requires_grad_(True)
+    xb = xa.detach().clone().requires_grad_(True)
+    w = torch.randn(B, 5, device="cuda:0")
+    (ref(xa) * w).sum().backward()
+    (fus(xb) * w).sum().backward()
+    for (n1, p1), (n2, p2) in zip(ref.named_parameters(), fus.named_parameters()):
+        scale = float(p1.grad.abs().max())
+        torch.testing.assert_close(p2.grad, p1.grad, rtol=2e-4, atol=2e-5 * scale, msg=n1)
+    torch.testing.assert_close(xb.grad, xa.grad, rtol=2e-4, atol=2e-5 * float(xa.grad.abs().max()))

@@ -38,6 +38,9 @@ if "--torch-sinkhorn" in sys.argv:      # A/B: force the torch statement of the 
 if "--no-lr-sync" in sys.argv:        # A/B: what the per-minibatch .item() of the adaptive-lr rule costs (lr simply stays fixed)
     import isaacgymloco_amd.learn.him_ppo as HP
     HP.HIMPPO._adapt_lr = lambda self, *a, **k: None
+if "--no-fused-elu" in sys.argv:       # A/B: Linear + ELU pairs through separate torch nodes (SkinnyLinear wgrad + elu_backward)
+    import isaacgymloco_amd.learn.fused_linear as FL
+    FL._eligible_fused_elu = lambda *a: False
 if "--nn-linear" in sys.argv:           # A/B: plain nn.Linear backward (BLAS wgrad)
     import isaacgymloco_amd.learn.fused_linear as FL
     FL._eligible = lambda *a: False
