@@ -152,7 +152,6 @@ class HIMPPO:
 
     def _adapt_lr(self, mu, sigma, old_mu, old_sigma, kl_mean=None):
         if self._lr_t is not None and kl_mean is not None:        # device path: no host round trip
-            import ctypes as _ct
             from .. import lib
             if self.dist_ctx is not None and self.dist_ctx.enabled:
                 kl_mean = self.dist_ctx.average_scalar(kl_mean)
