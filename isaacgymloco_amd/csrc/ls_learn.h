@@ -77,10 +77,15 @@ __global__ __launch_bounds__(64 * LS_WGRAD_WAVES_PER_BLOCK) void lsim_k_linear_w
 
 // out[o] = sum over waves of part[w][o] in a fixed order.  Block = 16 outputs x 16 wave-slices: thread (o, s) adds the partials
 // w = s, s + 16, ... with four independent accumulators (64-byte coalesced rows), then the 16 slices meet in LDS.
-__global__ __launch_bounds__(256) void lsim_k_wgrad_reduce(const float* __restrict__ part, int num_waves, int count, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void lsim_k_wgrad_reduce(const float* __restrict__ part, int num_waves, int count, float* __restrict__ out,
+                                                           const float* __restrict__ part2, int count2, float* __restrict__ out2) {
+    // one launch serves the weight-gradient partials (count outputs) and, in the blocks after them, the bias-gradient partials (count2)
     __shared__ float red[16][17];
     const int ol = threadIdx.x & 15, sl = threadIdx.x >> 4;
-    const int o = blockIdx.x * 16 + ol;
+    const int nb1 = (count + 15) >> 4;
+    const bool second = (int)blockIdx.x >= nb1;
+    if (second) { part = part2; out = out2; count = count2; }
+    const int o = ((int)blockIdx.x - (second ? nb1 : 0)) * 16 + ol;
     float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
     if (o < count) {
         int w = sl;
@@ -100,11 +105,6 @@ __global__ __launch_bounds__(256) void lsim_k_wgrad_reduce(const float* __restri
     }
 }
 
-// ---- larger layers: the output is cut into 64 (n) x 128 (k) tiles, one wave per (tile, batch slice), 32 MFMA accumulators.
-// Operand loads are 16-byte vectors: lane (sub, col) reads g[row][n_base + 4 col .. +3] and x[row][k_base + 64 q + 4 col .. +3], so
-// MFMA tile j of a 4-tile group holds the outputs n = n_base + 4 i + j (a permutation of the outputs inside the group that is
-// undone when the accumulators are written).  The next step's operands are loaded before the current step's 32 MFMAs issue
-// (register double buffer), two waves per SIMD.  VX / VG: the operand's rows are 16-byte aligned (ld % 4 == 0); otherwise scalars.
 // VEC: 2 = 16-byte vector load (rows 16-byte aligned), 1 = two 8-byte loads (rows 8-byte aligned, e.g. ld = 238 or 270), 0 = scalars
 // FULL: the four columns are inside the matrix (interior tile): no column tests, no branches -- the row test becomes a select on a
 // clamped row, so that all operand loads of a step issue back to back and overlap.
@@ -381,8 +381,8 @@ static int ls_linear_wgrad_impl(const float* x, int64_t ldx, const float* g, int
 #undef LS_T
     }
     const int count = n_out * k_in;
-    hipLaunchKernelGGL(lsim_k_wgrad_reduce, dim3((count + 15) / 16), dim3(256), 0, s, pdw, p.partials, count, dw);
-    if (db) hipLaunchKernelGGL(lsim_k_wgrad_reduce, dim3((n_out + 15) / 16), dim3(256), 0, s, pdb, p.partials, n_out, db);
+    hipLaunchKernelGGL(lsim_k_wgrad_reduce, dim3((count + 15) / 16 + (db ? (n_out + 15) / 16 : 0)), dim3(256), 0, s, (const float*)pdw, p.partials, count, dw,
+                       (const float*)pdb, n_out, db);
     return hipGetLastError() == hipSuccess ? LSIM_OK : LSIM_E_HIP;
 }
 
