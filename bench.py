@@ -69,11 +69,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("LSIM_DEBUG_SINGLE_DEVICE") == "1":         # debugging aid: exercise the N > 1 code path on a 1-GPU box (all ranks on
+        local_rank = 0                                            # cuda:0, gloo instead of RCCL); never set by the driver
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)   # RCCL; the rank's GPU is bound before the first collective
+        if os.environ.get("LSIM_DEBUG_SINGLE_DEVICE") == "1":
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)   # RCCL; the rank's GPU is bound before the first collective
 
     from isaacgymloco_amd.envs import config as C
     from isaacgymloco_amd.envs.legged_robot import LeggedRobot
