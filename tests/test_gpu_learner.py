@@ -404,3 +404,54 @@ def test_fused_linear_elu_backward_matches_torch(k_in, n_out):
         scale = float(p1.grad.abs().max())
         torch.testing.assert_close(p2.grad, p1.grad, rtol=2e-4, atol=2e-5 * scale, msg=n1)
     torch.testing.assert_close(xb.grad, xa.grad, rtol=2e-4, atol=2e-5 * float(xa.grad.abs().max()))
+
+
+def test_reference_style_step_tuple_and_strict_runner_path():
+    """LeggedRobot.step (LR:122-176): the 7-tuple (8 with AMP) with data-dependent shapes, consistent with step_device on a twin env; and
+    the runner's strict path (fast=False: the reference's call sequence incl. the next_critic_obs[termination_ids] patch, HIMR:119-123)
+    fills the same storage as the fast path."""
+    from isaacgymloco_amd.envs import config as C
+    from isaacgymloco_amd.envs.legged_robot import LeggedRobot
+    from isaacgymloco_amd.learn.bench_train import train_cfg_dict
+    from isaacgymloco_amd.learn.runner import HIMOnPolicyRunner
+
+    def mk(amp=False):
+        cfg = C.TASKS["aliengo_amp" if amp else "aliengo"][0]()
+        cfg.env.num_envs = 128
+        cfg.env.episode_length_s = 0.3          # time-outs inside the window
+        return LeggedRobot(cfg, sim_device="cuda:0", seed=12, using_amp=amp)
+    a, b = mk(), mk()
+    a.reset(); b.reset()
+    g = torch.Generator(device="cuda:0").manual_seed(2)
+    saw_reset = False
+    for _ in range(30):
+        act = torch.randn(128, 12, device="cuda:0", generator=g)
+        obs, priv, rew, done, extras, ids, term_priv = a.step(act)
+        o2, p2, r2, d2 = b.step_device(act)
+        assert obs.shape == (128, 270) and priv.shape == (128, 238) and rew.shape == (128,) and done.dtype == torch.bool
+        assert torch.equal(obs, o2) and torch.equal(priv, p2) and torch.equal(rew, r2) and torch.equal(done, d2)
+        assert ids.dtype == torch.int64 and torch.equal(ids, d2.nonzero(as_tuple=False).flatten())
+        assert term_priv.shape == (len(ids), 238) and torch.equal(term_priv, b.termination_privileged_obs_buf[ids])
+        assert "time_outs" in extras
+        saw_reset |= len(ids) > 0
+    assert saw_reset
+    amp = mk(amp=True)
+    amp.reset()
+    out = amp.step(torch.zeros(128, 12, device="cuda:0"))
+    assert len(out) == 8 and out[7].shape == (len(out[5]), 30)
+    # strict vs fast runner path: same storage after one rollout (same seeds -> same simulator trajectory given the same actions)
+    tc = train_cfg_dict("aliengo")
+    tc["runner"]["num_steps_per_env"] = 6
+    runs = []
+    for fast in (True, False):
+        env = mk()
+        torch.manual_seed(0)
+        run = HIMOnPolicyRunner(env, tc, log_dir=None, device="cuda:0", fast=fast)
+        torch.manual_seed(1)
+        obs, crit = env.get_observations().clone(), env.get_privileged_observations().clone()
+        with torch.inference_mode():
+            for _ in range(6):
+                obs, crit, *_ = run._rollout_step(obs, crit)
+        runs.append(run.alg.storage)
+    for name in ("observations", "privileged_observations", "next_privileged_observations", "actions", "rewards", "dones", "values"):
+        torch.testing.assert_close(getattr(runs[0], name).float(), getattr(runs[1], name).float(), rtol=1e-6, atol=1e-6, msg=name)
