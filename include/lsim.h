@@ -521,6 +521,20 @@ int lsim_sinkhorn_workspace(long batch, int K, size_t* bytes);
 int lsim_sinkhorn(const float* scores, int64_t lds, int64_t batch, int K, float eps, int iters, float* out,
                   void* workspace, size_t workspace_bytes, void* stream);
 
+/* Loss head of HIMEstimator.update (HES:76-108) forward AND backward, everything between the two encoder outputs and the scalar loss:
+ *   enc_out [batch, 3 + latent] (row stride ld_enc): predicted base velocity | student latent;  tgt_out [batch, latent]: target latent;
+ *   proto [K, latent] contiguous, rows already L2-normalised (HES:92-93);  vel [batch, 3] (row stride ld_vel): the regression target.
+ *   z = F.normalize(latent), scores = z proto^T, q = Sinkhorn(scores) (no gradient), swap = -0.5 mean(q_s log_softmax(S_t / T) +
+ *   q_t log_softmax(S_s / T)), est = mse(pred_vel, vel).
+ *   losses3 = { est, swap, est + swap };  grad_enc [batch, 3 + latent], grad_tgt [batch, latent], grad_proto [K, latent] contiguous =
+ *   d (est + swap) / d (enc_out, tgt_out, proto).  latent <= 32, K <= 64.  12 launches; sums in a fixed order (deterministic).
+ * workspace: lsim_estimator_loss_workspace() bytes, 16-byte aligned. */
+int lsim_estimator_loss_workspace(int64_t batch, int latent, int K, size_t* bytes);
+int lsim_estimator_loss(const float* enc_out, int64_t ld_enc, const float* tgt_out, int64_t ld_tgt, const float* proto, const float* vel,
+                        int64_t ld_vel, int64_t batch, int latent, int K, float temperature, float sinkhorn_eps, int sinkhorn_iters,
+                        float* losses3, float* grad_enc, float* grad_tgt, float* grad_proto, void* workspace, size_t workspace_bytes,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

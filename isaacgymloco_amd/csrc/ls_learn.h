@@ -409,9 +409,18 @@ extern "C" int lsim_linear_elu_wgrad(const float* x, int64_t ldx, const float* g
 
 __global__ __launch_bounds__(256) void lsim_k_sinkhorn_pass(const float* __restrict__ scores, long lds, long batch, int K, float inv_eps,
                                                             const float* __restrict__ u /* NULL in pass 0 */, float* __restrict__ E,
-                                                            float* __restrict__ part /* [blocks][K] or NULL */, float* __restrict__ out /* last pass */) {
+                                                            float* __restrict__ part /* [blocks][K] or NULL */, float* __restrict__ out /* last pass */,
+                                                            long scores_mat_stride) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    {   // blockIdx.y: independent matrices of the same shape laid out back to back (lsim_estimator_loss runs student and target together)
+        const long m = blockIdx.y;
+        scores += m * scores_mat_stride;
+        E += m * batch * K;
+        if (u) u += m * 64;
+        if (part) part += m * (long)gridDim.x * K;
+        if (out) out += m * batch * K;
+    }
     const long r0 = (long)blockIdx.x * LS_SK_ROWS;
     const float uk = (u && lane < K) ? u[lane] : 0.0f;
     float colsum = 0.0f;
@@ -440,6 +449,8 @@ __global__ __launch_bounds__(256) void lsim_k_sinkhorn_pass(const float* __restr
 __global__ __launch_bounds__(1024) void lsim_k_sinkhorn_scale(const float* __restrict__ part, int blocks, int K, float* __restrict__ u) {
     __shared__ float red[16][64];
     const int k = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    part += (size_t)blockIdx.y * blocks * K;
+    u += blockIdx.y * 64;
     float s0 = 0.0f, s1 = 0.0f;
     if (k < K) {
         int i = sl;
@@ -456,11 +467,35 @@ __global__ __launch_bounds__(1024) void lsim_k_sinkhorn_scale(const float* __res
     }
 }
 
+static size_t ls_sinkhorn_floats(long batch, int K, int mats) {
+    const long blocks = (batch + LS_SK_ROWS - 1) / LS_SK_ROWS;
+    return (size_t)mats * ((size_t)batch * K + (size_t)blocks * K + 64);
+}
+
 extern "C" int lsim_sinkhorn_workspace(long batch, int K, size_t* bytes) {
     if (!bytes || batch <= 0 || K <= 0 || K > 64) return LSIM_E_INVALID;
-    const long blocks = (batch + LS_SK_ROWS - 1) / LS_SK_ROWS;
-    *bytes = ((size_t)batch * K + (size_t)blocks * K + 64) * sizeof(float);
+    *bytes = ls_sinkhorn_floats(batch, K, 1) * sizeof(float);
     return LSIM_OK;
+}
+
+// `mats` matrices [batch, K] (row stride lds, matrix stride scores_mat_stride) -> out [mats][batch][K]; workspace: ls_sinkhorn_floats()
+static void ls_sinkhorn_launch(const float* scores, long lds, long scores_mat_stride, long batch, int K, int mats, float eps, int iters, float* out,
+                               float* workspace, hipStream_t s) {
+    const int blocks = (int)((batch + LS_SK_ROWS - 1) / LS_SK_ROWS);
+    float* E = workspace;
+    float* part = E + (size_t)mats * batch * K;
+    float* u = part + (size_t)mats * blocks * K;
+    const dim3 grid(blocks, mats), one(1, mats);
+    hipLaunchKernelGGL(lsim_k_sinkhorn_pass, grid, dim3(256), 0, s, scores, lds, batch, K, 1.0f / eps, (const float*)nullptr, E, part, (float*)nullptr,
+                       scores_mat_stride);
+    hipLaunchKernelGGL(lsim_k_sinkhorn_scale, one, dim3(1024), 0, s, part, blocks, K, u);
+    for (int it = 1; it < iters; ++it) {
+        hipLaunchKernelGGL(lsim_k_sinkhorn_pass, grid, dim3(256), 0, s, scores, lds, batch, K, 1.0f / eps, (const float*)u, E, part, (float*)nullptr,
+                           scores_mat_stride);
+        hipLaunchKernelGGL(lsim_k_sinkhorn_scale, one, dim3(1024), 0, s, part, blocks, K, u);
+    }
+    hipLaunchKernelGGL(lsim_k_sinkhorn_pass, grid, dim3(256), 0, s, scores, lds, batch, K, 1.0f / eps, (const float*)u, E, (float*)nullptr, out,
+                       scores_mat_stride);
 }
 
 extern "C" int lsim_sinkhorn(const float* scores, int64_t lds, int64_t batch, int K, float eps, int iters, float* out,
@@ -469,21 +504,201 @@ extern "C" int lsim_sinkhorn(const float* scores, int64_t lds, int64_t batch, in
     int rc = lsim_sinkhorn_workspace(batch, K, &need);
     if (rc != LSIM_OK) return rc;
     if (!scores || !out || !workspace || workspace_bytes < need || iters < 1 || lds < K || eps <= 0.0f) return LSIM_E_INVALID;
-    const int blocks = (int)((batch + LS_SK_ROWS - 1) / LS_SK_ROWS);
-    float* E = (float*)workspace;
-    float* part = E + (size_t)batch * K;
-    float* u = part + (size_t)blocks * K;
-    hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(lsim_k_sinkhorn_pass, dim3(blocks), dim3(256), 0, s, scores, (long)lds, (long)batch, K, 1.0f / eps, (const float*)nullptr, E, part,
-                       (float*)nullptr);
-    hipLaunchKernelGGL(lsim_k_sinkhorn_scale, dim3(1), dim3(1024), 0, s, part, blocks, K, u);
-    for (int it = 1; it < iters; ++it) {
-        hipLaunchKernelGGL(lsim_k_sinkhorn_pass, dim3(blocks), dim3(256), 0, s, scores, (long)lds, (long)batch, K, 1.0f / eps, (const float*)u, E, part,
-                           (float*)nullptr);
-        hipLaunchKernelGGL(lsim_k_sinkhorn_scale, dim3(1), dim3(1024), 0, s, part, blocks, K, u);
+    ls_sinkhorn_launch(scores, (long)lds, 0, (long)batch, K, 1, eps, iters, out, (float*)workspace, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? LSIM_OK : LSIM_E_HIP;
+}
+
+// ---- estimator loss head of HIMEstimator.update (HES:76-108), forward and backward around the two encoder outputs:
+//   pred_vel, l_s = enc[:, :3], enc[:, 3:];   z_s = l_s / max(|l_s|, 1e-12);   z_t = tgt / max(|tgt|, 1e-12)
+//   S_s = z_s P^T, S_t = z_t P^T (P: K row-normalised prototypes);   q_s, q_t = sinkhorn(S_s), sinkhorn(S_t)       (no gradient)
+//   swap = -0.5 mean_{b,k} (q_s log_softmax(S_t / T) + q_t log_softmax(S_s / T));   est = mean_{b,c} (pred_vel - vel)^2
+// and d (est + swap) / d enc [B, 3 + D], / d tgt [B, D], / d P [K, D].  Launches: scores (1), both Sinkhorn chains together (2 iters + 1
+// each for pass and scale), loss + row gradients (1), finish (1), prototype gradient through lsim_linear_wgrad's single-wave kernel (2):
+// 12 instead of the ~75 torch kernels of the same arithmetic.  One wave per sample row, lane = prototype (K <= 64), D <= 32.
+#define LS_EST_ROWS 64
+
+__global__ __launch_bounds__(256) void lsim_k_est_scores(const float* __restrict__ enc, long ld_o, const float* __restrict__ tgt, long ld_t,
+                                                         const float* __restrict__ proto, long batch, int D, int K,
+                                                         float* __restrict__ z /* [2][B][D] */, float* __restrict__ inv_n /* [2][B] */,
+                                                         float* __restrict__ S /* [2][B][K] */) {
+    __shared__ float P[64 * 33];           // P[k][d], row stride 33: lane = k reads are bank-conflict free
+    __shared__ float zrow[4][64];          // per wave: z_s | z_t of the current row
+    for (int i = threadIdx.x; i < K * D; i += 256) P[(i / D) * 33 + (i % D)] = proto[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, half = lane >> 5, d = lane & 31;
+    const long r0 = (long)blockIdx.x * LS_EST_ROWS;
+    for (int i = w; i < LS_EST_ROWS; i += 4) {
+        const long b = r0 + i;
+        if (b >= batch) break;
+        const float v = d < D ? (half ? tgt[b * ld_t + d] : enc[b * ld_o + 3 + d]) : 0.0f;
+        float ss = v * v;
+        for (int off = 16; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);        // within each 32-lane half
+        const float n = sqrtf(ss);
+        const float inv = 1.0f / fmaxf(n, 1e-12f);
+        const float zz = v * inv;
+        if (d < D) z[((long)half * batch + b) * D + d] = zz;
+        if (d == 0) inv_n[(long)half * batch + b] = n < 1e-12f ? -inv : inv;           // sign flags the clamped branch of F.normalize
+        zrow[w][lane] = zz;
+        __builtin_amdgcn_wave_barrier();
+        if (lane < K) {
+            float as = 0.0f, at = 0.0f;
+            for (int j = 0; j < D; ++j) {
+                const float pk = P[lane * 33 + j];
+                as = fmaf(zrow[w][j], pk, as);
+                at = fmaf(zrow[w][32 + j], pk, at);
+            }
+            S[b * K + lane] = as;
+            S[(batch + b) * K + lane] = at;
+        }
+        __builtin_amdgcn_wave_barrier();
     }
-    hipLaunchKernelGGL(lsim_k_sinkhorn_pass, dim3(blocks), dim3(256), 0, s, scores, (long)lds, (long)batch, K, 1.0f / eps, (const float*)u, E,
-                       (float*)nullptr, out);
+}
+
+static __device__ __forceinline__ float ls_wave_sum64(float t) {
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+    return t;
+}
+static __device__ __forceinline__ float ls_wave_max64(float t) {
+    for (int off = 32; off > 0; off >>= 1) t = fmaxf(t, __shfl_xor(t, off, 64));
+    return t;
+}
+
+template <int KMAX>
+__global__ __launch_bounds__(256) void lsim_k_est_loss(const float* __restrict__ enc, long ld_o, const float* __restrict__ vel, long ld_v,
+                                                       const float* __restrict__ proto, float* __restrict__ S /* in: scores, out: d loss / d scores */,
+                                                       const float* __restrict__ q /* [2][B][K] */, const float* __restrict__ z,
+                                                       const float* __restrict__ inv_n, long batch, int D, int K, float inv_T,
+                                                       float* __restrict__ d_enc /* [B][3 + D] */, float* __restrict__ d_tgt /* [B][D] */,
+                                                       float* __restrict__ part /* [blocks][2] */) {
+    __shared__ float ds_row[4][2 * KMAX];
+    __shared__ float red[4][2];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, half = lane >> 5, d = lane & 31;
+    const bool act = lane < K;
+    float pc[KMAX];                        // column d of the prototypes, for the (half, d) lane's  d z[d] = sum_k dS[k] P[k][d]
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) pc[k] = (k < K && d < D) ? proto[k * D + d] : 0.0f;
+    const float c = -0.5f / ((float)batch * (float)K), ce = 2.0f / (3.0f * (float)batch);
+    float est_acc = 0.0f, swap_acc = 0.0f;
+    const long r0 = (long)blockIdx.x * LS_EST_ROWS;
+    for (int i = w; i < LS_EST_ROWS; i += 4) {
+        const long b = r0 + i;
+        if (b >= batch) break;
+        const float xs = act ? S[b * K + lane] * inv_T : -INFINITY, xt = act ? S[(batch + b) * K + lane] * inv_T : -INFINITY;
+        const float qs = act ? q[b * K + lane] : 0.0f, qt = act ? q[(batch + b) * K + lane] : 0.0f;
+        const float ms = ls_wave_max64(xs), mt = ls_wave_max64(xt);
+        const float es = expf(xs - ms), et = expf(xt - mt);
+        const float sum_s = ls_wave_sum64(es), sum_t = ls_wave_sum64(et);
+        const float lps = xs - ms - logf(sum_s), lpt = xt - mt - logf(sum_t);
+        if (act) swap_acc += qs * lpt + qt * lps;
+        const float dlps = c * qt, dlpt = c * qs;                  // d loss / d log_p
+        const float gs = ls_wave_sum64(dlps), gt = ls_wave_sum64(dlpt);
+        const float dSs = (dlps - (es / sum_s) * gs) * inv_T, dSt = (dlpt - (et / sum_t) * gt) * inv_T;
+        if (act) { S[b * K + lane] = dSs; S[(batch + b) * K + lane] = dSt; }
+        if (lane < KMAX) { ds_row[w][lane] = act ? dSs : 0.0f; ds_row[w][KMAX + lane] = act ? dSt : 0.0f; }
+        __builtin_amdgcn_wave_barrier();
+        float dz = 0.0f;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) dz = fmaf(ds_row[w][half * KMAX + k], pc[k], dz);
+        __builtin_amdgcn_wave_barrier();
+        const float zz = d < D ? z[((long)half * batch + b) * D + d] : 0.0f;
+        float dot = zz * dz;
+        for (int off = 16; off > 0; off >>= 1) dot += __shfl_xor(dot, off, 64);
+        const float inv = inv_n[(long)half * batch + b];
+        const float dv = inv < 0.0f ? dz * -inv : (dz - zz * dot) * inv;    // F.normalize backward (clamped branch: plain scale)
+        if (d < D) {
+            if (half) d_tgt[b * D + d] = dv;
+            else d_enc[b * (3 + D) + 3 + d] = dv;
+        }
+        if (lane < 3) {
+            const float e = enc[b * ld_o + lane] - vel[b * ld_v + lane];
+            est_acc += e * e;
+            d_enc[b * (3 + D) + lane] = ce * e;
+        }
+    }
+    est_acc = ls_wave_sum64(est_acc);
+    swap_acc = ls_wave_sum64(swap_acc);
+    if (lane == 0) { red[w][0] = est_acc; red[w][1] = swap_acc; }
+    __syncthreads();
+    if (threadIdx.x < 2) part[(size_t)blockIdx.x * 2 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// losses[0] = est, [1] = swap, [2] = est + swap; partial sums added in a fixed order
+__global__ __launch_bounds__(256) void lsim_k_est_finish(const float* __restrict__ part, int blocks, long batch, int K, float* __restrict__ losses) {
+    __shared__ float red[256][2];
+    float a = 0.0f, s = 0.0f;
+    for (int i = threadIdx.x; i < blocks; i += 256) { a += part[(size_t)i * 2]; s += part[(size_t)i * 2 + 1]; }
+    red[threadIdx.x][0] = a; red[threadIdx.x][1] = s;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) { red[threadIdx.x][0] += red[threadIdx.x + st][0]; red[threadIdx.x][1] += red[threadIdx.x + st][1]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float est = red[0][0] / (3.0f * (float)batch), swap = -0.5f * red[0][1] / ((float)batch * (float)K);
+        losses[0] = est; losses[1] = swap; losses[2] = est + swap;
+    }
+}
+
+struct LsEstPlan { size_t z, inv_n, S, q, sk, part, wg, total; };
+static int ls_est_plan(long batch, int D, int K, LsEstPlan* p) {
+    if (batch <= 0 || D <= 0 || D > 32 || K <= 0 || K > 64) return LSIM_E_INVALID;
+    size_t wg_bytes; int np;
+    int rc = lsim_linear_wgrad_workspace(2 * batch, D, K, &wg_bytes, &np);
+    if (rc != LSIM_OK) return rc;
+    const size_t blocks = (size_t)((batch + LS_EST_ROWS - 1) / LS_EST_ROWS);
+    size_t o = 0;
+    auto take = [&o](size_t floats) { const size_t at = o; o += (floats + 63) & ~(size_t)63; return at; };    // 256-byte aligned pieces
+    p->z = take(2 * (size_t)batch * D);
+    p->inv_n = take(2 * (size_t)batch);
+    p->S = take(2 * (size_t)batch * K);
+    p->q = take(2 * (size_t)batch * K);
+    p->sk = take(ls_sinkhorn_floats(batch, K, 2));
+    p->part = take(blocks * 2);
+    p->wg = take((wg_bytes + 3) / 4);
+    p->total = o;
+    return LSIM_OK;
+}
+
+extern "C" int lsim_estimator_loss_workspace(int64_t batch, int latent, int K, size_t* bytes) {
+    if (!bytes) return LSIM_E_INVALID;
+    LsEstPlan p;
+    int rc = ls_est_plan((long)batch, latent, K, &p);
+    if (rc != LSIM_OK) return rc;
+    *bytes = p.total * sizeof(float);
+    return LSIM_OK;
+}
+
+extern "C" int lsim_estimator_loss(const float* enc_out, int64_t ld_enc, const float* tgt_out, int64_t ld_tgt, const float* proto, const float* vel,
+                                   int64_t ld_vel, int64_t batch, int latent, int K, float temperature, float sinkhorn_eps, int sinkhorn_iters,
+                                   float* losses3, float* grad_enc, float* grad_tgt, float* grad_proto, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
+    LsEstPlan p;
+    int rc = ls_est_plan((long)batch, latent, K, &p);
+    if (rc != LSIM_OK) return rc;
+    if (!enc_out || !tgt_out || !proto || !vel || !losses3 || !grad_enc || !grad_tgt || !grad_proto || !workspace ||
+        workspace_bytes < p.total * sizeof(float) || ld_enc < 3 + latent || ld_tgt < latent || ld_vel < 3 || temperature <= 0.0f ||
+        sinkhorn_eps <= 0.0f || sinkhorn_iters < 1 || ((uintptr_t)workspace & 15) != 0)
+        return LSIM_E_INVALID;
+    float* ws = (float*)workspace;
+    hipStream_t s = (hipStream_t)stream;
+    const int blocks = (int)((batch + LS_EST_ROWS - 1) / LS_EST_ROWS);
+    hipLaunchKernelGGL(lsim_k_est_scores, dim3(blocks), dim3(256), 0, s, enc_out, (long)ld_enc, tgt_out, (long)ld_tgt, proto, (long)batch, latent, K,
+                       ws + p.z, ws + p.inv_n, ws + p.S);
+    ls_sinkhorn_launch(ws + p.S, K, (long)batch * K, (long)batch, K, 2, sinkhorn_eps, sinkhorn_iters, ws + p.q, ws + p.sk, s);
+    if (K <= 32)
+        hipLaunchKernelGGL(lsim_k_est_loss<32>, dim3(blocks), dim3(256), 0, s, enc_out, (long)ld_enc, vel, (long)ld_vel, proto, ws + p.S,
+                           (const float*)(ws + p.q), (const float*)(ws + p.z), (const float*)(ws + p.inv_n), (long)batch, latent, K, 1.0f / temperature,
+                           grad_enc, grad_tgt, ws + p.part);
+    else
+        hipLaunchKernelGGL(lsim_k_est_loss<64>, dim3(blocks), dim3(256), 0, s, enc_out, (long)ld_enc, vel, (long)ld_vel, proto, ws + p.S,
+                           (const float*)(ws + p.q), (const float*)(ws + p.z), (const float*)(ws + p.inv_n), (long)batch, latent, K, 1.0f / temperature,
+                           grad_enc, grad_tgt, ws + p.part);
+    hipLaunchKernelGGL(lsim_k_est_finish, dim3(1), dim3(256), 0, s, (const float*)(ws + p.part), blocks, (long)batch, K, losses3);
+    // d P[k][d] = sum over both halves of dS[b][k] z[b][d]: a Linear weight gradient with x = z [2B, D], g = dS [2B, K]
+    size_t wg_bytes; int np;
+    lsim_linear_wgrad_workspace(2 * batch, latent, K, &wg_bytes, &np);
+    rc = ls_linear_wgrad_impl(ws + p.z, latent, ws + p.S, K, nullptr, 0, nullptr, 2 * batch, latent, K, grad_proto, nullptr, ws + p.wg, wg_bytes, s);
+    if (rc != LSIM_OK) return rc;
     return hipGetLastError() == hipSuccess ? LSIM_OK : LSIM_E_HIP;
 }
 

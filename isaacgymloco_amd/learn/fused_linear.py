@@ -198,3 +198,47 @@ class _PpoLossFn(torch.autograd.Function):
 def ppo_loss_hip(mu, sigma, value, actions, old_logp, adv, returns, target_values, old_mu, old_sigma, clip, vcoef, ecoef, clipped):
     """-> (total loss with autograd to mu / sigma / value, stats = [surrogate, value loss, entropy, kl] means, detached)"""
     return _PpoLossFn.apply(mu, sigma, value, actions, old_logp, adv, returns, target_values, old_mu, old_sigma, clip, vcoef, ecoef, clipped)
+
+
+class _EstimatorLossFn(torch.autograd.Function):
+    """loss head of HIMEstimator.update through lsim_estimator_loss: the loss and its three input gradients come from one call"""
+
+    @staticmethod
+    def forward(ctx, enc_out, tgt_out, proto, vel, temperature, eps, iters):
+        from .. import lib
+        L = lib.load()
+        row = lambda t: t.detach() if t.stride(-1) == 1 else t.detach().contiguous()
+        enc_, tgt_, vel_, proto_ = row(enc_out), row(tgt_out), row(vel), proto.detach().contiguous()
+        B, D = tgt_.shape
+        K = proto_.shape[0]
+        need = ctypes.c_size_t()
+        lib.check(L.lsim_estimator_loss_workspace(B, D, K, ctypes.byref(need)), what="lsim_estimator_loss_workspace")
+        ws = _workspaces.get(("estimator_loss", enc_.device))
+        if ws is None or ws.numel() < need.value:
+            ws = torch.empty(need.value, dtype=torch.uint8, device=enc_.device)
+            _workspaces[("estimator_loss", enc_.device)] = ws
+        out = torch.empty(3, device=enc_.device)
+        g_enc, g_tgt, g_proto = torch.empty(B, 3 + D, device=enc_.device), torch.empty(B, D, device=enc_.device), torch.empty_like(proto_)
+        lib.check(L.lsim_estimator_loss(enc_.data_ptr(), enc_.stride(0), tgt_.data_ptr(), tgt_.stride(0), proto_.data_ptr(), vel_.data_ptr(),
+                                        vel_.stride(0), B, D, K, float(temperature), float(eps), int(iters), out.data_ptr(), g_enc.data_ptr(),
+                                        g_tgt.data_ptr(), g_proto.data_ptr(), ws.data_ptr(), ws.numel(),
+                                        torch.cuda.current_stream(enc_.device).cuda_stream), what="lsim_estimator_loss")
+        ctx.save_for_backward(g_enc, g_tgt, g_proto)
+        parts = out[:2]
+        ctx.mark_non_differentiable(parts)
+        return out[2], parts
+
+    @staticmethod
+    def backward(ctx, g_total, _g_parts):
+        grads = list(ctx.saved_tensors)
+        torch._foreach_mul_(grads, g_total)       # private buffers of this call: scaled in place, one launch
+        return grads[0], grads[1], grads[2], None, None, None, None
+
+
+def estimator_loss_hip(enc_out, tgt_out, proto, vel, temperature, eps=0.05, iters=3):
+    """-> (est + swap with autograd to enc_out / tgt_out / proto, [est, swap] detached); see include/lsim.h lsim_estimator_loss"""
+    return _EstimatorLossFn.apply(enc_out, tgt_out, proto, vel, temperature, eps, iters)
+
+
+def estimator_loss_supported(latent, K):
+    return latent <= 32 and K <= 64

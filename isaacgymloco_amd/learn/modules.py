@@ -92,15 +92,22 @@ class HIMEstimator(nn.Module):
     get_latent = forward
 
     def losses(self, obs_history, next_critic_obs):
-        """estimation (MSE on base velocity) and swap (SwAV-style) losses of HES:76-108."""
+        """estimation (MSE on base velocity) and swap (SwAV-style) losses of HES:76-108 -> (est, swap, est + swap to back-propagate)."""
         n = self.num_one_step_obs
         vel = next_critic_obs[:, n:n + 3].detach()
         next_obs = next_critic_obs.detach()[:, 3:n + 3]
         out = self._encoder_out(obs_history, want_grad=True)
-        pred_vel, z_s = out[..., :3], F.normalize(out[..., 3:], dim=-1, p=2)
-        z_t = F.normalize(self.target(next_obs), dim=-1, p=2)
+        tgt = self.target(next_obs)
         with torch.no_grad():
             self.proto.weight.copy_(F.normalize(self.proto.weight.data.clone(), dim=-1, p=2))
+        if out.is_cuda and out.dim() == 2:
+            from .fused_linear import estimator_loss_hip, estimator_loss_supported
+            if estimator_loss_supported(tgt.shape[1], self.proto.weight.shape[0]):
+                # normalise + scores + both Sinkhorn chains + log-softmax + losses and their backward: 12 launches (include/lsim.h)
+                total, parts = estimator_loss_hip(out, tgt, self.proto.weight, vel, self.temperature)
+                return parts[0], parts[1], total
+        pred_vel, z_s = out[..., :3], F.normalize(out[..., 3:], dim=-1, p=2)
+        z_t = F.normalize(tgt, dim=-1, p=2)
         score_s = z_s @ self.proto.weight.T
         score_t = z_t @ self.proto.weight.T
         with torch.no_grad():
@@ -108,17 +115,18 @@ class HIMEstimator(nn.Module):
         log_p_s = F.log_softmax(score_s / self.temperature, dim=-1)
         log_p_t = F.log_softmax(score_t / self.temperature, dim=-1)
         swap = -0.5 * (q_s * log_p_t + q_t * log_p_s).mean()
-        return F.mse_loss(pred_vel, vel), swap
+        est = F.mse_loss(pred_vel, vel)
+        return est, swap, est + swap
 
     def update(self, obs_history, next_critic_obs, lr=None):
         if lr is not None:
             self.learning_rate = lr
             for g in self.optimizer.param_groups:
                 g["lr"] = lr
-        est, swap = self.losses(obs_history, next_critic_obs)
+        est, swap, total = self.losses(obs_history, next_critic_obs)
         self._primed = None
         self.optimizer.zero_grad()
-        (est + swap).backward()
+        total.backward()
         if self.grad_sync is not None:
             self.grad_sync(list(self.parameters()))
         nn.utils.clip_grad_norm_(self.parameters(), self.max_grad_norm)

@@ -455,3 +455,79 @@ def test_reference_style_step_tuple_and_strict_runner_path():
         runs.append(run.alg.storage)
     for name in ("observations", "privileged_observations", "next_privileged_observations", "actions", "rewards", "dones", "values"):
         torch.testing.assert_close(getattr(runs[0], name).float(), getattr(runs[1], name).float(), rtol=1e-6, atol=1e-6, msg=name)
+
+
+def test_fused_estimator_loss_matches_torch_autograd():
+    """lsim_estimator_loss (normalise, scores, Sinkhorn, log-softmax, swap + regression losses, backward) against the fp64 torch statement
+    of HES:76-108 with autograd; losses to 1e-5 relative, gradients to 1e-3 of their scale"""
+    from isaacgymloco_amd.learn.fused_linear import estimator_loss_hip
+    g = torch.Generator(device="cuda:0").manual_seed(11)
+    for B, D, K in ((102400, 16, 32), (5000, 16, 32), (777, 9, 50)):
+        big = torch.randn(B, 3 + D + 5, device="cuda:0", generator=g)
+        enc = big[:, :3 + D].clone().requires_grad_(True)
+        tgt = torch.randn(B, D, device="cuda:0", generator=g).requires_grad_(True)
+        proto = torch.nn.functional.normalize(torch.randn(K, D, device="cuda:0", generator=g), dim=-1).requires_grad_(True)
+        vel = big[:, 3 + D:3 + D + 3]                               # a strided view, as in HIMEstimator.losses
+        total, parts = estimator_loss_hip(enc, tgt, proto, vel, 3.0)
+        total.backward()
+        e64, t64, p64 = (t.detach().double().requires_grad_(True) for t in (enc, tgt, proto))
+        z_s = torch.nn.functional.normalize(e64[:, 3:], dim=-1)
+        z_t = torch.nn.functional.normalize(t64, dim=-1)
+        S_s, S_t = z_s @ p64.T, z_t @ p64.T
+
+        def sk(scores):
+            Q = torch.exp(scores.detach() / 0.05).T
+            Q /= Q.sum()
+            for _ in range(3):
+                Q /= Q.sum(dim=1, keepdim=True); Q /= Q.shape[0]
+                Q /= Q.sum(dim=0, keepdim=True); Q /= Q.shape[1]
+            return (Q * Q.shape[1]).T
+        swap = -0.5 * (sk(S_s) * torch.log_softmax(S_t / 3.0, -1) + sk(S_t) * torch.log_softmax(S_s / 3.0, -1)).mean()
+        est = torch.nn.functional.mse_loss(e64[:, :3], vel.double())
+        (est + swap).backward()
+        torch.testing.assert_close(parts.double(), torch.stack([est, swap]).detach(), rtol=1e-5, atol=1e-7)
+        torch.testing.assert_close(total.double(), (est + swap).detach(), rtol=1e-5, atol=1e-7)
+        for got, ref in ((enc.grad, e64.grad), (tgt.grad, t64.grad), (proto.grad, p64.grad)):
+            scale = ref.abs().max()
+            assert ((got.double() - ref).abs().max() / scale) < 1e-3, ((got.double() - ref).abs().max(), scale)
+        enc2 = enc.detach().clone().requires_grad_(True)
+        total2, _ = estimator_loss_hip(enc2, tgt.detach(), proto.detach(), vel, 3.0)
+        total2.backward()
+        assert torch.equal(total2, total) and torch.equal(enc2.grad, enc.grad)        # deterministic
+
+
+def test_estimator_update_uses_the_fused_loss_and_matches_the_torch_path():
+    """HIMEstimator.update on the GPU (fused loss head) moves the parameters like the torch statement of the same losses"""
+    import copy
+    from isaacgymloco_amd.learn import modules as M
+    torch.manual_seed(3)
+    est = M.HIMEstimator(6, 45).to("cuda:0")
+    ref = copy.deepcopy(est)
+    g = torch.Generator(device="cuda:0").manual_seed(2)
+    hist, nxt = torch.randn(8192, 270, device="cuda:0", generator=g), torch.randn(8192, 45 + 3 + 187, device="cuda:0", generator=g)
+    e1, s1 = est.update(hist, nxt)
+    # the torch statement, on the copy
+    import torch.nn.functional as F
+    n = ref.num_one_step_obs
+    vel, next_obs = nxt[:, n:n + 3], nxt[:, 3:n + 3]
+    out = ref.encoder(hist)
+    z_s, z_t = F.normalize(out[:, 3:], dim=-1), F.normalize(ref.target(next_obs), dim=-1)
+    with torch.no_grad():
+        ref.proto.weight.copy_(F.normalize(ref.proto.weight.data.clone(), dim=-1))
+    S_s, S_t = z_s @ ref.proto.weight.T, z_t @ ref.proto.weight.T
+    with torch.no_grad():
+        q_s, q_t = M.sinkhorn(S_s), M.sinkhorn(S_t)
+    swap = -0.5 * (q_s * F.log_softmax(S_t / ref.temperature, -1) + q_t * F.log_softmax(S_s / ref.temperature, -1)).mean()
+    e2 = F.mse_loss(out[:, :3], vel)
+    ref.optimizer.zero_grad()
+    (e2 + swap).backward()
+    torch.nn.utils.clip_grad_norm_(ref.parameters(), ref.max_grad_norm)
+    ref.optimizer.step()
+    torch.testing.assert_close(e1, e2.detach(), rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(s1, swap.detach(), rtol=1e-4, atol=1e-7)
+    for (k, a), b in zip(est.named_parameters(), ref.parameters()):     # the (clipped) gradients both optimisers consumed
+        if k.startswith("target.") or k.startswith("encoder.") or k.startswith("proto."):
+            assert a.grad is not None and b.grad is not None, k
+            assert (a.grad - b.grad).abs().max() <= 1e-3 * b.grad.abs().max() + 1e-9, k
+    moved = sum(float((a - b).abs().gt(2e-5).float().mean()) for a, b in zip(est.parameters(), ref.parameters()))
+    assert moved < 1e-2        # one Adam step of lr 1e-3 (sign-like): only gradients at the noise floor may step the other way
