@@ -301,9 +301,10 @@ struct LsWgradPlan {
 };
 static int ls_wgrad_plan(long batch, int k_in, int n_out, LsWgradPlan* p) {
     // measured against TunableOp-selected hipBLASLt (tools/wgrad_sweep.sh): the block-cooperative tiled kernel wins up to 512 -> 256
-    // (295 vs 363 us) when the operand rows are 16-byte aligned; with unaligned rows (k_in % 4 != 0: 238 -> 512) it only ties above ~40 k outputs
+    // (295 vs 363 us) when the operand rows are 16-byte aligned; with unaligned rows (k_in % 4 != 0: 238 -> 512) it ties on dW + db alone
+    // (394 + 7 vs 350 + 64 us, tools/wgrad_one.sh) and wins once the ELU backward rides along (saves elu_backward's 100 us pass)
     const long count = (long)k_in * n_out;
-    if (batch <= 0 || k_in <= 0 || n_out <= 0 || count > 140000 || ((k_in & 3) != 0 && count > 40000)) return LSIM_E_UNSUPPORTED;
+    if (batch <= 0 || k_in <= 0 || n_out <= 0 || count > 140000) return LSIM_E_UNSUPPORTED;
     const int nt = (n_out + 15) / 16, kt = (k_in + 15) / 16;
     if (nt <= 8 && kt <= 8 && nt * kt <= LS_WGRAD_MAX_TILES && (long)n_out * k_in <= 4096) {
         p->small = 1;
