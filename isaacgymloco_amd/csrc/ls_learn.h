@@ -119,19 +119,25 @@ __device__ __forceinline__ void ls_wgrad_load4(const float* __restrict__ p, long
         v[0] = row_ok ? t0 : 0.0f; v[1] = row_ok ? t1 : 0.0f; v[2] = row_ok ? t2 : 0.0f; v[3] = row_ok ? t3 : 0.0f;
         return;
     }
-    v[0] = v[1] = v[2] = v[3] = 0.0f;
-    if (!row_ok || c0 >= cmax) return;
-    const float* q = p + row * ld + c0;
-    if (VEC == 2 && c0 + 3 < cmax) {
-        const float4 t = *(const float4*)q;
-        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-    } else if (VEC == 1 && c0 + 3 < cmax) {
-        const float2 t0 = *(const float2*)q, t1 = *(const float2*)(q + 2);
-        v[0] = t0.x; v[1] = t0.y; v[2] = t1.x; v[3] = t1.y;
+    // edge tile: which columns exist is a per-lane constant of the whole batch loop, so there are no branches here either: the same
+    // vector loads as the interior path from a start column clamped into the row (rows are padded to the vector width by the VEC
+    // contract: ld % 4 == 0 resp. ld % 2 == 0), components of columns >= cmax masked to zero
+    const float* r = p + (row_ok ? row : safe_row) * ld;
+    float t[4];
+    if (VEC == 2) {
+        const int last = ((cmax + 3) & ~3) - 4;
+        const float4 u = *(const float4*)(r + (c0 < last ? c0 : last));
+        t[0] = u.x; t[1] = u.y; t[2] = u.z; t[3] = u.w;
+    } else if (VEC == 1) {
+        const int last = ((cmax + 1) & ~1) - 2;
+        const float2 ua = *(const float2*)(r + (c0 < last ? c0 : last)), ub = *(const float2*)(r + (c0 + 2 < last ? c0 + 2 : last));
+        t[0] = ua.x; t[1] = ua.y; t[2] = ub.x; t[3] = ub.y;
     } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) if (c0 + j < cmax) v[j] = q[j];
+        for (int j = 0; j < 4; ++j) t[j] = r[c0 + j < cmax ? c0 + j : cmax - 1];
     }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = (row_ok && c0 + j < cmax) ? t[j] : 0.0f;
 }
 
 // the batch loop of one (tile, slice): operands of the current step and of the next two are in registers (prefetch distance 2:
@@ -142,19 +148,29 @@ __device__ __forceinline__ void ls_wgrad_load4(const float* __restrict__ p, long
 template <int VX, int VG, int KG, bool FULL, bool FZ>
 __device__ __forceinline__ void ls_wgrad_tile_loop(const float* __restrict__ x, long ldx, const float* __restrict__ g, long ldg,
                                                    const float* __restrict__ z, long ldz, float* __restrict__ gy, bool write_gy, long b0, long b1,
-                                                   int n_base, int k_base, int n_out, int k_in, int sub, int col,
+                                                   long safe, int n_base, int k_base, int n_out, int k_in, int sub, int col,
                                                    ls_v4f (&acc)[4][4 * KG], float (&dbacc)[4]) {
     float a0[4], x0[KG][4], a1[4], x1[KG][4], a2[4], x2[KG][4], z1[4], z2[4];
+    // wave-uniform, loop-invariant: does the second 64-column k group of an edge tile exist at all
+    const bool live_k1 = FULL || k_base + 64 < k_in;
+    if (!FULL && KG > 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x1[KG - 1][j] = x2[KG - 1][j] = 0.0f;      // a dead second k group is never loaded
+    }
 #define LS_LOAD_STEP(ROW, A, Z, X) do { const long row_ = (ROW); const bool ok_ = row_ < b1;                                 \
-        ls_wgrad_load4<VG, FULL>(g, ldg, row_, ok_, b0, n_base + 4 * col, n_out, A);                                          \
-        if (FZ) ls_wgrad_load4<VG, FULL>(z, ldz, row_, ok_, b0, n_base + 4 * col, n_out, Z);                                  \
-        ls_wgrad_load4<VX, FULL>(x, ldx, row_, ok_, b0, k_base + 4 * col, k_in, X[0]);                                        \
-        if (KG > 1) ls_wgrad_load4<VX, FULL>(x, ldx, row_, ok_, b0, k_base + 64 + 4 * col, k_in, X[KG - 1]); } while (0)
+        ls_wgrad_load4<VG, FULL>(g, ldg, row_, ok_, safe, n_base + 4 * col, n_out, A);                                 \
+        if (FZ) ls_wgrad_load4<VG, FULL>(z, ldz, row_, ok_, safe, n_base + 4 * col, n_out, Z);                         \
+        ls_wgrad_load4<VX, FULL>(x, ldx, row_, ok_, safe, k_base + 4 * col, k_in, X[0]);                              \
+        if (KG > 1 && live_k1) ls_wgrad_load4<VX, FULL>(x, ldx, row_, ok_, safe, k_base + 64 + 4 * col, k_in, X[KG - 1]); } while (0)
 #define LS_MFMA_STEP(A, X) do {                                                                                              \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                      \
             dbacc[j] += A[j];                                                                                                \
-            _Pragma("unroll") for (int kt = 0; kt < 4 * KG; ++kt)                                                            \
-                acc[j][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[j], X[kt >> 2][kt & 3], acc[j][kt], 0, 0, 0);            \
+            _Pragma("unroll") for (int kt = 0; kt < 4; ++kt)                                                                 \
+                acc[j][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[j], X[0][kt], acc[j][kt], 0, 0, 0);                      \
+            if (KG > 1 && live_k1) {                                                                                         \
+                _Pragma("unroll") for (int kt = 4; kt < 4 * KG; ++kt)                                                        \
+                    acc[j][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[j], X[KG - 1][kt & 3], acc[j][kt], 0, 0, 0);         \
+            }                                                                                                                \
         } } while (0)
     // a0/x0 = operands of the current step, a1/x1 of the next, a2/x2 in flight for the one after.  The rotation copies sit at the
     // TOP of the iteration, so the s_waitcnt they need covers loads issued a whole iteration (32 MFMAs) earlier, and the loads
@@ -216,8 +232,9 @@ void lsim_k_linear_wgrad_tiled(const float* __restrict__ x, long ldx, const floa
 #pragma unroll
         for (int kt = 0; kt < 4 * KG; ++kt) acc[j][kt] = (ls_v4f){0.0f, 0.0f, 0.0f, 0.0f};
     const bool full = (n_base + 64 <= n_out) && (k_base + 64 * KG <= k_in);      // wave-uniform: interior tile
-    if (full) ls_wgrad_tile_loop<VX, VG, KG, true, FZ>(x, ldx, g, ldg, z, ldz, gy, kb == 0, b0, b1, n_base, k_base, n_out, k_in, sub, col, acc, dbacc);
-    else ls_wgrad_tile_loop<VX, VG, KG, false, FZ>(x, ldx, g, ldg, z, ldz, gy, kb == 0, b0, b1, n_base, k_base, n_out, k_in, sub, col, acc, dbacc);
+    const long safe = b0 < batch ? b0 : batch - 1;          // an existing row for the masked loads of rows past the slice
+    if (full) ls_wgrad_tile_loop<VX, VG, KG, true, FZ>(x, ldx, g, ldg, z, ldz, gy, kb == 0, b0, b1, safe, n_base, k_base, n_out, k_in, sub, col, acc, dbacc);
+    else ls_wgrad_tile_loop<VX, VG, KG, false, FZ>(x, ldx, g, ldg, z, ldz, gy, kb == 0, b0, b1, safe, n_base, k_base, n_out, k_in, sub, col, acc, dbacc);
     // block reduction: wave 0 stores its accumulators to LDS (lane-major, 16-byte vectors: no bank conflicts), waves 1-3 add theirs in
     // turn; wave 3 ends up with the block's sums and writes the partial tile
     __shared__ float4 red[4 * 4 * KG][64];
