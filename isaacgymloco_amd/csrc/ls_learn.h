@@ -121,7 +121,8 @@ __device__ __forceinline__ void ls_wgrad_load4(const float* __restrict__ p, long
     }
     // edge tile: which columns exist is a per-lane constant of the whole batch loop, so there are no branches here either: the same
     // vector loads as the interior path from a start column clamped into the row (rows are padded to the vector width by the VEC
-    // contract: ld % 4 == 0 resp. ld % 2 == 0), components of columns >= cmax masked to zero
+    // contract: ld % 4 == 0 resp. ld % 2 == 0).  Components of columns >= cmax are NOT masked: they only reach accumulators of outputs
+    // with n >= n_out or k >= k_in, which are never written (each MFMA output element depends on its own operand row / column only)
     const float* r = p + (row_ok ? row : safe_row) * ld;
     float t[4];
     if (VEC == 2) {
@@ -137,7 +138,7 @@ __device__ __forceinline__ void ls_wgrad_load4(const float* __restrict__ p, long
         for (int j = 0; j < 4; ++j) t[j] = r[c0 + j < cmax ? c0 + j : cmax - 1];
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = (row_ok && c0 + j < cmax) ? t[j] : 0.0f;
+    for (int j = 0; j < 4; ++j) v[j] = row_ok ? t[j] : 0.0f;
 }
 
 // the batch loop of one (tile, slice): operands of the current step and of the next two are in registers (prefetch distance 2:
