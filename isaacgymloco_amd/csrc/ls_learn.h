@@ -420,48 +420,126 @@ extern "C" int lsim_linear_elu_wgrad(const float* x, int64_t ldx, const float* g
 // sum to 1/B}, returned as (Q * B)^T.  Every step of the reference only rescales rows (one factor per prototype) or columns (one
 // factor per sample), so Q[k, b] = E[b, k] * u[k] * v[b] with E = exp(scores / eps) throughout (the initial division by the total
 // sum cancels in the first row normalisation).  Instead of ~26 torch kernels over the (K, B) matrix per call:
-//   pass 0: E, per-block partial column sums of E                     -> u[k] = 1 / (K * sum_b E[b, k])
-//   pass i: v[b] = 1 / (B * sum_k E[b, k] u[k]); partial column sums of E * v   -> u[k] = 1 / (K * sum_b E[b, k] v[b])
-//   last  : out[b, k] = B * E[b, k] * u[k] * v[b]
-// K <= 64 (one lane per prototype); a block owns LS_SK_ROWS consecutive samples; partial sums are added in a fixed order.
-#define LS_SK_ROWS 64            // 16 rows per wave: ~1600 blocks for a 102 400-row minibatch keep every SIMD several waves deep
+//   first: E, per-block partial column sums of E                                  -> u[k] = 1 / (K * sum_b E[b, k])
+//   mid  : v[b] = 1 / (B * sum_k E[b, k] u[k]); partial column sums of E * v       -> u[k] = 1 / (K * sum_b E[b, k] v[b])
+//   last : out[b, k] = B * E[b, k] * u[k] * v[b] = E[b, k] u[k] / sum_k' E[b, k'] u[k']
+// One THREAD per sample row with the row's K <= 64 values in registers (row sums, maxima and exponentials need no cross-lane
+// traffic); a block owns LS_SK_ROWS = 256 consecutive samples and forms its partial column sums through an LDS transpose in a
+// fixed order (deterministic).  blockIdx.y selects one of several independent matrices laid out back to back.
+#define LS_SK_ROWS 256
 
-__global__ __launch_bounds__(256) void lsim_k_sinkhorn_pass(const float* __restrict__ scores, long lds, long batch, int K, float inv_eps,
-                                                            const float* __restrict__ u /* NULL in pass 0 */, float* __restrict__ E,
-                                                            float* __restrict__ part /* [blocks][K] or NULL */, float* __restrict__ out /* last pass */,
-                                                            long scores_mat_stride) {
-    __shared__ float red[4][64];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    {   // blockIdx.y: independent matrices of the same shape laid out back to back (lsim_estimator_loss runs student and target together)
-        const long m = blockIdx.y;
-        scores += m * scores_mat_stride;
-        E += m * batch * K;
-        if (u) u += m * 64;
-        if (part) part += m * (long)gridDim.x * K;
-        if (out) out += m * batch * K;
-    }
-    const long r0 = (long)blockIdx.x * LS_SK_ROWS;
-    const float uk = (u && lane < K) ? u[lane] : 0.0f;
-    float colsum = 0.0f;
-    for (int i = w; i < LS_SK_ROWS; i += 4) {           // one wave per row, lane = prototype
-        const long b = r0 + i;
-        if (b >= batch) break;
-        float e = 0.0f;
-        if (lane < K) {
-            if (!u) { e = expf(scores[b * lds + lane] * inv_eps); E[b * K + lane] = e; }
-            else e = E[b * K + lane];
+template <int KMAX>
+__device__ __forceinline__ void ls_row_load(const float* __restrict__ p, int K, bool vec, float fill, float (&v)[KMAX]) {
+    // loads from clamped offsets + selects: no branch per element (K is a run-time value)
+    if (vec) {        // K % 4 == 0 and 16-byte aligned rows
+#pragma unroll
+        for (int k = 0; k < KMAX; k += 4) {
+            const float4 t = *(const float4*)(p + (k < K ? k : 0));
+            v[k] = k < K ? t.x : fill; v[k + 1] = k < K ? t.y : fill; v[k + 2] = k < K ? t.z : fill; v[k + 3] = k < K ? t.w : fill;
         }
-        if (!u) { colsum += e; continue; }
-        float t = e * uk;
-        for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
-        const float v = 1.0f / ((float)batch * t);
-        if (out) { if (lane < K) out[b * K + lane] = (float)batch * e * uk * v; }
-        else colsum += e * v;
+    } else {
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) { const float t = p[k < K ? k : 0]; v[k] = k < K ? t : fill; }
     }
-    if (!part) return;
-    red[w][lane] = colsum;
+}
+template <int KMAX>
+__device__ __forceinline__ void ls_row_store(float* __restrict__ p, int K, bool vec, const float (&v)[KMAX]) {
+    if (vec) {
+#pragma unroll
+        for (int k = 0; k < KMAX; k += 4) if (k < K) *(float4*)(p + k) = make_float4(v[k], v[k + 1], v[k + 2], v[k + 3]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) if (k < K) p[k] = v[k];
+    }
+}
+
+// partial column sums of a block's 256 rows (one row per thread, zeros for rows past the batch): rows go through an LDS tile in two
+// rounds of 128, thread (g, k) adds rows g, g + G, ... of column k, thread k adds the G group sums; every order is fixed.
+// tile: LS_COLSUM_TILE(KMAX) floats.
+#define LS_COLSUM_TILE(KMAX) (128 * ((KMAX) + 1))
+template <int KMAX>
+__device__ __forceinline__ void ls_block_colsum(const float (&v)[KMAX], float* __restrict__ tile, float* __restrict__ part_row /* [K] */, int K) {
+    constexpr int G = 256 / KMAX;
+    const int t = threadIdx.x, k = t & (KMAX - 1), g = t / KMAX;
+    float s = 0.0f;
+    for (int round = 0; round < 2; ++round) {
+        __syncthreads();                      // the tile may still be read (previous round / previous use)
+        if ((t >> 7) == round) {
+#pragma unroll
+            for (int j = 0; j < KMAX; ++j) tile[(t & 127) * (KMAX + 1) + j] = v[j];
+        }
+        __syncthreads();
+        for (int r = g; r < 128; r += G) s += tile[r * (KMAX + 1) + k];
+    }
     __syncthreads();
-    if (w == 0 && lane < K) part[(size_t)blockIdx.x * K + lane] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    tile[g * (KMAX + 1) + k] = s;
+    __syncthreads();
+    if (t < K) {
+        float a = 0.0f;
+#pragma unroll
+        for (int j = 0; j < G; ++j) a += tile[j * (KMAX + 1) + t];
+        part_row[t] = a;
+    }
+}
+
+template <int KMAX>
+__global__ __launch_bounds__(256) void lsim_k_sinkhorn_first(const float* __restrict__ scores, long lds, long scores_mat_stride, long batch, int K,
+                                                             float inv_eps, bool vec_in, float* __restrict__ E, float* __restrict__ part) {
+    __shared__ float tile[LS_COLSUM_TILE(KMAX)];
+    const long m = blockIdx.y, b = (long)blockIdx.x * LS_SK_ROWS + threadIdx.x;
+    const bool vec = (K & 3) == 0;
+    float v[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) v[k] = 0.0f;
+    if (b < batch) {
+        ls_row_load<KMAX>(scores + m * scores_mat_stride + b * lds, K, vec_in, 0.0f, v);
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) v[k] = k < K ? expf(v[k] * inv_eps) : 0.0f;
+        ls_row_store<KMAX>(E + (m * batch + b) * K, K, vec, v);
+    }
+    ls_block_colsum<KMAX>(v, tile, part + (m * gridDim.x + blockIdx.x) * K, K);
+}
+
+template <int KMAX>
+__global__ __launch_bounds__(256) void lsim_k_sinkhorn_mid(const float* __restrict__ E, const float* __restrict__ u, long batch, int K,
+                                                           float* __restrict__ part) {
+    __shared__ float tile[LS_COLSUM_TILE(KMAX)];
+    __shared__ float us[KMAX];
+    const long m = blockIdx.y, b = (long)blockIdx.x * LS_SK_ROWS + threadIdx.x;
+    if (threadIdx.x < KMAX) us[threadIdx.x] = (int)threadIdx.x < K ? u[m * 64 + threadIdx.x] : 0.0f;
+    __syncthreads();
+    float v[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) v[k] = 0.0f;
+    if (b < batch) {
+        ls_row_load<KMAX>(E + (m * batch + b) * K, K, (K & 3) == 0, 0.0f, v);
+        float t = 0.0f;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) t = fmaf(v[k], us[k], t);
+        const float vb = 1.0f / ((float)batch * t);
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) v[k] *= vb;
+    }
+    ls_block_colsum<KMAX>(v, tile, part + (m * gridDim.x + blockIdx.x) * K, K);
+}
+
+template <int KMAX>
+__global__ __launch_bounds__(256) void lsim_k_sinkhorn_last(const float* __restrict__ E, const float* __restrict__ u, long batch, int K,
+                                                            float* __restrict__ out) {
+    __shared__ float us[KMAX];
+    const long m = blockIdx.y, b = (long)blockIdx.x * LS_SK_ROWS + threadIdx.x;
+    if (threadIdx.x < KMAX) us[threadIdx.x] = (int)threadIdx.x < K ? u[m * 64 + threadIdx.x] : 0.0f;
+    __syncthreads();
+    if (b >= batch) return;
+    float v[KMAX];
+    ls_row_load<KMAX>(E + (m * batch + b) * K, K, (K & 3) == 0, 0.0f, v);
+    float t = 0.0f;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) { v[k] *= us[k]; t += v[k]; }
+    const float vb = 1.0f / ((float)batch * t);
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) v[k] = (float)batch * v[k] * vb;
+    ls_row_store<KMAX>(out + (m * batch + b) * K, K, (K & 3) == 0, v);
 }
 
 // u[k] = 1 / (K * sum over blocks of part[block][k]); 16 interleaved slices per prototype, combined in LDS in a fixed order
@@ -488,7 +566,16 @@ __global__ __launch_bounds__(1024) void lsim_k_sinkhorn_scale(const float* __res
 
 static size_t ls_sinkhorn_floats(long batch, int K, int mats) {
     const long blocks = (batch + LS_SK_ROWS - 1) / LS_SK_ROWS;
-    return (size_t)mats * ((size_t)batch * K + (size_t)blocks * K + 64);
+    return (size_t)mats * (((size_t)batch * K + 63) / 64 * 64 + (size_t)blocks * K + 64);
+}
+struct LsSkBufs { float *E, *part, *u; int blocks; };
+static LsSkBufs ls_sinkhorn_bufs(float* workspace, long batch, int K, int mats) {
+    LsSkBufs b;
+    b.blocks = (int)((batch + LS_SK_ROWS - 1) / LS_SK_ROWS);
+    b.E = workspace;
+    b.part = b.E + (size_t)mats * (((size_t)batch * K + 63) / 64 * 64);
+    b.u = b.part + (size_t)mats * b.blocks * K;
+    return b;
 }
 
 extern "C" int lsim_sinkhorn_workspace(long batch, int K, size_t* bytes) {
@@ -497,24 +584,23 @@ extern "C" int lsim_sinkhorn_workspace(long batch, int K, size_t* bytes) {
     return LSIM_OK;
 }
 
-// `mats` matrices [batch, K] (row stride lds, matrix stride scores_mat_stride) -> out [mats][batch][K]; workspace: ls_sinkhorn_floats()
-static void ls_sinkhorn_launch(const float* scores, long lds, long scores_mat_stride, long batch, int K, int mats, float eps, int iters, float* out,
-                               float* workspace, hipStream_t s) {
-    const int blocks = (int)((batch + LS_SK_ROWS - 1) / LS_SK_ROWS);
-    float* E = workspace;
-    float* part = E + (size_t)mats * batch * K;
-    float* u = part + (size_t)mats * blocks * K;
-    const dim3 grid(blocks, mats), one(1, mats);
-    hipLaunchKernelGGL(lsim_k_sinkhorn_pass, grid, dim3(256), 0, s, scores, lds, batch, K, 1.0f / eps, (const float*)nullptr, E, part, (float*)nullptr,
-                       scores_mat_stride);
-    hipLaunchKernelGGL(lsim_k_sinkhorn_scale, one, dim3(1024), 0, s, part, blocks, K, u);
+// the column / row rescaling rounds after `first` has filled E and its partial sums: leaves the final u (E and u define the result)
+template <int KMAX> static void ls_sinkhorn_rounds(const LsSkBufs& w, long batch, int K, int mats, int iters, hipStream_t s) {
+    const dim3 grid(w.blocks, mats), one(1, mats);
+    hipLaunchKernelGGL(lsim_k_sinkhorn_scale, one, dim3(1024), 0, s, (const float*)w.part, w.blocks, K, w.u);
     for (int it = 1; it < iters; ++it) {
-        hipLaunchKernelGGL(lsim_k_sinkhorn_pass, grid, dim3(256), 0, s, scores, lds, batch, K, 1.0f / eps, (const float*)u, E, part, (float*)nullptr,
-                           scores_mat_stride);
-        hipLaunchKernelGGL(lsim_k_sinkhorn_scale, one, dim3(1024), 0, s, part, blocks, K, u);
+        hipLaunchKernelGGL(lsim_k_sinkhorn_mid<KMAX>, grid, dim3(256), 0, s, (const float*)w.E, (const float*)w.u, batch, K, w.part);
+        hipLaunchKernelGGL(lsim_k_sinkhorn_scale, one, dim3(1024), 0, s, (const float*)w.part, w.blocks, K, w.u);
     }
-    hipLaunchKernelGGL(lsim_k_sinkhorn_pass, grid, dim3(256), 0, s, scores, lds, batch, K, 1.0f / eps, (const float*)u, E, (float*)nullptr, out,
-                       scores_mat_stride);
+}
+
+template <int KMAX> static void ls_sinkhorn_run(const float* scores, long lds, long batch, int K, float eps, int iters, float* out, float* workspace,
+                                                hipStream_t s) {
+    const LsSkBufs w = ls_sinkhorn_bufs(workspace, batch, K, 1);
+    const bool vec_in = (K & 3) == 0 && (lds & 3) == 0 && ((uintptr_t)scores & 15) == 0;
+    hipLaunchKernelGGL(lsim_k_sinkhorn_first<KMAX>, dim3(w.blocks, 1), dim3(256), 0, s, scores, lds, 0L, batch, K, 1.0f / eps, vec_in, w.E, w.part);
+    ls_sinkhorn_rounds<KMAX>(w, batch, K, 1, iters, s);
+    hipLaunchKernelGGL(lsim_k_sinkhorn_last<KMAX>, dim3(w.blocks, 1), dim3(256), 0, s, (const float*)w.E, (const float*)w.u, batch, K, out);
 }
 
 extern "C" int lsim_sinkhorn(const float* scores, int64_t lds, int64_t batch, int K, float eps, int iters, float* out,
@@ -522,8 +608,11 @@ extern "C" int lsim_sinkhorn(const float* scores, int64_t lds, int64_t batch, in
     size_t need;
     int rc = lsim_sinkhorn_workspace(batch, K, &need);
     if (rc != LSIM_OK) return rc;
-    if (!scores || !out || !workspace || workspace_bytes < need || iters < 1 || lds < K || eps <= 0.0f) return LSIM_E_INVALID;
-    ls_sinkhorn_launch(scores, (long)lds, 0, (long)batch, K, 1, eps, iters, out, (float*)workspace, (hipStream_t)stream);
+    if (!scores || !out || !workspace || workspace_bytes < need || iters < 1 || lds < K || eps <= 0.0f || ((uintptr_t)workspace & 15) != 0 ||
+        ((uintptr_t)out & 15) != 0)
+        return LSIM_E_INVALID;
+    if (K <= 32) ls_sinkhorn_run<32>(scores, (long)lds, (long)batch, K, eps, iters, out, (float*)workspace, (hipStream_t)stream);
+    else ls_sinkhorn_run<64>(scores, (long)lds, (long)batch, K, eps, iters, out, (float*)workspace, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? LSIM_OK : LSIM_E_HIP;
 }
 
@@ -531,45 +620,57 @@ extern "C" int lsim_sinkhorn(const float* scores, int64_t lds, int64_t batch, in
 //   pred_vel, l_s = enc[:, :3], enc[:, 3:];   z_s = l_s / max(|l_s|, 1e-12);   z_t = tgt / max(|tgt|, 1e-12)
 //   S_s = z_s P^T, S_t = z_t P^T (P: K row-normalised prototypes);   q_s, q_t = sinkhorn(S_s), sinkhorn(S_t)       (no gradient)
 //   swap = -0.5 mean_{b,k} (q_s log_softmax(S_t / T) + q_t log_softmax(S_s / T));   est = mean_{b,c} (pred_vel - vel)^2
-// and d (est + swap) / d enc [B, 3 + D], / d tgt [B, D], / d P [K, D].  Launches: scores (1), both Sinkhorn chains together (2 iters + 1
-// each for pass and scale), loss + row gradients (1), finish (1), prototype gradient through lsim_linear_wgrad's single-wave kernel (2):
-// 12 instead of the ~75 torch kernels of the same arithmetic.  One wave per sample row, lane = prototype (K <= 64), D <= 32.
-#define LS_EST_ROWS 64
+// and d (est + swap) / d enc [B, 3 + D], / d tgt [B, D], / d P [K, D].  Launches: scores + first Sinkhorn pass of both matrices (1),
+// the remaining Sinkhorn rounds of both together (2 iters - 1), loss + row gradients with the last Sinkhorn step folded in (1), finish
+// (1), prototype gradient through lsim_linear_wgrad's single-wave kernel (2): 10 instead of the ~75 torch kernels of the same
+// arithmetic.  One thread per sample row, the row's K <= 64 scores and D <= 32 latents in registers.
+template <int KMAX, int DMAX>
+__device__ __forceinline__ void ls_load_proto_lds(const float* __restrict__ proto, int K, int D, float* __restrict__ P /* [KMAX][DMAX] */) {
+    for (int i = threadIdx.x; i < KMAX * DMAX; i += 256) {
+        const int k = i / DMAX, d = i - k * DMAX;
+        P[i] = (k < K && d < D) ? proto[k * D + d] : 0.0f;
+    }
+}
 
-__global__ __launch_bounds__(256) void lsim_k_est_scores(const float* __restrict__ enc, long ld_o, const float* __restrict__ tgt, long ld_t,
-                                                         const float* __restrict__ proto, long batch, int D, int K,
+template <int KMAX, int DMAX>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void lsim_k_est_scores(const float* __restrict__ enc, long ld_o, const float* __restrict__ tgt, long ld_t,
+                                                         const float* __restrict__ proto, long batch, int D, int K, float inv_eps,
                                                          float* __restrict__ z /* [2][B][D] */, float* __restrict__ inv_n /* [2][B] */,
-                                                         float* __restrict__ S /* [2][B][K] */) {
-    __shared__ float P[64 * 33];           // P[k][d], row stride 33: lane = k reads are bank-conflict free
-    __shared__ float zrow[4][64];          // per wave: z_s | z_t of the current row
-    for (int i = threadIdx.x; i < K * D; i += 256) P[(i / D) * 33 + (i % D)] = proto[i];
+                                                         float* __restrict__ S /* [2][B][K] */, float* __restrict__ E /* [2][B][K] */,
+                                                         float* __restrict__ part /* [2][blocks][K] */) {
+    __shared__ float tile[LS_COLSUM_TILE(KMAX)];
+    __shared__ __attribute__((aligned(16))) float P[KMAX * DMAX];
+    ls_load_proto_lds<KMAX, DMAX>(proto, K, D, P);
     __syncthreads();
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, half = lane >> 5, d = lane & 31;
-    const long r0 = (long)blockIdx.x * LS_EST_ROWS;
-    for (int i = w; i < LS_EST_ROWS; i += 4) {
-        const long b = r0 + i;
-        if (b >= batch) break;
-        const float v = d < D ? (half ? tgt[b * ld_t + d] : enc[b * ld_o + 3 + d]) : 0.0f;
-        float ss = v * v;
-        for (int off = 16; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);        // within each 32-lane half
-        const float n = sqrtf(ss);
-        const float inv = 1.0f / fmaxf(n, 1e-12f);
-        const float zz = v * inv;
-        if (d < D) z[((long)half * batch + b) * D + d] = zz;
-        if (d == 0) inv_n[(long)half * batch + b] = n < 1e-12f ? -inv : inv;           // sign flags the clamped branch of F.normalize
-        zrow[w][lane] = zz;
-        __builtin_amdgcn_wave_barrier();
-        if (lane < K) {
-            float as = 0.0f, at = 0.0f;
-            for (int j = 0; j < D; ++j) {
-                const float pk = P[lane * 33 + j];
-                as = fmaf(zrow[w][j], pk, as);
-                at = fmaf(zrow[w][32 + j], pk, at);
+    const long b = (long)blockIdx.x * LS_SK_ROWS + threadIdx.x;
+    const bool vec = (K & 3) == 0;
+    for (int m = 0; m < 2; ++m) {            // student, target
+        float sc[KMAX];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) sc[k] = 0.0f;
+        if (b < batch) {
+            const float* src = m ? tgt + b * ld_t : enc + b * ld_o + 3;
+            float zz[DMAX], ss = 0.0f;
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) { const float t = src[d < D ? d : 0]; zz[d] = d < D ? t : 0.0f; ss = fmaf(zz[d], zz[d], ss); }
+            const float n = sqrtf(ss), inv = 1.0f / fmaxf(n, 1e-12f);
+            inv_n[(long)m * batch + b] = n < 1e-12f ? -inv : inv;          // sign flags the clamped branch of F.normalize
+            float* zdst = z + ((long)m * batch + b) * D;
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) { zz[d] *= inv; if (d < D) zdst[d] = zz[d]; }
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                float a = 0.0f;
+#pragma unroll
+                for (int d = 0; d < DMAX; ++d) a = fmaf(zz[d], P[k * DMAX + d], a);
+                sc[k] = a;
             }
-            S[b * K + lane] = as;
-            S[(batch + b) * K + lane] = at;
+            ls_row_store<KMAX>(S + ((long)m * batch + b) * K, K, vec, sc);
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) sc[k] = k < K ? expf(sc[k] * inv_eps) : 0.0f;
+            ls_row_store<KMAX>(E + ((long)m * batch + b) * K, K, vec, sc);
         }
-        __builtin_amdgcn_wave_barrier();
+        ls_block_colsum<KMAX>(sc, tile, part + ((long)m * gridDim.x + blockIdx.x) * K, K);
     }
 }
 
@@ -577,65 +678,95 @@ static __device__ __forceinline__ float ls_wave_sum64(float t) {
     for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
     return t;
 }
-static __device__ __forceinline__ float ls_wave_max64(float t) {
-    for (int off = 32; off > 0; off >>= 1) t = fmaxf(t, __shfl_xor(t, off, 64));
-    return t;
-}
 
-template <int KMAX>
-__global__ __launch_bounds__(256) void lsim_k_est_loss(const float* __restrict__ enc, long ld_o, const float* __restrict__ vel, long ld_v,
+template <int KMAX, int DMAX>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void lsim_k_est_loss(const float* __restrict__ enc, long ld_o, const float* __restrict__ vel, long ld_v,
                                                        const float* __restrict__ proto, float* __restrict__ S /* in: scores, out: d loss / d scores */,
-                                                       const float* __restrict__ q /* [2][B][K] */, const float* __restrict__ z,
+                                                       const float* __restrict__ E, const float* __restrict__ u, const float* __restrict__ z,
                                                        const float* __restrict__ inv_n, long batch, int D, int K, float inv_T,
                                                        float* __restrict__ d_enc /* [B][3 + D] */, float* __restrict__ d_tgt /* [B][D] */,
                                                        float* __restrict__ part /* [blocks][2] */) {
-    __shared__ float ds_row[4][2 * KMAX];
+    __shared__ __attribute__((aligned(16))) float P[KMAX * DMAX];
+    __shared__ float us[2][KMAX];
     __shared__ float red[4][2];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, half = lane >> 5, d = lane & 31;
-    const bool act = lane < K;
-    float pc[KMAX];                        // column d of the prototypes, for the (half, d) lane's  d z[d] = sum_k dS[k] P[k][d]
-#pragma unroll
-    for (int k = 0; k < KMAX; ++k) pc[k] = (k < K && d < D) ? proto[k * D + d] : 0.0f;
+    __shared__ float xt[32 * 256];
+    ls_load_proto_lds<KMAX, DMAX>(proto, K, D, P);
+    if (threadIdx.x < 2 * KMAX) { const int m = threadIdx.x / KMAX, k = threadIdx.x % KMAX; us[m][k] = k < K ? u[m * 64 + k] : 0.0f; }
+    __syncthreads();
+    const long b = (long)blockIdx.x * LS_SK_ROWS + threadIdx.x;
+    const bool vec = (K & 3) == 0;
     const float c = -0.5f / ((float)batch * (float)K), ce = 2.0f / (3.0f * (float)batch);
     float est_acc = 0.0f, swap_acc = 0.0f;
-    const long r0 = (long)blockIdx.x * LS_EST_ROWS;
-    for (int i = w; i < LS_EST_ROWS; i += 4) {
-        const long b = r0 + i;
-        if (b >= batch) break;
-        const float xs = act ? S[b * K + lane] * inv_T : -INFINITY, xt = act ? S[(batch + b) * K + lane] * inv_T : -INFINITY;
-        const float qs = act ? q[b * K + lane] : 0.0f, qt = act ? q[(batch + b) * K + lane] : 0.0f;
-        const float ms = ls_wave_max64(xs), mt = ls_wave_max64(xt);
-        const float es = expf(xs - ms), et = expf(xt - mt);
-        const float sum_s = ls_wave_sum64(es), sum_t = ls_wave_sum64(et);
-        const float lps = xs - ms - logf(sum_s), lpt = xt - mt - logf(sum_t);
-        if (act) swap_acc += qs * lpt + qt * lps;
-        const float dlps = c * qt, dlpt = c * qs;                  // d loss / d log_p
-        const float gs = ls_wave_sum64(dlps), gt = ls_wave_sum64(dlpt);
-        const float dSs = (dlps - (es / sum_s) * gs) * inv_T, dSt = (dlpt - (et / sum_t) * gt) * inv_T;
-        if (act) { S[b * K + lane] = dSs; S[(batch + b) * K + lane] = dSt; }
-        if (lane < KMAX) { ds_row[w][lane] = act ? dSs : 0.0f; ds_row[w][KMAX + lane] = act ? dSt : 0.0f; }
-        __builtin_amdgcn_wave_barrier();
-        float dz = 0.0f;
+    if (b < batch) {
+        // m = 0: the target's assignment q_t weights the student's log-softmax -> gradient to the student scores; m = 1 the other way
+#pragma unroll 1
+        for (int m = 0; m < 2; ++m) {
+            float q[KMAX], x[KMAX];
+            ls_row_load<KMAX>(E + ((long)(1 - m) * batch + b) * K, K, vec, 0.0f, q);
+            float qsum = 0.0f;
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k) dz = fmaf(ds_row[w][half * KMAX + k], pc[k], dz);
-        __builtin_amdgcn_wave_barrier();
-        const float zz = d < D ? z[((long)half * batch + b) * D + d] : 0.0f;
-        float dot = zz * dz;
-        for (int off = 16; off > 0; off >>= 1) dot += __shfl_xor(dot, off, 64);
-        const float inv = inv_n[(long)half * batch + b];
-        const float dv = inv < 0.0f ? dz * -inv : (dz - zz * dot) * inv;    // F.normalize backward (clamped branch: plain scale)
-        if (d < D) {
-            if (half) d_tgt[b * D + d] = dv;
-            else d_enc[b * (3 + D) + 3 + d] = dv;
+            for (int k = 0; k < KMAX; ++k) { q[k] *= us[1 - m][k]; qsum += q[k]; }
+            const float qn = 1.0f / qsum;                        // last Sinkhorn step: B E u v = E u / sum_k E u
+            float* srow = S + ((long)m * batch + b) * K;
+            ls_row_load<KMAX>(srow, K, vec, -INFINITY, x);
+            float mx = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) { x[k] *= inv_T; mx = fmaxf(mx, x[k]); }
+            float se = 0.0f;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) se += expf(x[k] - mx);
+            const float lse = mx + logf(se);
+            float gsum = 0.0f, dot = 0.0f;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                q[k] *= qn;
+                const float lp = k < K ? x[k] - lse : 0.0f;
+                dot = fmaf(q[k], lp, dot);
+                gsum += c * q[k];
+                x[k] = lp;
+            }
+            swap_acc += dot;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) x[k] = k < K ? (c * q[k] - expf(x[k]) * gsum) * inv_T : 0.0f;      // d loss / d score
+            ls_row_store<KMAX>(srow, K, vec, x);
+            // d z = dS P, then F.normalize backward
+            float dz[DMAX];
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) dz[d] = 0.0f;
+            // the row goes through a thread-private LDS column so that k can be a rolled loop (an unrolled K x D block of prototype
+            // reads blows the register allocation up): xt[j][t], 32 prototypes at a time
+#pragma unroll
+            for (int c0 = 0; c0 < KMAX; c0 += 32) {
+#pragma unroll
+                for (int j = 0; j < 32; ++j) xt[j * 256 + threadIdx.x] = x[c0 + j];
+#pragma unroll 4
+                for (int j = 0; j < 32; ++j) {
+                    const float xk = xt[j * 256 + threadIdx.x];
+                    const float* pr = P + (c0 + j) * DMAX;
+#pragma unroll
+                    for (int d = 0; d < DMAX; ++d) dz[d] = fmaf(xk, pr[d], dz[d]);
+                }
+            }
+            const float* zrow = z + ((long)m * batch + b) * D;
+            float zz[DMAX], zd = 0.0f;
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) { const float t = zrow[d < D ? d : 0]; zz[d] = d < D ? t : 0.0f; zd = fmaf(zz[d], dz[d], zd); }
+            const float inv = inv_n[(long)m * batch + b];
+            float* dst = m ? d_tgt + b * D : d_enc + b * (3 + D) + 3;
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d)
+                if (d < D) dst[d] = inv < 0.0f ? dz[d] * -inv : (dz[d] - zz[d] * zd) * inv;      // clamped branch: plain scale
         }
-        if (lane < 3) {
-            const float e = enc[b * ld_o + lane] - vel[b * ld_v + lane];
-            est_acc += e * e;
-            d_enc[b * (3 + D) + lane] = ce * e;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float e = enc[b * ld_o + j] - vel[b * ld_v + j];
+            est_acc = fmaf(e, e, est_acc);
+            d_enc[b * (3 + D) + j] = ce * e;
         }
     }
     est_acc = ls_wave_sum64(est_acc);
     swap_acc = ls_wave_sum64(swap_acc);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (lane == 0) { red[w][0] = est_acc; red[w][1] = swap_acc; }
     __syncthreads();
     if (threadIdx.x < 2) part[(size_t)blockIdx.x * 2 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
@@ -658,19 +789,18 @@ __global__ __launch_bounds__(256) void lsim_k_est_finish(const float* __restrict
     }
 }
 
-struct LsEstPlan { size_t z, inv_n, S, q, sk, part, wg, total; };
+struct LsEstPlan { size_t z, inv_n, S, sk, part, wg, total; };
 static int ls_est_plan(long batch, int D, int K, LsEstPlan* p) {
     if (batch <= 0 || D <= 0 || D > 32 || K <= 0 || K > 64) return LSIM_E_INVALID;
     size_t wg_bytes; int np;
     int rc = lsim_linear_wgrad_workspace(2 * batch, D, K, &wg_bytes, &np);
     if (rc != LSIM_OK) return rc;
-    const size_t blocks = (size_t)((batch + LS_EST_ROWS - 1) / LS_EST_ROWS);
+    const size_t blocks = (size_t)((batch + LS_SK_ROWS - 1) / LS_SK_ROWS);
     size_t o = 0;
     auto take = [&o](size_t floats) { const size_t at = o; o += (floats + 63) & ~(size_t)63; return at; };    // 256-byte aligned pieces
     p->z = take(2 * (size_t)batch * D);
     p->inv_n = take(2 * (size_t)batch);
     p->S = take(2 * (size_t)batch * K);
-    p->q = take(2 * (size_t)batch * K);
     p->sk = take(ls_sinkhorn_floats(batch, K, 2));
     p->part = take(blocks * 2);
     p->wg = take((wg_bytes + 3) / 4);
@@ -687,6 +817,30 @@ extern "C" int lsim_estimator_loss_workspace(int64_t batch, int latent, int K, s
     return LSIM_OK;
 }
 
+struct LsEstArgs {
+    const float *enc, *tgt, *proto, *vel;
+    long ld_enc, ld_tgt, ld_vel, batch;
+    int D, K, iters;
+    float inv_T, eps;
+    float *losses, *g_enc, *g_tgt;
+};
+template <int KMAX, int DMAX> static void ls_est_launch(const LsEstArgs& a, float* ws, const LsEstPlan& p, hipStream_t s) {
+    // the matrix pair of the Sinkhorn workspace: E of student and target back to back (a multiple of 64 floats apart only when
+    // batch * K is; the kernels index [m * batch + b], so use the unpadded layout: E for both matrices is contiguous)
+    LsSkBufs w;
+    w.blocks = (int)((a.batch + LS_SK_ROWS - 1) / LS_SK_ROWS);
+    w.E = ws + p.sk;
+    w.part = w.E + (((size_t)2 * a.batch * a.K + 63) / 64 * 64);
+    w.u = w.part + (size_t)2 * w.blocks * a.K;
+    hipLaunchKernelGGL((lsim_k_est_scores<KMAX, DMAX>), dim3(w.blocks), dim3(256), 0, s, a.enc, a.ld_enc, a.tgt, a.ld_tgt, a.proto, a.batch, a.D, a.K,
+                       1.0f / a.eps, ws + p.z, ws + p.inv_n, ws + p.S, w.E, w.part);
+    ls_sinkhorn_rounds<KMAX>(w, a.batch, a.K, 2, a.iters, s);
+    hipLaunchKernelGGL((lsim_k_est_loss<KMAX, DMAX>), dim3(w.blocks), dim3(256), 0, s, a.enc, a.ld_enc, a.vel, a.ld_vel, a.proto, ws + p.S,
+                       (const float*)w.E, (const float*)w.u, (const float*)(ws + p.z), (const float*)(ws + p.inv_n), a.batch, a.D, a.K, a.inv_T,
+                       a.g_enc, a.g_tgt, ws + p.part);
+    hipLaunchKernelGGL(lsim_k_est_finish, dim3(1), dim3(256), 0, s, (const float*)(ws + p.part), w.blocks, a.batch, a.K, a.losses);
+}
+
 extern "C" int lsim_estimator_loss(const float* enc_out, int64_t ld_enc, const float* tgt_out, int64_t ld_tgt, const float* proto, const float* vel,
                                    int64_t ld_vel, int64_t batch, int latent, int K, float temperature, float sinkhorn_eps, int sinkhorn_iters,
                                    float* losses3, float* grad_enc, float* grad_tgt, float* grad_proto, void* workspace, size_t workspace_bytes,
@@ -700,19 +854,12 @@ extern "C" int lsim_estimator_loss(const float* enc_out, int64_t ld_enc, const f
         return LSIM_E_INVALID;
     float* ws = (float*)workspace;
     hipStream_t s = (hipStream_t)stream;
-    const int blocks = (int)((batch + LS_EST_ROWS - 1) / LS_EST_ROWS);
-    hipLaunchKernelGGL(lsim_k_est_scores, dim3(blocks), dim3(256), 0, s, enc_out, (long)ld_enc, tgt_out, (long)ld_tgt, proto, (long)batch, latent, K,
-                       ws + p.z, ws + p.inv_n, ws + p.S);
-    ls_sinkhorn_launch(ws + p.S, K, (long)batch * K, (long)batch, K, 2, sinkhorn_eps, sinkhorn_iters, ws + p.q, ws + p.sk, s);
-    if (K <= 32)
-        hipLaunchKernelGGL(lsim_k_est_loss<32>, dim3(blocks), dim3(256), 0, s, enc_out, (long)ld_enc, vel, (long)ld_vel, proto, ws + p.S,
-                           (const float*)(ws + p.q), (const float*)(ws + p.z), (const float*)(ws + p.inv_n), (long)batch, latent, K, 1.0f / temperature,
-                           grad_enc, grad_tgt, ws + p.part);
-    else
-        hipLaunchKernelGGL(lsim_k_est_loss<64>, dim3(blocks), dim3(256), 0, s, enc_out, (long)ld_enc, vel, (long)ld_vel, proto, ws + p.S,
-                           (const float*)(ws + p.q), (const float*)(ws + p.z), (const float*)(ws + p.inv_n), (long)batch, latent, K, 1.0f / temperature,
-                           grad_enc, grad_tgt, ws + p.part);
-    hipLaunchKernelGGL(lsim_k_est_finish, dim3(1), dim3(256), 0, s, (const float*)(ws + p.part), blocks, (long)batch, K, losses3);
+    LsEstArgs a = {enc_out, tgt_out, proto, vel, (long)ld_enc, (long)ld_tgt, (long)ld_vel, (long)batch, latent, K, sinkhorn_iters,
+                   1.0f / temperature, sinkhorn_eps, losses3, grad_enc, grad_tgt};
+    if (K <= 32 && latent <= 16) ls_est_launch<32, 16>(a, ws, p, s);
+    else if (K <= 32) ls_est_launch<32, 32>(a, ws, p, s);
+    else if (latent <= 16) ls_est_launch<64, 16>(a, ws, p, s);
+    else ls_est_launch<64, 32>(a, ws, p, s);
     // d P[k][d] = sum over both halves of dS[b][k] z[b][d]: a Linear weight gradient with x = z [2B, D], g = dS [2B, K]
     size_t wg_bytes; int np;
     lsim_linear_wgrad_workspace(2 * batch, latent, K, &wg_bytes, &np);

@@ -200,7 +200,12 @@ class HIMPPO:
         for (obs, critic_obs, actions, next_critic_obs, target_values, advantages, returns, old_logp, old_mu, old_sigma) in \
                 self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs):
             ac.estimator.prime(obs)        # one encoder forward serves the policy features and the estimator loss below
-            ac.act(obs)
+            # the reference calls act() here (HIMP:141) and throws the sample away; torch.normal(mean, std) validates std >= 0 with a
+            # host read-back, i.e. one pipeline drain per minibatch on the GPU: only the distribution is needed
+            if obs.is_cuda:
+                ac.update_distribution(obs)
+            else:
+                ac.act(obs)
             value = ac.evaluate(critic_obs)
             mu, sigma = ac.action_mean, ac.action_std
             loss, surrogate_loss, value_loss, kl_mean = self._ppo_loss(ac, mu, sigma, value, actions, old_logp, advantages, returns, target_values,
