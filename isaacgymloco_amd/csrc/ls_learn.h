@@ -203,6 +203,83 @@ __device__ __forceinline__ void ls_wgrad_tile_loop(const float* __restrict__ x, 
 #undef LS_LOAD_STEP
 }
 
+// ---- the steady-state batch loop: three register stages used round-robin (loads for step i + 2 issue before the MFMAs of step i, no
+// register rotation), every row known to exist (no row selects), column offsets of the four loads precomputed per lane (clamped into
+// the row on edge tiles).  Per 32 MFMAs the wave issues 3-4 loads and, without the ELU factor, 4 VALU instructions (the bias sums);
+// the rotating loop above costs ~44 (PMC: 1.4 VALU per MFMA, MFMA pipe 60 % busy).  Rows [b, b1) that do not fill a whole round of
+// three steps, and slices shorter than 20 rows, are left to ls_wgrad_tile_loop.
+template <int VEC>
+__device__ __forceinline__ void ls_wgrad_offsets(int c0, int cmax, bool full, int (&o)[4]) {
+    if (full) { o[0] = c0; o[1] = c0 + 1; o[2] = c0 + 2; o[3] = c0 + 3; return; }
+    if (VEC == 2) { const int last = ((cmax + 3) & ~3) - 4; o[0] = c0 < last ? c0 : last; o[1] = o[2] = o[3] = o[0]; }
+    else if (VEC == 1) { const int last = ((cmax + 1) & ~1) - 2; o[0] = c0 < last ? c0 : last; o[2] = c0 + 2 < last ? c0 + 2 : last; o[1] = o[0]; o[3] = o[2]; }
+    else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = c0 + j < cmax ? c0 + j : cmax - 1;
+    }
+}
+template <int VEC>
+__device__ __forceinline__ void ls_wgrad_ld(const float* __restrict__ r, const int (&o)[4], float (&v)[4]) {
+    if (VEC == 2) { const float4 t = *(const float4*)(r + o[0]); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+    else if (VEC == 1) { const float2 ta = *(const float2*)(r + o[0]), tb = *(const float2*)(r + o[2]); v[0] = ta.x; v[1] = ta.y; v[2] = tb.x; v[3] = tb.y; }
+    else { v[0] = r[o[0]]; v[1] = r[o[1]]; v[2] = r[o[2]]; v[3] = r[o[3]]; }
+}
+template <int KG> struct LsWgradStage { float a[4], z[4], x[KG][4]; };
+
+template <int VX, int VG, int KG, bool FZ, bool LIVE1 /* the second 64-column k group exists (compile-time: no branch between MFMAs) */,
+          bool WGY /* this wave writes g_y, as whole 16-byte vectors (interior n tile, n_out % 4 == 0) */>
+__device__ __forceinline__ long ls_wgrad_tile_loop3(const float* __restrict__ x, long ldx, const float* __restrict__ g, long ldg,
+                                                    const float* __restrict__ z, long ldz, float* __restrict__ gy, long b0, long b1,
+                                                    bool full, int n_base, int k_base, int n_out, int k_in, int sub, int col,
+                                                    ls_v4f (&acc)[4][4 * KG], float (&dbacc)[4]) {
+    if (b1 - b0 < 20) return b0;
+    int og[4], ox0[4], ox1[4];
+    ls_wgrad_offsets<VG>(n_base + 4 * col, n_out, full, og);
+    ls_wgrad_offsets<VX>(k_base + 4 * col, k_in, full, ox0);
+    constexpr bool live_k1 = KG > 1 && LIVE1;
+    ls_wgrad_offsets<VX>(k_base + 64 + 4 * col, k_in, full, ox1);
+    LsWgradStage<KG> s0, s1, s2;
+    if (KG > 1 && !live_k1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s0.x[KG - 1][j] = s1.x[KG - 1][j] = s2.x[KG - 1][j] = 0.0f;
+    }
+#define LS_LD(ST, ROW) do { const long r_ = (ROW);                                                                           \
+        ls_wgrad_ld<VG>(g + r_ * ldg, og, ST.a);                                                                              \
+        if (FZ) ls_wgrad_ld<VG>(z + r_ * ldz, og, ST.z);                                                                      \
+        ls_wgrad_ld<VX>(x + r_ * ldx, ox0, ST.x[0]);                                                                          \
+        if (live_k1) ls_wgrad_ld<VX>(x + r_ * ldx, ox1, ST.x[KG - 1]); } while (0)
+#define LS_CMP(ST, ROW) do {                                                                                                 \
+        if (FZ) {                                                                                                            \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) ST.a[j] *= ST.z[j] > 0.0f ? 1.0f : ST.z[j] + 1.0f;                 \
+            if (WGY) *(float4*)(gy + (ROW) * (long)n_out + n_base + 4 * col) = make_float4(ST.a[0], ST.a[1], ST.a[2], ST.a[3]);     \
+        }                                                                                                                    \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                      \
+            dbacc[j] += ST.a[j];                                                                                             \
+            _Pragma("unroll") for (int kt = 0; kt < 4; ++kt)                                                                 \
+                acc[j][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ST.a[j], ST.x[0][kt], acc[j][kt], 0, 0, 0);                \
+            if (live_k1) {                                                                                                   \
+                _Pragma("unroll") for (int kt = 4; kt < 4 * KG; ++kt)                                                        \
+                    acc[j][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ST.a[j], ST.x[KG - 1][kt & 3], acc[j][kt], 0, 0, 0);   \
+            }                                                                                                                \
+        } } while (0)
+    long b = b0;
+    LS_LD(s0, b + sub);
+    LS_LD(s1, b + 4 + sub);
+    for (; b + 20 <= b1; b += 12) {
+        LS_LD(s2, b + 8 + sub);
+        LS_CMP(s0, b + sub);
+        LS_LD(s0, b + 12 + sub);
+        LS_CMP(s1, b + 4 + sub);
+        LS_LD(s1, b + 16 + sub);
+        LS_CMP(s2, b + 8 + sub);
+    }
+    LS_CMP(s0, b + sub);             // the two stages still in flight (their rows exist: loaded under the loop condition)
+    LS_CMP(s1, b + 4 + sub);
+#undef LS_CMP
+#undef LS_LD
+    return b + 8;
+}
+
 // KG: 64-wide k groups per tile (1 for k_in <= 64, else 2)
 template <int VX, int VG, int KG, bool FZ>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
@@ -234,8 +311,16 @@ void lsim_k_linear_wgrad_tiled(const float* __restrict__ x, long ldx, const floa
         for (int kt = 0; kt < 4 * KG; ++kt) acc[j][kt] = (ls_v4f){0.0f, 0.0f, 0.0f, 0.0f};
     const bool full = (n_base + 64 <= n_out) && (k_base + 64 * KG <= k_in);      // wave-uniform: interior tile
     const long safe = b0 < batch ? b0 : batch - 1;          // an existing row for the masked loads of rows past the slice
-    if (full) ls_wgrad_tile_loop<VX, VG, KG, true, FZ>(x, ldx, g, ldg, z, ldz, gy, kb == 0, b0, b1, safe, n_base, k_base, n_out, k_in, sub, col, acc, dbacc);
-    else ls_wgrad_tile_loop<VX, VG, KG, false, FZ>(x, ldx, g, ldg, z, ldz, gy, kb == 0, b0, b1, safe, n_base, k_base, n_out, k_in, sub, col, acc, dbacc);
+    {
+        const bool live1 = KG == 1 || k_base + 64 < k_in;
+        const bool wgy = FZ && kb == 0, wgy_vec = (n_out & 3) == 0 && n_base + 64 <= n_out;
+#define LS_L3(LIVE1, WGY) b0 = ls_wgrad_tile_loop3<VX, VG, KG, FZ, LIVE1, WGY>(x, ldx, g, ldg, z, ldz, gy, b0, b1, full, n_base, k_base, n_out, k_in, sub, col, acc, dbacc)
+        if (!wgy) { if (live1) LS_L3(true, false); else LS_L3(false, false); }
+        else if (wgy_vec) { if (live1) LS_L3(true, true); else LS_L3(false, true); }
+        // (g_y rows of an edge n tile: everything goes through the guarded loop below)
+#undef LS_L3
+    }
+    ls_wgrad_tile_loop<VX, VG, KG, false, FZ>(x, ldx, g, ldg, z, ldz, gy, kb == 0, b0, b1, safe, n_base, k_base, n_out, k_in, sub, col, acc, dbacc);   // the last < 12 rows
     // block reduction: wave 0 stores its accumulators to LDS (lane-major, 16-byte vectors: no bank conflicts), waves 1-3 add theirs in
     // turn; wave 3 ends up with the block's sums and writes the partial tile
     __shared__ float4 red[4 * 4 * KG][64];

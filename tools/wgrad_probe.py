@@ -3,7 +3,8 @@ kernel durations (host timing is launch-bound for the small shapes).  usage: pyt
 import os, sys, shutil, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-if len(sys.argv) > 3:
+ELU = "elu" in sys.argv[3:]          # time the (Linear, ELU) backward: lsim_linear_elu_wgrad vs elu_backward + BLAS
+if "tuned" in sys.argv[3:]:
     tdir = tempfile.mkdtemp(prefix="lsim_tunableop_")
     shutil.copy(os.path.join(ROOT, "isaacgymloco_amd", "learn", "tunableop_gfx950.csv"), os.path.join(tdir, "tuned0.csv"))
     os.environ["PYTORCH_TUNABLEOP_ENABLED"] = "1"; os.environ["PYTORCH_TUNABLEOP_FILENAME"] = os.path.join(tdir, "tuned.csv"); os.environ["PYTORCH_TUNABLEOP_TUNING"] = "0"
@@ -12,7 +13,16 @@ from isaacgymloco_amd.learn.fused_linear import linear_wgrad
 B = 102400
 k, n = int(sys.argv[1]), int(sys.argv[2])
 x = torch.randn(B, k, device="cuda"); g = torch.randn(B, n, device="cuda")
-for _ in range(12):
-    a = g.t() @ x; b = g.sum(0)
-    c, d = linear_wgrad(x, g)
+if ELU:
+    from isaacgymloco_amd.learn.fused_linear import _LinearEluFn
+    w = torch.randn(n, k, device="cuda") * 0.05; bias = torch.zeros(n, device="cuda")
+    for t in (x, w, bias):
+        t.requires_grad_(True)
+    for _ in range(12):
+        y = torch.nn.functional.elu(torch.nn.functional.linear(x, w, bias)); y.backward(g)
+        zf = _LinearEluFn.apply(x, w, bias); zf.backward(g)
+else:
+    for _ in range(12):
+        a = g.t() @ x; b = g.sum(0)
+        c, d = linear_wgrad(x, g)
 torch.cuda.synchronize()
