@@ -516,7 +516,7 @@ int lsim_adaptive_lr(const float* kl_mean_dev, float desired_kl, float lr_min, f
  *   Q = exp(scores / eps)^T;  Q /= sum(Q);  iters x { Q /= rowsum; Q /= K; Q /= colsum; Q /= B };  out = (Q * B)^T
  * scores [batch, K] with row stride lds (floats), K <= 64, out [batch, K] contiguous.  Computed as E * u[k] * v[b] with 2 * iters + 1
  * small launches instead of ~26 passes over the matrix; `workspace` holds E and the per-block partial sums
- * (lsim_sinkhorn_workspace() bytes); sums are formed in a fixed order (deterministic). */
+ * (lsim_sinkhorn_workspace() bytes, 16-byte aligned like `out`); sums are formed in a fixed order (deterministic). */
 int lsim_sinkhorn_workspace(long batch, int K, size_t* bytes);
 int lsim_sinkhorn(const float* scores, int64_t lds, int64_t batch, int K, float eps, int iters, float* out,
                   void* workspace, size_t workspace_bytes, void* stream);
@@ -527,7 +527,7 @@ int lsim_sinkhorn(const float* scores, int64_t lds, int64_t batch, int K, float 
  *   z = F.normalize(latent), scores = z proto^T, q = Sinkhorn(scores) (no gradient), swap = -0.5 mean(q_s log_softmax(S_t / T) +
  *   q_t log_softmax(S_s / T)), est = mse(pred_vel, vel).
  *   losses3 = { est, swap, est + swap };  grad_enc [batch, 3 + latent], grad_tgt [batch, latent], grad_proto [K, latent] contiguous =
- *   d (est + swap) / d (enc_out, tgt_out, proto).  latent <= 32, K <= 64.  12 launches; sums in a fixed order (deterministic).
+ *   d (est + swap) / d (enc_out, tgt_out, proto).  latent <= 32, K <= 64.  10 launches; sums in a fixed order (deterministic).
  * workspace: lsim_estimator_loss_workspace() bytes, 16-byte aligned. */
 int lsim_estimator_loss_workspace(int64_t batch, int latent, int K, size_t* bytes);
 int lsim_estimator_loss(const float* enc_out, int64_t ld_enc, const float* tgt_out, int64_t ld_tgt, const float* proto, const float* vel,
