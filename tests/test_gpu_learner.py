@@ -215,10 +215,12 @@ def test_fused_sinkhorn_matches_torch():
     """lsim_sinkhorn against the torch statement of HES:119-133 (modules.sinkhorn's small-batch branch), fp32 tolerance 1e-4 relative"""
     from isaacgymloco_amd.learn import modules as M
     g = torch.Generator(device="cuda:0").manual_seed(5)
-    for B, K in ((102400, 32), (5000, 7)):
+    for B, K in ((102400, 32), (5000, 7), (6001, 50), (4097, 64)):      # K <= 32 / K <= 64 kernels, vector and scalar row loads, ragged blocks
         z = torch.nn.functional.normalize(torch.randn(B, 16, device="cuda:0", generator=g), dim=-1)
         proto = torch.nn.functional.normalize(torch.randn(K, 16, device="cuda:0", generator=g), dim=-1)
         scores = z @ proto.T                                   # cosine similarities in [-1, 1], as in HES:96-97
+        if K == 64:
+            scores = torch.cat([scores, scores], dim=1)[:, :K]   # a strided view: row stride 128
         got = M.sinkhorn(scores)                               # HIP path (B >= 4096)
         Q = torch.exp(scores.double() / 0.05).T                # the reference arithmetic in fp64
         Kk, Bb = Q.shape
