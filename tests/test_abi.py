@@ -54,3 +54,28 @@ def test_env_refuses_to_run_without_gpu():
     from helpers import C
     with pytest.raises(lib.LsimError):
         LeggedRobot(C.aliengo_cfg(), sim_device="cuda:0")
+
+
+def test_learner_workspace_queries_validate_shapes():
+    """the host-side planners of the learner entry points (no launches): sizes grow with the batch, unsupported shapes are refused"""
+    from isaacgymloco_amd import lib
+    L = lib.load()             # loading needs no GPU; only the launches do
+    n, parts = ctypes.c_size_t(), ctypes.c_int()
+    B = 102400
+    # weight gradient: every layer of the three networks has a plan; a 1024 x 1024 layer (discriminator-sized) is left to BLAS
+    for k_in, n_out in ((270, 128), (128, 64), (64, 19), (64, 512), (512, 256), (256, 128), (128, 12), (238, 512), (128, 1), (45, 128), (64, 16)):
+        assert L.lsim_linear_wgrad_workspace(B, k_in, n_out, ctypes.byref(n), ctypes.byref(parts)) == 0, (k_in, n_out)
+        assert parts.value >= 1 and n.value >= parts.value * (k_in * n_out + n_out) * 4
+    assert L.lsim_linear_wgrad_workspace(B, 1024, 1024, ctypes.byref(n), ctypes.byref(parts)) == abi.E_UNSUPPORTED
+    assert L.lsim_linear_wgrad_workspace(0, 64, 64, ctypes.byref(n), ctypes.byref(parts)) == abi.E_UNSUPPORTED
+    # Sinkhorn / estimator loss head: K <= 64 prototypes, latent <= 32
+    assert L.lsim_sinkhorn_workspace(B, 32, ctypes.byref(n)) == 0 and n.value >= B * 32 * 4
+    assert L.lsim_sinkhorn_workspace(B, 65, ctypes.byref(n)) == abi.E_INVALID
+    small = ctypes.c_size_t()
+    assert L.lsim_estimator_loss_workspace(4096, 16, 32, ctypes.byref(small)) == 0
+    assert L.lsim_estimator_loss_workspace(B, 16, 32, ctypes.byref(n)) == 0 and n.value > small.value
+    assert n.value >= (2 * B * 16 + 4 * B * 32) * 4          # z, scores and E of both matrices at least
+    assert L.lsim_estimator_loss_workspace(B, 33, 32, ctypes.byref(n)) == abi.E_INVALID
+    assert L.lsim_estimator_loss_workspace(B, 16, 65, ctypes.byref(n)) == abi.E_INVALID
+    assert L.lsim_estimator_loss_workspace(B, 16, 32, None) == abi.E_INVALID
+    assert L.lsim_ppo_loss_workspace(B, ctypes.byref(n)) == 0 and n.value > 0
