@@ -103,7 +103,7 @@ class HIMEstimator(nn.Module):
         if out.is_cuda and out.dim() == 2:
             from .fused_linear import estimator_loss_hip, estimator_loss_supported
             if estimator_loss_supported(tgt.shape[1], self.proto.weight.shape[0]):
-                # normalise + scores + both Sinkhorn chains + log-softmax + losses and their backward: 12 launches (include/lsim.h)
+                # normalise + scores + both Sinkhorn chains + log-softmax + losses and their backward: 10 launches (include/lsim.h)
                 total, parts = estimator_loss_hip(out, tgt, self.proto.weight, vel, self.temperature)
                 return parts[0], parts[1], total
         pred_vel, z_s = out[..., :3], F.normalize(out[..., 3:], dim=-1, p=2)
