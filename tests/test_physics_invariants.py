@@ -222,3 +222,30 @@ def test_go1_table_emu_matches_oracle_and_stands():
     fz = orc.buf["contact_forces"][:, [4, 8, 12, 16], 2].sum(1)
     np.testing.assert_allclose(fz, mass * G, rtol=0.05)
     assert np.all(orc.buf["root_states"][:, 2] > 0.2) and np.all(orc.buf["root_states"][:, 2] < 0.45)
+
+
+@pytest.mark.parametrize("kind", ["oracle", "emu"])
+def test_foot_contact_forces_stay_in_the_friction_pyramid(kind):
+    """Flat ground, a robot thrashing under random actions: every foot force pushes (f_z >= 0) and its tangential components stay inside
+    the solver's friction pyramid |f_x|, |f_y| <= mu f_z with mu = average(terrain friction, robot friction); feet do not
+    sink into the ground by more than the contact offset."""
+    cfg = quiet_cfg()
+    cfg.terrain.mesh_type = "plane"
+    cfg.init_state.pos = [0.0, 0.0, 0.40]
+    sim, model = _make(kind, cfg, 4)
+    sim.reset_all()
+    mu = 0.5 * (float(cfg.terrain.static_friction) + float(sim.buf["friction"][0]))
+    rng = np.random.default_rng(3)
+    foot_r = [model.points[i].radius for i in range(model.num_collision_points) if model.points[i].body in (4, 8, 12, 16)][0]
+    seen = 0
+    for _ in range(60):
+        sim.step(rng.normal(0.0, 1.0, (4, 12)).astype(np.float32))
+        f = sim.buf["contact_forces"][:, [4, 8, 12, 16], :].astype(np.float64)
+        load = f[..., 2] > 1.0
+        seen += int(load.sum())
+        assert (f[..., 2] > -1e-3).all()
+        assert (np.abs(f[..., 0])[load] <= mu * f[..., 2][load] * (1 + 1e-3) + 1e-2).all()
+        assert (np.abs(f[..., 1])[load] <= mu * f[..., 2][load] * (1 + 1e-3) + 1e-2).all()
+        z = sim.buf["rigid_body_states"][:, [4, 8, 12, 16], 2]
+        assert (z > foot_r - 0.02).all(), z.min()
+    assert seen > 100           # the feet were on the ground most of the time
