@@ -32,7 +32,36 @@ __global__ __launch_bounds__(64 * LS_WGRAD_WAVES_PER_BLOCK) void lsim_k_linear_w
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) acc[nt][kt] = (ls_v4f){0.0f, 0.0f, 0.0f, 0.0f};
     }
-    for (long b = b0; b < b1; b += 4) {
+    long b = b0;
+    {   // steady state: 16 rows (four MFMA steps) per iteration, every row inside the slice, all 4 (NT + KT) loads issued before the
+        // first MFMA (one wave per SIMD: without this the loop runs at one memory latency per step).  Columns past the matrix are read
+        // from a clamped column and not masked: they only reach accumulators of outputs that are never written.
+        int gn[NT], xk[KT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) { const int n = nt * 16 + col; gn[nt] = n < n_out ? n : n_out - 1; }
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) { const int k = kt * 16 + col; xk[kt] = k < k_in ? k : k_in - 1; }
+        for (; b + 16 <= b1; b += 16) {
+            float a[4][NT], bb[4][KT];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const long row = b + 4 * s + sub;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) a[s][nt] = g[row * ldg + gn[nt]];
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) bb[s][kt] = x[row * ldx + xk[kt]];
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    dbacc[nt] += a[s][nt];
+#pragma unroll
+                    for (int kt = 0; kt < KT; ++kt) acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][nt], bb[s][kt], acc[nt][kt], 0, 0, 0);
+                }
+        }
+    }
+    for (; b < b1; b += 4) {
         const long row = b + sub;
         const bool valid = row < b1;
         float a[NT], bb[KT];
