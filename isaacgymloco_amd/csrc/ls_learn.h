@@ -291,19 +291,45 @@ __device__ __forceinline__ long ls_wgrad_tile_loop3(const float* __restrict__ x,
                     acc[j][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ST.a[j], ST.x[KG - 1][kt & 3], acc[j][kt], 0, 0, 0);   \
             }                                                                                                                \
         } } while (0)
+    // one step with the next-but-one stage's loads SPREAD between the four MFMA groups (a load every 8 MFMAs) and pinned there with
+    // scheduling barriers: clustered at the top of the step the same loads cost a quarter of the MFMA rate (tools/micro/mfma_peak:
+    // 102 -> 127 TFLOP/s for 3 loads per 32 MFMAs), and left alone hipcc sinks them to their first use
+#define LS_SB() __builtin_amdgcn_sched_barrier(0)
+#define LS_GRP(ST, J) do {                                                                                                   \
+        dbacc[J] += ST.a[J];                                                                                                 \
+        _Pragma("unroll") for (int kt = 0; kt < 4; ++kt)                                                                     \
+            acc[J][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ST.a[J], ST.x[0][kt], acc[J][kt], 0, 0, 0);                    \
+        if (live_k1) {                                                                                                       \
+            _Pragma("unroll") for (int kt = 4; kt < 4 * KG; ++kt)                                                            \
+                acc[J][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ST.a[J], ST.x[KG - 1][kt & 3], acc[J][kt], 0, 0, 0);       \
+        } } while (0)
+#define LS_STEP(CS, CROW, LS, LROW) do { const long lr_ = (LROW);                                                            \
+        if (FZ) {     /* g_z * elu'(z) for the whole step up front: spread between the MFMA groups it costs 10 % (measured) */   \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) CS.a[j] *= CS.z[j] > 0.0f ? 1.0f : CS.z[j] + 1.0f;                 \
+            if (WGY) *(float4*)(gy + (CROW) * (long)n_out + n_base + 4 * col) = make_float4(CS.a[0], CS.a[1], CS.a[2], CS.a[3]);  \
+        }                                                                                                                    \
+        LS_SB(); LS_GRP(CS, 0); LS_SB();                                                                                     \
+        ls_wgrad_ld<VG>(g + lr_ * ldg, og, LS.a); LS_SB();                                                                   \
+        LS_GRP(CS, 1); LS_SB();                                                                                              \
+        if (FZ) ls_wgrad_ld<VG>(z + lr_ * ldz, og, LS.z); else ls_wgrad_ld<VX>(x + lr_ * ldx, ox0, LS.x[0]);                 \
+        LS_SB(); LS_GRP(CS, 2); LS_SB();                                                                                     \
+        if (FZ) ls_wgrad_ld<VX>(x + lr_ * ldx, ox0, LS.x[0]); else if (live_k1) ls_wgrad_ld<VX>(x + lr_ * ldx, ox1, LS.x[KG - 1]);  \
+        LS_SB(); LS_GRP(CS, 3); LS_SB();                                                                                     \
+        if (FZ && live_k1) ls_wgrad_ld<VX>(x + lr_ * ldx, ox1, LS.x[KG - 1]);                                                \
+        LS_SB(); } while (0)
     long b = b0;
     LS_LD(s0, b + sub);
     LS_LD(s1, b + 4 + sub);
     for (; b + 20 <= b1; b += 12) {
-        LS_LD(s2, b + 8 + sub);
-        LS_CMP(s0, b + sub);
-        LS_LD(s0, b + 12 + sub);
-        LS_CMP(s1, b + 4 + sub);
-        LS_LD(s1, b + 16 + sub);
-        LS_CMP(s2, b + 8 + sub);
+        LS_STEP(s0, b + sub, s2, b + 8 + sub);
+        LS_STEP(s1, b + 4 + sub, s0, b + 12 + sub);
+        LS_STEP(s2, b + 8 + sub, s1, b + 16 + sub);
     }
     LS_CMP(s0, b + sub);             // the two stages still in flight (their rows exist: loaded under the loop condition)
     LS_CMP(s1, b + 4 + sub);
+#undef LS_STEP
+#undef LS_GRP
+#undef LS_SB
 #undef LS_CMP
 #undef LS_LD
     return b + 8;
