@@ -297,12 +297,14 @@ __device__ __forceinline__ long ls_wgrad_tile_loop3(const float* __restrict__ x,
 #define LS_SB() __builtin_amdgcn_sched_barrier(0)
 #define LS_GRP(ST, J) do {                                                                                                   \
         dbacc[J] += ST.a[J];                                                                                                 \
+        __builtin_amdgcn_s_setprio(1);          /* the wave entering an MFMA group wins arbitration over the one issuing loads: +5 % */  \
         _Pragma("unroll") for (int kt = 0; kt < 4; ++kt)                                                                     \
             acc[J][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ST.a[J], ST.x[0][kt], acc[J][kt], 0, 0, 0);                    \
         if (live_k1) {                                                                                                       \
             _Pragma("unroll") for (int kt = 4; kt < 4 * KG; ++kt)                                                            \
                 acc[J][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ST.a[J], ST.x[KG - 1][kt & 3], acc[J][kt], 0, 0, 0);       \
-        } } while (0)
+        }                                                                                                                    \
+        __builtin_amdgcn_s_setprio(0); } while (0)
 #define LS_STEP(CS, CROW, LS, LROW) do { const long lr_ = (LROW);                                                            \
         if (FZ) {     /* g_z * elu'(z) for the whole step up front: spread between the MFMA groups it costs 10 % (measured) */   \
             _Pragma("unroll") for (int j = 0; j < 4; ++j) CS.a[j] *= CS.z[j] > 0.0f ? 1.0f : CS.z[j] + 1.0f;                 \

@@ -77,6 +77,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 // the same work with the three loads of a step spread between the MFMAs (one load after every 8 / 12 / 12 MFMAs) instead of clustered
+template <int PRIO>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void kspread(const float* __restrict__ src, float* out, int iters, int mask) {
     v4f acc[4][8];
     for (int j = 0; j < 4; ++j) for (int t = 0; t < 8; ++t) acc[j][t] = (v4f){0.f, 0.f, 0.f, 0.f};
@@ -85,7 +86,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     a0 = x0 = y0 = a1 = x1 = y1 = a2 = x2 = y2 = p[0];
 #define SB() __builtin_amdgcn_sched_barrier(0)
 #define MF(A, X, Y, J) do { const float av = (J) == 0 ? A.x : (J) == 1 ? A.y : (J) == 2 ? A.z : A.w; const float bv[8] = {X.x, X.y, X.z, X.w, Y.x, Y.y, Y.z, Y.w}; \
-        _Pragma("unroll") for (int t = 0; t < 8; ++t) acc[J][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[t], acc[J][t], 0, 0, 0); } while (0)
+        if (PRIO) __builtin_amdgcn_s_setprio(1);                                                                                     \
+        _Pragma("unroll") for (int t = 0; t < 8; ++t) acc[J][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[t], acc[J][t], 0, 0, 0);  \
+        if (PRIO) __builtin_amdgcn_s_setprio(0); } while (0)
 #define STEP(CA, CX, CY, LA, LX, LY, I) do { const int o = ((I) * 768) & mask;                                               \
         MF(CA, CX, CY, 0); SB(); LA = p[o]; SB(); MF(CA, CX, CY, 1); SB(); LX = p[o + 256]; SB();                           \
         MF(CA, CX, CY, 2); SB(); LY = p[o + 512]; SB(); MF(CA, CX, CY, 3); SB(); } while (0)
@@ -102,13 +105,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int j = 0; j < 4; ++j) for (int t = 0; t < 8; ++t) s += acc[j][t][0] + acc[j][t][1] + acc[j][t][2] + acc[j][t][3];
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
-void runspread(int blocks, int iters, int mask, const char* what) {
+template <int PRIO> void runspread(int blocks, int iters, int mask, const char* what) {
     float *out, *src; hipMalloc(&out, (size_t)blocks * 256 * 4); hipMalloc(&src, ((size_t)mask + 1024) * 16 + (1 << 20)); hipMemset(src, 0, ((size_t)mask + 1024) * 16 + (1 << 20));
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(kspread, dim3(blocks), dim3(256), 0, 0, (const float*)src, out, iters, mask);
+    hipLaunchKernelGGL(kspread<PRIO>, dim3(blocks), dim3(256), 0, 0, (const float*)src, out, iters, mask);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    hipLaunchKernelGGL(kspread, dim3(blocks), dim3(256), 0, 0, (const float*)src, out, iters, mask);
+    hipLaunchKernelGGL(kspread<PRIO>, dim3(blocks), dim3(256), 0, 0, (const float*)src, out, iters, mask);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     double flop = (double)blocks * 4 * iters * 32 * 2.0 * 16 * 16 * 4;
@@ -173,7 +176,9 @@ int main() {
     runld<true, 0>(512, 3999, 0x3ff, "  0 loads per step");
     runld<true, 1>(512, 3999, 0x3ff, "  1 load per step");
     runld<true, 2>(512, 3999, 0x3ff, "  2 loads per step");
-    runspread(512, 3999, 0x3ff, "  3 loads per step SPREAD between the MFMAs, 16 KB window");
-    runspread(512, 3999, 0xfffff, "  3 loads per step SPREAD between the MFMAs, 16 MB window");
+    runspread<0>(512, 3999, 0x3ff, "  3 loads per step SPREAD between the MFMAs, 16 KB window");
+    runspread<0>(512, 3999, 0xfffff, "  3 loads per step SPREAD between the MFMAs, 16 MB window");
+    runspread<1>(512, 3999, 0x3ff, "  spread + s_setprio(1) around each MFMA group, 16 KB window");
+    runspread<1>(512, 3999, 0xfffff, "  spread + s_setprio(1) around each MFMA group, 16 MB window");
     return 0;
 }
