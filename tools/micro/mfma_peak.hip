@@ -105,6 +105,49 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int j = 0; j < 4; ++j) for (int t = 0; t < 8; ++t) s += acc[j][t][0] + acc[j][t][1] + acc[j][t][2] + acc[j][t][3];
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
+// one wave per SIMD owning a 128 x 128 tile: 64 accumulators (256 registers), four loads spread over the 64 MFMAs of a step
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void kbig(const float* __restrict__ src, float* out, int iters, int mask) {
+    v4f acc[8][8];
+    for (int j = 0; j < 8; ++j) for (int t = 0; t < 8; ++t) acc[j][t] = (v4f){0.f, 0.f, 0.f, 0.f};
+    const float4* p = (const float4*)src + threadIdx.x;
+    float4 st[3][4];
+    for (int s = 0; s < 3; ++s) for (int q = 0; q < 4; ++q) st[s][q] = p[0];
+#define SB() __builtin_amdgcn_sched_barrier(0)
+#define MF16(C, JJ) do { const float av[8] = {st[C][0].x, st[C][0].y, st[C][0].z, st[C][0].w, st[C][1].x, st[C][1].y, st[C][1].z, st[C][1].w};                  \
+        const float bv[8] = {st[C][2].x, st[C][2].y, st[C][2].z, st[C][2].w, st[C][3].x, st[C][3].y, st[C][3].z, st[C][3].w};                                    \
+        __builtin_amdgcn_s_setprio(1);                                                                                                                            \
+        _Pragma("unroll") for (int j = 2 * (JJ); j < 2 * (JJ) + 2; ++j) _Pragma("unroll") for (int t = 0; t < 8; ++t)                                          \
+            acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[t], acc[j][t], 0, 0, 0);                                                                   \
+        __builtin_amdgcn_s_setprio(0); } while (0)
+#define STEP(C, L, I) do { const int o = ((I) * 1024) & mask;                                                                \
+        MF16(C, 0); SB(); st[L][0] = p[o]; SB(); MF16(C, 1); SB(); st[L][1] = p[o + 256]; SB();                             \
+        MF16(C, 2); SB(); st[L][2] = p[o + 512]; SB(); MF16(C, 3); SB(); st[L][3] = p[o + 768]; SB(); } while (0)
+    int i = blockIdx.x;
+    for (int it = 0; it < iters; it += 3, i += 3) {
+        STEP(0, 2, i + 2);
+        STEP(1, 0, i + 3);
+        STEP(2, 1, i + 4);
+    }
+#undef STEP
+#undef MF16
+#undef SB
+    float s = 0.f;
+    for (int j = 0; j < 8; ++j) for (int t = 0; t < 8; ++t) s += acc[j][t][0] + acc[j][t][1] + acc[j][t][2] + acc[j][t][3];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+void runbig(int blocks, int iters, int mask, const char* what) {
+    float *out, *src; hipMalloc(&out, (size_t)blocks * 256 * 4); hipMalloc(&src, ((size_t)mask + 2048) * 16 + (1 << 20)); hipMemset(src, 0, ((size_t)mask + 2048) * 16 + (1 << 20));
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(kbig, dim3(blocks), dim3(256), 0, 0, (const float*)src, out, iters, mask);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(kbig, dim3(blocks), dim3(256), 0, 0, (const float*)src, out, iters, mask);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    double flop = (double)blocks * 4 * iters * 64 * 2.0 * 16 * 16 * 4;
+    printf("%s: %.3f ms, %.1f TFLOP/s\n", what, ms, flop / ms / 1e9);
+    hipFree(out); hipFree(src);
+}
 template <int PRIO> void runspread(int blocks, int iters, int mask, const char* what) {
     float *out, *src; hipMalloc(&out, (size_t)blocks * 256 * 4); hipMalloc(&src, ((size_t)mask + 1024) * 16 + (1 << 20)); hipMemset(src, 0, ((size_t)mask + 1024) * 16 + (1 << 20));
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -180,5 +223,6 @@ int main() {
     runspread<0>(512, 3999, 0xfffff, "  3 loads per step SPREAD between the MFMAs, 16 MB window");
     runspread<1>(512, 3999, 0x3ff, "  spread + s_setprio(1) around each MFMA group, 16 KB window");
     runspread<1>(512, 3999, 0xfffff, "  spread + s_setprio(1) around each MFMA group, 16 MB window");
+    runbig(256, 3999, 0xfffff, "  1 wave/SIMD, 128 x 128 tile: 4 loads spread over 64 MFMAs per step, 16 MB window");
     return 0;
 }
