@@ -535,6 +535,17 @@ int lsim_estimator_loss(const float* enc_out, int64_t ld_enc, const float* tgt_o
                         float* losses3, float* grad_enc, float* grad_tgt, float* grad_proto, void* workspace, size_t workspace_bytes,
                         void* stream);
 
+/* Gradient clipping + Adam of one optimiser step in three launches (HIMP:183-184, HES:113-114: clip_grad_norm_(params, max_grad_norm) then
+ * torch.optim.Adam.step(), no amsgrad / weight decay / maximize), on the caller's tensors: `count` <= 48 parameters with numel[i] elements
+ * each, their gradients (rescaled in place by min(max_grad_norm / (||g|| + 1e-6), 1), as clip_grad_norm_ does; max_grad_norm <= 0: no
+ * clipping), first / second moment estimates and per-parameter step counters (float scalars, incremented).  The pointer tables are HOST
+ * arrays of device pointers.  Learning rate: *lr_dev if lr_dev != NULL (device scalar, see lsim_adaptive_lr), else lr_host.
+ * grad_norm_out (device, may be NULL) receives the total norm before clipping.  workspace: lsim_adam_clip_step_workspace(count) bytes. */
+int lsim_adam_clip_step_workspace(int count, size_t* bytes);
+int lsim_adam_clip_step(int count, const int64_t* numel, float* const* params, float* const* grads, float* const* exp_avg,
+                        float* const* exp_avg_sq, float* const* steps, const float* lr_dev, float lr_host, float beta1, float beta2,
+                        float eps, float max_grad_norm, float* grad_norm_out, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1148,3 +1148,111 @@ extern "C" int lsim_adaptive_lr(const float* kl_mean_dev, float desired_kl, floa
     hipLaunchKernelGGL(lsim_k_adaptive_lr, dim3(1), dim3(1), 0, (hipStream_t)stream, kl_mean_dev, desired_kl, lr_min, lr_max, factor, lr_dev);
     return hipGetLastError() == hipSuccess ? LSIM_OK : LSIM_E_HIP;
 }
+
+// ---- gradient clipping + Adam in three launches (HIMP:183-184, HES:113-114: clip_grad_norm_ then optimizer.step(); torch's foreach
+// clipping and fused Adam need ~12 launches per optimiser step, 24 per minibatch):
+//   sumsq : per-tensor-slice partial sums of g^2                      (grid: LS_ADAM_SLICES x tensors)
+//   finish: total norm (fixed summation order), clip coefficient min(max_norm / (norm + 1e-6), 1), step counters += 1
+//   apply : g <- coef * g (written back, as clip_grad_norm_ does);  m <- lerp(m, g, 1 - b1);  v <- b2 v + (1 - b2) g^2;
+//           p <- p - (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)           (torch.optim.Adam, no amsgrad / weight decay)
+// The tensors are the caller's (torch's parameter, .grad and optimizer-state tensors: checkpoints stay torch's); pointers travel by
+// value in the kernel arguments, so nothing is staged on the device.
+#define LS_ADAM_MAX_TENSORS 48
+#define LS_ADAM_SLICES 32
+struct LsAdamTable {
+    float* p[LS_ADAM_MAX_TENSORS];
+    float* g[LS_ADAM_MAX_TENSORS];
+    float* m[LS_ADAM_MAX_TENSORS];
+    float* v[LS_ADAM_MAX_TENSORS];
+    float* step[LS_ADAM_MAX_TENSORS];
+    int n[LS_ADAM_MAX_TENSORS];
+    int count;
+};
+
+__global__ __launch_bounds__(256) void lsim_k_adam_sumsq(LsAdamTable t, float* __restrict__ part /* [count][LS_ADAM_SLICES] */) {
+    __shared__ float red[256];
+    const int ti = blockIdx.y, n = t.n[ti];
+    const float* __restrict__ g = t.g[ti];
+    float s = 0.0f;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += LS_ADAM_SLICES * 256) { const float x = g[i]; s = fmaf(x, x, s); }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[ti * LS_ADAM_SLICES + blockIdx.x] = red[0];
+}
+
+// scal[0] = clip coefficient, [1] = total gradient norm, [2] = step count after the increment
+__global__ __launch_bounds__(64) void lsim_k_adam_finish(LsAdamTable t, const float* __restrict__ part, float max_norm, float* __restrict__ scal) {
+    __shared__ float tot[LS_ADAM_MAX_TENSORS];
+    const int i = threadIdx.x;
+    if (i < t.count) {
+        float s = 0.0f;
+        for (int k = 0; k < LS_ADAM_SLICES; ++k) s += part[i * LS_ADAM_SLICES + k];
+        tot[i] = s;
+        *t.step[i] += 1.0f;
+    }
+    __syncthreads();
+    if (i == 0) {
+        float s = 0.0f;
+        for (int k = 0; k < t.count; ++k) s += tot[k];
+        const float norm = sqrtf(s);
+        scal[0] = max_norm > 0.0f ? fminf(max_norm / (norm + 1e-6f), 1.0f) : 1.0f;
+        scal[1] = norm;
+        scal[2] = *t.step[0];
+    }
+}
+
+__global__ __launch_bounds__(256) void lsim_k_adam_apply(LsAdamTable t, const float* __restrict__ scal, const float* __restrict__ lr_dev, float lr_host,
+                                                         float b1, float b2, float eps) {
+    const int ti = blockIdx.y, n = t.n[ti];
+    float* __restrict__ p = t.p[ti];
+    float* __restrict__ g = t.g[ti];
+    float* __restrict__ m = t.m[ti];
+    float* __restrict__ v = t.v[ti];
+    const float coef = scal[0], step = scal[2], lr = lr_dev ? *lr_dev : lr_host;
+    const float bc1 = 1.0f - powf(b1, step), bc2s = sqrtf(1.0f - powf(b2, step));
+    const float step_size = lr / bc1;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += LS_ADAM_SLICES * 256) {
+        const float gi = g[i] * coef;
+        const float mi = m[i] + (gi - m[i]) * (1.0f - b1);             // torch's lerp form
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        g[i] = gi; m[i] = mi; v[i] = vi;
+        p[i] -= step_size * mi / (sqrtf(vi) / bc2s + eps);
+    }
+}
+
+extern "C" int lsim_adam_clip_step_workspace(int count, size_t* bytes) {
+    if (!bytes || count <= 0 || count > LS_ADAM_MAX_TENSORS) return LSIM_E_INVALID;
+    *bytes = ((size_t)count * LS_ADAM_SLICES + 4) * sizeof(float);
+    return LSIM_OK;
+}
+
+extern "C" int lsim_adam_clip_step(int count, const int64_t* numel, float* const* params, float* const* grads, float* const* exp_avg,
+                                   float* const* exp_avg_sq, float* const* steps, const float* lr_dev, float lr_host, float beta1, float beta2,
+                                   float eps, float max_grad_norm, float* grad_norm_out, void* workspace, size_t workspace_bytes, void* stream) {
+    size_t need;
+    int rc = lsim_adam_clip_step_workspace(count, &need);
+    if (rc != LSIM_OK) return rc;
+    if (!numel || !params || !grads || !exp_avg || !exp_avg_sq || !steps || !workspace || workspace_bytes < need || beta1 < 0.0f || beta1 >= 1.0f ||
+        beta2 < 0.0f || beta2 >= 1.0f || eps <= 0.0f)
+        return LSIM_E_INVALID;
+    LsAdamTable t;
+    t.count = count;
+    for (int i = 0; i < count; ++i) {
+        if (!params[i] || !grads[i] || !exp_avg[i] || !exp_avg_sq[i] || !steps[i] || numel[i] <= 0 || numel[i] > 0x7fffffffLL) return LSIM_E_INVALID;
+        t.p[i] = params[i]; t.g[i] = grads[i]; t.m[i] = exp_avg[i]; t.v[i] = exp_avg_sq[i]; t.step[i] = steps[i]; t.n[i] = (int)numel[i];
+    }
+    for (int i = count; i < LS_ADAM_MAX_TENSORS; ++i) { t.p[i] = t.g[i] = t.m[i] = t.v[i] = t.step[i] = nullptr; t.n[i] = 0; }
+    float* part = (float*)workspace;
+    float* scal = part + (size_t)count * LS_ADAM_SLICES;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(lsim_k_adam_sumsq, dim3(LS_ADAM_SLICES, count), dim3(256), 0, s, t, part);
+    hipLaunchKernelGGL(lsim_k_adam_finish, dim3(1), dim3(64), 0, s, t, (const float*)part, max_grad_norm, scal);
+    hipLaunchKernelGGL(lsim_k_adam_apply, dim3(LS_ADAM_SLICES, count), dim3(256), 0, s, t, (const float*)scal, lr_dev, lr_host, beta1, beta2, eps);
+    if (grad_norm_out && hipMemcpyAsync(grad_norm_out, scal + 1, sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return LSIM_E_HIP;
+    return hipGetLastError() == hipSuccess ? LSIM_OK : LSIM_E_HIP;
+}
+

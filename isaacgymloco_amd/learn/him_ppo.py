@@ -101,7 +101,17 @@ class HIMPPO:
         self.optimizer = rebuild(self.optimizer)
         est = self.actor_critic.estimator
         est.optimizer = rebuild(est.optimizer)
+        est.fused_step = True
         return True
+
+    def _clip_and_step(self, optimizer, params, max_grad_norm):
+        """clip_grad_norm_ + optimizer.step() (HIMP:183-184); on the device-lr fast path one C-ABI call of three launches"""
+        if self._lr_t is not None:
+            from .fused_linear import adam_clip_step_hip
+            if adam_clip_step_hip(optimizer, max_grad_norm):
+                return
+        nn.utils.clip_grad_norm_(params, max_grad_norm)
+        optimizer.step()
 
     def _relink_lr(self):
         """optimizer.load_state_dict() restores plain float learning rates: point the groups at the device scalar again"""
@@ -217,8 +227,7 @@ class HIMPPO:
             loss.backward()
             if self.dist_ctx is not None:
                 self.dist_ctx.average_grads(list(ac.parameters()))   # clip AFTER the all-reduce (HIMP:183)
-            nn.utils.clip_grad_norm_(ac.parameters(), self.max_grad_norm)
-            self.optimizer.step()
+            self._clip_and_step(self.optimizer, ac.parameters(), self.max_grad_norm)
             sums += torch.stack((value_loss.detach(), surrogate_loss.detach(), est, swap))
             last_est, last_swap = est, swap
         n = self.num_learning_epochs * self.num_mini_batches

@@ -60,6 +60,7 @@ class HIMEstimator(nn.Module):
         self.num_one_step_obs = num_one_step_obs
         self.num_latent = enc_hidden_dims[-1]
         self.max_grad_norm = max_grad_norm
+        self.fused_step = False
         self.temperature = temperature
         self.encoder = mlp([temporal_steps * num_one_step_obs, *enc_hidden_dims[:-1], enc_hidden_dims[-1] + 3], act)
         self.target = mlp([num_one_step_obs, *tar_hidden_dims, enc_hidden_dims[-1]], act)
@@ -129,6 +130,10 @@ class HIMEstimator(nn.Module):
         total.backward()
         if self.grad_sync is not None:
             self.grad_sync(list(self.parameters()))
+        if self.fused_step:       # set by HIMPPO.enable_device_lr: clip + Adam in one C-ABI call (three launches)
+            from .fused_linear import adam_clip_step_hip
+            if adam_clip_step_hip(self.optimizer, self.max_grad_norm):
+                return est.detach(), swap.detach()
         nn.utils.clip_grad_norm_(self.parameters(), self.max_grad_norm)
         self.optimizer.step()
         return est.detach(), swap.detach()

@@ -533,3 +533,49 @@ def test_estimator_update_uses_the_fused_loss_and_matches_the_torch_path():
             assert (a.grad - b.grad).abs().max() <= 1e-3 * b.grad.abs().max() + 1e-9, k
     moved = sum(float((a - b).abs().gt(2e-5).float().mean()) for a, b in zip(est.parameters(), ref.parameters()))
     assert moved < 1e-2        # one Adam step of lr 1e-3 (sign-like): only gradients at the noise floor may step the other way
+
+
+def test_fused_clip_adam_step_matches_torch():
+    """lsim_adam_clip_step on the optimizer's own tensors against clip_grad_norm_ + torch.optim.Adam(fused=True).step(): parameters, moments,
+    step counters and the clipped gradients, with the clip active (max_norm 1) and inactive (1e9), host and device learning rate"""
+    import copy
+    from isaacgymloco_amd.learn.fused_linear import adam_clip_step_hip
+    torch.manual_seed(0)
+    for max_norm, dev_lr in ((1.0, True), (1e9, False)):
+        net = torch.nn.Sequential(torch.nn.Linear(270, 128), torch.nn.ELU(), torch.nn.Linear(128, 64), torch.nn.ELU(), torch.nn.Linear(64, 19)).to("cuda:0")
+        ref = copy.deepcopy(net)
+        lr_a = torch.tensor(1e-3, device="cuda:0") if dev_lr else 1e-3
+        lr_b = torch.tensor(1e-3, device="cuda:0") if dev_lr else 1e-3
+        oa = torch.optim.Adam(net.parameters(), lr=lr_a, fused=True)
+        ob = torch.optim.Adam(ref.parameters(), lr=lr_b, fused=True)
+        g = torch.Generator(device="cuda:0").manual_seed(1)
+        used = 0
+        for it in range(6):
+            x = torch.randn(4096, 270, device="cuda:0", generator=g)
+            for n_, o_ in ((net, oa), (ref, ob)):
+                o_.zero_grad()
+                (n_(x).square().mean() * 50.0).backward()
+            if dev_lr and it == 3:
+                lr_a.mul_(0.5); lr_b.mul_(0.5)                       # the adaptive rule rewrites the device scalar between steps
+            if adam_clip_step_hip(oa, max_norm):
+                used += 1
+            else:                                                    # first step: torch creates the state
+                torch.nn.utils.clip_grad_norm_(net.parameters(), max_norm)
+                oa.step()
+            torch.nn.utils.clip_grad_norm_(ref.parameters(), max_norm)
+            ob.step()
+            # the two networks drift apart by rounding (different summation order of the norm, then Adam's normalised step amplifies it where
+            # the second moment is tiny): tight for almost all elements, bounded for the rest
+            def close(a, b, tight, loose):
+                d = (a - b).abs()
+                scale = b.abs().max().clamp_min(1e-30)
+                assert float(d.max() / scale) < loose, (float(d.max()), float(scale))
+                assert float((d / scale > tight).float().mean()) < 0.02 or a.numel() < 64 and float(d.max() / scale) < 10 * tight
+            for pa, pb in zip(net.parameters(), ref.parameters()):
+                close(pa.grad.detach(), pb.grad.detach(), 1e-4, 2e-3)
+                close(pa.detach(), pb.detach(), 1e-4, 2e-3)
+                sa, sb = oa.state[pa], ob.state[pb]
+                assert float(sa["step"]) == float(sb["step"]) == it + 1
+                close(sa["exp_avg"], sb["exp_avg"], 1e-4, 2e-3)
+                close(sa["exp_avg_sq"], sb["exp_avg_sq"], 1e-4, 2e-3)
+        assert used == 5
