@@ -546,6 +546,12 @@ int lsim_adam_clip_step(int count, const int64_t* numel, float* const* params, f
                         float* const* exp_avg_sq, float* const* steps, const float* lr_dev, float lr_host, float beta1, float beta2,
                         float eps, float max_grad_norm, float* grad_norm_out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Actor input of HIMActorCritic (HAC:136-141; HES:64-68 for the normalisation): out[b] = [ obs[b, :num_one_step_obs] | enc_out[b, :3] |
+ * enc_out[b, 3:3+latent] / max(||.||, 1e-12) ], out [batch, num_one_step_obs + 3 + latent] contiguous; obs / enc_out with row strides
+ * ld_obs / ld_enc (floats).  No gradient flows through this (the estimator's outputs are detached there). */
+int lsim_actor_input(const float* obs, int64_t ld_obs, int num_one_step_obs, const float* enc_out, int64_t ld_enc, int latent,
+                     int64_t batch, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1256,3 +1256,34 @@ extern "C" int lsim_adam_clip_step(int count, const int64_t* numel, float* const
     return hipGetLastError() == hipSuccess ? LSIM_OK : LSIM_E_HIP;
 }
 
+// ---- actor input of HIMActorCritic (HAC:136-141): [current one-step observation | estimated velocity | L2-normalised latent] from the
+// observation history and the estimator's encoder output (no gradient flows through it): one launch instead of norm + clamp + div + cat
+__global__ __launch_bounds__(256) void lsim_k_actor_input(const float* __restrict__ obs, long ld_obs, int n_one, const float* __restrict__ enc, long ld_enc,
+                                                          int n_lat, long batch, float* __restrict__ out) {
+    const int W = n_one + 3 + n_lat;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= batch * W) return;
+    const long row = idx / W;
+    const int c = (int)(idx - row * W);
+    float v;
+    if (c < n_one) v = obs[row * ld_obs + c];
+    else if (c < n_one + 3) v = enc[row * ld_enc + (c - n_one)];
+    else {
+        const float* z = enc + row * ld_enc + 3;
+        float ss = 0.0f;
+        for (int k = 0; k < n_lat; ++k) ss = fmaf(z[k], z[k], ss);
+        v = z[c - n_one - 3] / fmaxf(sqrtf(ss), 1e-12f);              // F.normalize(p=2, eps=1e-12)
+    }
+    out[idx] = v;
+}
+
+extern "C" int lsim_actor_input(const float* obs, int64_t ld_obs, int num_one_step_obs, const float* enc_out, int64_t ld_enc, int latent,
+                                int64_t batch, float* out, void* stream) {
+    if (!obs || !enc_out || !out || batch <= 0 || num_one_step_obs <= 0 || latent <= 0 || ld_obs < num_one_step_obs || ld_enc < 3 + latent)
+        return LSIM_E_INVALID;
+    const long total = (long)batch * (num_one_step_obs + 3 + latent);
+    hipLaunchKernelGGL(lsim_k_actor_input, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, obs, (long)ld_obs, num_one_step_obs,
+                       enc_out, (long)ld_enc, latent, (long)batch, out);
+    return hipGetLastError() == hipSuccess ? LSIM_OK : LSIM_E_HIP;
+}
+

@@ -170,6 +170,16 @@ class HIMActorCritic(nn.Module):
         return self.distribution.entropy().sum(dim=-1)
 
     def _actor_input(self, obs_history):
+        if obs_history.is_cuda and obs_history.dim() == 2 and obs_history.dtype == torch.float32 and obs_history.stride(1) == 1:
+            from .. import lib        # one launch (lsim_actor_input) instead of norm + clamp + div + cat
+            with torch.no_grad():
+                enc = self.estimator._encoder_out(obs_history, want_grad=False)
+            n1, nl = self.num_one_step_obs, enc.shape[1] - 3
+            out = torch.empty(obs_history.shape[0], n1 + 3 + nl, device=obs_history.device, dtype=torch.float32)
+            lib.check(lib.load().lsim_actor_input(obs_history.data_ptr(), obs_history.stride(0), n1, enc.data_ptr(), enc.stride(0), nl,
+                                                  obs_history.shape[0], out.data_ptr(), torch.cuda.current_stream(obs_history.device).cuda_stream),
+                      what="lsim_actor_input")
+            return out
         with torch.no_grad():
             vel, latent = self.estimator(obs_history)
         return torch.cat((obs_history[:, :self.num_one_step_obs], vel, latent), dim=-1)

@@ -579,3 +579,20 @@ def test_fused_clip_adam_step_matches_torch():
                 close(sa["exp_avg"], sb["exp_avg"], 1e-4, 2e-3)
                 close(sa["exp_avg_sq"], sb["exp_avg_sq"], 1e-4, 2e-3)
         assert used == 5
+
+
+def test_fused_actor_input_matches_torch():
+    """lsim_actor_input against the torch statement of HAC:136-141 (slice, F.normalize, cat), contiguous and strided histories"""
+    from isaacgymloco_amd.learn import modules as M
+    torch.manual_seed(2)
+    ac = M.HIMActorCritic(270, 238, 45, 12).to("cuda:0")
+    g = torch.Generator(device="cuda:0").manual_seed(4)
+    for B in (102400, 4096, 37):
+        wide = torch.randn(B, 300, device="cuda:0", generator=g)
+        for hist in (wide[:, :270].contiguous(), wide[:, :270]):
+            got = ac._actor_input(hist)
+            with torch.no_grad():
+                vel, latent = ac.estimator(hist)
+                ref = torch.cat((hist[:, :45], vel, latent), dim=-1)
+            assert got.shape == ref.shape == (B, 64)
+            torch.testing.assert_close(got, ref, rtol=1e-6, atol=1e-6)
