@@ -163,7 +163,7 @@ def main():
                          "kernel": "lsim_k_step_a", "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * N,
                          "kernel_avg_ms": ka,
                          "valu_issue_frac": valu_frac,
-                         "note": "VALU-issue bound, not HBM bound: 6.9 KB and ~14 k VALU wave instructions per env-step (DESIGN.md, kernel A); "
+                         "note": "VALU-issue bound, not HBM bound: 6.9 KB and ~18 k VALU wave instructions per env-step (DESIGN.md, kernel A); "
                                  "traffic and valu_issue_frac come from separate rocprofv3 --pmc passes (profiles/pmc_traffic.json)"},
         }
         # measured device-memory copy rate on this box (quote the datasheet peak AND a measurement): 1 GiB fp32 copy
