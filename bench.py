@@ -1,17 +1,25 @@
 #!/usr/bin/env python3
 """bench.py -- env-steps/sec of the Aliengo hot path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs 4096] [--task aliengo] [--mode env|train]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs 4096] [--task aliengo] [--mode train|env]
 
 One "step" = one LeggedRobot.step() over the whole batch of envs of a rank (4 physics sub-steps + post-physics +
 reset + observations), driven the way the reference's runner drives it (HIMR:105-157).  Prints ONE JSON line from rank 0.
-Multi-GPU: one process per GPU (torchrun), environments sharded with no data-path collective (weak scaling); in
-train mode the PPO gradients are all-reduced over RCCL.
+
+--mode train (default) is the reference's `Perf/total_fps` (HIMR:179): value = N * T * iterations / (collection + learn).  The timed
+region always consists of WHOLE PPO iterations -- ceil(K / T) of them, T = num_steps_per_env = 100 -- each one = T x {policy
+inference + step + storage} + compute_returns + update(); `steps` echoes the request, `timed_env_steps` says what was timed.
+--mode env times step() back-to-back with pre-generated actions (exactly K steps), no learner.
+
+Multi-GPU: one process per GPU, environments sharded with no data-path collective (weak scaling); in train mode the PPO
+gradients are all-reduced over RCCL.  `python bench.py --gpus N` (no torchrun) starts the N rank processes itself, before
+anything touches a GPU, and relays rank 0's line; under `python -m torch.distributed.run ... bench.py --gpus N` it is one of the ranks.
 """
 import argparse
 import ctypes
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -21,44 +29,108 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 ALGO_BYTES_PER_ENV_STEP = 6900.0   # 3.07 KB read + 3.79 KB written per env-step (fused design)
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s spec
+N_SIMD = 1024                      # 256 CUs x 4 SIMD-32
+VALU_CYCLES_PER_WAVE_INST = 2.0    # MI355X_MICROARCH.md "Wave scheduling": a wave64 VALU instruction issues over 2 cycles on a SIMD-32
+                                   # (tools/micro/valu_peak.hip measures it: profiles/r02_valu_peak.json)
+MAX_CLOCK_HZ = 2.4e9
 
 
-def cpu_baseline(task, sample_envs=64, budget_s=12.0):
-    """Time the CPU oracle (build's scalar C twin of the same step; kind='port') on the host cores of this box: a child process
-    (oracle/cpu_bench.py, no GPU, no torch) runs one oracle instance per core for a bounded sample and reports the aggregate."""
-    import subprocess
-    procs = min(len(os.sched_getaffinity(0)), 64)          # bounded: 64 workers x 64 envs is plenty to show the per-core rate
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_bench.py"), "--task", task, "--envs", str(sample_envs),
-                          "--seconds", str(budget_s), "--procs", str(procs)], capture_output=True, text=True, timeout=600)
+def cpu_baseline(task, budget_s=24.0):
+    """Time the CPU oracle (the build's scalar-C twin of the same step, fp64 physics; kind='port') on the host cores of this box,
+    BASELINE.md section 3 plan A: OpenMP over envs on all host cores at N = 64 and N = 4096, plus the 1-core figure.  A child process
+    (oracle/cpu_bench.py: no GPU, no torch), started before this process touches the GPU."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_bench.py"), "--task", task, "--seconds", str(budget_s)],
+                         capture_output=True, text=True, timeout=900)
     if out.returncode != 0:
         raise RuntimeError(out.stderr[-400:])
     return json.loads(out.stdout.strip().splitlines()[-1])
 
 
-def main():
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (this parent never imports torch or touches a device),
+    relay rank 0's JSON line, exit with the worst return code."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc, pending = 0, set(range(n))
+    while pending:
+        for r in list(pending):
+            c = procs[r].poll()
+            if c is None:
+                continue
+            pending.discard(r)
+            if c != 0:
+                rc = rc or c
+                for o in pending:            # a dead rank leaves the others waiting in a collective: end exactly the processes started here
+                    procs[o].terminate()
+        time.sleep(0.05)
+    sys.exit(rc)
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--task", default="aliengo")
-    ap.add_argument("--mode", default="auto", choices=["auto", "env", "train"])
+    ap.add_argument("--mode", default="train", choices=["env", "train"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--actions", default="normal", choices=["normal", "zeros"],
                     help="env mode action source (SURVEY.md 8d): N(0,1) = an untrained policy (init_noise_std 1), or zeros = standing robots")
     ap.add_argument("--mixed-robots", action="store_true",
                     help="BASELINE config 5: the upper half of the ranks simulate Go1 instead of --task's robot (one shared policy; not reference-comparable)")
-    args = ap.parse_args()
+    return ap.parse_args()
+
+
+def pmc_for(task, n_envs, mode, actions):
+    """HBM traffic / instruction counts per launch of kernel A from separate rocprofv3 --pmc passes of this same command (PMC counters cannot
+    be read in-process); tools/pmc_summary.py writes them.  Only valid for the workload they were collected on: task, size, mode and action
+    source must all match, otherwise None."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    tj = json.load(open(path))
+    for rec in (tj.get("runs") or [tj]):
+        if (rec.get("task"), rec.get("envs_per_gpu"), rec.get("mode"), rec.get("actions")) == (task, n_envs, mode, actions):
+            return rec
+    return None
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args.gpus)             # never returns
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch one rank per GPU (or plain `python bench.py --gpus N`)")
+
+    # CPU baseline first: a child process on the host cores, while this process has not initialised the GPU yet (rank 0 at N = 1 only)
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline(args.task)
+        except Exception as e:  # the baseline is a reported extra, never the thing measured
+            cpu = {"value": None, "error": str(e)}
 
     # fp32 GEMMs of the learner: use the hipBLASLt/rocBLAS solutions pre-selected by PyTorch TunableOp on gfx950
     # (isaacgymloco_amd/learn/tunableop_gfx950.csv; LSIM_TUNE=1 re-tunes and rewrites it).  Must be set before torch loads.
     tuned = os.path.join(ROOT, "isaacgymloco_amd", "learn", "tunableop_gfx950.csv")
     if os.environ.get("LSIM_TUNE") == "1" or os.path.exists(tuned):
         import shutil, tempfile
-        lr_ = int(os.environ.get("LOCAL_RANK", "0"))
         tdir = tempfile.mkdtemp(prefix="lsim_tunableop_")
         if os.path.exists(tuned):
-            shutil.copy(tuned, os.path.join(tdir, f"tuned{lr_}.csv"))   # TunableOp appends the device ordinal to the name
+            shutil.copy(tuned, os.path.join(tdir, f"tuned{local_rank}.csv"))   # TunableOp appends the device ordinal to the name
         os.environ.setdefault("PYTORCH_TUNABLEOP_ENABLED", "1")
         os.environ.setdefault("PYTORCH_TUNABLEOP_FILENAME", os.path.join(tdir, "tuned.csv"))
         os.environ.setdefault("PYTORCH_TUNABLEOP_TUNING", "1" if os.environ.get("LSIM_TUNE") == "1" else "0")
@@ -66,16 +138,14 @@ def main():
         os.environ.setdefault("PYTORCH_TUNABLEOP_VERBOSE", "0")
     import torch
     import torch.distributed as dist
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if os.environ.get("LSIM_DEBUG_SINGLE_DEVICE") == "1":         # debugging aid: exercise the N > 1 code path on a 1-GPU box (all ranks on
-        local_rank = 0                                            # cuda:0, gloo instead of RCCL); never set by the driver
+    single_dev = os.environ.get("LSIM_DEBUG_SINGLE_DEVICE") == "1"   # debugging aid: exercise the N > 1 code path on a 1-GPU box (all ranks on
+    if single_dev:                                                   # cuda:0, gloo instead of RCCL); never set by the driver
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if os.environ.get("LSIM_DEBUG_SINGLE_DEVICE") == "1":
+        if single_dev:
             dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend="nccl", device_id=dev)   # RCCL; the rank's GPU is bound before the first collective
@@ -83,14 +153,7 @@ def main():
     from isaacgymloco_amd.envs import config as C
     from isaacgymloco_amd.envs.legged_robot import LeggedRobot
     mode = args.mode
-    try:
-        from isaacgymloco_amd.learn.runner import HIMOnPolicyRunner  # noqa: F401
-        have_learner = True
-    except Exception:
-        have_learner = False
-    if mode == "auto":
-        mode = "train" if have_learner else "env"
-
+    base_task = args.task
     if args.mixed_robots and world > 1 and rank >= world // 2:
         args.task = "go1"           # same observation / action layout, different model table and gains (envs/config.py GO1_OVERRIDES)
     cfg = C.TASKS[args.task][0]()
@@ -121,19 +184,23 @@ def main():
             env.step_device(acts[i % 16])
         barrier()
         elapsed = time.perf_counter() - t0
+        timed_steps = K
         ms_a = (ctypes.c_float * K)()
         ms_b = (ctypes.c_float * K)()
         n = ctypes.c_int(K)
         env._L.lsim_read_profile(env._h, ms_a, ms_b, ctypes.byref(n))
         ka = sum(ms_a[i] for i in range(n.value)) / max(n.value, 1)
         kb = sum(ms_b[i] for i in range(n.value)) / max(n.value, 1)
-        extra = {"kernel_a_ms": ka, "kernel_b_ms": kb}
+        extra = {"kernel_a_ms": ka, "kernel_b_ms": kb, "timed_env_steps": K}
+        actions_src = args.actions
         workload = (f"{args.task}: LeggedRobot.step() back-to-back, {'N(0,1)' if args.actions == 'normal' else 'zero'} actions, {N} envs/GPU "
                     "(no policy/learner in the loop)")
     else:
-        from isaacgymloco_amd.learn.bench_train import run_train_bench
+        from isaacgymloco_amd.learn.bench_train import run_train_bench   # raises if the learner is broken: no silent change of workload
         elapsed, extra, workload = run_train_bench(env, cfg, args, dev, rank, world, barrier)
-        ka = extra.get("kernel_a_ms", float("nan"))
+        ka = extra["kernel_a_ms"]
+        timed_steps = extra["timed_env_steps"]
+        actions_src = "policy"
 
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
@@ -141,30 +208,33 @@ def main():
     elapsed = float(t.item())
 
     if rank == 0:
-        value = world * N * K / elapsed
+        value = world * N * timed_steps / elapsed
         achieved = ALGO_BYTES_PER_ENV_STEP * N / (ka * 1e-3) / 1e9 if ka == ka and ka > 0 else None
-        # HBM traffic per launch of kernel A comes from separate rocprofv3 --pmc passes of this same command (PMC counters cannot be
-        # read in-process); tools/pmc_summary.py writes the corrected figure, valid for the workload it was collected on
-        traffic, valu_frac, tpath = None, None, os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            if tj.get("task") == args.task and tj.get("envs_per_gpu") == N:
-                traffic = tj["traffic_bytes_per_launch"]
-                if tj.get("valu_wave_insts_per_launch") and achieved:
-                    # the kernel's real limiter: wave64 VALU instructions issue over 4 cycles on each of 1024 SIMDs (256 CUs x 4) at 2.4 GHz
-                    valu_frac = tj["valu_wave_insts_per_launch"] * 4.0 / (1024 * 2.4e9 * ka * 1e-3)
+        pmc = pmc_for(args.task, N, mode, actions_src)
+        traffic = pmc["traffic_bytes_per_launch"] if pmc else None
+        valu_frac = None
+        if pmc and pmc.get("valu_wave_insts_per_launch") and achieved:
+            # share of the chip's VALU issue slots kernel A uses: wave64 VALU instructions x 2 cycles each / (1024 SIMDs x clock x duration).
+            # The clock is the measured effective clock of the PMC pass (GRBM_GUI_ACTIVE / duration) when it was collected, else the 2.4 GHz maximum.
+            clk = pmc.get("effective_clock_hz") or MAX_CLOCK_HZ
+            valu_frac = pmc["valu_wave_insts_per_launch"] * VALU_CYCLES_PER_WAVE_INST / (N_SIMD * clk * ka * 1e-3)
         out = {
             "metric": "env-steps/sec (whole node)", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": 1e3 * elapsed / timed_steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": workload, "task": args.task, "envs_per_gpu": N, "mode": mode, "parallelism": f"dp{world}"},
+            "config": {"workload": workload, "task": base_task, "envs_per_gpu": N, "mode": mode, "parallelism": f"dp{world}",
+                       "mixed_robots": bool(args.mixed_robots and world > 1)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "kernel": "lsim_k_step_a", "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * N,
                          "kernel_avg_ms": ka,
+                         "real_limiter": "latency / VALU issue inside each wave, not HBM (DESIGN.md section 6)",
                          "valu_issue_frac": valu_frac,
-                         "note": "VALU-issue bound, not HBM bound: 6.9 KB and ~18 k VALU wave instructions per env-step (DESIGN.md, kernel A); "
-                                 "traffic and valu_issue_frac come from separate rocprofv3 --pmc passes (profiles/pmc_traffic.json)"},
+                         "valu_cycles_per_wave_inst": VALU_CYCLES_PER_WAVE_INST,
+                         "pmc_source": ({k: pmc.get(k) for k in ("task", "envs_per_gpu", "mode", "actions", "effective_clock_hz", "file")} if pmc else None),
+                         "note": "the schema offers hbm|mfma; the path moves 6.9 KB per env-step and is bounded by per-wave dependency latency and VALU "
+                                 "issue, so frac is small by construction (SURVEY.md 8d); traffic and valu_issue_frac come from separate rocprofv3 --pmc "
+                                 "passes of the same workload (profiles/pmc_traffic.json) and are null when none matches task/size/mode/actions"},
         }
         # measured device-memory copy rate on this box (quote the datasheet peak AND a measurement): 1 GiB fp32 copy
         try:
@@ -180,12 +250,9 @@ def main():
         except Exception:
             out["roofline"]["measured_copy_gbs"] = None
         out.update({k: v for k, v in extra.items() if k not in out})
-        if world == 1 and not args.no_cpu_baseline:
-            try:
-                out["cpu_baseline"] = cpu_baseline(args.task if args.task in C.TASKS else "aliengo")
-            except Exception as e:  # the baseline is a reported extra, never the thing measured
-                out["cpu_baseline"] = {"value": None, "error": str(e)}
-        print(json.dumps(out))
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        print(json.dumps(out), flush=True)
     if os.environ.get("LSIM_TUNE") == "1" and rank == 0:   # keep the freshly tuned table (written at interpreter exit)
         import atexit, shutil
         src = os.environ["PYTORCH_TUNABLEOP_FILENAME"].replace(".csv", f"{local_rank}.csv")

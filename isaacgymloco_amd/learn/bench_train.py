@@ -1,6 +1,11 @@
 """Timed training loop for bench.py --mode train: the reference's total_fps definition (HIMR:179), i.e.
-env-steps/s over collection (policy inference + LeggedRobot.step + storage) PLUS compute_returns + update()."""
+env-steps/s over collection (policy inference + LeggedRobot.step + storage) PLUS compute_returns + update().
+
+The unit of timing is one WHOLE PPO iteration (HIMR:105-157): T = num_steps_per_env rollout steps, then GAE, then
+HIMPPO.update().  `--steps K` asks for K env-steps; ceil(K / T) iterations are timed (never zero updates), `--warmup W`
+likewise runs ceil(W / T) untimed iterations (at least two: the first update carries lazy library initialisation)."""
 import ctypes
+import os
 import time
 
 import torch
@@ -14,6 +19,12 @@ def train_cfg_dict(task):
     return {"runner": ppo["runner"], "algorithm": ppo["algorithm"], "policy": ppo["policy"]}
 
 
+def weights_digest(module):
+    """(sum, sum of squares) of every parameter in fp64 -- ranks that took identical optimiser steps agree to the last bit"""
+    flat = torch.cat([p.detach().reshape(-1) for p in module.parameters()]).double()
+    return [float(flat.sum()), float((flat * flat).sum())]
+
+
 def run_train_bench(env, cfg, args, dev, rank, world, barrier):
     task = args.task if args.task in C.TASKS else "aliengo"
     tc = train_cfg_dict(task)
@@ -25,63 +36,67 @@ def run_train_bench(env, cfg, args, dev, rank, world, barrier):
         runner = HybridPolicyRunner(env, tc, log_dir=None, device=str(dev))
     else:
         runner = HIMOnPolicyRunner(env, tc, log_dir=None, device=str(dev))
-    import os
     use_graphs = os.environ.get("LSIM_NO_GRAPHS") != "1" and runner.enable_graphs()
     T = runner.num_steps_per_env
-    K, W = args.steps, args.warmup
-    env.episode_length_buf = torch.randint_like(env.episode_length_buf, high=int(env.max_episode_length))
-    obs = env.get_observations().clone()
-    critic_obs = env.get_privileged_observations().clone()
+    iters = max(1, -(-args.steps // T))
+    warm_iters = max(2, -(-args.warmup // T))
+    env.episode_length_buf = torch.randint_like(env.episode_length_buf, high=int(env.max_episode_length))   # HIMR:90-91
+    state = dict(obs=env.get_observations().clone(), critic=env.get_privileged_observations().clone())
     runner.alg.actor_critic.train()
-    state = dict(obs=obs, critic=critic_obs, in_iter=0, coll=0.0, learn=0.0, iters=0)
 
-    def one_step(timed):
+    def one_iteration():
+        """HIMR:105-157 without the logging: returns (collection seconds, learn seconds), each closed by a device sync"""
         t0 = time.perf_counter()
-        if use_graphs:
-            runner.graphs.step()
-            state["critic"] = env.privileged_obs_buf
-        else:
-            with torch.inference_mode():
-                state["obs"], state["critic"], _, _, _ = runner._rollout_step(state["obs"], state["critic"])
-        state["in_iter"] += 1
-        if state["in_iter"] == T:
-            if timed:
-                torch.cuda.synchronize(dev)
-            t1 = time.perf_counter()
-            with torch.inference_mode():
-                runner.alg.compute_returns(state["critic"])
+        for _ in range(T):
             if use_graphs:
-                runner.graphs.end_iteration()
-            runner.alg.update()
-            state["in_iter"] = 0
-            if timed:
-                torch.cuda.synchronize(dev)
-                state["learn"] += time.perf_counter() - t1
-                state["iters"] += 1
-            return t1 - t0
-        return 0.0
+                runner.graphs.step()
+                state["critic"] = env.privileged_obs_buf
+            else:
+                with torch.inference_mode():
+                    state["obs"], state["critic"], _, _, _ = runner._rollout_step(state["obs"], state["critic"])
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        with torch.inference_mode():
+            runner.alg.compute_returns(state["critic"])
+        if use_graphs:
+            runner.graphs.end_iteration()
+        runner.alg.update()
+        torch.cuda.synchronize(dev)
+        return t1 - t0, time.perf_counter() - t1
 
-    for _ in range(W):
-        one_step(False)
-    env._L.lsim_set_profiling(env._h, K)
+    for _ in range(warm_iters):
+        one_iteration()
+    n_prof = iters * T
+    env._L.lsim_set_profiling(env._h, n_prof)
+    coll = learn = 0.0
     barrier()
     t0 = time.perf_counter()
-    for _ in range(K):
-        one_step(True)
+    for _ in range(iters):
+        c, l = one_iteration()
+        coll += c
+        learn += l
     barrier()
     elapsed = time.perf_counter() - t0
-    ms_a, ms_b, n = (ctypes.c_float * K)(), (ctypes.c_float * K)(), ctypes.c_int(K)
+    ms_a, ms_b, n = (ctypes.c_float * n_prof)(), (ctypes.c_float * n_prof)(), ctypes.c_int(n_prof)
     env._L.lsim_read_profile(env._h, ms_a, ms_b, ctypes.byref(n))
     ka = sum(ms_a[i] for i in range(n.value)) / max(n.value, 1)
     kb = sum(ms_b[i] for i in range(n.value)) / max(n.value, 1)
-    learn = state["learn"]
-    iters = max(state["iters"], 1)
-    extra = {"kernel_a_ms": ka, "kernel_b_ms": kb, "ppo_updates_timed": state["iters"],
-             "learn_s_per_update": learn / iters if state["iters"] else None,
-             "collection_s_per_iteration": (elapsed - learn) / (K / T) if K >= T else None,
-             "ppo_iteration_wall_s": elapsed / (K / T) if K >= T else None,
-             "collection_env_steps_per_s": world * env.num_envs * K / max(elapsed - learn, 1e-9),
-             "rollout_hip_graphs": bool(use_graphs)}
-    workload = (f"{task}: {type(runner).__name__} loop = policy inference + LeggedRobot.step + storage for {T} steps/iteration, then GAE + "
-                f"HIMPPO.update (5 epochs x 4 minibatches), {env.num_envs} envs/GPU")
+    digest = weights_digest(runner.alg.actor_critic)
+    if world > 1:
+        import torch.distributed as dist
+        d = torch.tensor(digest, device=dev, dtype=torch.float64)
+        all_d = [torch.zeros_like(d) for _ in range(world)]
+        dist.all_gather(all_d, d)
+        digests = [x.tolist() for x in all_d]
+    else:
+        digests = [digest]
+    extra = {"kernel_a_ms": ka, "kernel_b_ms": kb, "timed_env_steps": iters * T, "ppo_updates_timed": iters, "warmup_iterations": warm_iters,
+             "ppo_iteration_wall_s": elapsed / iters, "collection_s_per_iteration": coll / iters, "learn_s_per_update": learn / iters,
+             "collection_env_steps_per_s": world * env.num_envs * iters * T / max(coll, 1e-9),
+             "rollout_hip_graphs": bool(use_graphs), "weights_digest_by_rank": digests,
+             "ranks_in_lockstep": all(x == digests[0] for x in digests)}
+    alg = runner.alg
+    workload = (f"{task}: {type(runner).__name__} loop, {iters} whole PPO iteration(s) timed, each = {T} x (policy inference + LeggedRobot.step + "
+                f"storage) + GAE + {type(alg).__name__}.update ({alg.num_learning_epochs} epochs x {alg.num_mini_batches} minibatches), "
+                f"{env.num_envs} envs/GPU")
     return elapsed, extra, workload

@@ -535,8 +535,10 @@ static void reset_idx(orc_sim* s, const uint8_t* mask, int n_reset, uint32_t ste
         for (int f = 0; f < 4; ++f) ORC_F(s, LSIM_BUF_FEET_AIR_TIME)[4 * e + f] = 0.0f;
         ORC_U8(s, LSIM_BUF_RESET)[e] = 1;
     }
-    if (c->measure_heights) /* LR:332-333: all envs */
+    if (c->measure_heights) { /* LR:332-333: all envs */
+        #pragma omp parallel for schedule(static)
         for (int e = 0; e < N; ++e) get_heights(s, e, ORC_F(s, LSIM_BUF_MEASURED_HEIGHTS) + N_HP * e);
+    }
     for (int e = 0; e < N; ++e) {
         if (!mask[e]) continue;
         if (c->randomize_kp) ORC_F(s, LSIM_BUF_KP_FACTORS)[e] = rand_range(u01(s, e, stepw, LSIM_RNG_RESET_DR, 0), c->kp_range[0], c->kp_range[1]);
@@ -585,6 +587,7 @@ static void post_physics_step(orc_sim* s, uint32_t flags) {
     const float gvec[3] = {0.0f, 0.0f, -1.0f};
     const float fwd[3] = {1.0f, 0.0f, 0.0f};
 
+    #pragma omp parallel for schedule(dynamic, 16) reduction(+ : n_reset)
     for (int e = 0; e < N; ++e) {
         float* root = ORC_F(s, LSIM_BUF_ROOT_STATES) + 13 * e;
         const float* cf = ORC_F(s, LSIM_BUF_CONTACT_FORCES) + 3 * N_BODY * e;
@@ -691,6 +694,7 @@ static void post_physics_step(orc_sim* s, uint32_t flags) {
 
     /* LR:232 compute_observations + LR:167-171 clip + LR:235-241 tail */
     const int disturbed = c->disturbance && (s->step_counter % c->disturbance_interval == 0);
+    #pragma omp parallel for schedule(static)
     for (int e = 0; e < N; ++e) {
         float cur[LSIM_NUM_PRIV_OBS];
         float dist[3] = {0.0f, 0.0f, 0.0f};
@@ -831,6 +835,9 @@ int orc_step_ex(orc_sim* s, const float* actions, uint32_t flags) {
     const int N = c->num_envs;
     const uint32_t stepw = (uint32_t)(s->step_counter + 1);
     s->stats_row ^= 1;
+    /* envs are independent (no robot-robot contact, LR:1193) and every random draw is a pure function of (env, step, tag): the
+       result does not depend on the thread count.  OMP_NUM_THREADS = 1 is the scalar port. */
+    #pragma omp parallel for schedule(dynamic, 1)
     for (int e = 0; e < N; ++e) {
         float* act = ORC_F(s, LSIM_BUF_ACTIONS) + N_DOF * e;
         const float* last = ORC_F(s, LSIM_BUF_LAST_ACTIONS) + N_DOF * e;

@@ -1,0 +1,69 @@
+"""bench.py's command line: the N > 1 launcher, the rank/world check, and that a train-mode line always contains whole PPO
+iterations (update included) whatever --steps / --warmup the driver passes."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from helpers import ROOT
+
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(argv, env=None, timeout=900):
+    e = dict(os.environ)
+    e.update(env or {})
+    return subprocess.run([sys.executable, BENCH] + argv, env=e, capture_output=True, text=True, timeout=timeout)
+
+
+def test_world_size_mismatch_fails_loudly():
+    """a rank started with the wrong world size must not report dp1 quietly; this exits before torch is imported"""
+    r = _run(["--gpus", "2", "--no-cpu-baseline"], env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}, timeout=120)
+    assert r.returncode != 0
+    assert "WORLD_SIZE=1" in r.stderr and "--gpus 2" in r.stderr
+    assert r.stdout.strip() == ""
+
+
+def test_launcher_relays_failure_of_ranks():
+    """`bench.py --gpus 2` starts two rank processes itself; here (no GPU) both fail, and the parent must return non-zero
+    without printing a JSON line of its own"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("CPU-container check")
+    r = _run(["--gpus", "2", "--no-cpu-baseline", "--envs", "16", "--steps", "1", "--warmup", "1"], timeout=600)
+    assert r.returncode != 0
+    assert r.stdout.strip() == ""
+
+
+@pytest.mark.gpu
+def test_driver_arguments_time_a_full_ppo_iteration():
+    """the driver's `--steps 20 --warmup 5`: one whole iteration (100 steps + GAE + update) must be inside the timed region"""
+    r = _run(["--gpus", "1", "--steps", "20", "--warmup", "5", "--envs", "512", "--no-cpu-baseline"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    assert j["n_gpus"] == 1 and j["steps"] == 20 and j["warmup"] == 5
+    assert j["ppo_updates_timed"] >= 1 and j["timed_env_steps"] == 100 * j["ppo_updates_timed"]
+    assert j["learn_s_per_update"] > 0 and j["collection_s_per_iteration"] > 0 and j["ppo_iteration_wall_s"] > 0
+    # value = N * T * iterations / (collection + learn), HIMR:179
+    expect = 512 * j["timed_env_steps"] / (j["ppo_iteration_wall_s"] * j["ppo_updates_timed"])
+    assert abs(j["value"] - expect) / expect < 0.02
+    assert "update" in j["config"]["workload"] and j["config"]["mode"] == "train"
+    assert j["roofline"]["kernel_avg_ms"] > 0
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_the_fused_gpu_path_stay_in_lockstep():
+    """N > 1 path on the fused GPU kernels: two rank processes (both on cuda:0, gloo -- RCCL refuses two ranks on one device) shard
+    the envs, all-reduce the gradients and must end with bit-identical weights; rank 0 prints n_gpus = 2"""
+    r = _run(["--gpus", "2", "--steps", "100", "--warmup", "100", "--envs", "256", "--no-cpu-baseline"],
+             env={"LSIM_DEBUG_SINGLE_DEVICE": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["parallelism"] == "dp2"
+    assert j["ppo_updates_timed"] >= 1
+    assert len(j["weights_digest_by_rank"]) == 2 and j["ranks_in_lockstep"] is True
+    assert abs(j["value"] - 2 * 256 * j["timed_env_steps"] / (j["ppo_iteration_wall_s"] * j["ppo_updates_timed"])) / j["value"] < 0.02
