@@ -14,6 +14,10 @@
 #include "ls_shared.h"
 
 LS_FN int ls_leg_of_body(int b) { return (b - 1) >> 2; }   // b >= 1
+// Constraint-row slots (lane = slot): contact k owns slots 3k .. 3k+2 (normal, t1, t2), joint-limit row i owns slot LS_LIM0 + i.
+// Fixed slots give every slot a static row type, so the Gauss-Seidel sweep is specialised per type with no per-row masks or selects.
+#define LS_LIM0 (3 * LS_MAXC)
+LS_FN bool ls_slot_active(const WaveShared& sh, int slot) { return slot < 3 * sh.nc || (slot >= LS_LIM0 && slot < LS_LIM0 + sh.nlim); }
 LS_FN int ls_depth_of_body(int b) { return (b - 1) & 3; }  // 0 hip, 1 thigh, 2 calf, 3 foot
 
 // ---- phase K: forward kinematics, motion subspaces, twists, bias accelerations (lane = leg; lane 4 = base)
@@ -482,7 +486,7 @@ LS_FN void ph_limits(const LsCtx& cx, WaveShared& sh, int lane, float dt) {
 LS_FN void ph_rows(const LsCtx& cx, WaveShared& sh, LaneRegs& r, int lane, float dt) {
     r.row_kind = -1;
     r.row_rng = __builtin_inff();
-    if (lane >= sh.nrows) return;
+    if (!ls_slot_active(sh, lane)) return;
     const lsim_config& c = cx.cfg;
     float vt, rng = __builtin_inff();     // rng: width of a two-sided row's velocity interval (joint limits), +inf for one-sided rows
     int leg;
@@ -510,7 +514,7 @@ LS_FN void ph_rows(const LsCtx& cx, WaveShared& sh, LaneRegs& r, int lane, float
             else vt = fminf(c.max_depenetration_velocity, c.erp * fmaxf(-dist - c.contact_slop, 0.0f) / dt);
         } else vt = 0.0f;
     } else {
-        int i = lane - 3 * sh.nc;
+        int i = lane - LS_LIM0;
         int j = sh.limdof[i];
         leg = j / 3;
         Jl[j - 3 * leg] = 1.0f;
@@ -557,8 +561,7 @@ LS_FN void ph_rows(const LsCtx& cx, WaveShared& sh, LaneRegs& r, int lane, float
 // ---- phase R2 (lane emulator only; the GPU fuses it into wc_delassus_pgs): Delassus row W_i. = J_i Y^T (lane = row i)
 #if defined(LS_EMU)
 LS_FN void ph_delassus(WaveShared& sh, LaneRegs& r, int lane) {
-    if (lane >= sh.nrows) return;
-    const int R = sh.nrows;
+    if (!ls_slot_active(sh, lane)) return;
     const int leg = r.row_leg;
     const int lo = leg >= 0 ? 6 + 3 * leg : 6;
     const float jl0 = leg >= 0 ? r.Jl[0] : 0.0f, jl1 = leg >= 0 ? r.Jl[1] : 0.0f, jl2 = leg >= 0 ? r.Jl[2] : 0.0f;
@@ -566,8 +569,8 @@ LS_FN void ph_delassus(WaveShared& sh, LaneRegs& r, int lane) {
 #if !defined(LS_EMU)
 #pragma unroll
 #endif
-    for (int j = 0; j < LS_MAXR; ++j) {   // fully unrolled on the GPU so that W[] is register-resident
-        if (j < R) {
+    for (int j = 0; j < LS_MAXR; ++j) {
+        if (ls_slot_active(sh, j)) {
             const float* Y = sh.u.c.Y[j];
             float w = 0.0f;
             for (int k = 0; k < 6; ++k) w += r.Jb[k] * Y[k];
@@ -584,11 +587,12 @@ LS_FN void ph_delassus(WaveShared& sh, LaneRegs& r, int lane) {
 //      w_i = b_i + sum_j W_ij lam_j is kept up to date by every lane; rows are relaxed in order r = 0..R-1.
 #if defined(LS_EMU)
 static inline void wc_pgs(WaveShared& sh, LaneRegs* L, int iters) {
-    const int R = sh.nrows;
+    const int R = LS_MAXR;
     float lam[LS_MAXR], w[LS_MAXR];
-    for (int i = 0; i < R; ++i) { lam[i] = 0.0f; w[i] = L[i].brow; }
+    for (int i = 0; i < R; ++i) { lam[i] = 0.0f; w[i] = ls_slot_active(sh, i) ? L[i].brow : 0.0f; }
     for (int it = 0; it < iters; ++it)
         for (int r = 0; r < R; ++r) {
+            if (!ls_slot_active(sh, r)) continue;
             float nl = lam[r] - w[r] / L[r].wdiag;
             int kind = L[r].row_kind;
             if (kind == 0) nl = fmaxf(nl, 0.0f);
@@ -596,9 +600,9 @@ static inline void wc_pgs(WaveShared& sh, LaneRegs* L, int iters) {
             else { float lim = sh.mu * lam[r - kind]; nl = clampf(nl, -lim, lim); }
             float delta = nl - lam[r];
             lam[r] = nl;
-            for (int i = 0; i < R; ++i) w[i] += L[i].W[r] * delta;
+            for (int i = 0; i < R; ++i) if (ls_slot_active(sh, i)) w[i] += L[i].W[r] * delta;
         }
-    for (int i = 0; i < R; ++i) sh.lam[i] = lam[i];
+    for (int i = 0; i < R; ++i) if (ls_slot_active(sh, i)) sh.lam[i] = lam[i];
 }
 #else
 LS_FN float ls_readlane(float v, int srclane) {  // srclane is wave-uniform
@@ -608,50 +612,67 @@ LS_FN float ls_readlane(float v, int srclane) {  // srclane is wave-uniform
 template <int LANE> __device__ __forceinline__ void ls_writelane(float& v, float s) {
     asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(s), "n"(LANE));
 }
-// one Gauss-Seidel relaxation per row r = R0 .. LS_MAXR-1 (compile-time recursion: W[r] is a register, r an immediate).
-// Every lane evaluates its own candidate; only lane r's is real: readlane broadcasts it and its delta, lane r keeps it.
-template <int R0> __device__ __forceinline__ void ls_pgs_rows(int R, int ncr, const float (&W)[LS_MAXR], float cf, float hi_add, float inv_d, float rng_d,
-                                                             float& lam, float& lam_n, float& w) {
-    if constexpr (R0 < LS_MAXR) {
-        if (R0 < R) {
-            const float t = cf * lam_n, thi = fmaf(cf, lam_n, hi_add);
-            const float raw = fmaf(-w, inv_d, lam);
-            // one-sided rows: clamp into [-t, thi]; two-sided (joint limit) rows add the push-down of the upper bound: min(raw + range / d, 0)
-            const float nl = __builtin_amdgcn_fmed3f(raw, -t, thi) + fminf(raw + rng_d, 0.0f);
-            const float d = nl - lam;
-            const float s_nl = ls_readlane(nl, R0), s_d = ls_readlane(d, R0);
-            ls_writelane<R0>(lam, s_nl);
-            if constexpr (R0 % 3 == 0 && R0 + 2 < 3 * LS_MAXC) {
-                if (R0 < ncr) {                      // a normal row: hand its impulse to its two friction rows
-                    ls_writelane<R0 + 1>(lam_n, s_nl);
-                    ls_writelane<R0 + 2>(lam_n, s_nl);
-                }
-            }
-            w = fmaf(W[R0], s_d, w);
-            ls_pgs_rows<R0 + 1>(R, ncr, W, cf, hi_add, inv_d, rng_d, lam, lam_n, w);   // rows are contiguous: r >= R ends the sweep
+// One Gauss-Seidel relaxation of slot R.  Every lane evaluates its own candidate; only lane R's is real: readlane broadcasts it and
+// its delta, lane R keeps it (v_writelane with an immediate lane).  The clamp is specialised by the slot's static row type:
+//   normal    lam >= 0, and its impulse is handed to its two friction rows (their box is +-mu * lam_n)
+//   friction  |lam| <= mu * lam_n
+//   limit     two-sided velocity interval [L, L + rng]: lam = raw - clamp(raw, -rng / d, 0)   (push up at L, push down at the upper bound)
+enum { LS_ROW_NORMAL = 0, LS_ROW_FRICTION = 1, LS_ROW_LIMIT = 3 };
+template <int R, int KIND> __device__ __forceinline__ void ls_pgs_row(const float (&W)[LS_MAXR], float cf, float inv_d, float neg_rng_d,
+                                                                     float& lam, float& lam_n, float& w) {
+    const float raw = fmaf(-w, inv_d, lam);
+    float nl;
+    if constexpr (KIND == LS_ROW_NORMAL) nl = fmaxf(raw, 0.0f);
+    else if constexpr (KIND == LS_ROW_FRICTION) { const float t = cf * lam_n; nl = __builtin_amdgcn_fmed3f(raw, -t, t); }
+    else nl = raw - __builtin_amdgcn_fmed3f(raw, neg_rng_d, 0.0f);
+    const float d = nl - lam;
+    const float s_nl = ls_readlane(nl, R), s_d = ls_readlane(d, R);
+    ls_writelane<R>(lam, s_nl);
+    if constexpr (KIND == LS_ROW_NORMAL) {
+        ls_writelane<R + 1>(lam_n, s_nl);
+        ls_writelane<R + 2>(lam_n, s_nl);
+    }
+    w = fmaf(W[R], s_d, w);
+}
+// contacts K0 .. nc-1 (three slots each), then limit rows I0 .. nlim-1: compile-time recursion, one uniform branch per contact / limit row
+template <int K0> __device__ __forceinline__ void ls_pgs_contacts(int nc, const float (&W)[LS_MAXR], float cf, float inv_d, float& lam, float& lam_n, float& w) {
+    if constexpr (K0 < LS_MAXC) {
+        if (K0 < nc) {
+            ls_pgs_row<3 * K0, LS_ROW_NORMAL>(W, cf, inv_d, 0.0f, lam, lam_n, w);
+            ls_pgs_row<3 * K0 + 1, LS_ROW_FRICTION>(W, cf, inv_d, 0.0f, lam, lam_n, w);
+            ls_pgs_row<3 * K0 + 2, LS_ROW_FRICTION>(W, cf, inv_d, 0.0f, lam, lam_n, w);
+            ls_pgs_contacts<K0 + 1>(nc, W, cf, inv_d, lam, lam_n, w);
         }
     }
 }
-// W[j] = J_lane . Y_j for rows j = J0 .. R-1 (compile-time recursion; rows are contiguous, so j >= R ends it with one branch)
-template <int J0> __device__ __forceinline__ void ls_delassus_rows(const WaveShared& sh, int R, int lane, int lo, const float (&jb)[6],
-                                                                  float jl0, float jl1, float jl2, float (&W)[LS_MAXR], float& wd) {
-    if constexpr (J0 < LS_MAXR) {
-        if (J0 < R) {
+template <int I0> __device__ __forceinline__ void ls_pgs_limits(int nlim, const float (&W)[LS_MAXR], float inv_d, float neg_rng_d, float& lam, float& lam_n, float& w) {
+    if constexpr (I0 < LSIM_NUM_DOF) {
+        if (I0 < nlim) {
+            ls_pgs_row<LS_LIM0 + I0, LS_ROW_LIMIT>(W, 0.0f, inv_d, neg_rng_d, lam, lam_n, w);
+            ls_pgs_limits<I0 + 1>(nlim, W, inv_d, neg_rng_d, lam, lam_n, w);
+        }
+    }
+}
+// W[j] = J_lane . Y_j for slots j = J0 .. END-1 while j < cnt (compile-time recursion; active slots of a range are contiguous)
+template <int J0, int END> __device__ __forceinline__ void ls_delassus_rows(const WaveShared& sh, int cnt, int lane, int lo, const float (&jb)[6],
+                                                                           float jl0, float jl1, float jl2, float (&W)[LS_MAXR], float& wd) {
+    if constexpr (J0 < END) {
+        if (J0 < cnt) {
             const float* Y = sh.u.c.Y[J0];
             float w = 0.0f;
             for (int k = 0; k < 6; ++k) w += jb[k] * Y[k];
             w += jl0 * Y[lo] + jl1 * Y[lo + 1] + jl2 * Y[lo + 2];
             if (J0 == lane) { w += 1e-6f; wd = w; }   // constraint-force mixing keeps the diagonal positive
             W[J0] = w;
-            ls_delassus_rows<J0 + 1>(sh, R, lane, lo, jb, jl0, jl1, jl2, W, wd);
+            ls_delassus_rows<J0 + 1, END>(sh, cnt, lane, lo, jb, jl0, jl1, jl2, W, wd);
         }
     }
 }
 // GPU form: Delassus row and sweep fused so that the 36-entry row lives in registers only between here and the end of
-// the sweep (written unconditionally: no liveness across sub-steps); rows relaxed in order, impulse broadcast by readlane.
+// the sweep (written unconditionally: no liveness across sub-steps); rows relaxed in slot order, impulse broadcast by readlane.
 LS_FN void wc_delassus_pgs(WaveShared& sh, const LaneRegs& rg, int lane, int iters) {
-    const int R = sh.nrows;
-    const bool act = lane < R;
+    const int nc = sh.nc, nlim = sh.nlim;
+    const bool act = ls_slot_active(sh, lane);
     const int leg = rg.row_leg;
     const int lo = (act && leg >= 0) ? 6 + 3 * leg : 6;
     const bool has_leg = act && leg >= 0;
@@ -660,18 +681,16 @@ LS_FN void wc_delassus_pgs(WaveShared& sh, const LaneRegs& rg, int lane, int ite
     for (int k = 0; k < 6; ++k) jb[k] = act ? rg.Jb[k] : 0.0f;
     float W[LS_MAXR] = {};
     float wd = 1.0f;
-    ls_delassus_rows<0>(sh, R, lane, lo, jb, jl0, jl1, jl2, W, wd);
+    ls_delassus_rows<0, LS_LIM0>(sh, 3 * nc, lane, lo, jb, jl0, jl1, jl2, W, wd);
+    ls_delassus_rows<LS_LIM0, LS_MAXR>(sh, LS_LIM0 + nlim, lane, lo, jb, jl0, jl1, jl2, W, wd);
     float lam = 0.0f, lam_n = 0.0f, w = act ? rg.brow : 0.0f;
     const float inv_d = act ? 1.0f / wd : 0.0f;
-    const int kind = act ? rg.row_kind : -1;
-    const bool fric = (kind == 1 || kind == 2);
-    // bounds without per-row lane masks: lo = -cf * lam_n, hi = cf * lam_n + hi_add  (normal / limit rows: [0, +inf))
-    const float cf = fric ? sh.mu : 0.0f;
-    const float hi_add = fric ? 0.0f : __builtin_inff();
-    const int ncr = 3 * sh.nc;                 // rows [0, ncr) are contact rows laid out (normal, t1, t2) per contact
-    const float rng_d = act ? rg.row_rng * inv_d : __builtin_inff();     // +inf for one-sided rows: the extra term vanishes
-    for (int it = 0; it < iters; ++it)
-        ls_pgs_rows<0>(R, ncr, W, cf, hi_add, inv_d, rng_d, lam, lam_n, w);
+    const float cf = sh.mu;                                                 // only the friction slots use it
+    const float neg_rng_d = act ? -(rg.row_rng * inv_d) : 0.0f;            // only the limit slots use it (their range is finite)
+    for (int it = 0; it < iters; ++it) {
+        ls_pgs_contacts<0>(nc, W, cf, inv_d, lam, lam_n, w);
+        ls_pgs_limits<0>(nlim, W, inv_d, neg_rng_d, lam, lam_n, w);
+    }
     if (act) sh.lam[lane] = lam;
 }
 #endif
@@ -680,7 +699,8 @@ LS_FN void wc_delassus_pgs(WaveShared& sh, const LaneRegs& rg, int lane, int ite
 LS_FN void ph_apply_impulses(WaveShared& sh, int lane) {
     if (lane >= LS_NV) return;
     float v = sh.vfree[lane];
-    for (int r = 0; r < sh.nrows; ++r) v += sh.u.c.Y[r][lane] * sh.lam[r];
+    for (int r = 0; r < 3 * sh.nc; ++r) v += sh.u.c.Y[r][lane] * sh.lam[r];
+    for (int r = LS_LIM0; r < LS_LIM0 + sh.nlim; ++r) v += sh.u.c.Y[r][lane] * sh.lam[r];
     sh.vnew[lane] = v;
 }
 
