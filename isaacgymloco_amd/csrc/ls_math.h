@@ -34,6 +34,24 @@ LS_FN float ls_div_exact(float a, float b) {
 #endif
 }
 
+// Hardware reciprocal / reciprocal square root (v_rcp_f32 / v_rsq_f32, 1 ulp) for the dynamics: a plain `a / b` compiles to an 8-instruction
+// range-safe sequence (frexp / rcp / ldexp) even with fast division enabled, and the physics does ~60 of them per sub-step.  The
+// operands here are O(1e-6 .. 1e4) by construction (guarded by fmaxf where they could vanish); the lane emulator and the oracle divide.
+LS_FN float ls_rcp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
+LS_FN float ls_rsqrt(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rsqf(x);
+#else
+    return 1.0f / sqrtf(x);
+#endif
+}
+
 // row-major 3x3
 struct M3 {
     float m[9];
@@ -61,10 +79,19 @@ LS_FN M3 quat_to_R(const float* q) {  // xyzw
 LS_FN void R_to_quat(const M3& Rm, float* q) {
     const float* R = Rm.m;
     float tr = R[0] + R[4] + R[8];
-    if (tr > 0) { float s = sqrtf(tr + 1.0f) * 2; q[3] = 0.25f * s; q[0] = (R[7] - R[5]) / s; q[1] = (R[2] - R[6]) / s; q[2] = (R[3] - R[1]) / s; }
-    else if (R[0] > R[4] && R[0] > R[8]) { float s = sqrtf(1.0f + R[0] - R[4] - R[8]) * 2; q[3] = (R[7] - R[5]) / s; q[0] = 0.25f * s; q[1] = (R[1] + R[3]) / s; q[2] = (R[2] + R[6]) / s; }
-    else if (R[4] > R[8]) { float s = sqrtf(1.0f + R[4] - R[0] - R[8]) * 2; q[3] = (R[2] - R[6]) / s; q[0] = (R[1] + R[3]) / s; q[1] = 0.25f * s; q[2] = (R[5] + R[7]) / s; }
-    else { float s = sqrtf(1.0f + R[8] - R[0] - R[4]) * 2; q[3] = (R[3] - R[1]) / s; q[0] = (R[2] + R[6]) / s; q[1] = (R[5] + R[7]) / s; q[2] = 0.25f * s; }
+    // same case selection as the textbook form (trace > 0, else the largest diagonal entry), but one rsqrt and the same products for
+    // every case instead of a division per component
+    const int m = (tr > 0) ? 0 : ((R[0] > R[4] && R[0] > R[8]) ? 1 : (R[4] > R[8] ? 2 : 3));
+    const float dg = (m == 1) ? R[0] : (m == 2 ? R[4] : R[8]);
+    const float t = (m == 0) ? tr + 1.0f : 1.0f + 2.0f * dg - tr;          // 4 * (selected component)^2
+    const float is = 0.5f * ls_rsqrt(t);                                     // 1 / (4 * largest component)
+    const float big = t * is;                                                // the largest component itself
+    const float a = (R[7] - R[5]) * is, b = (R[2] - R[6]) * is, c = (R[3] - R[1]) * is;      // antisymmetric part: w * (x, y, z) / big
+    const float d = (R[1] + R[3]) * is, e = (R[2] + R[6]) * is, f = (R[5] + R[7]) * is;      // symmetric part:   (xy, xz, yz) / big
+    if (m == 0) { q[3] = big; q[0] = a; q[1] = b; q[2] = c; }
+    else if (m == 1) { q[0] = big; q[3] = a; q[1] = d; q[2] = e; }
+    else if (m == 2) { q[1] = big; q[3] = b; q[0] = d; q[2] = f; }
+    else { q[2] = big; q[3] = c; q[0] = e; q[1] = f; }
 }
 // joint angles are a few radians at most: the hardware v_sin_f32 / v_cos_f32 (abs error ~1e-6) replace ocml's ~60-instruction
 // range-reduced sinf / cosf on the device; the lane emulator and the oracle use libm

@@ -66,7 +66,7 @@ LS_FN void ph_body_inertia(const LsCtx& cx, WaveShared& sh, int lane, bool apply
     if (lane == 0) {  // payload / COM randomisation (LR:591-596); inertia scaled with the mass
         mass = bd.mass + sh.payload;
         cl = cl + v3p(sh.comd);
-        sc = mass / bd.mass;
+        sc = mass * ls_rcp(bd.mass);
     }
     M3 R = m3p(sh.R[lane]);
     V3 c = mul(R, cl) + v3p(sh.p[lane]);
@@ -101,34 +101,40 @@ LS_FN void ph_body_inertia(const LsCtx& cx, WaveShared& sh, int lane, bool apply
     s6st(sh.Fb[lane], F);
 }
 
-// 3x3 SPD Cholesky (l00,l10,l11,l20,l21,l22) and solve
+// 3x3 SPD Cholesky and solve.  L = (l00, l10, l11, l20, l21, l22, 1/l00, 1/l11, 1/l22): the reciprocal diagonal comes out of the
+// rsqrt that forms the factor, so no solve ever divides
+#define LS_CHOL3 9
 LS_FN void chol3(const float* M /*m00,m10,m11,m20,m21,m22*/, float* L) {
-    L[0] = sqrtf(M[0]);
-    L[1] = M[1] / L[0];
-    L[2] = sqrtf(M[2] - L[1] * L[1]);
-    L[3] = M[3] / L[0];
-    L[4] = (M[4] - L[3] * L[1]) / L[2];
-    L[5] = sqrtf(M[5] - L[3] * L[3] - L[4] * L[4]);
+    const float r0 = ls_rsqrt(M[0]);
+    L[0] = M[0] * r0;
+    L[1] = M[1] * r0;
+    L[3] = M[3] * r0;
+    const float d1 = M[2] - L[1] * L[1], r1 = ls_rsqrt(d1);
+    L[2] = d1 * r1;
+    L[4] = (M[4] - L[3] * L[1]) * r1;
+    const float d2 = M[5] - L[3] * L[3] - L[4] * L[4], r2 = ls_rsqrt(d2);
+    L[5] = d2 * r2;
+    L[6] = r0; L[7] = r1; L[8] = r2;
 }
 LS_FN void chol3_solve(const float* L, float* b) {
-    b[0] = b[0] / L[0];
-    b[1] = (b[1] - L[1] * b[0]) / L[2];
-    b[2] = (b[2] - L[3] * b[0] - L[4] * b[1]) / L[5];
-    b[2] = b[2] / L[5];
-    b[1] = (b[1] - L[4] * b[2]) / L[2];
-    b[0] = (b[0] - L[1] * b[1] - L[3] * b[2]) / L[0];
+    b[0] = b[0] * L[6];
+    b[1] = (b[1] - L[1] * b[0]) * L[7];
+    b[2] = (b[2] - L[3] * b[0] - L[4] * b[1]) * L[8];
+    b[2] = b[2] * L[8];
+    b[1] = (b[1] - L[4] * b[2]) * L[7];
+    b[0] = (b[0] - L[1] * b[1] - L[3] * b[2]) * L[6];
 }
-// 6x6 Cholesky solve with the lower factor stored row-major in a 36-float array
+// 6x6 Cholesky solve; lower factor row-major in a 36-float array with the RECIPROCAL of the diagonal stored on the diagonal
 LS_FN void chol6_solve(const float* L, float* b) {
     for (int i = 0; i < 6; ++i) {
         float v = b[i];
         for (int k = 0; k < i; ++k) v -= L[6 * i + k] * b[k];
-        b[i] = v / L[6 * i + i];
+        b[i] = v * L[6 * i + i];
     }
     for (int i = 5; i >= 0; --i) {
         float v = b[i];
         for (int k = i + 1; k < 6; ++k) v -= L[6 * k + i] * b[k];
-        b[i] = v / L[6 * i + i];
+        b[i] = v * L[6 * i + i];
     }
 }
 
@@ -181,9 +187,9 @@ LS_FN void ph_leg_block(WaveShared& sh, int lane) {
 LS_FN void ph_leg_schur(WaveShared& sh, int lane) {
     if (lane >= 24) return;
     int l = lane / 6, c = lane - 6 * l;
-    float L[6];
+    float L[LS_CHOL3];
     chol3(sh.lam + 6 * l, L);
-    if (c == 0) for (int e = 0; e < 6; ++e) sh.Lll[l][e] = L[e];
+    if (c == 0) for (int e = 0; e < LS_CHOL3; ++e) sh.Lll[l][e] = L[e];
     float col[3] = {sh.Mbl[l][3 * c], sh.Mbl[l][3 * c + 1], sh.Mbl[l][3 * c + 2]};   // (F_h[c], F_t[c], F_c[c])
     chol3_solve(L, col);
     sh.G[l][c] = col[0]; sh.G[l][6 + c] = col[1]; sh.G[l][12 + c] = col[2];
@@ -216,12 +222,12 @@ LS_FN void ph_base_factor(WaveShared& sh, int lane) {
     for (int j = 0; j < 6; ++j) {
         float d = A[6 * j + j];
         for (int k = 0; k < j; ++k) d -= A[6 * j + k] * A[6 * j + k];
-        d = sqrtf(fmaxf(d, 1e-12f));
-        A[6 * j + j] = d;
+        const float rd = ls_rsqrt(fmaxf(d, 1e-12f));
+        A[6 * j + j] = rd;                      // reciprocal of the diagonal entry (chol6_solve multiplies by it)
         for (int i = j + 1; i < 6; ++i) {
             float v = A[6 * i + j];
             for (int k = 0; k < j; ++k) v -= A[6 * i + k] * A[6 * j + k];
-            A[6 * i + j] = v / d;
+            A[6 * i + j] = v * rd;
         }
     }
     float col[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
@@ -231,21 +237,27 @@ LS_FN void ph_base_factor(WaveShared& sh, int lane) {
 }
 
 // ---- free velocity: three small phases
-LS_FN void ph_free_leg(WaveShared& sh, int lane) {  // lane = leg: y_l = Mll^-1 (tau_l - h_l)
-    if (lane >= 4) return;
-    float y[3];
-    for (int k = 0; k < 3; ++k) y[k] = sh.tau[3 * lane + k] - sh.hl[lane][k];
-    chol3_solve(sh.Lll[lane], y);
-    for (int k = 0; k < 3; ++k) sh.yl[lane][k] = y[k];
+//      1. lanes 0-3 (leg): y_l = Mll^-1 (tau_l - h_l);  lanes 8-13 (base row r): s_r = -h_b[r] - sum_l (G_l^T (tau_l - h_l))[r]
+//         (Mbl Mll^-1 = G^T, so the base right-hand side needs no leg solve and both run in the same phase)
+//      2. lanes 0-5: a_b = Sb^-1 s      3. ph_free_finish
+LS_FN void ph_free_leg(WaveShared& sh, int lane) {
+    if (lane < 4) {
+        float y[3];
+        for (int k = 0; k < 3; ++k) y[k] = sh.tau[3 * lane + k] - sh.hl[lane][k];
+        chol3_solve(sh.Lll[lane], y);
+        for (int k = 0; k < 3; ++k) sh.yl[lane][k] = y[k];
+    } else if (lane >= 8 && lane < 14) {
+        const int r = lane - 8;
+        float s = -sh.hb[r];
+        for (int l = 0; l < 4; ++l)
+            for (int k = 0; k < 3; ++k) s -= sh.G[l][6 * k + r] * (sh.tau[3 * l + k] - sh.hl[l][k]);
+        sh.rb[r] = s;
+    }
 }
-LS_FN void ph_free_base(WaveShared& sh, int lane) {  // lane = row of a_b = Sb^-1 (-h_b - sum_l Mbl y_l)
+LS_FN void ph_free_base(WaveShared& sh, int lane) {  // lane = row of a_b = Sb^-1 s
     if (lane >= 6) return;
     float a = 0.0f;
-    for (int r = 0; r < 6; ++r) {
-        float s = -sh.hb[r];
-        for (int l = 0; l < 4; ++l) s -= sh.Mbl[l][3 * r] * sh.yl[l][0] + sh.Mbl[l][3 * r + 1] * sh.yl[l][1] + sh.Mbl[l][3 * r + 2] * sh.yl[l][2];
-        a += sh.Sinv[6 * lane + r] * s;
-    }
+    for (int r = 0; r < 6; ++r) a += sh.Sinv[6 * lane + r] * sh.rb[r];
     sh.ab[lane] = a;
 }
 LS_FN void ph_free_finish(WaveShared& sh, int lane, float dt) {  // lane = generalized velocity index
@@ -269,7 +281,8 @@ LS_FN void ls_terrain_query(const LsCtx& cx, float x, float y, float& h, V3& n) 
     if (c.mesh_type == 0) { h = 0.0f; n = v3(0, 0, 1); return; }
     const int16_t* g = (const int16_t*)cx.buf[LSIM_BUF_HEIGHT_GRID];
     float hs = c.horizontal_scale, vs = c.vertical_scale;
-    float gx = (x + c.border_size) / hs, gy = (y + c.border_size) / hs;
+    const float ihs = ls_rcp(hs);
+    float gx = (x + c.border_size) * ihs, gy = (y + c.border_size) * ihs;
     float fi = clampf(floorf(gx), 0.0f, (float)(c.grid_rows - 2)), fj = clampf(floorf(gy), 0.0f, (float)(c.grid_cols - 2));
     int i = (int)fi, j = (int)fj;
     float u = clampf(gx - fi, 0.0f, 1.0f), v = clampf(gy - fj, 0.0f, 1.0f);
@@ -278,15 +291,14 @@ LS_FN void ls_terrain_query(const LsCtx& cx, float x, float y, float& h, V3& n) 
     float dhx, dhy;
     if (u >= v) { dhx = h10 - h00; dhy = h11 - h10; h = h00 + u * dhx + v * dhy; }
     else { dhx = h11 - h01; dhy = h01 - h00; h = h00 + v * dhy + u * dhx; }
-    float nx = -dhx / hs, ny = -dhy / hs, inv = 1.0f / sqrtf(nx * nx + ny * ny + 1.0f);
+    float nx = -dhx * ihs, ny = -dhy * ihs, inv = ls_rsqrt(nx * nx + ny * ny + 1.0f);
     n = v3(nx * inv, ny * inv, inv);
 }
 
 LS_FN void ls_tangent_basis(V3 n, V3& t1, V3& t2) {
     V3 ref = (fabsf(n.x) > 0.9f) ? v3(0, 1, 0) : v3(1, 0, 0);
     t1 = cross(n, ref);
-    float l = sqrtf(dot(t1, t1));
-    t1 = t1 * (1.0f / l);
+    t1 = t1 * ls_rsqrt(dot(t1, t1));
     t2 = cross(n, t1);
 }
 
@@ -299,15 +311,15 @@ LS_FN V3 ls_closest_on_triangle(V3 p, V3 a, V3 b, V3 c) {
     float d3 = dot(ab, bp), d4 = dot(ac, bp);
     if (d3 >= 0.0f && d4 <= d3) return b;
     float vc = d1 * d4 - d3 * d2;
-    if (vc <= 0.0f && d1 >= 0.0f && d3 <= 0.0f) return a + ab * (d1 / fmaxf(d1 - d3, 1e-20f));
+    if (vc <= 0.0f && d1 >= 0.0f && d3 <= 0.0f) return a + ab * (d1 * ls_rcp(fmaxf(d1 - d3, 1e-20f)));
     V3 cp = p - c;
     float d5 = dot(ab, cp), d6 = dot(ac, cp);
     if (d6 >= 0.0f && d5 <= d6) return c;
     float vb = d5 * d2 - d1 * d6;
-    if (vb <= 0.0f && d2 >= 0.0f && d6 <= 0.0f) return a + ac * (d2 / fmaxf(d2 - d6, 1e-20f));
+    if (vb <= 0.0f && d2 >= 0.0f && d6 <= 0.0f) return a + ac * (d2 * ls_rcp(fmaxf(d2 - d6, 1e-20f)));
     float va = d3 * d6 - d5 * d4;
-    if (va <= 0.0f && (d4 - d3) >= 0.0f && (d5 - d6) >= 0.0f) return b + (c - b) * ((d4 - d3) / fmaxf((d4 - d3) + (d5 - d6), 1e-20f));
-    float denom = 1.0f / fmaxf(va + vb + vc, 1e-20f);
+    if (va <= 0.0f && (d4 - d3) >= 0.0f && (d5 - d6) >= 0.0f) return b + (c - b) * ((d4 - d3) * ls_rcp(fmaxf((d4 - d3) + (d5 - d6), 1e-20f)));
+    float denom = ls_rcp(fmaxf(va + vb + vc, 1e-20f));
     return a + ab * (vb * denom) + ac * (vc * denom);
 }
 
@@ -328,7 +340,8 @@ LS_FN void ls_terrain_contact(const LsCtx& cx, V3 cw, float radius, float& dist,
     if (c.mesh_type == 0) { dist = cw.z; n = v3(0, 0, 1); return; }
     const int* mesh = (const int*)cx.buf[LSIM_BUF_TERRAIN_MESH];
     const float hs = c.horizontal_scale, vs = c.vertical_scale;
-    float gx = (cw.x + c.border_size) / hs, gy = (cw.y + c.border_size) / hs;
+    const float ihs = ls_rcp(hs);
+    float gx = (cw.x + c.border_size) * ihs, gy = (cw.y + c.border_size) * ihs;
     float fi = clampf(floorf(gx), 0.0f, (float)(c.grid_rows - 2)), fj = clampf(floorf(gy), 0.0f, (float)(c.grid_cols - 2));
     int i = (int)fi, j = (int)fj;
     const int w00 = mesh[i * c.grid_cols + j];
@@ -345,7 +358,7 @@ LS_FN void ls_terrain_contact(const LsCtx& cx, V3 cw, float radius, float& dist,
         float dhx, dhy, h;
         if (u >= v) { dhx = h10 - h00; dhy = h11 - h10; h = h00 + u * dhx + v * dhy; }
         else { dhx = h11 - h01; dhy = h01 - h00; h = h00 + v * dhy + u * dhx; }
-        float nx = -dhx / hs, ny = -dhy / hs, inv = 1.0f / sqrtf(nx * nx + ny * ny + 1.0f);
+        float nx = -dhx * ihs, ny = -dhy * ihs, inv = ls_rsqrt(nx * nx + ny * ny + 1.0f);
         n = v3(nx * inv, ny * inv, inv);
         dist = (cw.z - h) * inv;
         return;
@@ -377,7 +390,7 @@ LS_FN void ls_terrain_contact(const LsCtx& cx, V3 cw, float radius, float& dist,
                 V3 q = ls_closest_on_triangle(cw, a, b, cc);
                 V3 dq = cw - q;
                 float d2 = dot(dq, dq);
-                if (d2 < best) { best = d2; bq = q; bn = nt * (1.0f / nl); }
+                if (d2 < best) { best = d2; bq = q; bn = nt * ls_rcp(nl); }
             }
         }
     }
@@ -386,7 +399,7 @@ LS_FN void ls_terrain_contact(const LsCtx& cx, V3 cw, float radius, float& dist,
     V3 dq = cw - bq;
     float side = dot(bn, dq);
     if (side < -1e-6f) { dist = -d; n = bn; }                  // centre behind the face: inside the ground
-    else if (d > 1e-6f) { dist = d; n = dq * (1.0f / d); }
+    else if (d > 1e-6f) { dist = d; n = dq * ls_rcp(d); }
     else { dist = 0.0f; n = bn; }
 }
 
@@ -445,11 +458,12 @@ LS_FN void wc_compact_contacts(WaveShared& sh, LaneRegs& r, int lane) {
 //      GPU: lane = joint, ordered compaction by ballot; lane emulator: lane 0 walks the joints (same order, same result)
 #define LS_LIMIT_MARGIN 0.2f    // a joint "needs" its row when the free velocity is within this fraction of vmax of a bound (or beyond it)
 LS_FN bool ls_joint_limit_bounds(const LsCtx& cx, const WaveShared& sh, int j, float dt, float& Lb, float& Ub) {
+    const float idt = ls_rcp(dt);
     const float lo = sh.q[j] - cx.model.dof_pos_lower[j], hi = cx.model.dof_pos_upper[j] - sh.q[j];
     const float vmax = cx.model.dof_vel_limit[j], vf = sh.vfree[6 + j];
     Lb = -vmax; Ub = vmax;
-    if (lo < 0.1f) Lb = fmaxf(Lb, lo >= 0.0f ? -lo / dt : fminf(1.0f, cx.cfg.erp * (-lo) / dt));
-    if (hi < 0.1f) Ub = fminf(Ub, hi >= 0.0f ? hi / dt : -fminf(1.0f, cx.cfg.erp * (-hi) / dt));
+    if (lo < 0.1f) Lb = fmaxf(Lb, lo >= 0.0f ? -lo * idt : fminf(1.0f, cx.cfg.erp * (-lo) * idt));
+    if (hi < 0.1f) Ub = fminf(Ub, hi >= 0.0f ? hi * idt : -fminf(1.0f, cx.cfg.erp * (-hi) * idt));
     if (Ub < Lb) Ub = Lb;                                   // both stops violated at once cannot happen; keep the box well formed
     return fminf(vf - Lb, Ub - vf) < LS_LIMIT_MARGIN * vmax;
 }
@@ -510,8 +524,9 @@ LS_FN void ph_rows(const LsCtx& cx, WaveShared& sh, LaneRegs& r, int lane, float
         r.row_kind = a;
         if (a == 0) {
             float dist = sh.cdist[k];
-            if (dist >= 0.0f) vt = -dist / dt;
-            else vt = fminf(c.max_depenetration_velocity, c.erp * fmaxf(-dist - c.contact_slop, 0.0f) / dt);
+            const float idt = ls_rcp(dt);
+            if (dist >= 0.0f) vt = -dist * idt;
+            else vt = fminf(c.max_depenetration_velocity, c.erp * fmaxf(-dist - c.contact_slop, 0.0f) * idt);
         } else vt = 0.0f;
     } else {
         int i = lane - LS_LIM0;
@@ -684,7 +699,7 @@ LS_FN void wc_delassus_pgs(WaveShared& sh, const LaneRegs& rg, int lane, int ite
     ls_delassus_rows<0, LS_LIM0>(sh, 3 * nc, lane, lo, jb, jl0, jl1, jl2, W, wd);
     ls_delassus_rows<LS_LIM0, LS_MAXR>(sh, LS_LIM0 + nlim, lane, lo, jb, jl0, jl1, jl2, W, wd);
     float lam = 0.0f, lam_n = 0.0f, w = act ? rg.brow : 0.0f;
-    const float inv_d = act ? 1.0f / wd : 0.0f;
+    const float inv_d = act ? ls_rcp(wd) : 0.0f;
     const float cf = sh.mu;                                                 // only the friction slots use it
     const float neg_rng_d = act ? -(rg.row_rng * inv_d) : 0.0f;            // only the limit slots use it (their range is finite)
     for (int it = 0; it < iters; ++it) {
@@ -708,9 +723,10 @@ LS_FN void ph_apply_impulses(WaveShared& sh, int lane) {
 LS_FN void ph_contact_forces(WaveShared& sh, int lane, float dt) {
     if (lane >= LS_NB) return;
     V3 f = v3(0, 0, 0);
+    const float idt = ls_rcp(dt);
     for (int k = 0; k < sh.nc; ++k)
         if (sh.cbody[k] == lane)
-            for (int a = 0; a < 3; ++a) f = f + v3p(sh.u.c.dirs[3 * k + a]) * (sh.lam[3 * k + a] / dt);
+            for (int a = 0; a < 3; ++a) f = f + v3p(sh.u.c.dirs[3 * k + a]) * (sh.lam[3 * k + a] * idt);
     v3st(sh.cf[lane], f);
 }
 
@@ -725,20 +741,20 @@ LS_FN void ph_integrate(const LsCtx& cx, WaveShared& sh, int lane, float dt) {
         V3 w = v3p(sh.vnew), vl = v3p(sh.vnew + 3);
         {   // body velocity caps of the asset options (LRC:229-230; PhysX clamps there too): a safety net, never reached by a sane robot
             const float wn = sqrtf(dot(w, w)), ln = sqrtf(dot(vl, vl));
-            if (cx.cfg.max_angular_velocity > 0.0f && wn > cx.cfg.max_angular_velocity) w = w * (cx.cfg.max_angular_velocity / wn);
-            if (cx.cfg.max_linear_velocity > 0.0f && ln > cx.cfg.max_linear_velocity) vl = vl * (cx.cfg.max_linear_velocity / ln);
+            if (cx.cfg.max_angular_velocity > 0.0f && wn > cx.cfg.max_angular_velocity) w = w * (cx.cfg.max_angular_velocity * ls_rcp(wn));
+            if (cx.cfg.max_linear_velocity > 0.0f && ln > cx.cfg.max_linear_velocity) vl = vl * (cx.cfg.max_linear_velocity * ls_rcp(ln));
         }
         V3 dp = vl * dt;
         V3 vo = vl + cross(w, dp);   // velocity of the base origin after it moved by dp
         float* q = sh.root + 3;
-        float qn = 1.0f / sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+        float qn = ls_rsqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
         float q0 = q[0] * qn, q1 = q[1] * qn, q2 = q[2] * qn, q3 = q[3] * qn;
         float h = 0.5f * dt;
         float n0 = q0 + h * (w.x * q3 + w.y * q2 - w.z * q1);
         float n1 = q1 + h * (-w.x * q2 + w.y * q3 + w.z * q0);
         float n2 = q2 + h * (w.x * q1 - w.y * q0 + w.z * q3);
         float n3 = q3 + h * (-w.x * q0 - w.y * q1 - w.z * q2);
-        float nn = 1.0f / sqrtf(n0 * n0 + n1 * n1 + n2 * n2 + n3 * n3);
+        float nn = ls_rsqrt(n0 * n0 + n1 * n1 + n2 * n2 + n3 * n3);
         q[0] = n0 * nn; q[1] = n1 * nn; q[2] = n2 * nn; q[3] = n3 * nn;
         sh.root[0] += dp.x; sh.root[1] += dp.y; sh.root[2] += dp.z;
         v3st(sh.root + 7, vo);

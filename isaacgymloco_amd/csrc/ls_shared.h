@@ -83,7 +83,7 @@ struct WaveShared {
     } u;
     float Mbl[4][18];        // 6x3: columns F_hip, F_thigh, F_calf
     float G[4][18];          // 3x6: Mll^-1 Mlb^T
-    float Lll[4][6];         // Cholesky of the 3x3 leg block (l00,l10,l11,l20,l21,l22)
+    float Lll[4][9];         // Cholesky of the 3x3 leg block (l00,l10,l11,l20,l21,l22) and the reciprocals of its diagonal
     float hl[4][3];
     float legF[4][6];
     float yl[4][3];
