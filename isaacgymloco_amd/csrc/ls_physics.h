@@ -538,34 +538,25 @@ LS_FN void ph_rows(const LsCtx& cx, WaveShared& sh, LaneRegs& r, int lane, float
         r.row_kind = 3;
     }
     r.row_leg = leg;
-    for (int k = 0; k < 6; ++k) r.Jb[k] = Jb[k];
     for (int k = 0; k < 3; ++k) r.Jl[k] = Jl[k];
     v3st(sh.u.c.dirs[lane], d);
-    // Y = M^-1 J^T
-    float y[3] = {0, 0, 0}, rb[6];
-    for (int k = 0; k < 6; ++k) rb[k] = Jb[k];
+    // M^-1 J^T without the base-coupling leg terms (ls_shared.h, Y): y = Mll^-1 Jl, a = Jb - Mbl y (kept in r.Jb), z = Sb^-1 a
+    float y[3] = {0, 0, 0}, av[6];
+    for (int k = 0; k < 6; ++k) av[k] = Jb[k];
     if (leg >= 0) {
         for (int k = 0; k < 3; ++k) y[k] = Jl[k];
         chol3_solve(sh.Lll[leg], y);
-        for (int k = 0; k < 6; ++k) rb[k] -= sh.Mbl[leg][3 * k] * y[0] + sh.Mbl[leg][3 * k + 1] * y[1] + sh.Mbl[leg][3 * k + 2] * y[2];
+        for (int k = 0; k < 6; ++k) av[k] -= sh.Mbl[leg][3 * k] * y[0] + sh.Mbl[leg][3 * k + 1] * y[1] + sh.Mbl[leg][3 * k + 2] * y[2];
     }
-    {
-        float t[6];
-        for (int k = 0; k < 6; ++k) {
-            float s = 0.0f;
-            for (int cc = 0; cc < 6; ++cc) s += sh.Sinv[6 * k + cc] * rb[cc];
-            t[k] = s;
-        }
-        for (int k = 0; k < 6; ++k) rb[k] = t[k];
-    }
+    for (int k = 0; k < 6; ++k) r.Jb[k] = av[k];
     float* Y = sh.u.c.Y[lane];
-    for (int k = 0; k < 6; ++k) Y[k] = rb[k];
+    for (int k = 0; k < 6; ++k) {
+        float s = 0.0f;
+        for (int cc = 0; cc < 6; ++cc) s += sh.Sinv[6 * k + cc] * av[cc];
+        Y[k] = s;
+    }
     for (int l = 0; l < 4; ++l)
-        for (int k = 0; k < 3; ++k) {
-            float s = (l == leg) ? y[k] : 0.0f;
-            for (int cc = 0; cc < 6; ++cc) s -= sh.G[l][6 * k + cc] * rb[cc];
-            Y[6 + 3 * l + k] = s;
-        }
+        for (int k = 0; k < 3; ++k) Y[6 + 3 * l + k] = (l == leg) ? y[k] : 0.0f;
     float jv = 0.0f;
     for (int k = 0; k < 6; ++k) jv += Jb[k] * sh.vfree[k];
     if (leg >= 0) for (int k = 0; k < 3; ++k) jv += Jl[k] * sh.vfree[6 + 3 * leg + k];
@@ -581,9 +572,6 @@ LS_FN void ph_delassus(WaveShared& sh, LaneRegs& r, int lane) {
     const int lo = leg >= 0 ? 6 + 3 * leg : 6;
     const float jl0 = leg >= 0 ? r.Jl[0] : 0.0f, jl1 = leg >= 0 ? r.Jl[1] : 0.0f, jl2 = leg >= 0 ? r.Jl[2] : 0.0f;
     float wd = 0.0f;
-#if !defined(LS_EMU)
-#pragma unroll
-#endif
     for (int j = 0; j < LS_MAXR; ++j) {
         if (ls_slot_active(sh, j)) {
             const float* Y = sh.u.c.Y[j];
@@ -668,7 +656,8 @@ template <int I0> __device__ __forceinline__ void ls_pgs_limits(int nlim, const 
         }
     }
 }
-// W[j] = J_lane . Y_j for slots j = J0 .. END-1 while j < cnt (compile-time recursion; active slots of a range are contiguous)
+// W[j] = a_lane . z_j + Jl_lane . y_j[leg_lane] for slots j = J0 .. END-1 while j < cnt (compile-time recursion; the active slots of a
+// range are contiguous); y_j is zero on every leg but row j's own, so no leg comparison is needed
 template <int J0, int END> __device__ __forceinline__ void ls_delassus_rows(const WaveShared& sh, int cnt, int lane, int lo, const float (&jb)[6],
                                                                            float jl0, float jl1, float jl2, float (&W)[LS_MAXR], float& wd) {
     if constexpr (J0 < END) {
@@ -710,13 +699,16 @@ LS_FN void wc_delassus_pgs(WaveShared& sh, const LaneRegs& rg, int lane, int ite
 }
 #endif
 
-// ---- phase V: constrained velocity (lane = generalized velocity index)
+// ---- phase V: constrained velocity v+ = vfree + M^-1 J^T lam from the stored rows (lane = generalized velocity index): the base part
+//      dvb = sum_r z_r lam_r is final here (and parked in sh.ab, dead since ph_free_finish); a joint gets its own-leg part here and the
+//      coupling term - G_l dvb in ph_integrate, once dvb is complete
 LS_FN void ph_apply_impulses(WaveShared& sh, int lane) {
     if (lane >= LS_NV) return;
-    float v = sh.vfree[lane];
-    for (int r = 0; r < 3 * sh.nc; ++r) v += sh.u.c.Y[r][lane] * sh.lam[r];
-    for (int r = LS_LIM0; r < LS_LIM0 + sh.nlim; ++r) v += sh.u.c.Y[r][lane] * sh.lam[r];
-    sh.vnew[lane] = v;
+    float acc = 0.0f;
+    for (int r = 0; r < 3 * sh.nc; ++r) acc += sh.u.c.Y[r][lane] * sh.lam[r];
+    for (int r = LS_LIM0; r < LS_LIM0 + sh.nlim; ++r) acc += sh.u.c.Y[r][lane] * sh.lam[r];
+    if (lane < 6) sh.ab[lane] = acc;
+    sh.vnew[lane] = sh.vfree[lane] + acc;
 }
 
 // ---- phase B: net contact force per body, world frame (LR:944) (lane = body)
@@ -734,7 +726,10 @@ LS_FN void ph_contact_forces(WaveShared& sh, int lane, float dt) {
 LS_FN void ph_integrate(const LsCtx& cx, WaveShared& sh, int lane, float dt) {
     if (lane < 12) {
         float lim = 1.5f * cx.model.dof_vel_limit[lane];     // the limit itself is a constraint row; this only bounds solver residue
-        float v = clampf(sh.vnew[6 + lane], -lim, lim);
+        const int l = lane / 3, k = lane - 3 * l;
+        float vj = sh.vnew[6 + lane];
+        for (int c = 0; c < 6; ++c) vj -= sh.G[l][6 * k + c] * sh.ab[c];      // - G_l dvb: the base impulse response on this joint (ph_apply_impulses)
+        float v = clampf(vj, -lim, lim);
         sh.q[lane] += dt * v;
         sh.qd[lane] = v;
     } else if (lane == 12) {

@@ -77,7 +77,11 @@ struct WaveShared {
     union {
         float I6[LS_NB][36];                 // spatial inertias (dead after the composite pass)
         struct {
-            float Y[LS_MAXR][LS_NV];         // M^-1 J^T rows
+            // Per constraint row i, M^-1 J_i^T WITHOUT its base-coupling leg terms: [0..5] z = Sb^-1 (Jb - Mbl y), [6 + 3l + k] = y[k] = (Mll^-1 Jl)[k]
+            // on the row's own leg and 0 on the others.  The full vector has - G_l z on every leg; the solver never needs it:
+            //   W_ij = J_i M^-1 J_j^T = a_i . z_j + Jl_i . y_j[leg_i]   with a_i = Jb_i - Mbl y_i (registers),   v+ = vfree + sum_r Y_r lam_r - G (sum_r z_r lam_r)
+            // which saves 72 FMAs and as many LDS reads per row against forming - G_l z for all four legs.
+            float Y[LS_MAXR][LS_NV];
             float dirs[LS_MAXR][3];
         } c;
     } u;
