@@ -50,10 +50,10 @@ LS_FN void ph_load_a(const LsCtx& cx, WaveShared& sh, LaneRegs& rg, int lane, in
     const lsim_config& c = cx.cfg;
     if (lane < 13) sh.root[lane] = LSB(cx, LSIM_BUF_ROOT_STATES, float)[13 * env + lane];
     if (lane < 12) {
-        const float* dof = LSB(cx, LSIM_BUF_DOF_STATE, float) + 24 * env;
+        LS_GLOBAL const float* dof = LSB(cx, LSIM_BUF_DOF_STATE, float) + 24 * env;
         sh.q[lane] = dof[2 * lane];
         sh.qd[lane] = dof[2 * lane + 1];
-        float act = clampf(a.actions[12 * env + lane], -c.clip_actions, c.clip_actions);
+        float act = clampf(LS_G(const float, a.actions)[12 * env + lane], -c.clip_actions, c.clip_actions);
         sh.act[lane] = act;
         LSB(cx, LSIM_BUF_ACTIONS, float)[12 * env + lane] = act;
         sh.last_act[lane] = LSB(cx, LSIM_BUF_LAST_ACTIONS, float)[12 * env + lane];
@@ -66,7 +66,7 @@ LS_FN void ph_load_a(const LsCtx& cx, WaveShared& sh, LaneRegs& rg, int lane, in
         sh.payload = LSB(cx, LSIM_BUF_PAYLOAD, float)[env];
     }
     if (lane == 14) {
-        float* pf = LSB(cx, LSIM_BUF_PENDING_FORCE, float) + 3 * env;
+        LS_GLOBAL float* pf = LSB(cx, LSIM_BUF_PENDING_FORCE, float) + 3 * env;
         for (int k = 0; k < 3; ++k) {
             sh.comd[k] = LSB(cx, LSIM_BUF_COM_DISPLACEMENT, float)[3 * env + k];
             sh.pend[k] = pf[k];
@@ -110,7 +110,7 @@ LS_FN void ph_torques(const LsCtx& cx, WaveShared& sh, int lane, int env, int su
 LS_FN void ph_store_sim_state(const LsCtx& cx, WaveShared& sh, int lane, int env) {
     if (lane < 13) LSB(cx, LSIM_BUF_ROOT_STATES, float)[13 * env + lane] = sh.root[lane];
     if (lane < 12) {
-        float* dof = LSB(cx, LSIM_BUF_DOF_STATE, float) + 24 * env;
+        LS_GLOBAL float* dof = LSB(cx, LSIM_BUF_DOF_STATE, float) + 24 * env;
         dof[2 * lane] = sh.q[lane]; dof[2 * lane + 1] = sh.qd[lane];
         sh.dofs[2 * lane] = sh.q[lane]; sh.dofs[2 * lane + 1] = sh.qd[lane];
         LSB(cx, LSIM_BUF_TORQUES, float)[12 * env + lane] = sh.tau[lane];
@@ -118,12 +118,12 @@ LS_FN void ph_store_sim_state(const LsCtx& cx, WaveShared& sh, int lane, int env
     if (lane < 3 * LS_NB) LSB(cx, LSIM_BUF_CONTACT_FORCES, float)[3 * LS_NB * env + lane] = sh.cf[lane / 3][lane % 3];
 }
 LS_FN void ph_body_states_all(const LsCtx& cx, WaveShared& sh, int lane, int env) {
-    float* out = LSB(cx, LSIM_BUF_RIGID_BODY_STATES, float) + 13 * LS_NB * env;
+    LS_GLOBAL float* out = LSB(cx, LSIM_BUF_RIGID_BODY_STATES, float) + 13 * LS_NB * env;
     ph_body_states(sh, lane, out);
     if (lane < LS_NB)
         for (int f = 0; f < 4; ++f)
             if (cx.model.feet_bodies[f] == lane) {
-                const float* o = out + 13 * lane;
+                LS_GLOBAL const float* o = out + 13 * lane;
                 for (int k = 0; k < 3; ++k) { sh.feet[f][k] = o[k]; sh.feet[f][3 + k] = o[7 + k]; }
             }
 }
@@ -136,20 +136,20 @@ LS_FN void ph_load_injected(const LsCtx& cx, WaveShared& sh, int lane, int env) 
     if (lane < 3 * LS_NB) sh.cf[lane / 3][lane % 3] = LSB(cx, LSIM_BUF_CONTACT_FORCES, float)[3 * LS_NB * env + lane];
     if (lane < 24) {
         int f = lane / 6, k = lane % 6;
-        const float* bs = LSB(cx, LSIM_BUF_RIGID_BODY_STATES, float) + 13 * (LS_NB * env + cx.model.feet_bodies[f]);
+        LS_GLOBAL const float* bs = LSB(cx, LSIM_BUF_RIGID_BODY_STATES, float) + 13 * (LS_NB * env + cx.model.feet_bodies[f]);
         sh.feet[f][k] = k < 3 ? bs[k] : bs[7 + k - 3];
     }
 }
 
 LS_FN void ph_store_root_cmd_ranges(const LsCtx& cx, WaveShared& sh, int lane, int env, const LsStepArgs& a) {
-    if (lane < 8) sh.ranges[lane] = cx.accum[a.row_in * LSIM_STATS_SIZE + LSIM_STATS_CMD_RANGES + lane];
+    if (lane < 8) sh.ranges[lane] = LS_G(const float, cx.accum)[a.row_in * LSIM_STATS_SIZE + LSIM_STATS_CMD_RANGES + lane];
 }
 
 // ---- termination observations / terminal AMP states of the pre-reset state + per-step reductions (LR:227-228)
 LS_FN void ph_term_outputs(const LsCtx& cx, WaveShared& sh, int lane, int env, const LsStepArgs& a) {
     if (lane < 13) LSB(cx, LSIM_BUF_ROOT_STATES, float)[13 * env + lane] = sh.root[lane];   // push may have changed the velocity
     if (!sh.reset) return;
-    float* tp = LSB(cx, LSIM_BUF_TERM_PRIV_OBS, float) + LSIM_NUM_PRIV_OBS * env;
+    LS_GLOBAL float* tp = LSB(cx, LSIM_BUF_TERM_PRIV_OBS, float) + LSIM_NUM_PRIV_OBS * env;
     for (int k = lane; k < LSIM_NUM_PRIV_OBS; k += 64) tp[k] = sh.cur[k];
     if (lane < LSIM_NUM_AMP_OBS) {
         float v;
@@ -160,7 +160,7 @@ LS_FN void ph_term_outputs(const LsCtx& cx, WaveShared& sh, int lane, int env, c
         LSB(cx, LSIM_BUF_TERM_AMP_OBS, float)[LSIM_NUM_AMP_OBS * env + lane] = v;
     }
     if (lane == 0 && !(a.flags & LSIM_STEP_NO_RESET)) {
-        float* acc = cx.accum + a.row_out * LSIM_STATS_SIZE;
+        LS_GLOBAL float* acc = LS_G(float, cx.accum) + a.row_out * LSIM_STATS_SIZE;
         LS_ATOMIC_ADD(acc + LSIM_STATS_RESET_COUNT, 1.0f);
         LS_ATOMIC_ADD(acc + LSIM_STATS_TRACK_SUM, LSB(cx, LSIM_BUF_EPISODE_SUMS, float)[env * LSIM_NUM_REWARD_TERMS + LSIM_R_TRACKING_LIN_VEL]);
     }
@@ -236,8 +236,8 @@ LS_FN void ph_load_b(const LsCtx& cx, WaveShared& sh, int lane, int env, const L
     if (lane < 4) sh.cmd[lane] = LSB(cx, LSIM_BUF_COMMANDS, float)[4 * env + lane];
     for (int k = lane; k < LS_NHP; k += 64) sh.heights[k] = LSB(cx, LSIM_BUF_MEASURED_HEIGHTS, float)[LS_NHP * env + k];
     if (lane == 32) {
-        const float* acc_out = cx.accum + a.row_out * LSIM_STATS_SIZE;
-        const float* acc_in = cx.accum + a.row_in * LSIM_STATS_SIZE;
+        LS_GLOBAL const float* acc_out = LS_G(const float, cx.accum) + a.row_out * LSIM_STATS_SIZE;
+        LS_GLOBAL const float* acc_in = LS_G(const float, cx.accum) + a.row_in * LSIM_STATS_SIZE;
         int reset = LSB(cx, LSIM_BUF_RESET, uint8_t)[env];
         sh.reset = reset;
         sh.eplen = (int)LSB(cx, LSIM_BUF_EPISODE_LENGTH, int64_t)[env];
@@ -264,10 +264,10 @@ LS_FN void ph_load_b(const LsCtx& cx, WaveShared& sh, int lane, int env, const L
 // env 0 publishes the ranges of this step and clears the accumulator row the NEXT step will use
 LS_FN void ph_b_housekeeping(const LsCtx& cx, WaveShared& sh, int lane, int env, const LsStepArgs& a) {
     if (env != 0) return;
-    float* out = cx.accum + a.row_out * LSIM_STATS_SIZE;
+    LS_GLOBAL float* out = LS_G(float, cx.accum) + a.row_out * LSIM_STATS_SIZE;
     if (lane < 8) out[LSIM_STATS_CMD_RANGES + lane] = sh.ranges[lane];
     if (a.reset_all && lane == 8) out[LSIM_STATS_RESET_COUNT] = (float)cx.cfg.num_envs;
-    float* nxt = cx.accum + a.row_in * LSIM_STATS_SIZE;   // the next call accumulates into the row this call read
+    LS_GLOBAL float* nxt = LS_G(float, cx.accum) + a.row_in * LSIM_STATS_SIZE;   // the next call accumulates into the row this call read
     if (lane == 9) nxt[LSIM_STATS_RESET_COUNT] = 0.0f;
     if (lane == 10) nxt[LSIM_STATS_TRACK_SUM] = 0.0f;
     for (int k = lane; k < LSIM_NUM_REWARD_TERMS; k += 64) nxt[LSIM_STATS_EPISODE_SUMS + k] = 0.0f;
@@ -277,8 +277,8 @@ LS_FN void ph_b_housekeeping(const LsCtx& cx, WaveShared& sh, int lane, int env,
 LS_FN void ph_b_terrain_curriculum(const LsCtx& cx, WaveShared& sh, int lane, int env, const LsStepArgs& a) {
     const lsim_config& c = cx.cfg;
     if (lane != 0 || !sh.do_reset || !c.terrain_curriculum || c.mesh_type == 0 || !a.init_done) return;
-    float* org = LSB(cx, LSIM_BUF_ENV_ORIGINS, float) + 3 * env;
-    int64_t* lvlp = LSB(cx, LSIM_BUF_TERRAIN_LEVELS, int64_t) + env;
+    LS_GLOBAL float* org = LSB(cx, LSIM_BUF_ENV_ORIGINS, float) + 3 * env;
+    LS_GLOBAL int64_t* lvlp = LSB(cx, LSIM_BUF_TERRAIN_LEVELS, int64_t) + env;
     int64_t type = LSB(cx, LSIM_BUF_TERRAIN_TYPES, int64_t)[env];
     float dx = sh.root[0] - org[0], dy = sh.root[1] - org[1];
     float dist = sqrtf(dx * dx + dy * dy);
@@ -288,7 +288,7 @@ LS_FN void ph_b_terrain_curriculum(const LsCtx& cx, WaveShared& sh, int lane, in
     if (lvl >= c.terrain_num_rows) lvl = (int64_t)(ls_draw(cx, env, (uint32_t)a.step_counter, LSIM_RNG_RESET_LEVEL, 0) * (float)c.terrain_num_rows);
     else if (lvl < 0) lvl = 0;
     *lvlp = lvl;
-    const float* to = LSB(cx, LSIM_BUF_TERRAIN_ORIGINS, float) + (lvl * c.terrain_num_cols + type) * 3;
+    LS_GLOBAL const float* to = LSB(cx, LSIM_BUF_TERRAIN_ORIGINS, float) + (lvl * c.terrain_num_cols + type) * 3;
     for (int k = 0; k < 3; ++k) org[k] = to[k];
 }
 
@@ -307,7 +307,7 @@ LS_FN void ph_b_reset(const LsCtx& cx, WaveShared& sh, int lane, int env, const 
             vel = ls_draw(cx, env, stepw, LSIM_RNG_RESET_DOF, (uint32_t)(12 + lane)) * fabsf(hi - lo) + fminf(lo, hi);
         }
         sh.dofs[2 * lane] = pos; sh.dofs[2 * lane + 1] = vel;
-        float* dof = LSB(cx, LSIM_BUF_DOF_STATE, float) + 24 * env;
+        LS_GLOBAL float* dof = LSB(cx, LSIM_BUF_DOF_STATE, float) + 24 * env;
         dof[2 * lane] = pos; dof[2 * lane + 1] = vel;
         LSB(cx, LSIM_BUF_LAST_ACTIONS, float)[12 * env + lane] = 0.0f;       // LR:323-327
         LSB(cx, LSIM_BUF_LAST_LAST_ACTIONS, float)[12 * env + lane] = 0.0f;
@@ -315,7 +315,7 @@ LS_FN void ph_b_reset(const LsCtx& cx, WaveShared& sh, int lane, int env, const 
         LSB(cx, LSIM_BUF_LAST_DOF_VEL, float)[12 * env + lane] = 0.0f;
         LSB(cx, LSIM_BUF_LAST_TORQUES, float)[12 * env + lane] = 0.0f;
     } else if (lane == 12) {  // _reset_root_states (LR:718-820)
-        const float* org = LSB(cx, LSIM_BUF_ENV_ORIGINS, float) + 3 * env;
+        LS_GLOBAL const float* org = LSB(cx, LSIM_BUF_ENV_ORIGINS, float) + 3 * env;
         float u[12];
         for (int b = 0; b < 3; ++b) ls_u01x4(c.seed, c.rank, (uint32_t)env, stepw, LSIM_RNG_RESET_ROOT, (uint32_t)b, u + 4 * b);
         float r[13];
@@ -333,7 +333,7 @@ LS_FN void ph_b_reset(const LsCtx& cx, WaveShared& sh, int lane, int env, const 
         for (int k = 0; k < 6; ++k) r[7 + k] = rand_range(u[6 + k], c.base_init_vel_range[k][0], c.base_init_vel_range[k][1]);
         for (int k = 0; k < 13; ++k) { sh.root[k] = r[k]; LSB(cx, LSIM_BUF_ROOT_STATES, float)[13 * env + k] = r[k]; }
     } else if (lane == 13) {  // _resample_commands (LR:320)
-        float* cmd = LSB(cx, LSIM_BUF_COMMANDS, float) + 4 * env;
+        LS_GLOBAL float* cmd = LSB(cx, LSIM_BUF_COMMANDS, float) + 4 * env;
         float cm[4] = {sh.cmd[0], sh.cmd[1], sh.cmd[2], sh.cmd[3]};
         ls_resample_commands(cx, env, stepw, LSIM_RNG_RESET_CMD, sh.ranges, cm);
         for (int k = 0; k < 4; ++k) { cmd[k] = cm[k]; }
@@ -358,9 +358,9 @@ LS_FN void ph_b_episode_stats(const LsCtx& cx, WaveShared& sh, int lane, int env
     if (!sh.do_reset) return;
     if (lane == 13) for (int k = 0; k < 4; ++k) sh.cmd[k] = sh.rewv[k];
     float den = (float)(sh.eplen < 1 ? 1 : sh.eplen);
-    float* acc = cx.accum + a.row_out * LSIM_STATS_SIZE;
+    LS_GLOBAL float* acc = LS_G(float, cx.accum) + a.row_out * LSIM_STATS_SIZE;
     for (int k = lane; k < LSIM_NUM_REWARD_TERMS; k += 64) {
-        float* es = LSB(cx, LSIM_BUF_EPISODE_SUMS, float) + env * LSIM_NUM_REWARD_TERMS + k;
+        LS_GLOBAL float* es = LSB(cx, LSIM_BUF_EPISODE_SUMS, float) + env * LSIM_NUM_REWARD_TERMS + k;
         float v = *es;
         if (v != 0.0f) LS_ATOMIC_ADD(acc + LSIM_STATS_EPISODE_SUMS + k, v / den);
         *es = 0.0f;
@@ -369,7 +369,7 @@ LS_FN void ph_b_episode_stats(const LsCtx& cx, WaveShared& sh, int lane, int env
 
 // observation history: the 225 values that shift by one frame are staged in LDS first (LR:403)
 LS_FN void ph_b_stage_history(const LsCtx& cx, WaveShared& sh, int lane, int env) {
-    const float* obs = LSB(cx, LSIM_BUF_OBS, float) + LSIM_NUM_OBS * env;
+    LS_GLOBAL const float* obs = LSB(cx, LSIM_BUF_OBS, float) + LSIM_NUM_OBS * env;
     float* scratch = &sh.u.I6[0][0];
     for (int k = lane; k < LSIM_NUM_OBS - LSIM_ONE_STEP_OBS; k += 64) scratch[k] = obs[k];
 }
@@ -377,11 +377,11 @@ LS_FN void ph_b_stage_history(const LsCtx& cx, WaveShared& sh, int lane, int env
 LS_FN void ph_b_store(const LsCtx& cx, WaveShared& sh, int lane, int env, const LsStepArgs& a) {
     const lsim_config& c = cx.cfg;
     const float clipv = c.clip_observations;
-    float* obs = LSB(cx, LSIM_BUF_OBS, float) + LSIM_NUM_OBS * env;
+    LS_GLOBAL float* obs = LSB(cx, LSIM_BUF_OBS, float) + LSIM_NUM_OBS * env;
     const float* scratch = &sh.u.I6[0][0];
     for (int k = lane; k < LSIM_NUM_OBS - LSIM_ONE_STEP_OBS; k += 64) obs[k + LSIM_ONE_STEP_OBS] = clampf(scratch[k], -clipv, clipv);
     if (lane < LSIM_ONE_STEP_OBS) obs[lane] = clampf(sh.cur[lane], -clipv, clipv);
-    float* priv = LSB(cx, LSIM_BUF_PRIV_OBS, float) + LSIM_NUM_PRIV_OBS * env;
+    LS_GLOBAL float* priv = LSB(cx, LSIM_BUF_PRIV_OBS, float) + LSIM_NUM_PRIV_OBS * env;
     for (int k = lane; k < LSIM_NUM_PRIV_OBS; k += 64) priv[k] = clampf(sh.cur[k], -clipv, clipv);
     if (lane < LSIM_NUM_AMP_OBS) {
         float v;

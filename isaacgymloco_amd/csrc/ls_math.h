@@ -11,6 +11,16 @@
 #define LS_FN static inline
 #endif
 
+// Every simulator buffer lives in device global memory.  The pointers come out of a table (cx.buf[]), so the compiler cannot know their
+// address space and would emit FLAT loads / stores, which count in lgkmcnt as well as vmcnt: every LDS wait (each phase boundary) would
+// then also wait for all outstanding global stores.  Casting to the global address space gives global_load / global_store (vmcnt only).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LS_GLOBAL __attribute__((address_space(1)))
+#else
+#define LS_GLOBAL
+#endif
+#define LS_G(T, ptr) ((LS_GLOBAL T*)(ptr))
+
 struct V3 {
     float x, y, z;
 };
@@ -88,10 +98,11 @@ LS_FN void R_to_quat(const M3& Rm, float* q) {
     const float big = t * is;                                                // the largest component itself
     const float a = (R[7] - R[5]) * is, b = (R[2] - R[6]) * is, c = (R[3] - R[1]) * is;      // antisymmetric part: w * (x, y, z) / big
     const float d = (R[1] + R[3]) * is, e = (R[2] + R[6]) * is, f = (R[5] + R[7]) * is;      // symmetric part:   (xy, xz, yz) / big
-    if (m == 0) { q[3] = big; q[0] = a; q[1] = b; q[2] = c; }
-    else if (m == 1) { q[0] = big; q[3] = a; q[1] = d; q[2] = e; }
-    else if (m == 2) { q[1] = big; q[3] = b; q[0] = d; q[2] = f; }
-    else { q[2] = big; q[3] = c; q[0] = e; q[1] = f; }
+    // selects, not stores through a computed index (that would put q into scratch memory on the GPU)
+    q[0] = (m == 1) ? big : (m == 0 ? a : (m == 2 ? d : e));
+    q[1] = (m == 2) ? big : (m == 0 ? b : (m == 1 ? d : f));
+    q[2] = (m == 3) ? big : (m == 0 ? c : (m == 1 ? e : f));
+    q[3] = (m == 0) ? big : (m == 1 ? a : (m == 2 ? b : c));
 }
 // joint angles are a few radians at most: the hardware v_sin_f32 / v_cos_f32 (abs error ~1e-6) replace ocml's ~60-instruction
 // range-reduced sinf / cosf on the device; the lane emulator and the oracle use libm

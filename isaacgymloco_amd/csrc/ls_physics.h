@@ -279,7 +279,7 @@ LS_FN void ph_free_finish(WaveShared& sh, int lane, float dt) {  // lane = gener
 LS_FN void ls_terrain_query(const LsCtx& cx, float x, float y, float& h, V3& n) {
     const lsim_config& c = cx.cfg;
     if (c.mesh_type == 0) { h = 0.0f; n = v3(0, 0, 1); return; }
-    const int16_t* g = (const int16_t*)cx.buf[LSIM_BUF_HEIGHT_GRID];
+    LS_GLOBAL const int16_t* g = LS_G(const int16_t, cx.buf[LSIM_BUF_HEIGHT_GRID]);
     float hs = c.horizontal_scale, vs = c.vertical_scale;
     const float ihs = ls_rcp(hs);
     float gx = (x + c.border_size) * ihs, gy = (y + c.border_size) * ihs;
@@ -338,7 +338,7 @@ LS_FN V3 ls_mesh_vertex(const lsim_config& c, int word, int a, int b) {
 LS_FN void ls_terrain_contact(const LsCtx& cx, V3 cw, float radius, float& dist, V3& n) {
     const lsim_config& c = cx.cfg;
     if (c.mesh_type == 0) { dist = cw.z; n = v3(0, 0, 1); return; }
-    const int* mesh = (const int*)cx.buf[LSIM_BUF_TERRAIN_MESH];
+    LS_GLOBAL const int* mesh = LS_G(const int, cx.buf[LSIM_BUF_TERRAIN_MESH]);
     const float hs = c.horizontal_scale, vs = c.vertical_scale;
     const float ihs = ls_rcp(hs);
     float gx = (cw.x + c.border_size) * ihs, gy = (cw.y + c.border_size) * ihs;
@@ -372,7 +372,7 @@ LS_FN void ls_terrain_contact(const LsCtx& cx, V3 cw, float radius, float& dist,
         {
             const int ci = i - 1 + cell / 3, cj = j - 1 + cell % 3;
             if (ci < 0 || cj < 0 || ci > c.grid_rows - 2 || cj > c.grid_cols - 2) continue;
-            const int* row = mesh + ci * c.grid_cols + cj;
+            LS_GLOBAL const int* row = mesh + ci * c.grid_cols + cj;
             V3 p00 = ls_mesh_vertex(c, row[0], ci, cj), p10 = ls_mesh_vertex(c, row[c.grid_cols], ci + 1, cj);
             V3 p01 = ls_mesh_vertex(c, row[1], ci, cj + 1), p11 = ls_mesh_vertex(c, row[c.grid_cols + 1], ci + 1, cj + 1);
             float xlo = fminf(fminf(p00.x, p10.x), fminf(p01.x, p11.x)), xhi = fmaxf(fmaxf(p00.x, p10.x), fmaxf(p01.x, p11.x));
@@ -758,15 +758,17 @@ LS_FN void ph_integrate(const LsCtx& cx, WaveShared& sh, int lane, float dt) {
 }
 
 // ---- phase B: world state of every body (rigid_body_states, LR:938) from the kinematics phase (lane = body)
-LS_FN void ph_body_states(WaveShared& sh, int lane, float* out /* [17][13] of this env */) {
+LS_FN void ph_body_states(WaveShared& sh, int lane, LS_GLOBAL float* out /* [17][13] of this env */) {
     if (lane >= LS_NB) return;
-    float* o = out + 13 * lane;
+    LS_GLOBAL float* o = out + 13 * lane;
     V3 p = v3p(sh.p[lane]);
     S6 V = s6p(sh.V[lane]);
     V3 vel = V.l + cross(V.a, p);
     o[0] = sh.root[0] + p.x; o[1] = sh.root[1] + p.y; o[2] = sh.root[2] + p.z;
-    if (lane == 0) { for (int k = 0; k < 4; ++k) o[3 + k] = sh.root[3 + k]; }
-    else R_to_quat(m3p(sh.R[lane]), o + 3);
+    float q4[4];
+    if (lane == 0) { for (int k = 0; k < 4; ++k) q4[k] = sh.root[3 + k]; }
+    else R_to_quat(m3p(sh.R[lane]), q4);
+    for (int k = 0; k < 4; ++k) o[3 + k] = q4[k];
     v3st(o + 7, vel);
     v3st(o + 10, V.a);
 }

@@ -4,7 +4,7 @@
 #pragma once
 #include "ls_shared.h"
 
-#define LSB(cx, id, T) ((T*)(cx).buf[id])
+#define LSB(cx, id, T) LS_G(T, (cx).buf[id])
 #define LS_NHP LSIM_NUM_HEIGHT_PTS
 
 LS_FN float ls_draw(const LsCtx& cx, int env, uint32_t stepw, uint32_t tag, uint32_t idx) {
@@ -22,7 +22,7 @@ LS_FN float ls_sample_height_min3(const LsCtx& cx, float x, float y) {
     int px = (int)fx, py = (int)fy;
     px = px < 0 ? 0 : (px > c.grid_rows - 2 ? c.grid_rows - 2 : px);
     py = py < 0 ? 0 : (py > c.grid_cols - 2 ? c.grid_cols - 2 : py);
-    const int16_t* g = LSB(cx, LSIM_BUF_HEIGHT_GRID, const int16_t);
+    LS_GLOBAL const int16_t* g = LSB(cx, LSIM_BUF_HEIGHT_GRID, const int16_t);
     int16_t h1 = g[px * c.grid_cols + py], h2 = g[(px + 1) * c.grid_cols + py], h3 = g[px * c.grid_cols + py + 1];
     int16_t h = h1 < h2 ? h1 : h2;
     h = h < h3 ? h : h3;
@@ -40,7 +40,7 @@ LS_FN V3 ls_yaw_point(const float* root, float px, float py) {
 // LeggedRobot._get_heights (LR:1318-1355): lanes stride over the 187 points
 LS_FN void ph_heights(const LsCtx& cx, WaveShared& sh, int lane, int env, bool store_global) {
     const lsim_config& c = cx.cfg;
-    float* mh = LSB(cx, LSIM_BUF_MEASURED_HEIGHTS, float) + LS_NHP * env;
+    LS_GLOBAL float* mh = LSB(cx, LSIM_BUF_MEASURED_HEIGHTS, float) + LS_NHP * env;
     for (int k = lane; k < LS_NHP; k += 64) {
         float h = 0.0f;
         if (c.mesh_type != 0) {
@@ -85,7 +85,7 @@ LS_FN void ls_resample_commands(const LsCtx& cx, int env, uint32_t stepw, uint32
 // ---- Q1: derived base state, contact filter, episode counter (LR:193-209)
 LS_FN void ph_post_state(const LsCtx& cx, WaveShared& sh, int lane, int env) {
     if (lane == 0) {
-        int64_t* ep = LSB(cx, LSIM_BUF_EPISODE_LENGTH, int64_t) + env;
+        LS_GLOBAL int64_t* ep = LSB(cx, LSIM_BUF_EPISODE_LENGTH, int64_t) + env;
         int64_t v = *ep + 1;
         *ep = v;
         sh.eplen = (int)v;
@@ -100,7 +100,7 @@ LS_FN void ph_post_state(const LsCtx& cx, WaveShared& sh, int lane, int env) {
         v3st(sh.grav, v); v3st(LSB(cx, LSIM_BUF_PROJECTED_GRAVITY, float) + 3 * env, v);
     } else if (lane < 8) {
         int f = lane - 4;
-        uint8_t* lc = LSB(cx, LSIM_BUF_LAST_CONTACTS, uint8_t) + 4 * env + f;
+        LS_GLOBAL uint8_t* lc = LSB(cx, LSIM_BUF_LAST_CONTACTS, uint8_t) + 4 * env + f;
         uint8_t contact = sh.cf[cx.model.feet_bodies[f]][2] > 1.0f;
         LSB(cx, LSIM_BUF_CONTACT_FILT, uint8_t)[4 * env + f] = contact | *lc;
         *lc = contact;
@@ -112,7 +112,7 @@ LS_FN void ph_callback(const LsCtx& cx, WaveShared& sh, int lane, int env, const
     const lsim_config& c = cx.cfg;
     const uint32_t stepw = (uint32_t)a.step_counter;
     if (lane == 0) {
-        float* cmd = LSB(cx, LSIM_BUF_COMMANDS, float) + 4 * env;
+        LS_GLOBAL float* cmd = LSB(cx, LSIM_BUF_COMMANDS, float) + 4 * env;
         float cm[4] = {cmd[0], cmd[1], cmd[2], cmd[3]};
         if (sh.eplen % c.resampling_steps == 0) ls_resample_commands(cx, env, stepw, LSIM_RNG_CMD, ranges, cm);
         if (c.heading_command) {
@@ -133,7 +133,7 @@ LS_FN void ph_callback(const LsCtx& cx, WaveShared& sh, int lane, int env, const
         if (c.disturbance && (a.step_counter % c.disturbance_interval == 0)) {  // LR:838-844
             float u[4];
             ls_u01x4(c.seed, c.rank, (uint32_t)env, stepw, LSIM_RNG_DISTURB, 0, u);
-            float* pf = LSB(cx, LSIM_BUF_PENDING_FORCE, float) + 3 * env;
+            LS_GLOBAL float* pf = LSB(cx, LSIM_BUF_PENDING_FORCE, float) + 3 * env;
             for (int k = 0; k < 3; ++k) { d[k] = rand_range(u[k], c.disturbance_range[0], c.disturbance_range[1]); pf[k] = d[k]; }
         }
         for (int k = 0; k < 3; ++k) sh.disturbance[k] = d[k];
@@ -172,8 +172,9 @@ LS_FN void ph_termination(const LsCtx& cx, WaveShared& sh, int lane, int env) {
 
 // ---------------------------------------------------------------------------------------------- rewards
 struct LsRewCtx {
-    const float *dof, *act, *last_act, *last_last_act, *last_dof_pos, *last_dof_vel, *tau, *last_tau;
-    const uint8_t* filt;
+    const float *dof, *act, *tau;                                                        // LDS
+    LS_GLOBAL const float *last_act, *last_last_act, *last_dof_pos, *last_dof_vel, *last_tau;   // simulator buffers (global memory)
+    LS_GLOBAL const uint8_t* filt;
 };
 LS_FN float ls_up(const WaveShared& sh) { return clampf(-sh.grav[2], 0.0f, 1.0f); }
 LS_FN float ls_cmd_norm(const WaveShared& sh) { return sqrtf(sh.cmd[0] * sh.cmd[0] + sh.cmd[1] * sh.cmd[1]); }
@@ -205,7 +206,7 @@ LS_FN float ls_foot_clearance_terrain(const LsCtx& cx, const WaveShared& sh, int
             int ix = (int)ls_div_exact(px, c.horizontal_scale), iy = (int)ls_div_exact(py, c.horizontal_scale);
             ix = ix < 0 ? 0 : (ix > c.grid_rows - 2 ? c.grid_rows - 2 : ix);
             iy = iy < 0 ? 0 : (iy > c.grid_cols - 2 ? c.grid_cols - 2 : iy);
-            const int16_t* g = LSB(cx, LSIM_BUF_HEIGHT_GRID, const int16_t);
+            LS_GLOBAL const int16_t* g = LSB(cx, LSIM_BUF_HEIGHT_GRID, const int16_t);
             int16_t h1 = g[ix * c.grid_cols + iy], h2 = g[(ix + 1) * c.grid_cols + iy], h3 = g[ix * c.grid_cols + iy + 1];
             int16_t h = h1 < h2 ? h1 : h2; h = h < h3 ? h : h3;
             fh = pz - (float)h * c.vertical_scale;
@@ -254,8 +255,8 @@ LS_FN float ls_reward_term(const LsCtx& cx, WaveShared& sh, const LsRewCtx& x, i
         }
         case LSIM_R_TRACKING_ANG_VEL: { float e = sh.cmd[2] - sh.bav[2]; return expf(-(e * e) / c.tracking_sigma); }
         case LSIM_R_FEET_AIR_TIME: {  // LR:1459-1470 (mutates last_contacts and feet_air_time)
-            float* air = LSB(cx, LSIM_BUF_FEET_AIR_TIME, float) + 4 * env;
-            uint8_t* lc = LSB(cx, LSIM_BUF_LAST_CONTACTS, uint8_t) + 4 * env;
+            LS_GLOBAL float* air = LSB(cx, LSIM_BUF_FEET_AIR_TIME, float) + 4 * env;
+            LS_GLOBAL uint8_t* lc = LSB(cx, LSIM_BUF_LAST_CONTACTS, uint8_t) + 4 * env;
             float r = 0.0f;
             uint8_t filt[4];
             for (int f = 0; f < 4; ++f) {
