@@ -46,35 +46,60 @@ __device__ unsigned long long g_ls_phase_calls[64];
 #endif
 
 // ---- load the robot's state into LDS, clip the actions (LR:129-130), draw the action delay (LR:134)
+// Load phases: every global load is issued first, unconditionally -- a lane with no use for a value reads element 0 of the same row, always
+// a valid address -- and the LDS writes follow.  `if (lane < n) sh.x[lane] = buf[...]` per quantity compiles to one branch per quantity with
+// the load AND its wait inside, i.e. a chain of ~20 serialised memory round trips (12 k of the 27 k ticks of a kernel-B wave).
 LS_FN void ph_load_a(const LsCtx& cx, WaveShared& sh, LaneRegs& rg, int lane, int env, const LsStepArgs& a) {
     const lsim_config& c = cx.cfg;
-    if (lane < 13) sh.root[lane] = LSB(cx, LSIM_BUF_ROOT_STATES, float)[13 * env + lane];
+    const int l12 = lane < 12 ? lane : 0;
+    const float v_root = LSB(cx, LSIM_BUF_ROOT_STATES, float)[13 * env + (lane < 13 ? lane : 0)];
+    const float v_q = LSB(cx, LSIM_BUF_DOF_STATE, float)[24 * env + 2 * l12];
+    const float v_qd = LSB(cx, LSIM_BUF_DOF_STATE, float)[24 * env + 2 * l12 + 1];
+    const float v_act = LS_G(const float, a.actions)[12 * env + l12];
+    const float v_last = LSB(cx, LSIM_BUF_LAST_ACTIONS, float)[12 * env + l12];
+    const float v_ms = LSB(cx, LSIM_BUF_MOTOR_STRENGTH, float)[12 * env + l12];
+    // per-env scalars: the same address in every lane
+    const float v_kpf = LSB(cx, LSIM_BUF_KP_FACTORS, float)[env], v_kdf = LSB(cx, LSIM_BUF_KD_FACTORS, float)[env];
+    const float v_fric = LSB(cx, LSIM_BUF_FRICTION, float)[env], v_payload = LSB(cx, LSIM_BUF_PAYLOAD, float)[env];
+    const int l3 = lane < 3 ? lane : 0;
+    const float v_comd = LSB(cx, LSIM_BUF_COM_DISPLACEMENT, float)[3 * env + l3];
+    const float v_pend = LSB(cx, LSIM_BUF_PENDING_FORCE, float)[3 * env + l3];
+    // inputs of the post-physics stack (see WaveShared::pre_*): their latency hides behind the physics, and no load has to queue behind the
+    // state stores that follow the last sub-step
+    const int which = lane < 48 ? lane / 12 : 0, j = lane < 48 ? lane - 12 * which : 0;
+    LS_GLOBAL const float* src = LSB(cx, which == 0 ? LSIM_BUF_LAST_LAST_ACTIONS : (which == 1 ? LSIM_BUF_LAST_DOF_POS : (which == 2 ? LSIM_BUF_LAST_DOF_VEL : LSIM_BUF_LAST_TORQUES)), const float);
+    const float v_pre = src[12 * env + j];
+    const int l4 = lane & 3;
+    const float v_cmd = LSB(cx, LSIM_BUF_COMMANDS, float)[4 * env + l4];
+    const float v_air = LSB(cx, LSIM_BUF_FEET_AIR_TIME, float)[4 * env + l4];
+    const int v_eplen = (int)LSB(cx, LSIM_BUF_EPISODE_LENGTH, int64_t)[env];
+    const unsigned int v_lc = LSB(cx, LSIM_BUF_LAST_CONTACTS, unsigned int)[env];
+    const int v_level = (int)LSB(cx, LSIM_BUF_TERRAIN_LEVELS, int64_t)[env];
+    const float v_es = LSB(cx, LSIM_BUF_EPISODE_SUMS, float)[env * LSIM_NUM_REWARD_TERMS + (lane < LSIM_NUM_REWARD_TERMS ? lane : 0)];
+    // ---- LDS writes
+    if (lane < 13) sh.root[lane] = v_root;
     if (lane < 12) {
-        LS_GLOBAL const float* dof = LSB(cx, LSIM_BUF_DOF_STATE, float) + 24 * env;
-        sh.q[lane] = dof[2 * lane];
-        sh.qd[lane] = dof[2 * lane + 1];
-        float act = clampf(LS_G(const float, a.actions)[12 * env + lane], -c.clip_actions, c.clip_actions);
+        sh.q[lane] = v_q;
+        sh.qd[lane] = v_qd;
+        const float act = clampf(v_act, -c.clip_actions, c.clip_actions);    // LR:129-130
         sh.act[lane] = act;
         LSB(cx, LSIM_BUF_ACTIONS, float)[12 * env + lane] = act;
-        sh.last_act[lane] = LSB(cx, LSIM_BUF_LAST_ACTIONS, float)[12 * env + lane];
-        sh.ms[lane] = LSB(cx, LSIM_BUF_MOTOR_STRENGTH, float)[12 * env + lane];
+        sh.last_act[lane] = v_last;
+        sh.ms[lane] = v_ms;
     }
     if (lane == 13) {
-        sh.kpf = LSB(cx, LSIM_BUF_KP_FACTORS, float)[env];
-        sh.kdf = LSB(cx, LSIM_BUF_KD_FACTORS, float)[env];
-        sh.mu = 0.5f * (c.terrain_friction + LSB(cx, LSIM_BUF_FRICTION, float)[env]);   // PhysX default combine mode: average
-        sh.payload = LSB(cx, LSIM_BUF_PAYLOAD, float)[env];
+        sh.kpf = v_kpf;
+        sh.kdf = v_kdf;
+        sh.mu = 0.5f * (c.terrain_friction + v_fric);   // PhysX default combine mode: average
+        sh.payload = v_payload;
     }
-    if (lane == 14) {
-        LS_GLOBAL float* pf = LSB(cx, LSIM_BUF_PENDING_FORCE, float) + 3 * env;
-        for (int k = 0; k < 3; ++k) {
-            sh.comd[k] = LSB(cx, LSIM_BUF_COM_DISPLACEMENT, float)[3 * env + k];
-            sh.pend[k] = pf[k];
-            if (!(a.flags & LSIM_STEP_SKIP_PHYSICS)) pf[k] = 0.0f;   // consumed by the first sub-step
-        }
+    if (lane < 3) {
+        sh.comd[lane] = v_comd;
+        sh.pend[lane] = v_pend;
+        if (!(a.flags & LSIM_STEP_SKIP_PHYSICS)) LSB(cx, LSIM_BUF_PENDING_FORCE, float)[3 * env + lane] = 0.0f;   // consumed by the first sub-step
     }
     if (lane == 15) {
-        int delay = (int)(ls_draw(cx, env, (uint32_t)a.step_counter, LSIM_RNG_DELAY, 0) * (float)c.decimation);
+        int delay = (int)(ls_draw(cx, env, (uint32_t)a.step_counter, LSIM_RNG_DELAY, 0) * (float)c.decimation);   // LR:134
         sh.delay = delay;
         LSB(cx, LSIM_BUF_DELAY_STEPS, int32_t)[env] = delay;
     }
@@ -85,6 +110,13 @@ LS_FN void ph_load_a(const LsCtx& cx, WaveShared& sh, LaneRegs& rg, int lane, in
         for (int k = 0; k < 3; ++k) { o.com[k] = b.com[k]; o.jpos[k] = b.joint_pos[k]; o.axis[k] = b.joint_axis[k]; }
         for (int k = 0; k < 6; ++k) o.inertia[k] = b.inertia[k];
     }
+    if (lane < 48) sh.pre_lla[lane] = v_pre;            // pre_lla .. pre_ltau are contiguous
+    else if (lane < 52) sh.pre_cmd[lane - 48] = v_cmd;
+    else if (lane < 56) sh.pre_air[lane - 52] = v_air;
+    else if (lane == 56) sh.pre_eplen = v_eplen;
+    else if (lane == 57) sh.pre_lc = v_lc;
+    else if (lane == 58) sh.pre_level = v_level;
+    if (lane < LSIM_NUM_REWARD_TERMS) sh.pre_es[lane] = v_es;
     rg.cp_active = 0;
     rg.row_kind = -1;
 }
@@ -101,7 +133,7 @@ LS_FN void ph_torques(const LsCtx& cx, WaveShared& sh, int lane, int env, int su
     float target = c.default_dof_pos[lane] + as;
     float q = sh.q[lane], qd = sh.qd[lane], t;
     if (c.control_type == 0) t = c.p_gains[lane] * sh.kpf * (target - q) - c.d_gains[lane] * sh.kdf * qd;
-    else if (c.control_type == 1) t = c.p_gains[lane] * (as - qd) - c.d_gains[lane] * (qd - LSB(cx, LSIM_BUF_LAST_DOF_VEL, float)[12 * env + lane]) / c.sim_dt;
+    else if (c.control_type == 1) t = c.p_gains[lane] * (as - qd) - c.d_gains[lane] * (qd - sh.pre_ldv[lane]) / c.sim_dt;
     else t = as;
     sh.tau[lane] = clampf(t, -c.torque_limits[lane], c.torque_limits[lane]);
 }
@@ -150,7 +182,7 @@ LS_FN void ph_term_outputs(const LsCtx& cx, WaveShared& sh, int lane, int env, c
     if (lane < 13) LSB(cx, LSIM_BUF_ROOT_STATES, float)[13 * env + lane] = sh.root[lane];   // push may have changed the velocity
     if (!sh.reset) return;
     LS_GLOBAL float* tp = LSB(cx, LSIM_BUF_TERM_PRIV_OBS, float) + LSIM_NUM_PRIV_OBS * env;
-    for (int k = lane; k < LSIM_NUM_PRIV_OBS; k += 64) tp[k] = sh.cur[k];
+    LS_STRIDED(k, lane, LSIM_NUM_PRIV_OBS) tp[k] = sh.cur[k];
     if (lane < LSIM_NUM_AMP_OBS) {
         float v;
         if (lane < 12) v = sh.dofs[2 * lane];
@@ -162,7 +194,7 @@ LS_FN void ph_term_outputs(const LsCtx& cx, WaveShared& sh, int lane, int env, c
     if (lane == 0 && !(a.flags & LSIM_STEP_NO_RESET)) {
         LS_GLOBAL float* acc = LS_G(float, cx.accum) + a.row_out * LSIM_STATS_SIZE;
         LS_ATOMIC_ADD(acc + LSIM_STATS_RESET_COUNT, 1.0f);
-        LS_ATOMIC_ADD(acc + LSIM_STATS_TRACK_SUM, LSB(cx, LSIM_BUF_EPISODE_SUMS, float)[env * LSIM_NUM_REWARD_TERMS + LSIM_R_TRACKING_LIN_VEL]);
+        LS_ATOMIC_ADD(acc + LSIM_STATS_TRACK_SUM, sh.pre_es[LSIM_R_TRACKING_LIN_VEL]);    // updated by ph_reward_terms
     }
 }
 
@@ -223,33 +255,70 @@ LS_WAVE_FN void ls_wave_step_a(const LsCtx& cx, const LsStepArgs& a, const int e
 // =============================================================================================== kernel B
 LS_FN void ph_load_b(const LsCtx& cx, WaveShared& sh, int lane, int env, const LsStepArgs& a) {
     const lsim_config& c = cx.cfg;
-    if (lane < 13) sh.root[lane] = LSB(cx, LSIM_BUF_ROOT_STATES, float)[13 * env + lane];
-    if (lane < 24) sh.dofs[lane] = LSB(cx, LSIM_BUF_DOF_STATE, float)[24 * env + lane];
-    if (lane < 12) sh.act[lane] = LSB(cx, LSIM_BUF_ACTIONS, float)[12 * env + lane];
-    if (lane < 3) {
-        sh.blv[lane] = LSB(cx, LSIM_BUF_BASE_LIN_VEL, float)[3 * env + lane];
-        sh.bav[lane] = LSB(cx, LSIM_BUF_BASE_ANG_VEL, float)[3 * env + lane];
-        sh.grav[lane] = LSB(cx, LSIM_BUF_PROJECTED_GRAVITY, float)[3 * env + lane];
-        const bool disturbed = !a.reset_all && c.disturbance && (a.step_counter % c.disturbance_interval == 0);
-        sh.disturbance[lane] = disturbed ? LSB(cx, LSIM_BUF_PENDING_FORCE, float)[3 * env + lane] : 0.0f;
+    // ---- loads (see ph_load_a): everything this kernel reads, including what its store phase needs, before any of its stores is in flight
+    const float v_root = LSB(cx, LSIM_BUF_ROOT_STATES, float)[13 * env + (lane < 13 ? lane : 0)];
+    const float v_dof = LSB(cx, LSIM_BUF_DOF_STATE, float)[24 * env + (lane < 24 ? lane : 0)];
+    const int l12 = lane < 12 ? lane : 0, l3 = lane < 3 ? lane : 0;
+    const float v_act = LSB(cx, LSIM_BUF_ACTIONS, float)[12 * env + l12];
+    const float v_blv = LSB(cx, LSIM_BUF_BASE_LIN_VEL, float)[3 * env + l3];
+    const float v_bav = LSB(cx, LSIM_BUF_BASE_ANG_VEL, float)[3 * env + l3];
+    const float v_grav = LSB(cx, LSIM_BUF_PROJECTED_GRAVITY, float)[3 * env + l3];
+    const float v_pend = LSB(cx, LSIM_BUF_PENDING_FORCE, float)[3 * env + l3];
+    const float v_cmd = LSB(cx, LSIM_BUF_COMMANDS, float)[4 * env + (lane & 3)];
+    const float v_la = LSB(cx, LSIM_BUF_LAST_ACTIONS, float)[12 * env + l12];
+    const float v_tq = LSB(cx, LSIM_BUF_TORQUES, float)[12 * env + l12];
+    float v_h[(LS_NHP + 63) / 64], v_o[(LSIM_NUM_OBS - LSIM_ONE_STEP_OBS + 63) / 64];
+    for (int it = 0; it < (LS_NHP + 63) / 64; ++it) {
+        const int k = lane + 64 * it;
+        v_h[it] = LSB(cx, LSIM_BUF_MEASURED_HEIGHTS, float)[LS_NHP * env + (k < LS_NHP ? k : 0)];
     }
-    if (lane < 4) sh.cmd[lane] = LSB(cx, LSIM_BUF_COMMANDS, float)[4 * env + lane];
-    for (int k = lane; k < LS_NHP; k += 64) sh.heights[k] = LSB(cx, LSIM_BUF_MEASURED_HEIGHTS, float)[LS_NHP * env + k];
+    for (int it = 0; it < (LSIM_NUM_OBS - LSIM_ONE_STEP_OBS + 63) / 64; ++it) {   // observation history: the 225 values that shift by one frame (LR:403)
+        const int k = lane + 64 * it;
+        v_o[it] = LSB(cx, LSIM_BUF_OBS, float)[LSIM_NUM_OBS * env + (k < LSIM_NUM_OBS - LSIM_ONE_STEP_OBS ? k : 0)];
+    }
+    // per-env / per-step scalars: the same address in every lane
+    LS_GLOBAL const float* acc_out = LS_G(const float, cx.accum) + a.row_out * LSIM_STATS_SIZE;
+    LS_GLOBAL const float* acc_in = LS_G(const float, cx.accum) + a.row_in * LSIM_STATS_SIZE;
+    const float v_nreset = acc_out[LSIM_STATS_RESET_COUNT], v_track = acc_out[LSIM_STATS_TRACK_SUM];
+    float r[8];
+    for (int k = 0; k < 8; ++k) r[k] = acc_in[LSIM_STATS_CMD_RANGES + k];
+    const int v_reset = LSB(cx, LSIM_BUF_RESET, uint8_t)[env];
+    const int v_tout = LSB(cx, LSIM_BUF_TIME_OUT, uint8_t)[env];
+    const int v_eplen = (int)LSB(cx, LSIM_BUF_EPISODE_LENGTH, int64_t)[env];
+    // ---- LDS writes
+    if (lane < 13) sh.root[lane] = v_root;
+    if (lane < 24) sh.dofs[lane] = v_dof;
+    if (lane < 12) { sh.act[lane] = v_act; sh.pre_lla[lane] = v_la; sh.pre_ltau[lane] = v_tq; }
+    if (lane < 3) {
+        sh.blv[lane] = v_blv;
+        sh.bav[lane] = v_bav;
+        sh.grav[lane] = v_grav;
+        const bool disturbed = !a.reset_all && c.disturbance && (a.step_counter % c.disturbance_interval == 0);
+        sh.disturbance[lane] = disturbed ? v_pend : 0.0f;
+    }
+    if (lane < 4) sh.cmd[lane] = v_cmd;
+    for (int it = 0; it < (LS_NHP + 63) / 64; ++it) {
+        const int k = lane + 64 * it;
+        if (k < LS_NHP) sh.heights[k] = v_h[it];
+    }
+    {
+        float* scratch = &sh.u.I6[0][0];
+        for (int it = 0; it < (LSIM_NUM_OBS - LSIM_ONE_STEP_OBS + 63) / 64; ++it) {
+            const int k = lane + 64 * it;
+            if (k < LSIM_NUM_OBS - LSIM_ONE_STEP_OBS) scratch[k] = v_o[it];
+        }
+    }
     if (lane == 32) {
-        LS_GLOBAL const float* acc_out = LS_G(const float, cx.accum) + a.row_out * LSIM_STATS_SIZE;
-        LS_GLOBAL const float* acc_in = LS_G(const float, cx.accum) + a.row_in * LSIM_STATS_SIZE;
-        int reset = LSB(cx, LSIM_BUF_RESET, uint8_t)[env];
-        sh.reset = reset;
-        sh.eplen = (int)LSB(cx, LSIM_BUF_EPISODE_LENGTH, int64_t)[env];
-        float nreset = a.reset_all ? (float)c.num_envs : acc_out[LSIM_STATS_RESET_COUNT];
+        sh.reset = v_reset;
+        sh.pre_lc = (unsigned int)v_tout;
+        sh.eplen = v_eplen;
+        float nreset = a.reset_all ? (float)c.num_envs : v_nreset;
         const bool no_reset = (a.flags & LSIM_STEP_NO_RESET) != 0;
-        sh.do_reset = a.reset_all || (reset && !no_reset);
+        sh.do_reset = a.reset_all || (v_reset && !no_reset);
         sh.any_reset = a.reset_all || (!no_reset && nreset > 0.5f);
         // command curriculum (LR:307-308, LR:868-880): every wave derives the same new ranges from the reduced sums
-        float r[8];
-        for (int k = 0; k < 8; ++k) r[k] = acc_in[LSIM_STATS_CMD_RANGES + k];
         if (sh.any_reset && c.commands_curriculum && (a.step_counter % c.max_episode_length == 0)) {
-            float mean = acc_out[LSIM_STATS_TRACK_SUM] / nreset;
+            float mean = v_track / nreset;
             if (mean / (float)c.max_episode_length > 0.8f * c.reward_scales[LSIM_R_TRACKING_LIN_VEL]) {
                 r[0] = fmaxf(fminf(r[0] - 0.1f, 0.0f), -c.max_backward_curriculum);
                 r[1] = fmaxf(fminf(r[1] + 0.1f, c.max_forward_curriculum), 0.0f);
@@ -270,7 +339,7 @@ LS_FN void ph_b_housekeeping(const LsCtx& cx, WaveShared& sh, int lane, int env,
     LS_GLOBAL float* nxt = LS_G(float, cx.accum) + a.row_in * LSIM_STATS_SIZE;   // the next call accumulates into the row this call read
     if (lane == 9) nxt[LSIM_STATS_RESET_COUNT] = 0.0f;
     if (lane == 10) nxt[LSIM_STATS_TRACK_SUM] = 0.0f;
-    for (int k = lane; k < LSIM_NUM_REWARD_TERMS; k += 64) nxt[LSIM_STATS_EPISODE_SUMS + k] = 0.0f;
+    LS_STRIDED(k, lane, LSIM_NUM_REWARD_TERMS) nxt[LSIM_STATS_EPISODE_SUMS + k] = 0.0f;
 }
 
 // LeggedRobot._update_terrain_curriculum (LR:846-866), lane 0 of a resetting env
@@ -359,7 +428,7 @@ LS_FN void ph_b_episode_stats(const LsCtx& cx, WaveShared& sh, int lane, int env
     if (lane == 13) for (int k = 0; k < 4; ++k) sh.cmd[k] = sh.rewv[k];
     float den = (float)(sh.eplen < 1 ? 1 : sh.eplen);
     LS_GLOBAL float* acc = LS_G(float, cx.accum) + a.row_out * LSIM_STATS_SIZE;
-    for (int k = lane; k < LSIM_NUM_REWARD_TERMS; k += 64) {
+    LS_STRIDED(k, lane, LSIM_NUM_REWARD_TERMS) {
         LS_GLOBAL float* es = LSB(cx, LSIM_BUF_EPISODE_SUMS, float) + env * LSIM_NUM_REWARD_TERMS + k;
         float v = *es;
         if (v != 0.0f) LS_ATOMIC_ADD(acc + LSIM_STATS_EPISODE_SUMS + k, v / den);
@@ -367,22 +436,28 @@ LS_FN void ph_b_episode_stats(const LsCtx& cx, WaveShared& sh, int lane, int env
     }
 }
 
-// observation history: the 225 values that shift by one frame are staged in LDS first (LR:403)
-LS_FN void ph_b_stage_history(const LsCtx& cx, WaveShared& sh, int lane, int env) {
-    LS_GLOBAL const float* obs = LSB(cx, LSIM_BUF_OBS, float) + LSIM_NUM_OBS * env;
-    float* scratch = &sh.u.I6[0][0];
-    for (int k = lane; k < LSIM_NUM_OBS - LSIM_ONE_STEP_OBS; k += 64) scratch[k] = obs[k];
-}
 // publish observations (LR:403-404 + clip LR:167-171), AMP features (LR:406-416), last_* roll (LR:235-241)
 LS_FN void ph_b_store(const LsCtx& cx, WaveShared& sh, int lane, int env, const LsStepArgs& a) {
     const lsim_config& c = cx.cfg;
     const float clipv = c.clip_observations;
     LS_GLOBAL float* obs = LSB(cx, LSIM_BUF_OBS, float) + LSIM_NUM_OBS * env;
     const float* scratch = &sh.u.I6[0][0];
-    for (int k = lane; k < LSIM_NUM_OBS - LSIM_ONE_STEP_OBS; k += 64) obs[k + LSIM_ONE_STEP_OBS] = clampf(scratch[k], -clipv, clipv);
-    if (lane < LSIM_ONE_STEP_OBS) obs[lane] = clampf(sh.cur[lane], -clipv, clipv);
+    // rows of 270 / 238 floats start on 8-byte boundaries for every env: two floats per lane and store (half the store instructions)
+    static_assert(LSIM_NUM_OBS % 2 == 0 && LSIM_NUM_PRIV_OBS % 2 == 0, "float2 rows");
+    LS_STRIDED(m, lane, LSIM_NUM_OBS / 2) {
+        LsF2 v;
+        const int k0 = 2 * m, k1 = 2 * m + 1;
+        v.x = clampf(k0 < LSIM_ONE_STEP_OBS ? sh.cur[k0] : scratch[k0 - LSIM_ONE_STEP_OBS], -clipv, clipv);
+        v.y = clampf(k1 < LSIM_ONE_STEP_OBS ? sh.cur[k1] : scratch[k1 - LSIM_ONE_STEP_OBS], -clipv, clipv);
+        ((LS_GLOBAL LsF2*)obs)[m] = v;
+    }
     LS_GLOBAL float* priv = LSB(cx, LSIM_BUF_PRIV_OBS, float) + LSIM_NUM_PRIV_OBS * env;
-    for (int k = lane; k < LSIM_NUM_PRIV_OBS; k += 64) priv[k] = clampf(sh.cur[k], -clipv, clipv);
+    LS_STRIDED(m, lane, LSIM_NUM_PRIV_OBS / 2) {
+        LsF2 v;
+        v.x = clampf(sh.cur[2 * m], -clipv, clipv);
+        v.y = clampf(sh.cur[2 * m + 1], -clipv, clipv);
+        ((LS_GLOBAL LsF2*)priv)[m] = v;
+    }
     if (lane < LSIM_NUM_AMP_OBS) {
         float v;
         if (lane < 12) v = sh.dofs[2 * lane];
@@ -393,22 +468,21 @@ LS_FN void ph_b_store(const LsCtx& cx, WaveShared& sh, int lane, int env, const 
     }
     if (lane >= 48 && lane < 60) {
         int j = lane - 48;
-        float la = LSB(cx, LSIM_BUF_LAST_ACTIONS, float)[12 * env + j];
-        LSB(cx, LSIM_BUF_LAST_LAST_ACTIONS, float)[12 * env + j] = la;
+        LSB(cx, LSIM_BUF_LAST_LAST_ACTIONS, float)[12 * env + j] = sh.do_reset ? 0.0f : sh.pre_lla[j];   // last_actions as of LR:236: fetched by ph_load_b, zeroed by reset_idx (LR:323)
         LSB(cx, LSIM_BUF_LAST_ACTIONS, float)[12 * env + j] = sh.act[j];
         LSB(cx, LSIM_BUF_LAST_DOF_POS, float)[12 * env + j] = sh.dofs[2 * j];
         LSB(cx, LSIM_BUF_LAST_DOF_VEL, float)[12 * env + j] = sh.dofs[2 * j + 1];
-        LSB(cx, LSIM_BUF_LAST_TORQUES, float)[12 * env + j] = LSB(cx, LSIM_BUF_TORQUES, float)[12 * env + j];
+        LSB(cx, LSIM_BUF_LAST_TORQUES, float)[12 * env + j] = sh.pre_ltau[j];
     }
     if (lane >= 42 && lane < 48) LSB(cx, LSIM_BUF_LAST_ROOT_VEL, float)[6 * env + lane - 42] = sh.root[7 + lane - 42];
     if (lane == 40 && sh.do_reset) LSB(cx, LSIM_BUF_EPISODE_LENGTH, int64_t)[env] = 0;                       // LR:361
     if (lane == 41 && sh.any_reset && c.send_timeouts)                                                        // LR:358-359
-        LSB(cx, LSIM_BUF_EXTRAS_TIME_OUTS, uint8_t)[env] = LSB(cx, LSIM_BUF_TIME_OUT, uint8_t)[env];
+        LSB(cx, LSIM_BUF_EXTRAS_TIME_OUTS, uint8_t)[env] = (uint8_t)sh.pre_lc;
 }
 // tail of a bare reset_idx(all) (BT:113): no observation / last_* roll
 LS_FN void ph_b_store_reset_all(const LsCtx& cx, WaveShared& sh, int lane, int env, const LsStepArgs& a) {
     if (lane == 40) LSB(cx, LSIM_BUF_EPISODE_LENGTH, int64_t)[env] = 0;
-    if (lane == 41 && cx.cfg.send_timeouts) LSB(cx, LSIM_BUF_EXTRAS_TIME_OUTS, uint8_t)[env] = LSB(cx, LSIM_BUF_TIME_OUT, uint8_t)[env];
+    if (lane == 41 && cx.cfg.send_timeouts) LSB(cx, LSIM_BUF_EXTRAS_TIME_OUTS, uint8_t)[env] = (uint8_t)sh.pre_lc;
 }
 
 LS_WAVE_FN void ls_wave_step_b(const LsCtx& cx, const LsStepArgs& a, const int env, WaveShared& sh, LS_LANES_PARAM) {
@@ -424,7 +498,7 @@ LS_WAVE_FN void ls_wave_step_b(const LsCtx& cx, const LsStepArgs& a, const int e
         LS_PHASE(ph_b_store_reset_all(cx, sh, lane, env, a));
         return;
     }
-    LS_PHASE(ph_build_obs(cx, sh, lane, env, (uint32_t)a.step_counter, LSIM_RNG_OBS_NOISE, sh.cur); ph_b_stage_history(cx, sh, lane, env));
+    LS_PHASE(ph_build_obs(cx, sh, lane, env, (uint32_t)a.step_counter, LSIM_RNG_OBS_NOISE, sh.cur));
     LS_PHASE(ph_b_store(cx, sh, lane, env, a));
     LS_TICK_FLUSH();
 }

@@ -21,6 +21,16 @@
 #endif
 #define LS_G(T, ptr) ((LS_GLOBAL T*)(ptr))
 
+// lane-strided loop over N items with a compile-time trip count: `for (k = lane; k < N; k += 64)` has a per-lane trip count, which the
+// compiler turns into a vectorised monster with 64-bit address arithmetic per element; this form unrolls into ceil(N / 64) predicated bodies
+#if defined(LS_EMU) || !defined(__HIPCC__)
+#define LS_STRIDED(k, lane, N) for (int k = (lane); k < (N); k += 64)
+#else
+#define LS_STRIDED(k, lane, N) _Pragma("unroll") for (int it_ = 0, k = (lane); it_ < ((N) + 63) / 64; ++it_, k += 64) if (k < (N))
+#endif
+
+struct alignas(8) LsF2 { float x, y; };   // one 8-byte global store
+
 struct V3 {
     float x, y, z;
 };

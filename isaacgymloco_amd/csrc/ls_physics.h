@@ -539,7 +539,7 @@ LS_FN void ph_rows(const LsCtx& cx, WaveShared& sh, LaneRegs& r, int lane, float
     }
     r.row_leg = leg;
     for (int k = 0; k < 3; ++k) r.Jl[k] = Jl[k];
-    v3st(sh.u.c.dirs[lane], d);
+    if (lane < 3 * LS_MAXC) v3st(sh.u.c.dirs[lane], d);
     // M^-1 J^T without the base-coupling leg terms (ls_shared.h, Y): y = Mll^-1 Jl, a = Jb - Mbl y (kept in r.Jb), z = Sb^-1 a
     float y[3] = {0, 0, 0}, av[6];
     for (int k = 0; k < 6; ++k) av[k] = Jb[k];

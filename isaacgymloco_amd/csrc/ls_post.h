@@ -41,7 +41,7 @@ LS_FN V3 ls_yaw_point(const float* root, float px, float py) {
 LS_FN void ph_heights(const LsCtx& cx, WaveShared& sh, int lane, int env, bool store_global) {
     const lsim_config& c = cx.cfg;
     LS_GLOBAL float* mh = LSB(cx, LSIM_BUF_MEASURED_HEIGHTS, float) + LS_NHP * env;
-    for (int k = lane; k < LS_NHP; k += 64) {
+    LS_STRIDED(k, lane, LS_NHP) {
         float h = 0.0f;
         if (c.mesh_type != 0) {
             int ix = k / c.num_points_y, iy = k - ix * c.num_points_y;
@@ -85,10 +85,9 @@ LS_FN void ls_resample_commands(const LsCtx& cx, int env, uint32_t stepw, uint32
 // ---- Q1: derived base state, contact filter, episode counter (LR:193-209)
 LS_FN void ph_post_state(const LsCtx& cx, WaveShared& sh, int lane, int env) {
     if (lane == 0) {
-        LS_GLOBAL int64_t* ep = LSB(cx, LSIM_BUF_EPISODE_LENGTH, int64_t) + env;
-        int64_t v = *ep + 1;
-        *ep = v;
-        sh.eplen = (int)v;
+        const int v = sh.pre_eplen + 1;
+        LSB(cx, LSIM_BUF_EPISODE_LENGTH, int64_t)[env] = (int64_t)v;
+        sh.eplen = v;
     } else if (lane == 1) {
         V3 v = quat_rotate_inverse(sh.root + 3, v3p(sh.root + 7));
         v3st(sh.blv, v); v3st(LSB(cx, LSIM_BUF_BASE_LIN_VEL, float) + 3 * env, v);
@@ -100,10 +99,12 @@ LS_FN void ph_post_state(const LsCtx& cx, WaveShared& sh, int lane, int env) {
         v3st(sh.grav, v); v3st(LSB(cx, LSIM_BUF_PROJECTED_GRAVITY, float) + 3 * env, v);
     } else if (lane < 8) {
         int f = lane - 4;
-        LS_GLOBAL uint8_t* lc = LSB(cx, LSIM_BUF_LAST_CONTACTS, uint8_t) + 4 * env + f;
+        const uint8_t lc = (uint8_t)((sh.pre_lc >> (8 * f)) & 0xffu);
         uint8_t contact = sh.cf[cx.model.feet_bodies[f]][2] > 1.0f;
-        LSB(cx, LSIM_BUF_CONTACT_FILT, uint8_t)[4 * env + f] = contact | *lc;
-        *lc = contact;
+        const uint8_t filt = contact | lc;
+        sh.filt[f] = filt;
+        LSB(cx, LSIM_BUF_CONTACT_FILT, uint8_t)[4 * env + f] = filt;
+        LSB(cx, LSIM_BUF_LAST_CONTACTS, uint8_t)[4 * env + f] = contact;
     }
 }
 
@@ -113,7 +114,7 @@ LS_FN void ph_callback(const LsCtx& cx, WaveShared& sh, int lane, int env, const
     const uint32_t stepw = (uint32_t)a.step_counter;
     if (lane == 0) {
         LS_GLOBAL float* cmd = LSB(cx, LSIM_BUF_COMMANDS, float) + 4 * env;
-        float cm[4] = {cmd[0], cmd[1], cmd[2], cmd[3]};
+        float cm[4] = {sh.pre_cmd[0], sh.pre_cmd[1], sh.pre_cmd[2], sh.pre_cmd[3]};
         if (sh.eplen % c.resampling_steps == 0) ls_resample_commands(cx, env, stepw, LSIM_RNG_CMD, ranges, cm);
         if (c.heading_command) {
             V3 f = quat_apply(sh.root + 3, v3(1.0f, 0.0f, 0.0f));
@@ -155,7 +156,7 @@ LS_FN void ph_termination(const LsCtx& cx, WaveShared& sh, int lane, int env) {
     if (c.term_base_vel_violate_commands) {
         float ve = sh.blv[0] - sh.cmd[0];
         int v = ((ve > 2.0f) && (sh.cmd[0] < 0.0f)) || ((ve < -2.0f) && (sh.cmd[0] > 0.0f));
-        v = v && (LSB(cx, LSIM_BUF_TERRAIN_LEVELS, int64_t)[env] > 3);
+        v = v && (sh.pre_level > 3);
         r |= v;
     }
     if (c.term_out_of_border) {  // TER:220-227
@@ -172,9 +173,8 @@ LS_FN void ph_termination(const LsCtx& cx, WaveShared& sh, int lane, int env) {
 
 // ---------------------------------------------------------------------------------------------- rewards
 struct LsRewCtx {
-    const float *dof, *act, *tau;                                                        // LDS
-    LS_GLOBAL const float *last_act, *last_last_act, *last_dof_pos, *last_dof_vel, *last_tau;   // simulator buffers (global memory)
-    LS_GLOBAL const uint8_t* filt;
+    const float *dof, *act, *last_act, *last_last_act, *last_dof_pos, *last_dof_vel, *tau, *last_tau;   // all staged in LDS
+    const uint8_t* filt;
 };
 LS_FN float ls_up(const WaveShared& sh) { return clampf(-sh.grav[2], 0.0f, 1.0f); }
 LS_FN float ls_cmd_norm(const WaveShared& sh) { return sqrtf(sh.cmd[0] * sh.cmd[0] + sh.cmd[1] * sh.cmd[1]); }
@@ -229,7 +229,7 @@ LS_FN float ls_stumble(const LsCtx& cx, const WaveShared& sh, int env, float rat
         const float* F = sh.cf[cx.model.feet_bodies[f]];
         if (sqrtf(F[0] * F[0] + F[1] * F[1]) > ratio * fabsf(F[2])) any = 1;
     }
-    float r = (any && LSB(cx, LSIM_BUF_TERRAIN_LEVELS, int64_t)[env] > 3) ? 1.0f : 0.0f;
+    float r = (any && sh.pre_level > 3) ? 1.0f : 0.0f;
     int in_slice = (env >= c.stairsup_start_idx && env < c.stairsup_end_idx) || (env >= c.pit_start_idx && env < c.gap_end_idx);
     return in_slice ? r : 0.0f;
 }
@@ -255,22 +255,19 @@ LS_FN float ls_reward_term(const LsCtx& cx, WaveShared& sh, const LsRewCtx& x, i
         }
         case LSIM_R_TRACKING_ANG_VEL: { float e = sh.cmd[2] - sh.bav[2]; return expf(-(e * e) / c.tracking_sigma); }
         case LSIM_R_FEET_AIR_TIME: {  // LR:1459-1470 (mutates last_contacts and feet_air_time)
+            // quirk 2: the reference recomputes contact | last_contacts here AFTER post_physics_step already set last_contacts = contact
+            // (LR:207-209), so the filter of this term is the raw contact flag and rewriting last_contacts changes nothing
             LS_GLOBAL float* air = LSB(cx, LSIM_BUF_FEET_AIR_TIME, float) + 4 * env;
-            LS_GLOBAL uint8_t* lc = LSB(cx, LSIM_BUF_LAST_CONTACTS, uint8_t) + 4 * env;
             float r = 0.0f;
-            uint8_t filt[4];
             for (int f = 0; f < 4; ++f) {
-                uint8_t contact = sh.cf[cx.model.feet_bodies[f]][2] > 1.0f;
-                filt[f] = contact | lc[f];
-                lc[f] = contact;
-                float a = air[f];
-                float first = (a > 0.0f && filt[f]) ? 1.0f : 0.0f;
+                const bool contact = sh.cf[cx.model.feet_bodies[f]][2] > 1.0f;
+                float a = sh.pre_air[f];
+                float first = (a > 0.0f && contact) ? 1.0f : 0.0f;
                 a += dt;
                 r += (a - 0.5f) * first;
-                air[f] = a;
+                air[f] = a * (contact ? 0.0f : 1.0f);
             }
             r *= (ls_cmd_norm(sh) > 0.1f) ? 1.0f : 0.0f;
-            for (int f = 0; f < 4; ++f) air[f] *= filt[f] ? 0.0f : 1.0f;
             return r;
         }
         case LSIM_R_UPWARD: return 1.0f - sh.grav[2];
@@ -369,19 +366,21 @@ LS_FN void ph_reward_terms(const LsCtx& cx, WaveShared& sh, int lane, int env) {
     LsRewCtx x;
     x.dof = sh.dofs;
     x.act = sh.act;
-    x.last_act = LSB(cx, LSIM_BUF_LAST_ACTIONS, const float) + 12 * env;
-    x.last_last_act = LSB(cx, LSIM_BUF_LAST_LAST_ACTIONS, const float) + 12 * env;
-    x.last_dof_pos = LSB(cx, LSIM_BUF_LAST_DOF_POS, const float) + 12 * env;
-    x.last_dof_vel = LSB(cx, LSIM_BUF_LAST_DOF_VEL, const float) + 12 * env;
+    x.last_act = sh.last_act;
+    x.last_last_act = sh.pre_lla;
+    x.last_dof_pos = sh.pre_ldp;
+    x.last_dof_vel = sh.pre_ldv;
     x.tau = sh.tau;
-    x.last_tau = LSB(cx, LSIM_BUF_LAST_TORQUES, const float) + 12 * env;
-    x.filt = LSB(cx, LSIM_BUF_CONTACT_FILT, const uint8_t) + 4 * env;
+    x.last_tau = sh.pre_ltau;
+    x.filt = sh.filt;
     // quirk 3: each earlier active foot_clearance_terrain* term has already shifted self.feet_pos by +border
     int shifts = 1;
     if (id == LSIM_R_FOOT_CLEARANCE_TERRAIN_UP && cx.cfg.reward_scales[LSIM_R_FOOT_CLEARANCE_TERRAIN] != 0.0f) shifts = 2;
     float v = ls_reward_term(cx, sh, x, id, env, shifts) * cx.cfg.reward_scales[id];
     sh.rewv[lane] = v;
-    LSB(cx, LSIM_BUF_EPISODE_SUMS, float)[env * LSIM_NUM_REWARD_TERMS + id] += v;
+    const float es = sh.pre_es[id] + v;
+    sh.pre_es[id] = es;
+    LSB(cx, LSIM_BUF_EPISODE_SUMS, float)[env * LSIM_NUM_REWARD_TERMS + id] = es;
 }
 LS_FN void ph_reward_total(const LsCtx& cx, WaveShared& sh, int lane, int env) {
     if (lane != 0) return;
@@ -392,7 +391,7 @@ LS_FN void ph_reward_total(const LsCtx& cx, WaveShared& sh, int lane, int env) {
     if (c.reward_scales[LSIM_R_TERMINATION] != 0.0f) {
         float v = ((sh.reset && !sh.timeout) ? 1.0f : 0.0f) * c.reward_scales[LSIM_R_TERMINATION];
         rew += v;
-        LSB(cx, LSIM_BUF_EPISODE_SUMS, float)[env * LSIM_NUM_REWARD_TERMS + LSIM_R_TERMINATION] += v;
+        LSB(cx, LSIM_BUF_EPISODE_SUMS, float)[env * LSIM_NUM_REWARD_TERMS + LSIM_R_TERMINATION] = sh.pre_es[LSIM_R_TERMINATION] + v;
     }
     LSB(cx, LSIM_BUF_REW, float)[env] = rew;
 }

@@ -54,6 +54,14 @@ struct WaveShared {
     float comd[3], pend[3];
     int delay;
     LsBodyLds body[LS_NB];
+    // ---- inputs of the post-physics stack, fetched by ph_load_a before the kernel has any store in flight: a global load issued after
+    //      stores waits for every one of them (vmcnt is in order), so nothing after the physics loop reads global state buffers
+    float pre_lla[12], pre_ldp[12], pre_ldv[12], pre_ltau[12];   // last_last_actions, last_dof_pos, last_dof_vel, last_torques (contiguous)
+    float pre_cmd[4], pre_air[4];                                // commands, feet_air_time
+    int pre_eplen, pre_level;                                    // episode_length_buf, terrain_levels (low words)
+    unsigned int pre_lc;                                         // last_contacts: 4 bytes
+    float pre_es[LSIM_NUM_REWARD_TERMS];                         // episode_sums row
+    unsigned char filt[4];                                       // contact_filt of this step (LR:207-209)
     // ---- kinematics / dynamics of the current sub-step (world axes, positions relative to the base origin), overlaid
     //      with the post-physics scratch that is only used once the last sub-step is over (keeps the block <= 10 KB so
     //      that 16 robots per CU -- all 4096 of a 256-CU launch -- are resident at once)
@@ -82,7 +90,7 @@ struct WaveShared {
             //   W_ij = J_i M^-1 J_j^T = a_i . z_j + Jl_i . y_j[leg_i]   with a_i = Jb_i - Mbl y_i (registers),   v+ = vfree + sum_r Y_r lam_r - G (sum_r z_r lam_r)
             // which saves 72 FMAs and as many LDS reads per row against forming - G_l z for all four legs.
             float Y[LS_MAXR][LS_NV];
-            float dirs[LS_MAXR][3];
+            float dirs[3 * LS_MAXC][3];      // contact rows only
         } c;
     } u;
     float Mbl[4][18];        // 6x3: columns F_hip, F_thigh, F_calf
