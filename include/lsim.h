@@ -50,7 +50,9 @@ extern "C" {
 #define LSIM_NUM_AMP_OBS 30     /* LR:416 */
 #define LSIM_NUM_BASE_HEIGHT_PTS 63 /* 7 x 9, LR:1308-1312 */
 #define LSIM_MAX_COLLISION_POINTS 64
+#ifndef LSIM_MAX_CONTACTS      /* the CPU oracle can be compiled with a larger cap to measure what the cap costs (tests/test_contact_cap.py) */
 #define LSIM_MAX_CONTACTS 8
+#endif
 #define LSIM_TERRAIN_LEVELS_MAX 32
 #define LSIM_TERRAIN_TYPES_MAX 32
 
@@ -324,6 +326,8 @@ enum lsim_buffer_id {
     LSIM_BUF_TERM_AMP_OBS,       /* f32 [N,30]    rows valid where reset_buf (LR:228) */
     LSIM_BUF_AMP_OBS,            /* f32 [N,30]    get_amp_observations() of the post-step state (LR:406-416) */
     LSIM_BUF_DELAY_STEPS,        /* i32 [N]       last drawn action delay (LR:134) */
+    LSIM_BUF_CONTACT_COUNT,      /* i32 [N,2]     diagnostic: collision points within contact_offset of the terrain BEFORE the cap of
+                                                  LSIM_MAX_CONTACTS -- [0] maximum over the sub-steps of this step, [1] last sub-step */
     LSIM_BUF_STATS,              /* f32 [2,LSIM_STATS_SIZE] device-side per-step reductions, see below */
     LSIM_BUF_HEIGHT_GRID,        /* i16 [rows,cols] */
     LSIM_BUF_TERRAIN_ORIGINS,    /* f32 [levels,types,3] */
@@ -341,8 +345,12 @@ enum lsim_buffer_id {
  *   [1 .. 1+T)               sum over reset envs of episode_sums[k] / clip(ep_len,1)   (LR:349; divide by [0] and dt)
  *   [1+T]                    reserved (the host forms mean(terrain_levels), LR:353, from LSIM_BUF_TERRAIN_LEVELS)
  *   [2+T .. 10+T)            command_ranges[4][2] live values (LR:877-880)
- *   [10+T]                   sum over reset envs of episode_sums[tracking_lin_vel]      (LR:875)
+ *   [10+T]                   reserved (the tracking sum of LR:875 is kept in fixed point, below)
  *   [11+T]                   reserved
+ *   [LSIM_STATS_FIX ..)      internal, not for the host: int64 fixed-point (2^-40) accumulators of [1 .. 1+T) and of the sum over reset envs of
+ *                            episode_sums[tracking_lin_vel] (LR:875), and a ticket counter.  Waves add to them with integer atomics, so the sums
+ *                            -- extras["episode"] and the command-curriculum decision -- do not depend on the order the waves arrive in; the last
+ *                            resetting wave of a step converts [1 .. 1+T) to fp32.
  */
 #define LSIM_STATS_RESET_COUNT 0
 #define LSIM_STATS_EPISODE_SUMS 1
@@ -350,7 +358,11 @@ enum lsim_buffer_id {
 #define LSIM_STATS_CMD_RANGES (2 + LSIM_NUM_REWARD_TERMS)
 #define LSIM_STATS_TRACK_SUM (10 + LSIM_NUM_REWARD_TERMS)
 #define LSIM_STATS_RESET_STEPS (11 + LSIM_NUM_REWARD_TERMS)
-#define LSIM_STATS_SIZE (16 + LSIM_NUM_REWARD_TERMS)
+#define LSIM_STATS_FIX ((17 + LSIM_NUM_REWARD_TERMS) & ~1)      /* even float index: the int64 words are 8-byte aligned (rows are too) */
+#define LSIM_STATS_FIX_TRACK LSIM_NUM_REWARD_TERMS             /* word index of the tracking sum */
+#define LSIM_STATS_FIX_TICKET (LSIM_NUM_REWARD_TERMS + 1)      /* word index of the ticket counter */
+#define LSIM_STATS_FIX_WORDS (LSIM_NUM_REWARD_TERMS + 2)
+#define LSIM_STATS_SIZE (LSIM_STATS_FIX + 2 * LSIM_STATS_FIX_WORDS)
 
 /* flags of lsim_step_ex */
 #define LSIM_STEP_DEFAULT 0u

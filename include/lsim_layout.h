@@ -5,6 +5,7 @@
  */
 #ifndef LSIM_LAYOUT_H
 #define LSIM_LAYOUT_H
+#include <math.h>
 #include "lsim.h"
 
 #ifdef __cplusplus
@@ -20,6 +21,27 @@ static inline size_t lsim_dtype_size(int dtype) {
         case LSIM_DT_I16: return 2;
         default: return 0;
     }
+}
+
+/* torch.div(a, b, rounding_mode="floor") on fp32 (c10::div_floor_floating): the floor of the EXACT quotient of the two floats, not of
+ * their rounded fp32 quotient.  LR:1234 assigns terrain types with it: at N = 4096, 20 columns, env 1024 has 1024 / 204.8f = 4.99999993,
+ * which plain fp32 division rounds to 5.0 while torch returns 4 (found by pinning E21, tests/test_init_golden.py). */
+static inline float lsim_div_floor_f32(float a, float b) {
+    if (b == 0.0f) return a / b;
+    float mod = fmodf(a, b);
+    float div = (a - mod) / b;
+    if (mod != 0.0f && ((b < 0.0f) != (mod < 0.0f))) div -= 1.0f;
+    if (div == 0.0f) return copysignf(0.0f, a / b);
+    float fl = floorf(div);
+    if (div - fl > 0.5f) fl += 1.0f;
+    return fl;
+}
+/* LeggedRobot._get_env_origins, LR:1234: terrain_types = floor(arange(N) / (N / num_cols)); the divisor is a Python float (fp64 quotient)
+ * that torch converts to fp32 for the fp32 result */
+static inline int64_t lsim_terrain_type_of_env(int env, int num_envs, int num_cols) {
+    float b = (float)((double)num_envs / (double)num_cols);
+    int64_t t = (int64_t)lsim_div_floor_f32((float)env, b);
+    return t > num_cols - 1 ? num_cols - 1 : t;
 }
 
 /* returns 0 on success; shape entries beyond ndim are set to 1 */
@@ -72,6 +94,7 @@ static inline int lsim_buffer_desc(const lsim_config* cfg, int id, int64_t shape
         case LSIM_BUF_TERM_AMP_OBS:
         case LSIM_BUF_AMP_OBS: s1 = LSIM_NUM_AMP_OBS; nd = 2; break;
         case LSIM_BUF_DELAY_STEPS: dt = LSIM_DT_I32; break;
+        case LSIM_BUF_CONTACT_COUNT: s1 = 2; nd = 2; dt = LSIM_DT_I32; break;
         case LSIM_BUF_STATS: s0 = 2; s1 = LSIM_STATS_SIZE; nd = 2; break;
         case LSIM_BUF_HEIGHT_GRID:
             s0 = cfg->grid_rows > 0 ? cfg->grid_rows : 1; s1 = cfg->grid_cols > 0 ? cfg->grid_cols : 1;
@@ -102,7 +125,7 @@ static const char* const lsim_buffer_names[LSIM_NUM_BUFFERS] = {
     "feet_air_time", "last_contacts", "contact_filt", "measured_heights", "pending_force", "terrain_levels",
     "terrain_types", "env_origins", "kp_factors", "kd_factors", "motor_strength", "motor_strength_factors", "friction",
     "restitution", "payload", "com_displacement", "episode_sums", "term_priv_obs", "term_amp_obs", "amp_obs",
-    "delay_steps", "stats", "height_grid", "terrain_origins", "terrain_mesh"};
+    "delay_steps", "contact_count", "stats", "height_grid", "terrain_origins", "terrain_mesh"};
 
 static const char* const lsim_reward_names[LSIM_NUM_REWARD_TERMS] = {
     "action_rate", "ang_vel_xy", "ang_vel_xy_up", "base_height", "base_height_up", "calf_pose", "calf_pose_up",

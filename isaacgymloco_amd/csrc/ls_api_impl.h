@@ -151,8 +151,7 @@ extern "C" int LS_API(create)(const lsim_config* cfg, const lsim_robot_model* mo
         if (c.mesh_type != 0) {
             int max_init = c.terrain_curriculum ? c.max_init_terrain_level : c.terrain_num_rows - 1;
             lvl[e] = (int64_t)(u(e, LSIM_RNG_INIT, 20) * (float)(max_init + 1));
-            int64_t t = (int64_t)floorf((float)e / ((float)N / (float)c.terrain_num_cols));
-            typ[e] = t > c.terrain_num_cols - 1 ? c.terrain_num_cols - 1 : t;
+            typ[e] = lsim_terrain_type_of_env(e, N, c.terrain_num_cols);     // LR:1234 (torch's floor division, see lsim_layout.h)
             for (int k = 0; k < 3; ++k) org[3 * e + k] = terrain_origins[(lvl[e] * c.terrain_num_cols + typ[e]) * 3 + k];
         }
         for (int k = 0; k < 13; ++k) root[13 * e + k] = c.base_init_state[k];

@@ -17,6 +17,11 @@
 #define LS_PHASE(call) do { for (int lane = 0; lane < 64; ++lane) { LaneRegs& rg = L[lane]; (void)rg; call; } } while (0)
 #define LS_COLLECTIVE(gpu_call, emu_call) do { emu_call; } while (0)
 #define LS_ATOMIC_ADD(ptr, v) (*(ptr) += (v))
+#define LS_ATOMIC_ADD_I64(ptr, v) (*(ptr) += (v))
+#define LS_ATOMIC_FETCH_ADD_I64(ptr, v) ls_emu_fetch_add((ptr), (v))
+#define LS_ATOMIC_READ_I64(ptr) (*(ptr))
+#define LS_THREADFENCE() do { } while (0)
+static inline long long ls_emu_fetch_add(long long* p, long long v) { long long o = *p; *p = o + v; return o; }
 #define LS_WAVE_FN static inline
 #define LS_TICK_INIT() do { } while (0)
 #define LS_TICK_FLUSH() do { } while (0)
@@ -42,8 +47,20 @@ __device__ unsigned long long g_ls_phase_calls[64];
 #define LS_PHASE(call) do { { const int lane = ls_opaque_lane(lane0); call; } __syncthreads(); LS_TICK(__LINE__ - ls_line0); } while (0)
 #define LS_COLLECTIVE(gpu_call, emu_call) do { { const int lane = ls_opaque_lane(lane0); gpu_call; } __syncthreads(); LS_TICK(__LINE__ - ls_line0); } while (0)
 #define LS_ATOMIC_ADD(ptr, v) atomicAdd((ptr), (v))
+// 64-bit integer atomics on the fixed-point accumulators (device scope: they are performed at the memory side, coherent across the XCDs)
+#define LS_ATOMIC_ADD_I64(ptr, v) ((void)atomicAdd((unsigned long long*)(ptr), (unsigned long long)(v)))
+#define LS_ATOMIC_FETCH_ADD_I64(ptr, v) ((long long)atomicAdd((unsigned long long*)(ptr), (unsigned long long)(v)))
+#define LS_ATOMIC_READ_I64(ptr) ((long long)atomicAdd((unsigned long long*)(ptr), 0ull))
+#define LS_THREADFENCE() __threadfence()
 #define LS_WAVE_FN __device__ __forceinline__
 #endif
+
+// Order-independent reductions over waves (float atomics made extras["episode"] and the command-curriculum decision depend on the
+// arrival order of the waves): values are added as 2^-40 fixed-point int64, integer addition being associative.  |v| < 2^23 by construction
+// (episode sums of rewards); the conversion error 2^-41 is far below fp32 resolution of the sums that are reported.
+LS_FN long long ls_to_fix(float v) { return (long long)llrintf(v * 1099511627776.0f); }
+LS_FN float ls_from_fix(long long f) { return (float)((double)f * (1.0 / 1099511627776.0)); }
+LS_FN long long* ls_fix_row(const LsCtx& cx, int row) { return (long long*)(cx.accum + row * LSIM_STATS_SIZE + LSIM_STATS_FIX); }
 
 // ---- load the robot's state into LDS, clip the actions (LR:129-130), draw the action delay (LR:134)
 // Load phases: every global load is issued first, unconditionally -- a lane with no use for a value reads element 0 of the same row, always
@@ -101,6 +118,7 @@ LS_FN void ph_load_a(const LsCtx& cx, WaveShared& sh, LaneRegs& rg, int lane, in
     if (lane == 15) {
         int delay = (int)(ls_draw(cx, env, (uint32_t)a.step_counter, LSIM_RNG_DELAY, 0) * (float)c.decimation);   // LR:134
         sh.delay = delay;
+        sh.nact = 0; sh.nact_max = 0;
         LSB(cx, LSIM_BUF_DELAY_STEPS, int32_t)[env] = delay;
     }
     if (lane >= 16 && lane < 16 + LS_NB) {
@@ -148,6 +166,7 @@ LS_FN void ph_store_sim_state(const LsCtx& cx, WaveShared& sh, int lane, int env
         LSB(cx, LSIM_BUF_TORQUES, float)[12 * env + lane] = sh.tau[lane];
     }
     if (lane < 3 * LS_NB) LSB(cx, LSIM_BUF_CONTACT_FORCES, float)[3 * LS_NB * env + lane] = sh.cf[lane / 3][lane % 3];
+    if (lane == 52) { LSB(cx, LSIM_BUF_CONTACT_COUNT, int32_t)[2 * env] = sh.nact_max; LSB(cx, LSIM_BUF_CONTACT_COUNT, int32_t)[2 * env + 1] = sh.nact; }
 }
 LS_FN void ph_body_states_all(const LsCtx& cx, WaveShared& sh, int lane, int env) {
     LS_GLOBAL float* out = LSB(cx, LSIM_BUF_RIGID_BODY_STATES, float) + 13 * LS_NB * env;
@@ -193,8 +212,8 @@ LS_FN void ph_term_outputs(const LsCtx& cx, WaveShared& sh, int lane, int env, c
     }
     if (lane == 0 && !(a.flags & LSIM_STEP_NO_RESET)) {
         LS_GLOBAL float* acc = LS_G(float, cx.accum) + a.row_out * LSIM_STATS_SIZE;
-        LS_ATOMIC_ADD(acc + LSIM_STATS_RESET_COUNT, 1.0f);
-        LS_ATOMIC_ADD(acc + LSIM_STATS_TRACK_SUM, sh.pre_es[LSIM_R_TRACKING_LIN_VEL]);    // updated by ph_reward_terms
+        LS_ATOMIC_ADD(acc + LSIM_STATS_RESET_COUNT, 1.0f);                                   // integer-valued: exact in any order
+        LS_ATOMIC_ADD_I64(ls_fix_row(cx, a.row_out) + LSIM_STATS_FIX_TRACK, ls_to_fix(sh.pre_es[LSIM_R_TRACKING_LIN_VEL]));   // updated by ph_reward_terms
     }
 }
 
@@ -279,7 +298,8 @@ LS_FN void ph_load_b(const LsCtx& cx, WaveShared& sh, int lane, int env, const L
     // per-env / per-step scalars: the same address in every lane
     LS_GLOBAL const float* acc_out = LS_G(const float, cx.accum) + a.row_out * LSIM_STATS_SIZE;
     LS_GLOBAL const float* acc_in = LS_G(const float, cx.accum) + a.row_in * LSIM_STATS_SIZE;
-    const float v_nreset = acc_out[LSIM_STATS_RESET_COUNT], v_track = acc_out[LSIM_STATS_TRACK_SUM];
+    const float v_nreset = acc_out[LSIM_STATS_RESET_COUNT];
+    const float v_track = ls_from_fix(LS_G(const long long, ls_fix_row(cx, a.row_out))[LSIM_STATS_FIX_TRACK]);
     float r[8];
     for (int k = 0; k < 8; ++k) r[k] = acc_in[LSIM_STATS_CMD_RANGES + k];
     const int v_reset = LSB(cx, LSIM_BUF_RESET, uint8_t)[env];
@@ -316,6 +336,7 @@ LS_FN void ph_load_b(const LsCtx& cx, WaveShared& sh, int lane, int env, const L
         const bool no_reset = (a.flags & LSIM_STEP_NO_RESET) != 0;
         sh.do_reset = a.reset_all || (v_reset && !no_reset);
         sh.any_reset = a.reset_all || (!no_reset && nreset > 0.5f);
+        sh.flags64[1] = (unsigned int)nreset;          // number of envs that reset this step (the ticket of the last one is this minus 1)
         // command curriculum (LR:307-308, LR:868-880): every wave derives the same new ranges from the reduced sums
         if (sh.any_reset && c.commands_curriculum && (a.step_counter % c.max_episode_length == 0)) {
             float mean = v_track / nreset;
@@ -338,7 +359,8 @@ LS_FN void ph_b_housekeeping(const LsCtx& cx, WaveShared& sh, int lane, int env,
     if (a.reset_all && lane == 8) out[LSIM_STATS_RESET_COUNT] = (float)cx.cfg.num_envs;
     LS_GLOBAL float* nxt = LS_G(float, cx.accum) + a.row_in * LSIM_STATS_SIZE;   // the next call accumulates into the row this call read
     if (lane == 9) nxt[LSIM_STATS_RESET_COUNT] = 0.0f;
-    if (lane == 10) nxt[LSIM_STATS_TRACK_SUM] = 0.0f;
+    LS_GLOBAL long long* fnxt = LS_G(long long, ls_fix_row(cx, a.row_in));
+    LS_STRIDED(k, lane, LSIM_STATS_FIX_WORDS) fnxt[k] = 0;
     LS_STRIDED(k, lane, LSIM_NUM_REWARD_TERMS) nxt[LSIM_STATS_EPISODE_SUMS + k] = 0.0f;
 }
 
@@ -422,18 +444,34 @@ LS_FN void ph_b_reset(const LsCtx& cx, WaveShared& sh, int lane, int env, const 
         LSB(cx, LSIM_BUF_RESET, uint8_t)[env] = 1;                                                 // LR:329
     }
 }
-// extras["episode"] sums (LR:346-350); lane = reward term
+// extras["episode"] sums (LR:346-350); lane = reward term.  Three steps so that the result is the same whatever order the waves run in:
+//   1. every resetting env adds its terms to the fixed-point accumulators
+//   2. and then takes a ticket; the env that draws the last ticket of the step (count known from kernel A) knows every add has landed
+//   3. and converts the sums to the fp32 row the host reads (ph_b_store)
 LS_FN void ph_b_episode_stats(const LsCtx& cx, WaveShared& sh, int lane, int env, const LsStepArgs& a) {
+    if (lane == 0) sh.flags64[0] = 0;
     if (!sh.do_reset) return;
     if (lane == 13) for (int k = 0; k < 4; ++k) sh.cmd[k] = sh.rewv[k];
     float den = (float)(sh.eplen < 1 ? 1 : sh.eplen);
-    LS_GLOBAL float* acc = LS_G(float, cx.accum) + a.row_out * LSIM_STATS_SIZE;
+    long long* fix = ls_fix_row(cx, a.row_out);
     LS_STRIDED(k, lane, LSIM_NUM_REWARD_TERMS) {
         LS_GLOBAL float* es = LSB(cx, LSIM_BUF_EPISODE_SUMS, float) + env * LSIM_NUM_REWARD_TERMS + k;
         float v = *es;
-        if (v != 0.0f) LS_ATOMIC_ADD(acc + LSIM_STATS_EPISODE_SUMS + k, v / den);
+        if (v != 0.0f) LS_ATOMIC_ADD_I64(fix + k, ls_to_fix(v / den));
         *es = 0.0f;
     }
+}
+LS_FN void ph_b_stats_ticket(const LsCtx& cx, WaveShared& sh, int lane, int env, const LsStepArgs& a) {
+    if (!sh.do_reset || lane != 0) return;
+    LS_THREADFENCE();                                  // this wave's adds are ordered before its ticket
+    const long long t = LS_ATOMIC_FETCH_ADD_I64(ls_fix_row(cx, a.row_out) + LSIM_STATS_FIX_TICKET, 1);
+    sh.flags64[0] = (t + 1 == (long long)sh.flags64[1]) ? 1u : 0u;
+}
+LS_FN void ph_b_stats_publish(const LsCtx& cx, WaveShared& sh, int lane, const LsStepArgs& a) {
+    if (!sh.flags64[0]) return;
+    long long* fix = ls_fix_row(cx, a.row_out);
+    LS_GLOBAL float* out = LS_G(float, cx.accum) + a.row_out * LSIM_STATS_SIZE;
+    LS_STRIDED(k, lane, LSIM_NUM_REWARD_TERMS) out[LSIM_STATS_EPISODE_SUMS + k] = ls_from_fix(LS_ATOMIC_READ_I64(fix + k));
 }
 
 // publish observations (LR:403-404 + clip LR:167-171), AMP features (LR:406-416), last_* roll (LR:235-241)
@@ -493,12 +531,13 @@ LS_WAVE_FN void ls_wave_step_b(const LsCtx& cx, const LsStepArgs& a, const int e
     LS_PHASE(ph_b_housekeeping(cx, sh, lane, env, a); ph_b_terrain_curriculum(cx, sh, lane, env, a));
     LS_PHASE(ph_b_reset(cx, sh, lane, env, a));
     LS_PHASE(ph_b_episode_stats(cx, sh, lane, env, a));
+    LS_PHASE(ph_b_stats_ticket(cx, sh, lane, env, a));
     LS_PHASE(if (sh.do_reset && c.measure_heights) ph_heights(cx, sh, lane, env, true));
     if (a.reset_all) {   // reset_idx only: the observation roll belongs to the step that follows (BT:114)
-        LS_PHASE(ph_b_store_reset_all(cx, sh, lane, env, a));
+        LS_PHASE(ph_b_store_reset_all(cx, sh, lane, env, a); ph_b_stats_publish(cx, sh, lane, a));
         return;
     }
     LS_PHASE(ph_build_obs(cx, sh, lane, env, (uint32_t)a.step_counter, LSIM_RNG_OBS_NOISE, sh.cur));
-    LS_PHASE(ph_b_store(cx, sh, lane, env, a));
+    LS_PHASE(ph_b_store(cx, sh, lane, env, a); ph_b_stats_publish(cx, sh, lane, a));
     LS_TICK_FLUSH();
 }

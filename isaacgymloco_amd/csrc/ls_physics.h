@@ -428,14 +428,18 @@ LS_FN void ph_collide(const LsCtx& cx, WaveShared& sh, LaneRegs& r, int lane) {
 // ---- wave collective: ordered compaction of the active points into at most LS_MAXC contacts
 #if defined(LS_EMU)
 static inline void wc_compact_contacts(WaveShared& sh, LaneRegs* L) {
-    int nc = 0;
-    for (int lane = 0; lane < 64 && nc < LS_MAXC; ++lane)
+    int nc = 0, nact = 0;
+    for (int lane = 0; lane < 64; ++lane)
         if (L[lane].cp_active) {
+            ++nact;
+            if (nc >= LS_MAXC) continue;
             sh.cbody[nc] = L[lane].cp_body; sh.cdist[nc] = L[lane].cp_dist;
             for (int k = 0; k < 3; ++k) { sh.cn[nc][k] = L[lane].cp_n[k]; sh.cpos[nc][k] = L[lane].cp_x[k]; }
             ++nc;
         }
     sh.nc = nc;
+    sh.nact = nact;
+    sh.nact_max = nact > sh.nact_max ? nact : sh.nact_max;
 }
 #else
 LS_FN void wc_compact_contacts(WaveShared& sh, LaneRegs& r, int lane) {
@@ -445,7 +449,12 @@ LS_FN void wc_compact_contacts(WaveShared& sh, LaneRegs& r, int lane) {
         sh.cbody[rank] = r.cp_body; sh.cdist[rank] = r.cp_dist;
         for (int k = 0; k < 3; ++k) { sh.cn[rank][k] = r.cp_n[k]; sh.cpos[rank][k] = r.cp_x[k]; }
     }
-    if (lane == 0) { int n = __popcll(m); sh.nc = n < LS_MAXC ? n : LS_MAXC; }
+    if (lane == 0) {
+        int n = __popcll(m);
+        sh.nc = n < LS_MAXC ? n : LS_MAXC;
+        sh.nact = n;
+        sh.nact_max = n > sh.nact_max ? n : sh.nact_max;
+    }
 }
 #endif
 

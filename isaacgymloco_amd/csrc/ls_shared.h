@@ -105,6 +105,7 @@ struct WaveShared {
     float vfree[LS_NV], vnew[LS_NV];
     // ---- contacts
     int nc, nrows;
+    int nact, nact_max;      // collision points in contact before the cap (diagnostic, LSIM_BUF_CONTACT_COUNT)
     int cbody[LS_MAXC];
     float cpos[LS_MAXC][3], cn[LS_MAXC][3], cdist[LS_MAXC];
     int limdof[12];

@@ -30,9 +30,9 @@ __device__ __forceinline__ int ls_env_of_block(int b, int num_envs) {
     return (b & 7) * chunk + (b >> 3);
 }
 
-// Kernel A is VALU-issue bound with ~45 % of wave cycles waiting on LDS/memory: 4 waves per SIMD (<= 128 VGPRs, a few dozen
-// spilled to scratch in the PGS sweep) beat 1-2 waves with everything in registers by 1.35x at N = 4096, where 4 waves/SIMD
-// is also exactly the whole batch resident at once (4096 waves / 1024 SIMDs; the 9.1 KB LDS struct allows 17 blocks per CU).
+// Kernel A is bound by per-wave latency (dependent VALU chains, LDS round trips at ~19 phase boundaries per sub-step):
+// 4 waves per SIMD (<= 128 VGPRs, no scratch) beat 1-2 waves with more registers by 1.35x at N = 4096, where 4 waves/SIMD is also exactly
+// the whole batch resident at once (4096 waves / 1024 SIMDs; the 9.6 KB LDS struct allows 16 blocks per CU).
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void lsim_k_step_a(const LsCtx* __restrict__ ctx, LsStepArgs a) {
     __shared__ WaveShared sh;
     const int env = ls_env_of_block((int)blockIdx.x, ctx->cfg.num_envs);
@@ -62,7 +62,8 @@ __global__ __launch_bounds__(256) void lsim_k_track_sum(const LsCtx* __restrict_
         if ((int)threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
         __syncthreads();
     }
-    if (threadIdx.x == 0) atomicAdd(cx.accum + a.row_out * LSIM_STATS_SIZE + LSIM_STATS_TRACK_SUM, part[0]);
+    // block partials are formed in a fixed order; their fixed-point sum does not depend on the order the blocks arrive in
+    if (threadIdx.x == 0) LS_ATOMIC_ADD_I64(ls_fix_row(cx, a.row_out) + LSIM_STATS_FIX_TRACK, ls_to_fix(part[0]));
 }
 
 static int ls_grid(const lsim_sim* s) { return 8 * ((s->cfg.num_envs + 7) / 8); }

@@ -94,6 +94,8 @@ class LeggedRobot:
         torch.cuda.synchronize(dev)
         self._bind_buffers()
         self.extras = {}
+        self._disturbance = None
+        self.reward_curriculum_coef = []
         if cfg.env.send_timeouts:
             self.extras["time_outs"] = self._extras_time_outs
         self.common_step_counter = 0
@@ -170,9 +172,17 @@ class LeggedRobot:
         return self.buf["rigid_body_states"][:, self.feet_indices, 7:10]
 
     @property
-    def disturbance(self):                     # (N,17,3) view semantics of LR:1017: only row 0 can be non-zero
-        d = torch.zeros(self.num_envs, self.num_bodies, 3, device=self._arena.device)
-        return d
+    def disturbance(self):
+        """self.disturbance (LR:1017), (N, 17, 3): the body-local force applied to every body in the next simulate().  Only row 0 (the base)
+        is ever written (LR:843) and the reference zeroes the whole buffer at the end of each step (LR:235), so what a caller can observe
+        between steps is zeros; the force drawn at LR:842 lives on in `pending_force` until the first sub-step consumes it."""
+        if self._disturbance is None:
+            self._disturbance = torch.zeros(self.num_envs, self.num_bodies, 3, device=self._arena.device)
+        return self._disturbance
+
+    @property
+    def pending_force(self):                   # (N,3) base force of the next step, body-local frame (what LR:844 hands to the simulator)
+        return self.buf["pending_force"]
 
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self._arena.device).cuda_stream)
@@ -206,7 +216,8 @@ class LeggedRobot:
         buffers (overwritten by the next step): clone what must survive."""
         if actions.dtype != torch.float32 or not actions.is_contiguous() or actions.device != self._arena.device:
             actions = actions.to(device=self._arena.device, dtype=torch.float32).contiguous()
-        lib.check(self._L.lsim_step_ex(self._h, actions.data_ptr(), ctypes.c_uint32(flags), self._stream()), self._h, "lsim_step")
+        with lib.roctx_range("lsim_step"):
+            lib.check(self._L.lsim_step_ex(self._h, actions.data_ptr(), ctypes.c_uint32(flags), self._stream()), self._h, "lsim_step")
         self.common_step_counter += 1
         self._last_actions_ref = actions   # keep alive until the kernels ran
         return self.obs_buf, self.privileged_obs_buf, self.rew_buf, self.reset_buf
@@ -269,8 +280,18 @@ class LeggedRobot:
             ep["max_command_x"] = st[S["cmd_ranges"] + 1]
         self.extras["episode"] = ep
 
-    def update_reward_curriculum(self, current_iter):   # LR:830-836; flag is False in every shipped config
-        pass
+    def update_reward_curriculum(self, current_iter):
+        """LR:830-836: linear schedule (iter0, iter1, coef0, coef1) per entry -> reward_curriculum_coef.  As in the reference the coefficients are
+        only stored: no reward term reads them (cfg.rewards.reward_curriculum is False in every shipped config and HYBR:162 is the only
+        caller).  The reference's default schedule is a flat list (LRC:181), which its own loop cannot index; a flat list counts as one entry."""
+        sched = getattr(self.cfg.rewards, "reward_curriculum_schedule", None) or []
+        if sched and not isinstance(sched[0], (list, tuple)):
+            sched = [sched]
+        coefs = []
+        for it0, it1, c0, c1 in sched:
+            p = max(min((current_iter - it0) / (it1 - it0), 1), 0)
+            coefs.append((1 - p) * c0 + p * c1)
+        self.reward_curriculum_coef = coefs
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:

@@ -91,12 +91,14 @@ class GraphedRollout:
     def step(self):
         """one rollout step: networks + fused sample/store (two launches, or one graph replay), simulator step, fused post-step store"""
         self._sync_weights()
-        if self.packed is not None:
-            self._act()
-        else:
-            self.graph_a.replay()
+        with lib.roctx_range("policy_forward+sample+store"):
+            if self.packed is not None:
+                self._act()
+            else:
+                self.graph_a.replay()
         self.env.step_device(self.actions)
-        self._post()
+        with lib.roctx_range("rollout_post"):
+            self._post()
         self.storage.step += 1
 
     def _sync_weights(self):

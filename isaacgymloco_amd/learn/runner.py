@@ -127,7 +127,9 @@ class HIMOnPolicyRunner:
                 self.alg.compute_returns(critic_obs)
             if self.graphs is not None:
                 self.graphs.end_iteration()
-            update_out = self.alg.update()      # HIMPPO: 4 values; HybridPPO: 8 (adds AMP loss, grad penalty, policy / expert prediction)
+            from .. import lib as _lib
+            with _lib.roctx_range("ppo_update"):
+                update_out = self.alg.update()  # HIMPPO: 4 values; HybridPPO: 8 (adds AMP loss, grad penalty, policy / expert prediction)
             mean_value_loss, mean_surrogate_loss, mean_estimation_loss, mean_swap_loss = update_out[:4]
             self.last_update = update_out
             if self.device != "cpu" and torch.cuda.is_available():

@@ -65,6 +65,49 @@ def load():
     return L
 
 
+# ---- roctx ranges (SURVEY.md 8d "roctx ranges per K1-K4"): LSIM_ROCTX=1 brackets the simulator step, the policy / storage kernels of the
+# rollout and the learner update with named ranges that `rocprofv3 --marker-trace` shows on the timeline.  Off by default: a push / pop
+# pair is two library calls per range on the host-bound rollout loop.
+_roctx = None
+
+
+def _roctx_lib():
+    global _roctx
+    if _roctx is None:
+        _roctx = False
+        if os.environ.get("LSIM_ROCTX") == "1":
+            for name in ("librocprofiler-sdk-roctx.so", "libroctx64.so"):
+                try:
+                    R = ctypes.CDLL(name)
+                    R.roctxRangePushA.argtypes = [ctypes.c_char_p]
+                    _roctx = R
+                    break
+                except OSError:
+                    continue
+    return _roctx
+
+
+class roctx_range:
+    """with roctx_range("lsim_step"): ...   (no-op unless LSIM_ROCTX=1 and a roctx library is present)"""
+    __slots__ = ("name", "on")
+
+    def __init__(self, name):
+        self.name = name.encode()
+        self.on = False
+
+    def __enter__(self):
+        R = _roctx_lib()
+        if R:
+            R.roctxRangePushA(self.name)
+            self.on = True
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            _roctx.roctxRangePop()
+        return False
+
+
 def check(rc, handle=None, what="lsim call"):
     if rc != 0:
         msg = ""

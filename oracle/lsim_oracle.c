@@ -787,8 +787,7 @@ int orc_create(const lsim_config* cfg, const lsim_robot_model* model, const int1
         if (c->mesh_type != 0) {
             int max_init = c->terrain_curriculum ? c->max_init_terrain_level : c->terrain_num_rows - 1;
             int64_t lvl = (int64_t)(u01(s, e, W, LSIM_RNG_INIT, 20) * (float)(max_init + 1));
-            int64_t type = (int64_t)floorf((float)e / ((float)N / (float)c->terrain_num_cols)); /* LR:1234 */
-            if (type > c->terrain_num_cols - 1) type = c->terrain_num_cols - 1;
+            int64_t type = lsim_terrain_type_of_env(e, N, c->terrain_num_cols); /* LR:1234 */
             ORC_I64(s, LSIM_BUF_TERRAIN_LEVELS)[e] = lvl;
             ORC_I64(s, LSIM_BUF_TERRAIN_TYPES)[e] = type;
             const float* to = ORC_F(s, LSIM_BUF_TERRAIN_ORIGINS) + (lvl * c->terrain_num_cols + type) * 3;
@@ -844,6 +843,7 @@ int orc_step_ex(orc_sim* s, const float* actions, uint32_t flags) {
         for (int j = 0; j < N_DOF; ++j) act[j] = clipf(actions[N_DOF * e + j], -c->clip_actions, c->clip_actions); /* LR:129-130 */
         int delay = (int)(u01(s, e, stepw, LSIM_RNG_DELAY, 0) * (float)c->decimation); /* LR:134 */
         ORC_I32(s, LSIM_BUF_DELAY_STEPS)[e] = delay;
+        ORC_I32(s, LSIM_BUF_CONTACT_COUNT)[2 * e] = 0; ORC_I32(s, LSIM_BUF_CONTACT_COUNT)[2 * e + 1] = 0;
         for (int sub = 0; sub < c->decimation; ++sub) { /* LR:144-152 */
             float a[N_DOF], tau[N_DOF];
             for (int j = 0; j < N_DOF; ++j)

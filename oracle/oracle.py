@@ -38,11 +38,20 @@ def lib():
     return _lib
 
 
+def variant(name):
+    """another build of the same sources (oracle/Makefile target lib<name>.so), e.g. "orc_cap32": the contact cap lifted to 32"""
+    path = os.path.join(_HERE, f"lib{name}.so")
+    subprocess.check_call(["make", "-C", _HERE, f"lib{name}.so"], stdout=subprocess.DEVNULL)
+    L = ctypes.CDLL(path)
+    abi.check_abi(L, prefix="orc")
+    return L
+
+
 class OracleSim:
     """orc_create / orc_step_ex / orc_reset_all with numpy buffer views (`sim.buf["root_states"]` ...)."""
 
-    def __init__(self, cfg, model, height_grid=None, terrain_origins=None):
-        L = lib()
+    def __init__(self, cfg, model, height_grid=None, terrain_origins=None, library=None):
+        L = self._L = library if library is not None else lib()
         self._h = ctypes.c_void_p()
         self.cfg = cfg
         grid_p = orig_p = None
@@ -70,40 +79,40 @@ class OracleSim:
     def step(self, actions, flags=0):
         a = np.ascontiguousarray(actions, dtype=np.float32)
         assert a.shape == (self.cfg.num_envs, 12)
-        rc = lib().orc_step_ex(self._h, a.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint32(flags))
+        rc = self._L.orc_step_ex(self._h, a.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint32(flags))
         assert rc == 0
 
     def reset_all(self):
-        assert lib().orc_reset_all(self._h) == 0
+        assert self._L.orc_reset_all(self._h) == 0
 
     @property
     def step_counter(self):
         v = ctypes.c_int64()
-        lib().orc_get_step_counter(self._h, ctypes.byref(v))
+        self._L.orc_get_step_counter(self._h, ctypes.byref(v))
         return v.value
 
     @step_counter.setter
     def step_counter(self, v):
-        lib().orc_set_step_counter(self._h, ctypes.c_int64(v))
+        self._L.orc_set_step_counter(self._h, ctypes.c_int64(v))
 
     @property
     def stats_row(self):
         v = ctypes.c_int()
-        lib().orc_get_stats_row(self._h, ctypes.byref(v))
+        self._L.orc_get_stats_row(self._h, ctypes.byref(v))
         return v.value
 
     def set_init_done(self, v):
-        lib().orc_set_init_done(self._h, ctypes.c_int(int(v)))
+        self._L.orc_set_init_done(self._h, ctypes.c_int(int(v)))
 
     def command_ranges(self):
         out = (ctypes.c_double * 8)()
-        lib().orc_get_command_ranges(self._h, out)
+        self._L.orc_get_command_ranges(self._h, out)
         return np.array(out).reshape(4, 2)
 
     def close(self):
         if self._h:
             self.buf = {}
-            lib().orc_destroy(self._h)
+            self._L.orc_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -427,9 +427,9 @@ void orc_physics_substep(orc_sim* s, int e, const float tau_f[12], int apply_for
     for (int k = 0; k < NV; ++k) vfree[k] = v[k] + dt * rhs[k];
 
     /* 6. collision detection: sphere-swept points vs terrain */
-    int nc = 0, cbody[MAXC];
+    int nc = 0, nact = 0, cbody[MAXC];
     double cpos[MAXC][3], cn[MAXC][3], cdist[MAXC];
-    for (int pidx = 0; pidx < m->num_collision_points && nc < MAXC; ++pidx) {
+    for (int pidx = 0; pidx < m->num_collision_points; ++pidx) {
         const lsim_collision_point* cp = &m->points[pidx];
         double pl[3] = {cp->pos[0], cp->pos[1], cp->pos[2]}, pw[3];
         m3v(X[cp->body].R, pl, pw);
@@ -438,10 +438,17 @@ void orc_physics_substep(orc_sim* s, int e, const float tau_f[12], int apply_for
         orc_terrain_contact(s, cw, cp->radius, &dsurf, n);
         double dist = dsurf - cp->radius;
         if (dist < c->contact_offset) {
+            ++nact;
+            if (nc >= MAXC) continue;            /* the cap: points are ordered by priority, overflow is dropped from the end */
             cbody[nc] = cp->body; cdist[nc] = dist;
             for (int k = 0; k < 3; ++k) { cn[nc][k] = n[k]; cpos[nc][k] = pw[k] - n[k] * cp->radius; }
             ++nc;
         }
+    }
+    {   /* diagnostic: contacts before the cap (LSIM_BUF_CONTACT_COUNT) */
+        int32_t* cc = ORC_I32(s, LSIM_BUF_CONTACT_COUNT) + 2 * e;
+        if (nact > cc[0]) cc[0] = nact;
+        cc[1] = nact;
     }
     /* 7. constraint rows */
     int R = 0, rkind[MAXR], rcontact[MAXR];

@@ -46,7 +46,7 @@ static int lsbk_launch_reduce(lsim_sim* s, const LsStepArgs& a, void*) {   // re
     const LsCtx& cx = *s->dev_ctx;
     float acc = 0.0f;
     for (int env = 0; env < s->cfg.num_envs; ++env) acc += LSB(cx, LSIM_BUF_EPISODE_SUMS, float)[env * LSIM_NUM_REWARD_TERMS + LSIM_R_TRACKING_LIN_VEL];
-    cx.accum[a.row_out * LSIM_STATS_SIZE + LSIM_STATS_TRACK_SUM] = acc;
+    ls_fix_row(cx, a.row_out)[LSIM_STATS_FIX_TRACK] = ls_to_fix(acc);
     return 0;
 }
 extern "C" int emu_sizeof_shared(void) { return (int)sizeof(WaveShared); }

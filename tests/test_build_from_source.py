@@ -1,0 +1,29 @@
+"""build(): the HIP library compiles from its sources alone.  `csrc/build.py` skips hipcc when an up-to-date .so is present (the artefact
+travels with the tree but is git-ignored), so a fresh clone has never been exercised by the other tests: this one cross-compiles
+the library for gfx950 into a scratch directory (no GPU needed, ~40 s) and checks that every symbol include/lsim.h declares is there."""
+import ctypes
+import os
+import subprocess
+
+from helpers import ROOT, abi
+
+
+def test_from_source_compile_exports_the_abi(tmp_path):
+    from isaacgymloco_amd.csrc import build as B
+    out = os.path.join(tmp_path, "liblsim_fresh.so")
+    cmd = [os.environ.get("HIPCC", "hipcc")] + B.FLAGS + [os.path.join(B.HERE, s) for s in B.SOURCES] + ["-o", out]
+    subprocess.check_call(cmd, cwd=str(tmp_path))
+    assert os.path.getsize(out) > 100_000
+    L = ctypes.CDLL(out)                          # loading needs no GPU; no compute call is made
+    missing = [f for f in abi.declared_functions() if not hasattr(L, f)]
+    assert not missing, missing
+    abi.check_abi(L, prefix="lsim")
+    L.lsim_abi_version.restype = ctypes.c_int
+    assert L.lsim_abi_version() == abi.ABI_VERSION
+
+
+def test_build_rebuilds_when_the_artefact_is_missing(tmp_path, monkeypatch):
+    """stale(): no .so -> must compile; here only the decision is checked (the compile itself is the test above)"""
+    from isaacgymloco_amd.csrc import build as B
+    monkeypatch.setattr(B, "LIB", os.path.join(tmp_path, "absent.so"))
+    assert B.stale()

@@ -165,16 +165,25 @@ def test_hip_is_deterministic_per_seed_and_rank():
         env.reset()
         g = torch.Generator(device="cuda:0").manual_seed(0)
         out = []
-        for _ in range(40):
+        for t in range(40):
+            if t == 20:      # make the next step a command-curriculum step (LR:307: common_step_counter % max_episode_length == 0)
+                env._L.lsim_set_step_counter(env._h, __import__("ctypes").c_int64(int(env.max_episode_length) * 3 - 1))
             obs, priv, rew, done = env.step_device(torch.randn(96, 12, device="cuda:0", generator=g))
-            out.append((obs.clone(), rew.clone(), done.clone()))
+            out.append((obs.clone(), rew.clone(), done.clone(), env.stats_row().clone()))
         torch.cuda.synchronize()
-        assert sum(int(d.sum()) for _, _, d in out) > 0
+        assert sum(int(d.sum()) for _, _, d, _ in out) > 0
         return out
     a, b, c = run(0), run(0), run(1)
-    for (o1, r1, d1), (o2, r2, d2) in zip(a, b):
+    S = abi.STATS
+    multi = 0
+    for (o1, r1, d1, s1), (o2, r2, d2, s2) in zip(a, b):
         assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2)
-    assert any(not torch.equal(o1, o3) for (o1, _, _), (o3, _, _) in zip(a, c))
+        # the per-step reductions over waves -- extras["episode"] sums, reset count, live command ranges -- are bitwise reproducible too:
+        # they are accumulated in fixed point, so the arrival order of the waves cannot show
+        assert torch.equal(s1[:S["fix"]], s2[:S["fix"]])
+        multi += int(s1[S["reset_count"]] > 1)
+    assert multi > 0, "no step with several resets: the order-independence of the sums was not exercised"
+    assert any(not torch.equal(o1, o3) for (o1, _, _, _), (o3, _, _, _) in zip(a, c))
 
 
 def test_hip_api_rejects_bad_arguments():

@@ -1,0 +1,151 @@
+"""GPU: anchors for the unpinned dynamics that do not need PhysX.  The reference's simulator is closed source, so none
+of this is reference parity; these tests bound the discretisation and solver errors of the build's own physics on the HIP library:
+  * time-step halving: the integrator is first order, so the error against a 4x finer run falls by ~3x when the step is halved;
+  * Gauss-Seidel sweeps: 8 (shipped) against 64 -- the state difference after one second is bounded;
+  * the 8-contact cap: how often it binds at BASELINE size on the stairs task (histogram from LSIM_BUF_CONTACT_COUNT);
+  * BASELINE-size (N = 4096) invariants for the stairs and AMP configurations (the flat one is in test_gpu_parity.py).
+The configuration being replaced is legged_robot_config.py:238-255 (dt 5 ms, TGS, 4 position iterations)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import C, T, quiet_cfg
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _env(cfg, N, seed=1):
+    from isaacgymloco_amd.envs.legged_robot import LeggedRobot
+    cfg.env.num_envs = N
+    return LeggedRobot(cfg, sim_device=DEV, seed=seed)
+
+
+def _trajectory(refine, scenario, steps=25):
+    """25 control steps (0.5 s) at sim dt = 5 ms / refine with decimation 4 * refine: the control period stays 20 ms"""
+    cfg = quiet_cfg()
+    cfg.sim.dt = 0.005 / refine
+    cfg.control.decimation = 4 * refine
+    cfg.termination.fall_down = False
+    if scenario == "flight":       # tumbling free flight under gravity, PD loop holding a moving pose: no contact within 0.5 s from 3 m
+        cfg.init_state.pos = [0.0, 0.0, 3.0]
+        cfg.domain_rand.base_init_vel_range = dict(x=[0.3, 0.3], y=[-0.2, -0.2], z=[0.0, 0.0], roll=[0.8, 0.8], pitch=[-0.5, -0.5], yaw=[0.4, 0.4])
+    else:                          # dropped from just above its standing height: settles on four feet
+        cfg.init_state.pos = [0.0, 0.0, 0.40]
+    env = _env(cfg, 8)
+    env.reset()
+    g = torch.Generator(device=DEV).manual_seed(3)
+    amp = 0.5 if scenario == "flight" else 0.1
+    for t in range(steps):
+        env.step_device(amp * torch.randn(8, 12, device=DEV, generator=g).clamp(-2, 2))
+    torch.cuda.synchronize()
+    assert int(env.reset_buf.sum()) == 0
+    out = np.concatenate([env.root_states[:, :7].cpu().numpy(), env.dof_pos.cpu().numpy()], axis=1).astype(np.float64)
+    cf = env.contact_forces.abs().sum().item()
+    env.close()
+    return out, cf
+
+
+@pytest.mark.parametrize("scenario", ["flight", "stance"])
+def test_time_step_halving_is_first_order(scenario):
+    x1, c1 = _trajectory(1, scenario)
+    x2, _ = _trajectory(2, scenario)
+    x4, _ = _trajectory(4, scenario)
+    assert (c1 == 0.0) == (scenario == "flight")                        # flight: no contact at all; stance: feet loaded
+    e1 = np.abs(x1 - x4).max(axis=1)                                    # per env, against the 1.25 ms run
+    e2 = np.abs(x2 - x4).max(axis=1)
+    # x(dt) = x* + C dt + O(dt^2):  e1 = 0.75 C dt,  e2 = 0.25 C dt  ->  ratio 3 for a first-order scheme
+    ratio = np.median(e1 / np.maximum(e2, 1e-9))
+    print(f"{scenario}: median error 5 ms {np.median(e1):.2e}, 2.5 ms {np.median(e2):.2e}, ratio {ratio:.2f}")
+    if scenario == "flight":
+        assert 2.2 < ratio < 4.2, ratio
+        assert np.median(e1) < 2e-2                                     # 0.5 s of tumbling at 5 ms: centimetres / centiradians
+    else:                                                               # contacts switch on and off: only monotone improvement is asserted
+        assert np.median(e2) < np.median(e1)
+        assert np.median(e1) < 2e-2
+
+
+def test_eight_gauss_seidel_sweeps_against_sixty_four(monkeypatch):
+    """the shipped 8 sweeps against 64 on the same seeds: one second of standing / small-action motion on flat ground"""
+    from isaacgymloco_amd.envs import lsim_config as LC
+
+    def run(iters):
+        monkeypatch.setitem(LC.SOLVER_DEFAULTS, "solver_iterations", iters)
+        cfg = quiet_cfg()
+        cfg.init_state.pos = [0.0, 0.0, 0.40]
+        env = _env(cfg, 64)
+        assert env.lcfg.solver_iterations == iters
+        env.reset()
+        g = torch.Generator(device=DEV).manual_seed(5)
+        for t in range(50):
+            env.step_device(0.25 * torch.randn(64, 12, device=DEV, generator=g))
+        torch.cuda.synchronize()
+        assert int(env.reset_buf.sum()) == 0
+        out = (env.root_states.cpu().numpy().astype(np.float64), env.dof_pos.cpu().numpy().astype(np.float64),
+               env.contact_forces[:, :, 2].sum(1).cpu().numpy())
+        env.close()
+        return out
+    r8, q8, f8 = run(8)
+    r64, q64, f64 = run(64)
+    dz = np.abs(r8[:, 2] - r64[:, 2])
+    dxy = np.linalg.norm(r8[:, :2] - r64[:, :2], axis=1)
+    dq = np.abs(q8 - q64).max(axis=1)
+    print(f"8 vs 64 sweeps after 1 s: base height diff median {np.median(dz):.2e} max {dz.max():.2e} m; xy {np.median(dxy):.2e} / {dxy.max():.2e} m; "
+          f"joint {np.median(dq):.2e} / {dq.max():.2e} rad; vertical load {np.median(f8):.1f} vs {np.median(f64):.1f} N")
+    assert np.median(dz) < 2e-3 and dz.max() < 2e-2
+    assert np.median(dxy) < 1e-2
+    assert np.median(dq) < 2e-2
+    assert abs(np.median(f8) - np.median(f64)) < 0.03 * np.median(f64)          # both carry the robot's weight
+
+
+def test_contact_cap_histogram_at_baseline_size_on_stairs():
+    """aliengo_stairs, N = 4096, 1000 steps of N(0,1) actions: share of env-steps whose uncapped contact count exceeds LSIM_MAX_CONTACTS"""
+    cfg = C.TASKS["aliengo_stairs"][0]()
+    env = _env(cfg, 4096)
+    env.reset()
+    env.episode_length_buf = torch.randint_like(env.episode_length_buf, high=int(env.max_episode_length))
+    g = torch.Generator(device=DEV).manual_seed(0)
+    hist = torch.zeros(65, dtype=torch.long, device=DEV)
+    for t in range(1000):
+        env.step_device(torch.randn(4096, 12, device=DEV, generator=g))
+        hist += torch.bincount(env.buf["contact_count"][:, 0].long().clamp(0, 64), minlength=65)
+    torch.cuda.synchronize()
+    h = hist.cpu().numpy()
+    over = h[9:].sum() / h.sum()
+    print("active collision points per env-step (max over sub-steps), counts 0..12:", h[:13].tolist(), f"-> cap binds in {100 * over:.3f} % of env-steps")
+    assert h.sum() == 4096 * 1000
+    assert over < 0.02
+    assert h[1:9].sum() > 0.5 * h.sum()          # the robots were on the ground most of the time
+
+
+@pytest.mark.parametrize("task", ["aliengo_stairs", "aliengo_amp"])
+def test_full_size_invariants_for_the_other_baseline_configs(task):
+    """BASELINE configs 3 and 4 at N = 4096: finite state, unit quaternions, torque / joint-velocity limits, bounded observations, reset
+    bookkeeping, weight support of the standing robots"""
+    cfg = C.TASKS[task][0]()
+    cfg.env.num_envs = 4096
+    from isaacgymloco_amd.envs.legged_robot import LeggedRobot
+    env = LeggedRobot(cfg, sim_device=DEV, seed=1, using_amp=(task == "aliengo_amp"))
+    env.reset()
+    g = torch.Generator(device=DEV).manual_seed(0)
+    for t in range(60):
+        env.step_device(torch.randn(4096, 12, device=DEV, generator=g) * 0.3)
+    torch.cuda.synchronize()
+    root = env.root_states.cpu().numpy()
+    for name in ("obs_buf", "privileged_obs_buf", "rew_buf", "amp_obs_buf"):
+        assert np.isfinite(getattr(env, name).cpu().numpy()).all(), name
+    assert np.isfinite(root).all()
+    np.testing.assert_allclose(np.linalg.norm(root[:, 3:7], axis=1), 1.0, atol=1e-4)
+    assert (np.abs(env.torques.cpu().numpy()) <= np.array([44, 44, 55] * 4) + 1e-4).all()
+    assert (np.abs(env.dof_vel.cpu().numpy()) <= 1.5 * np.array([20, 20, 15.89] * 4) + 1e-3).all()
+    ep = env.episode_length_buf.cpu().numpy()
+    assert ep.min() >= 0 and ep.max() <= 61
+    assert np.abs(env.obs_buf.cpu().numpy()).max() <= 100.0
+    fz = env.contact_forces[:, :, 2].sum(1).cpu().numpy()
+    standing = (root[:, 2] - env.env_origins[:, 2].cpu().numpy() > 0.25) & (fz > 50)
+    assert standing.sum() > 500
+    assert 180.0 < np.median(fz[standing]) < 340.0
+    if task == "aliengo_amp":     # AMP features are the raw joint / base state (LR:406-416)
+        amp = env.amp_obs_buf.cpu().numpy()
+        np.testing.assert_allclose(amp[:, :12], env.dof_pos.cpu().numpy(), atol=1e-6)
+        np.testing.assert_allclose(amp[:, 18:30], env.dof_vel.cpu().numpy(), atol=1e-6)

@@ -1,5 +1,5 @@
 """Physical invariants of the build's dynamics (no reference oracle exists for PhysX): checked on the CPU
-oracle and on the lane-emulated kernel sources.  These are NOT reference parity."""
+oracle, on the lane-emulated kernel sources and (-m gpu) on the HIP library itself.  These are NOT reference parity."""
 import numpy as np
 import pytest
 
@@ -8,7 +8,36 @@ from helpers import C, make_oracle, quiet_cfg, abi, LC, aliengo, T
 G = 9.81
 
 
+class _HipSim:
+    """the HIP library behind the same numpy surface as the oracle / emulator objects (sim.buf[name] is a host copy)"""
+
+    class _Buf:
+        def __init__(self, be):
+            self.be = be
+
+        def __getitem__(self, name):
+            return self.be.get(name)
+
+    def __init__(self, cfg, N, ter, seed):
+        from hip_backend import HipBackend
+        self.be = HipBackend(cfg, N, ter, seed=seed)
+        self.buf = _HipSim._Buf(self.be)
+
+    def step(self, a, flags=0):
+        self.be.step(a, flags)
+
+    def reset_all(self):
+        self.be.reset_all()
+
+
+KINDS = ["oracle", "emu", pytest.param("hip", marks=pytest.mark.gpu)]      # the HIP leg runs with -m gpu on the MI355X
+
+
 def _make(kind, cfg, N, seed=1):
+    if kind == "hip":
+        from isaacgymloco_amd.envs.legged_robot import build_robot_model
+        ter = T.Terrain(cfg.terrain, N, seed=1)
+        return _HipSim(cfg, N, ter, seed), build_robot_model(cfg.asset)
     orc, lc, model, ter = make_oracle(cfg, N, seed=seed)
     if kind == "oracle":
         return orc, model
@@ -56,7 +85,7 @@ def _tumble(kind, sim_dt, steps, gz):
     return P0, L0, P1, L1, sum(b.mass for b in model.bodies)
 
 
-@pytest.mark.parametrize("kind", ["oracle", "emu"])
+@pytest.mark.parametrize("kind", KINDS)
 def test_momentum_conserved_without_gravity(kind):
     """Free flight, g = 0, tumbling robot holding its pose with the PD loop (internal forces only): linear and angular
     momentum are conserved; the residual is the first-order integration error and halves with the time step."""
@@ -68,7 +97,7 @@ def test_momentum_conserved_without_gravity(kind):
     assert np.linalg.norm(Lh1 - Lh0) < 0.65 * np.linalg.norm(L1 - L0)
 
 
-@pytest.mark.parametrize("kind", ["oracle", "emu"])
+@pytest.mark.parametrize("kind", KINDS)
 def test_free_fall_under_gravity(kind):
     """dP_z = -m g t (to the integrator's first order); the horizontal leak of the semi-implicit Euler step is O(dt)."""
     P0, L0, P1, L1, mass = _tumble(kind, 0.005, 10, -G)
@@ -79,7 +108,7 @@ def test_free_fall_under_gravity(kind):
     assert np.linalg.norm((P1 - P0)[:2]) < 0.04 * np.linalg.norm(P0[:2])
 
 
-@pytest.mark.parametrize("kind", ["oracle", "emu"])
+@pytest.mark.parametrize("kind", KINDS)
 def test_static_stance_supports_weight(kind):
     cfg = quiet_cfg()
     cfg.init_state.pos = [0.0, 0.0, 0.40]
@@ -100,7 +129,7 @@ def test_static_stance_supports_weight(kind):
     np.testing.assert_allclose(q[1:3], q[4:6], atol=0.02)
 
 
-@pytest.mark.parametrize("kind", ["oracle", "emu"])
+@pytest.mark.parametrize("kind", KINDS)
 def test_limits_respected(kind):
     cfg = quiet_cfg()
     sim, model = _make(kind, cfg, 4)
@@ -123,7 +152,7 @@ def test_limits_respected(kind):
     assert within >= 0.95 * total, (within, total)
 
 
-@pytest.mark.parametrize("kind", ["oracle", "emu"])
+@pytest.mark.parametrize("kind", KINDS)
 def test_saturated_motors_do_not_spin_up_a_robot_in_free_flight(kind):
     """Regression for the joint-velocity clamp: with gravity off, far from the ground and every motor saturated against its velocity
     limit or its stops, the robot is a closed system -- its linear momentum must stay (nearly) constant, the joint velocities must hold
@@ -224,7 +253,7 @@ def test_go1_table_emu_matches_oracle_and_stands():
     assert np.all(orc.buf["root_states"][:, 2] > 0.2) and np.all(orc.buf["root_states"][:, 2] < 0.45)
 
 
-@pytest.mark.parametrize("kind", ["oracle", "emu"])
+@pytest.mark.parametrize("kind", KINDS)
 def test_foot_contact_forces_stay_in_the_friction_pyramid(kind):
     """Flat ground, a robot thrashing under random actions: every foot force pushes (f_z >= 0) and its tangential components stay inside
     the solver's friction pyramid |f_x|, |f_y| <= mu f_z with mu = average(terrain friction, robot friction); feet do not
