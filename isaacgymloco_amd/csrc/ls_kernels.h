@@ -448,8 +448,8 @@ LS_FN void ph_b_reset(const LsCtx& cx, WaveShared& sh, int lane, int env, const 
 //   1. every resetting env adds its terms to the fixed-point accumulators
 //   2. and then takes a ticket; the env that draws the last ticket of the step (count known from kernel A) knows every add has landed
 //   3. and converts the sums to the fp32 row the host reads (ph_b_store)
-LS_FN void ph_b_episode_stats(const LsCtx& cx, WaveShared& sh, int lane, int env, const LsStepArgs& a) {
-    if (lane == 0) sh.flags64[0] = 0;
+LS_FN void ph_b_episode_stats(const LsCtx& cx, WaveShared& sh, LaneRegs& rg, int lane, int env, const LsStepArgs& a) {
+    rg.ticket = -1;
     if (!sh.do_reset) return;
     if (lane == 13) for (int k = 0; k < 4; ++k) sh.cmd[k] = sh.rewv[k];
     float den = (float)(sh.eplen < 1 ? 1 : sh.eplen);
@@ -460,14 +460,14 @@ LS_FN void ph_b_episode_stats(const LsCtx& cx, WaveShared& sh, int lane, int env
         if (v != 0.0f) LS_ATOMIC_ADD_I64(fix + k, ls_to_fix(v / den));
         *es = 0.0f;
     }
+    LS_THREADFENCE();                                  // the whole wave waits for its adds: they are ordered before its ticket
+    // the ticket is only looked at in the last phase (ph_b_stats_publish): the round trip of this returning atomic overlaps the reset / observation work
+    if (lane == 0) rg.ticket = (int)LS_ATOMIC_FETCH_ADD_I64(fix + LSIM_STATS_FIX_TICKET, 1);
 }
-LS_FN void ph_b_stats_ticket(const LsCtx& cx, WaveShared& sh, int lane, int env, const LsStepArgs& a) {
-    if (!sh.do_reset || lane != 0) return;
-    LS_THREADFENCE();                                  // this wave's adds are ordered before its ticket
-    const long long t = LS_ATOMIC_FETCH_ADD_I64(ls_fix_row(cx, a.row_out) + LSIM_STATS_FIX_TICKET, 1);
-    sh.flags64[0] = (t + 1 == (long long)sh.flags64[1]) ? 1u : 0u;
+LS_FN void ph_b_stats_publish(const LsCtx& cx, WaveShared& sh, LaneRegs& rg, int lane, const LsStepArgs& a) {
+    if (lane == 0) sh.flags64[0] = (rg.ticket >= 0 && rg.ticket + 1 == (int)sh.flags64[1]) ? 1u : 0u;
 }
-LS_FN void ph_b_stats_publish(const LsCtx& cx, WaveShared& sh, int lane, const LsStepArgs& a) {
+LS_FN void ph_b_stats_convert(const LsCtx& cx, WaveShared& sh, int lane, const LsStepArgs& a) {
     if (!sh.flags64[0]) return;
     long long* fix = ls_fix_row(cx, a.row_out);
     LS_GLOBAL float* out = LS_G(float, cx.accum) + a.row_out * LSIM_STATS_SIZE;
@@ -530,14 +530,15 @@ LS_WAVE_FN void ls_wave_step_b(const LsCtx& cx, const LsStepArgs& a, const int e
     LS_PHASE(ph_load_b(cx, sh, lane, env, a));
     LS_PHASE(ph_b_housekeeping(cx, sh, lane, env, a); ph_b_terrain_curriculum(cx, sh, lane, env, a));
     LS_PHASE(ph_b_reset(cx, sh, lane, env, a));
-    LS_PHASE(ph_b_episode_stats(cx, sh, lane, env, a));
-    LS_PHASE(ph_b_stats_ticket(cx, sh, lane, env, a));
+    LS_PHASE(ph_b_episode_stats(cx, sh, rg, lane, env, a));
     LS_PHASE(if (sh.do_reset && c.measure_heights) ph_heights(cx, sh, lane, env, true));
     if (a.reset_all) {   // reset_idx only: the observation roll belongs to the step that follows (BT:114)
-        LS_PHASE(ph_b_store_reset_all(cx, sh, lane, env, a); ph_b_stats_publish(cx, sh, lane, a));
+        LS_PHASE(ph_b_store_reset_all(cx, sh, lane, env, a); ph_b_stats_publish(cx, sh, rg, lane, a));
+        LS_PHASE(ph_b_stats_convert(cx, sh, lane, a));
         return;
     }
     LS_PHASE(ph_build_obs(cx, sh, lane, env, (uint32_t)a.step_counter, LSIM_RNG_OBS_NOISE, sh.cur));
-    LS_PHASE(ph_b_store(cx, sh, lane, env, a); ph_b_stats_publish(cx, sh, lane, a));
+    LS_PHASE(ph_b_store(cx, sh, lane, env, a); ph_b_stats_publish(cx, sh, rg, lane, a));
+    LS_PHASE(ph_b_stats_convert(cx, sh, lane, a));
     LS_TICK_FLUSH();
 }

@@ -137,6 +137,7 @@ struct LaneRegs {
     float Jb[6], Jl[3];
     float brow, wdiag;
     float row_rng;           // width of a two-sided row's interval (+inf: one-sided)
+    int ticket;              // kernel B, lane 0: this env's ticket among the envs that reset in this step (-1: none)
 #if defined(LS_EMU)
     float W[LS_MAXR];        // Delassus row (the GPU path keeps it local to wc_delassus_pgs)
 #endif
