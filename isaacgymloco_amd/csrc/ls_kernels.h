@@ -16,6 +16,7 @@
 #define LS_LANES_PARAM LaneRegs* L
 #define LS_PHASE(call) do { for (int lane = 0; lane < 64; ++lane) { LaneRegs& rg = L[lane]; (void)rg; call; } } while (0)
 #define LS_COLLECTIVE(gpu_call, emu_call) do { emu_call; } while (0)
+#define LS_KINEMATICS() LS_PHASE(ph_kinematics(sh, lane))
 #define LS_ATOMIC_ADD(ptr, v) (*(ptr) += (v))
 #define LS_ATOMIC_ADD_I64(ptr, v) (*(ptr) += (v))
 #define LS_ATOMIC_FETCH_ADD_I64(ptr, v) ls_emu_fetch_add((ptr), (v))
@@ -46,6 +47,7 @@ __device__ unsigned long long g_ls_phase_calls[64];
 #endif
 #define LS_PHASE(call) do { { const int lane = ls_opaque_lane(lane0); call; } __syncthreads(); LS_TICK(__LINE__ - ls_line0); } while (0)
 #define LS_COLLECTIVE(gpu_call, emu_call) do { { const int lane = ls_opaque_lane(lane0); gpu_call; } __syncthreads(); LS_TICK(__LINE__ - ls_line0); } while (0)
+#define LS_KINEMATICS() do { if (cx.kin_aligned) LS_COLLECTIVE(wc_kinematics(sh, lane), (void)0); else LS_PHASE(ph_kinematics(sh, lane)); } while (0)
 #define LS_ATOMIC_ADD(ptr, v) atomicAdd((ptr), (v))
 // 64-bit integer atomics on the fixed-point accumulators (device scope: they are performed at the memory side, coherent across the XCDs)
 #define LS_ATOMIC_ADD_I64(ptr, v) ((void)atomicAdd((unsigned long long*)(ptr), (unsigned long long)(v)))
@@ -227,7 +229,7 @@ LS_WAVE_FN void ls_wave_step_a(const LsCtx& cx, const LsStepArgs& a, const int e
     for (int sub = 0; sub < c.decimation; ++sub) {
         LS_PHASE(ph_torques(cx, sh, lane, env, sub));
         if (skip) continue;
-        LS_PHASE(ph_kinematics(sh, lane));
+        LS_KINEMATICS();
         LS_PHASE(ph_body_inertia(cx, sh, lane, sub == 0));
         LS_PHASE(ph_leg_composite(sh, lane));
         LS_PHASE(ph_leg_block(sh, lane));
@@ -252,7 +254,7 @@ LS_WAVE_FN void ls_wave_step_a(const LsCtx& cx, const LsStepArgs& a, const int e
         LS_PHASE(ph_integrate(cx, sh, lane, dt));
     }
     if (!skip) {
-        LS_PHASE(ph_kinematics(sh, lane));
+        LS_KINEMATICS();
         LS_PHASE(ph_body_states_all(cx, sh, lane, env));
         LS_PHASE(ph_store_sim_state(cx, sh, lane, env));
     } else {

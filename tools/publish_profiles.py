@@ -1,5 +1,5 @@
-"""Copy the judged summaries of one tools/gpu_round.sh run (gpurun_out/<tag>/) into profiles/ under round-prefixed names.
-usage: python tools/publish_profiles.py r01e r01"""
+"""Copy the judged summaries of one tools/gpu_round2.sh run (gpurun_out/<tag>/) into profiles/ under round-prefixed names.
+usage: python tools/publish_profiles.py r02a r02"""
 import csv
 import os
 import shutil
@@ -8,21 +8,33 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, rnd = sys.argv[1], sys.argv[2]
 O, P = os.path.join(ROOT, "gpurun_out", tag), os.path.join(ROOT, "profiles")
-for src, dst in (("bench_default", "bench_default_train"), ("bench_env", "bench_env_only"), ("bench_aliengo_stairs", "bench_aliengo_stairs"),
-                 ("bench_aliengo_amp", "bench_aliengo_amp"), ("bench_env_N262144", "bench_env_only_N262144"), ("bench_env_N64", "bench_env_only_N64"),
-                 ("bench_env_zero_actions", "bench_env_only_zero_actions")):
+for src, dst in (("bench_default", "bench_default_train"), ("bench_driver_args", "bench_driver_args_steps20_warmup5"), ("bench_env", "bench_env_only"),
+                 ("bench_aliengo_stairs", "bench_aliengo_stairs"), ("bench_aliengo_amp", "bench_aliengo_amp"), ("bench_go1", "bench_go1"),
+                 ("bench_env_N262144", "bench_env_only_N262144"), ("bench_env_N64", "bench_env_only_N64"),
+                 ("bench_env_zero_actions", "bench_env_only_zero_actions"), ("bench_2ranks_debug", "bench_2ranks_one_gpu_debug"),
+                 ("bench_2ranks_mixed_debug", "bench_2ranks_mixed_robots_one_gpu_debug"), ("valu_peak", "valu_peak")):
     f = os.path.join(O, src + ".json")
     if os.path.exists(f) and open(f).read().lstrip().startswith("{"):
         shutil.copy(f, os.path.join(P, f"{rnd}_{dst}.json"))
     else:
         print("missing / invalid:", f)
-shutil.copy(os.path.join(O, "pmc_env_N4096.csv"), os.path.join(P, f"{rnd}_pmc_env_only_N4096.csv"))
-shutil.copy(os.path.join(O, "pmc_traffic.json"), os.path.join(P, "pmc_traffic.json"))
-for src, dst in (("prof_env/env_kernel_stats.csv", "kernel_stats_env_only"), ("prof_train/train_kernel_stats.csv", "kernel_stats_train")):
-    rows = list(csv.reader(open(os.path.join(O, src))))
+if os.path.exists(os.path.join(O, "pmc_N4096.csv")):
+    shutil.copy(os.path.join(O, "pmc_N4096.csv"), os.path.join(P, f"{rnd}_pmc_N4096.csv"))
+    shutil.copy(os.path.join(O, "pmc_traffic.json"), os.path.join(P, "pmc_traffic.json"))
+for src, dst in (("prof_env/env_kernel_stats.csv", "kernel_stats_env_only"), ("prof_train/train_kernel_stats.csv", "kernel_stats_train"),
+                 ("prof_amp/amp_kernel_stats.csv", "kernel_stats_amp")):
+    path = os.path.join(O, src)
+    if not os.path.exists(path):
+        print("missing:", path)
+        continue
+    rows = list(csv.reader(open(path)))
     with open(os.path.join(P, f"{rnd}_{dst}.csv"), "w", newline="") as fh:
         w = csv.writer(fh)
         for r in rows:
             r[0] = r[0][:160]     # torch's templated kernel names run to kilobytes
             w.writerow(r)
+for name in ("gpu_tests.log",):
+    f = os.path.join(O, name)
+    if os.path.exists(f):
+        open(os.path.join(P, f"{rnd}_{name}"), "w").write("".join(open(f).readlines()[-6:]))
 print("published", tag, "->", P)
