@@ -177,15 +177,6 @@ extern "C" int LS_API(create)(const lsim_config* cfg, const lsim_robot_model* mo
     h.cfg = c; h.model = s->model;
     for (int id = 0; id < LSIM_NUM_BUFFERS; ++id) h.buf[id] = s->arena + s->offsets[id];
     h.accum = (float*)h.buf[LSIM_BUF_STATS];
-    h.kin_aligned = 1;      // signed coordinate joint axes (hip x, thigh y, calf y ...): the element-parallel kinematics applies (ls_physics.h)
-    for (int b = 1; b < LSIM_NUM_BODIES; ++b) {
-        if (((b - 1) & 3) == 3) continue;          // foot: fixed joint
-        const float* ax = s->model.bodies[b].joint_axis;
-        int nz = 0;
-        for (int k = 0; k < 3; ++k) nz += (ax[k] > 1e-6f || ax[k] < -1e-6f) ? 1 : 0;
-        const float sum = ax[0] + ax[1] + ax[2];
-        if (nz != 1 || !((sum > 0.999999f && sum < 1.000001f) || (sum < -0.999999f && sum > -1.000001f))) h.kin_aligned = 0;
-    }
     h.num_active = 0;
     for (int id = 0; id < LSIM_NUM_REWARD_TERMS; ++id)
         if (id != LSIM_R_TERMINATION && c.reward_scales[id] != 0.0f) h.active_terms[h.num_active++] = id;

@@ -47,7 +47,7 @@ __device__ unsigned long long g_ls_phase_calls[64];
 #endif
 #define LS_PHASE(call) do { { const int lane = ls_opaque_lane(lane0); call; } __syncthreads(); LS_TICK(__LINE__ - ls_line0); } while (0)
 #define LS_COLLECTIVE(gpu_call, emu_call) do { { const int lane = ls_opaque_lane(lane0); gpu_call; } __syncthreads(); LS_TICK(__LINE__ - ls_line0); } while (0)
-#define LS_KINEMATICS() do { if (cx.kin_aligned) LS_COLLECTIVE(wc_kinematics(sh, lane), (void)0); else LS_PHASE(ph_kinematics(sh, lane)); } while (0)
+#define LS_KINEMATICS() LS_COLLECTIVE(wc_kinematics(sh, lane), (void)0)
 #define LS_ATOMIC_ADD(ptr, v) atomicAdd((ptr), (v))
 // 64-bit integer atomics on the fixed-point accumulators (device scope: they are performed at the memory side, coherent across the XCDs)
 #define LS_ATOMIC_ADD_I64(ptr, v) ((void)atomicAdd((unsigned long long*)(ptr), (unsigned long long)(v)))

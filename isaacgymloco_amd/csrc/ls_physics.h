@@ -60,16 +60,20 @@ LS_FN void ph_kinematics(WaveShared& sh, int lane) {
 // ---- wave collective: the same kinematics, one MATRIX ELEMENT per lane instead of one leg per lane (the per-leg form above runs a 590-
 //      instruction program on 4 of the 64 lanes).  lane = 16 * leg + 4 * iq + j: row iq and column j of the 3 x 3 rotation (iq = 3 repeats
 //      row 0, j = 3 idles), so a matrix row lives in one quad and a vector component in one quad of the leg's 16-lane DPP row:
-//        child(i, j) = sum_m par(i, m) Rloc(m, j)     the row's elements come in by quad_perm broadcasts, no LDS round trip
-//        cross(a, b)_i = a_{i+1} b_{i+2} - a_{i+2} b_{i+1}   the neighbouring components by row rotations of 4 / 8 lanes; quad 3 (the copy of
-//                                                            component 0) receives the wrong neighbours and is repaired from quad 0
-//      Joint axes must be signed coordinate axes (every Unitree-type leg: hip x, thigh y, calf y); lsim_create checks the model (LsCtx::kin_aligned)
-//      and the per-leg form remains for anything else.  Results are those of ph_kinematics up to fp32 summation order.
+//        child(i, j) = c par(i, j) + (1 - c) a_j (x . a) + s (x x a)_j,  x = row i of the parent     Rodrigues' formula for one element; the
+//                                                            row comes in by three quad_perm broadcasts, no LDS round trip, any joint axis a
+//        cross(u, v)_i = u_{i+1} v_{i+2} - u_{i+2} v_{i+1}   the neighbouring components by row rotations (three components on four quads: quad 3
+//                                                            copies component 0 so that quad 2 finds its successor; what quad 3 itself
+//                                                            derives from rotations is wrong and is repaired from quad 0 where it is re-used)
+//      Results are those of ph_kinematics up to fp32 summation order (tests: HIP against the oracle, tests/test_gpu_parity.py).
 template <int CTRL> __device__ __forceinline__ float ls_dpp(float v) {
     return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));
 }
 __device__ __forceinline__ float ls_rot1(float v) { return ls_dpp<0x120 + 12>(v); }   // component i + 1: from lane + 4 (row_ror:12)
-__device__ __forceinline__ float ls_rot2(float v) { return ls_dpp<0x120 + 8>(v); }    // component i + 2: from lane + 8 (row_ror:8)
+__device__ __forceinline__ float ls_rot2(float v) {                                    // component i + 2 = i - 1 (mod 3): from lane - 4 (row_ror:4);
+    const float t = ls_dpp<0x120 + 4>(v);                                              // quad 0 would read quad 3 (the copy of component 0): it takes
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(t), __float_as_int(v), 0x120 + 8, 0xF, 0x1, false));   // component 2 from lane + 8
+}
 __device__ __forceinline__ float ls_fix_quad3(float v) {                               // quad 3 <- quad 0 of the same row
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x120 + 12, 0xF, 0x8, false));
 }
@@ -77,15 +81,24 @@ __device__ __forceinline__ float ls_cross_i(float a1, float a2, float b1, float 
 
 LS_FN void wc_kinematics(WaveShared& sh, int lane) {
     const int l = lane >> 4, iq = (lane >> 2) & 3, j = lane & 3;
-    const int i = iq == 3 ? 0 : iq;
+    const int i = iq == 3 ? 0 : iq, jj = j < 3 ? j : 0;
     const bool elem = iq < 3 && j < 3, comp = iq < 3 && j == 0;
-    // base rotation element R0(i, j) from the quaternion (x, y, z, w)
+    // per-lane bases: body 1 + 4 l of every array, so that level k is a compile-time offset
+    const LsBodyLds* bl = &sh.body[1 + 4 * l];
+    float* Rl = &sh.R[1 + 4 * l][3 * i + jj];
+    float* pl = &sh.p[1 + 4 * l][i];
+    float* Vl_ = &sh.V[1 + 4 * l][i];
+    float* Al_ = &sh.Ab[1 + 4 * l][i];
+    float* Sl = &sh.S[3 * l][i];
+    const float* ql = &sh.q[3 * l];
+    const float* qdl = &sh.qd[3 * l];
+    // base rotation element R0(i, j) from the quaternion (x, y, z, w): diag 1 - 2 (|v|^2 - v_i^2), off-diag 2 (v_i v_j - w eps_ijk v_k)
     const float qx = sh.root[3], qy = sh.root[4], qz = sh.root[5], qw = sh.root[6];
-    const int jj = j < 3 ? j : 0, kk = (i == jj) ? 0 : 3 - i - jj;
+    const int kk = (i == jj) ? 0 : 3 - i - jj;
     const float vi = sh.root[3 + i], vj = sh.root[3 + jj], vk = sh.root[3 + kk];
     const float n2 = qx * qx + qy * qy + qz * qz;
-    const float eps = ((jj - i + 3) % 3 == 1) ? 1.0f : -1.0f;
-    float Re = (i == jj) ? 1.0f - 2.0f * (n2 - vi * vi) : 2.0f * (vi * vj - qw * eps * vk);
+    const float weps = ((jj - i + 3) % 3 == 1) ? qw : -qw;
+    float Re = (i == jj) ? 1.0f - 2.0f * (n2 - vi * vi) : 2.0f * (vi * vj - weps * vk);
     if (j == 3) Re = 0.0f;
     float pe = 0.0f;                                   // component i of the body origin (relative to the base origin, world axes)
     float Va = sh.root[10 + i], Vl = sh.root[7 + i];   // twist (angular, linear at the base origin)
@@ -96,40 +109,33 @@ LS_FN void wc_kinematics(WaveShared& sh, int lane) {
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int b = 1 + 4 * l + k;
-        const LsBodyLds& bd = sh.body[b];
         const float x0 = ls_dpp<0x00>(Re), x1 = ls_dpp<0x55>(Re), x2 = ls_dpp<0xAA>(Re);   // row i of the parent rotation
-        pe = fmaf(x0, bd.jpos[0], fmaf(x1, bd.jpos[1], fmaf(x2, bd.jpos[2], pe)));
+        pe = fmaf(x0, bl[k].jpos[0], fmaf(x1, bl[k].jpos[1], fmaf(x2, bl[k].jpos[2], pe)));
+        float aw = 0.0f, c = 0.0f;
         if (k < 3) {
-            const int d = 3 * l + k;
-            const float a0 = bd.axis[0], a1 = bd.axis[1], a2 = bd.axis[2];
-            const float sg = a0 + a1 + a2;                                                   // +-1: the sign of the coordinate axis
-            const int p = fabsf(a1) > 0.5f ? 1 : (fabsf(a2) > 0.5f ? 2 : 0);
-            const int u = p == 2 ? 0 : p + 1, v = u == 2 ? 0 : u + 1;
+            const float a0 = bl[k].axis[0], a1 = bl[k].axis[1], a2 = bl[k].axis[2];
+            aw = fmaf(x0, a0, fmaf(x1, a1, x2 * a2));                                       // (x . a): component i of the axis in world axes
+            const float w0 = ls_cross_i(x1, x2, a1, a2), w1 = ls_cross_i(x2, x0, a2, a0), w2 = ls_cross_i(x0, x1, a0, a1);   // x x a
+            const float aj = jj == 0 ? a0 : (jj == 1 ? a1 : a2), wj = jj == 0 ? w0 : (jj == 1 ? w1 : w2);
             float sn, cs;
-            ls_sincos_joint(sh.q[d], sn, cs);
-            sn *= sg;
-            const float aw = sg * (p == 0 ? x0 : (p == 1 ? x1 : x2));                      // joint axis in world axes: +- column p of the parent
-            // child = par * Rot_p(theta): column p unchanged, (u, v) rotated
-            const float alpha = (jj == p) ? 1.0f : cs;
-            const float beta = (jj == p) ? 0.0f : (jj == u ? sn : -sn);
-            const int jp = (jj == u) ? v : u;
-            const float xo = jp == 0 ? x0 : (jp == 1 ? x1 : x2);
-            Re = fmaf(xo, beta, Re * alpha);
+            ls_sincos_joint(ql[k], sn, cs);
+            Re = fmaf(cs, Re, fmaf((1.0f - cs) * aj, aw, sn * wj));
             if (j == 3) Re = 0.0f;
-            float c = ls_cross_i(ls_rot1(pe), ls_rot2(pe), ls_rot1(aw), ls_rot2(aw));       // (p x aw)_i
+            c = ls_cross_i(ls_rot1(pe), ls_rot2(pe), ls_rot1(aw), ls_rot2(aw));             // (p x aw)_i
             c = ls_fix_quad3(c);
-            const float qd = sh.qd[d];
+            const float qd = qdl[k];
             const float ja = aw * qd, jl = c * qd;                                           // joint twist S qd
             Va += ja; Vl += jl;
             const float Va1 = ls_rot1(Va), Va2 = ls_rot2(Va), Vl1 = ls_rot1(Vl), Vl2 = ls_rot2(Vl);
             const float ja1 = ls_rot1(ja), ja2 = ls_rot2(ja), jl1 = ls_rot1(jl), jl2 = ls_rot2(jl);
             Aa += ls_cross_i(Va1, Va2, ja1, ja2);                                            // crm(V, vj): (w x ja ; w x jl + v x ja)
             Al += ls_cross_i(Va1, Va2, jl1, jl2) + ls_cross_i(Vl1, Vl2, ja1, ja2);
-            if (comp) { sh.S[d][i] = aw; sh.S[d][3 + i] = c; }
         }
-        if (elem) sh.R[b][3 * i + j] = Re;
-        if (comp) { sh.p[b][i] = pe; sh.V[b][i] = Va; sh.V[b][3 + i] = Vl; sh.Ab[b][i] = Aa; sh.Ab[b][3 + i] = Al; }
+        if (elem) Rl[9 * k] = Re;
+        if (comp) {
+            if (k < 3) { Sl[6 * k] = aw; Sl[6 * k + 3] = c; }
+            pl[3 * k] = pe; Vl_[6 * k] = Va; Vl_[6 * k + 3] = Vl; Al_[6 * k] = Aa; Al_[6 * k + 3] = Al;
+        }
     }
 }
 #endif

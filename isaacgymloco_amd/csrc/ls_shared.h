@@ -26,7 +26,6 @@ struct LsCtx {
     int32_t active_terms[LSIM_NUM_REWARD_TERMS];
     int32_t num_active;
     float cmd_span_init[4];
-    int32_t kin_aligned;              // every joint axis is a signed coordinate axis: the element-parallel kinematics applies (ls_physics.h)
 };
 
 // per-launch arguments (by value)

@@ -133,6 +133,42 @@ extern "C" int lsim_read_profile(lsim_sim* s, float* ms_a, float* ms_b, int* n_i
     return LSIM_OK;
 }
 
+#if defined(LS_DEBUG_KIN)
+// diagnostics build only (tools/kin_check.py): run one of the two kinematics forms on a given state and return every array it fills
+__global__ __launch_bounds__(64) void lsim_k_debug_kin(const LsCtx* __restrict__ ctx, const float* __restrict__ in, float* __restrict__ out, int variant) {
+    __shared__ WaveShared sh;
+    const int lane = (int)threadIdx.x;
+    const LsCtx& cx = *ctx;
+    if (lane < 13) sh.root[lane] = in[lane];
+    if (lane < 12) { sh.q[lane] = in[13 + lane]; sh.qd[lane] = in[25 + lane]; }
+    if (lane >= 16 && lane < 16 + LS_NB) {
+        const lsim_body& b = cx.model.bodies[lane - 16];
+        LsBodyLds& o = sh.body[lane - 16];
+        o.mass = b.mass;
+        for (int k = 0; k < 3; ++k) { o.com[k] = b.com[k]; o.jpos[k] = b.joint_pos[k]; o.axis[k] = b.joint_axis[k]; }
+        for (int k = 0; k < 6; ++k) o.inertia[k] = b.inertia[k];
+    }
+    __syncthreads();
+    if (variant == 0) ph_kinematics(sh, lane); else wc_kinematics(sh, lane);
+    __syncthreads();
+    for (int k = lane; k < 153; k += 64) out[k] = (&sh.R[0][0])[k];
+    for (int k = lane; k < 51; k += 64) out[153 + k] = (&sh.p[0][0])[k];
+    for (int k = lane; k < 72; k += 64) out[204 + k] = (&sh.S[0][0])[k];
+    for (int k = lane; k < 102; k += 64) out[276 + k] = (&sh.V[0][0])[k];
+    for (int k = lane; k < 102; k += 64) out[378 + k] = (&sh.Ab[0][0])[k];
+}
+extern "C" int lsim_debug_kinematics(lsim_sim* s, const float* in_host, float* out_host, int variant) {
+    float *din, *dout;
+    if (hipMalloc(&din, 37 * 4) != hipSuccess || hipMalloc(&dout, 480 * 4) != hipSuccess) return 1;
+    (void)hipMemcpy(din, in_host, 37 * 4, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(lsim_k_debug_kin, dim3(1), dim3(64), 0, 0, (const LsCtx*)s->dev_ctx, din, dout, variant);
+    if (hipDeviceSynchronize() != hipSuccess) return 2;
+    (void)hipMemcpy(out_host, dout, 480 * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(din); (void)hipFree(dout);
+    return 0;
+}
+#endif
+
 #if defined(LS_PHASE_TIMING)
 // diagnostics build only: read and clear the per-site tick / call accumulators (tools/phase_profile.py)
 extern "C" int lsim_debug_read_phase_ticks(unsigned long long* ticks, unsigned long long* calls) {
