@@ -17,6 +17,7 @@
 #define LS_PHASE(call) do { for (int lane = 0; lane < 64; ++lane) { LaneRegs& rg = L[lane]; (void)rg; call; } } while (0)
 #define LS_COLLECTIVE(gpu_call, emu_call) do { emu_call; } while (0)
 #define LS_KINEMATICS() LS_PHASE(ph_kinematics(sh, lane))
+#define LS_TORQUES_KINEMATICS() LS_PHASE(ph_torques(cx, sh, lane, env, sub); ph_kinematics(sh, lane))
 #define LS_ATOMIC_ADD(ptr, v) (*(ptr) += (v))
 #define LS_ATOMIC_ADD_I64(ptr, v) (*(ptr) += (v))
 #define LS_ATOMIC_FETCH_ADD_I64(ptr, v) ls_emu_fetch_add((ptr), (v))
@@ -48,6 +49,7 @@ __device__ unsigned long long g_ls_phase_calls[64];
 #define LS_PHASE(call) do { { const int lane = ls_opaque_lane(lane0); call; } __syncthreads(); LS_TICK(__LINE__ - ls_line0); } while (0)
 #define LS_COLLECTIVE(gpu_call, emu_call) do { { const int lane = ls_opaque_lane(lane0); gpu_call; } __syncthreads(); LS_TICK(__LINE__ - ls_line0); } while (0)
 #define LS_KINEMATICS() LS_COLLECTIVE(wc_kinematics(sh, lane), (void)0)
+#define LS_TORQUES_KINEMATICS() LS_COLLECTIVE(ph_torques(cx, sh, lane, env, sub); wc_kinematics(sh, lane), (void)0)
 #define LS_ATOMIC_ADD(ptr, v) atomicAdd((ptr), (v))
 // 64-bit integer atomics on the fixed-point accumulators (device scope: they are performed at the memory side, coherent across the XCDs)
 #define LS_ATOMIC_ADD_I64(ptr, v) ((void)atomicAdd((unsigned long long*)(ptr), (unsigned long long)(v)))
@@ -227,9 +229,10 @@ LS_WAVE_FN void ls_wave_step_a(const LsCtx& cx, const LsStepArgs& a, const int e
     LS_TICK_INIT();
     LS_PHASE(ph_load_a(cx, sh, rg, lane, env, a));
     for (int sub = 0; sub < c.decimation; ++sub) {
-        LS_PHASE(ph_torques(cx, sh, lane, env, sub));
-        if (skip) continue;
-        LS_KINEMATICS();
+        if (skip) { LS_PHASE(ph_torques(cx, sh, lane, env, sub)); continue; }
+        // phases that do not depend on each other share a barrier: (torques, kinematics), (free velocity, narrow phase),
+        // (contact compaction, joint-limit rows), (apply impulses, contact forces)
+        LS_TORQUES_KINEMATICS();
         LS_PHASE(ph_body_inertia(cx, sh, lane, sub == 0));
         LS_PHASE(ph_leg_composite(sh, lane));
         LS_PHASE(ph_leg_block(sh, lane));
@@ -238,10 +241,8 @@ LS_WAVE_FN void ls_wave_step_a(const LsCtx& cx, const LsStepArgs& a, const int e
         LS_PHASE(ph_base_factor(sh, lane));
         LS_PHASE(ph_free_leg(sh, lane));
         LS_PHASE(ph_free_base(sh, lane));
-        LS_PHASE(ph_free_finish(sh, lane, dt));
-        LS_PHASE(ph_collide(cx, sh, rg, lane));
-        LS_COLLECTIVE(wc_compact_contacts(sh, rg, lane), wc_compact_contacts(sh, L));
-        LS_COLLECTIVE(wc_limits(cx, sh, lane, dt), LS_PHASE(ph_limits(cx, sh, lane, dt)));
+        LS_PHASE(ph_free_finish(sh, lane, dt); ph_collide_prefetch(cx, rg, lane); ph_collide(cx, sh, rg, lane));
+        LS_COLLECTIVE(wc_compact_contacts(sh, rg, lane); wc_limits(cx, sh, lane, dt), wc_compact_contacts(sh, L); LS_PHASE(ph_limits(cx, sh, lane, dt)));
         LS_PHASE(ph_rows(cx, sh, rg, lane, dt));
 #if defined(LS_EMU)
         LS_PHASE(ph_delassus(sh, rg, lane));
@@ -249,8 +250,7 @@ LS_WAVE_FN void ls_wave_step_a(const LsCtx& cx, const LsStepArgs& a, const int e
 #else
         LS_PHASE(wc_delassus_pgs(sh, rg, lane, c.solver_iterations));
 #endif
-        LS_PHASE(ph_apply_impulses(sh, lane));
-        LS_PHASE(ph_contact_forces(sh, lane, dt));
+        LS_PHASE(ph_apply_impulses(sh, lane); ph_contact_forces(sh, lane, dt));
         LS_PHASE(ph_integrate(cx, sh, lane, dt));
     }
     if (!skip) {

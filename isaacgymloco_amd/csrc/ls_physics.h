@@ -487,16 +487,21 @@ LS_FN void ls_terrain_contact(const LsCtx& cx, V3 cw, float radius, float& dist,
     else { dist = 0.0f; n = bn; }
 }
 
+// ---- the collision point's constants (lane = point): re-read from the cache-resident model every sub-step rather than held in registers through
+//      the solver (the register peak), but at the TOP of the sub-step, so that the load latency hides behind the dynamics phases
+LS_FN void ph_collide_prefetch(const LsCtx& cx, LaneRegs& r, int lane) {
+    const lsim_collision_point& cp = cx.model.points[lane < cx.model.num_collision_points ? lane : 0];
+    r.cp_body = cp.body;
+    r.cp_r = cp.radius;
+    for (int k = 0; k < 3; ++k) r.cp_pos[k] = cp.pos[k];
+}
 // ---- phase P: narrow phase, one collision point per lane
 LS_FN void ph_collide(const LsCtx& cx, WaveShared& sh, LaneRegs& r, int lane) {
     r.cp_active = 0;
     if (lane >= cx.model.num_collision_points) return;
-    // the point's constants are re-read from the (cache-resident) model every sub-step rather than held in registers
-    const lsim_collision_point& cp = cx.model.points[lane];
-    const int b = cp.body;
-    const float cp_r = cp.radius;
-    r.cp_body = b;
-    V3 pw = mul(m3p(sh.R[b]), v3(cp.pos[0], cp.pos[1], cp.pos[2])) + v3p(sh.p[b]);
+    const int b = r.cp_body;
+    const float cp_r = r.cp_r;
+    V3 pw = mul(m3p(sh.R[b]), v3(r.cp_pos[0], r.cp_pos[1], r.cp_pos[2])) + v3p(sh.p[b]);
     float d;
     V3 n;
     ls_terrain_contact(cx, v3(sh.root[0] + pw.x, sh.root[1] + pw.y, sh.root[2] + pw.z), cp_r, d, n);

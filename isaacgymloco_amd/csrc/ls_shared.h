@@ -131,6 +131,7 @@ struct LaneRegs {
     int cp_body;
     int cp_active;
     float cp_dist, cp_n[3], cp_x[3];
+    float cp_r, cp_pos[3];   // the point's constants, fetched from the model at the top of the sub-step (ph_collide_prefetch)
     // constraint row owned by this lane
     int row_kind;            // 0 normal, 1/2 friction, 3 joint limit, -1 none
     int row_leg;             // leg whose dofs the row touches, -1 for the base body
