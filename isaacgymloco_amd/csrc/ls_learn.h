@@ -1212,7 +1212,9 @@ __global__ __launch_bounds__(256) void lsim_k_adam_apply(LsAdamTable t, const fl
     float* __restrict__ g = t.g[ti];
     float* __restrict__ m = t.m[ti];
     float* __restrict__ v = t.v[ti];
-    const float coef = scal[0], step = scal[2], lr = lr_dev ? *lr_dev : lr_host;
+    // the bias correction uses THIS tensor's step count (already incremented by lsim_k_adam_finish), as torch's Adam does: a parameter that
+    // received gradients on fewer steps (frozen layer, partially restored state) must not borrow tensor 0's counter
+    const float coef = scal[0], step = *t.step[ti], lr = lr_dev ? *lr_dev : lr_host;
     const float bc1 = 1.0f - powf(b1, step), bc2s = sqrtf(1.0f - powf(b2, step));
     const float step_size = lr / bc1;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += LS_ADAM_SLICES * 256) {

@@ -45,6 +45,7 @@ class HIMOnPolicyRunner:
         env.reset()
 
     graphs = None   # GraphedRollout once enable_graphs() succeeded (subclasses with their own __init__ inherit the default)
+    _pending_draw_counter = None   # a checkpoint's sampler counter loaded before enable_graphs()
 
     def enable_graphs(self):
         """Switch the rollout step to the fused device path (graph_rollout.py): HIP kernels for the policy forward, sampling and
@@ -53,6 +54,9 @@ class HIMOnPolicyRunner:
             self.graphs = self._make_fused_rollout()
             if self.graphs is not None:
                 self.alg.enable_device_lr()
+                if self._pending_draw_counter is not None:
+                    self.graphs.draws.fill_(self._pending_draw_counter)
+                    self._pending_draw_counter = None
         return self.graphs is not None
 
     def _make_fused_rollout(self):
@@ -218,11 +222,22 @@ class HIMOnPolicyRunner:
         if self.dist_ctx.enabled and self.dist_ctx.dist.get_rank() != 0:
             return
         os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
-        d = {"model_state_dict": self.alg.actor_critic.state_dict(), "optimizer_state_dict": self.alg.optimizer.state_dict(),
-             "estimator_optimizer_state_dict": self.alg.actor_critic.estimator.optimizer.state_dict(),
+        d = {"model_state_dict": self.alg.actor_critic.state_dict(), "optimizer_state_dict": self._portable_optimizer_state(self.alg.optimizer),
+             "estimator_optimizer_state_dict": self._portable_optimizer_state(self.alg.actor_critic.estimator.optimizer),
              "iter": self.current_learning_iteration, "infos": infos}            # the reference's keys (HIMR:233-240): play.py loads these
         d.update(self._extra_checkpoint_state())                                 # ... plus what it forgets; extra keys are ignored by its load()
         torch.save(d, path)
+
+    def _portable_optimizer_state(self, opt):
+        """optimizer.state_dict() as the reference's runner.load(load_optimizer=True) can adopt it: on the fused path the learning rate of the
+        param groups is a CUDA tensor and `fused=True` is set (enable_device_lr); a checkpoint carries the plain float and no backend flag"""
+        sd = opt.state_dict()
+        groups = []
+        for g in sd["param_groups"]:
+            g = {k: v for k, v in g.items() if k != "fused"}
+            g["lr"] = float(self.alg.learning_rate)
+            groups.append(g)
+        return {"state": sd["state"], "param_groups": groups}
 
     def _extra_checkpoint_state(self):
         out = {"learning_rate": self.alg.learning_rate}
@@ -230,6 +245,8 @@ class HIMOnPolicyRunner:
             out["env_state_dict"] = self.env.state_dict()
         if self.graphs is not None:
             out["rollout_draw_counter"] = int(self.graphs.draws.item())
+        elif self._pending_draw_counter is not None:
+            out["rollout_draw_counter"] = int(self._pending_draw_counter)
         return out
 
     def _load_extra_checkpoint_state(self, d):
@@ -237,8 +254,11 @@ class HIMOnPolicyRunner:
             self.alg._set_learning_rate(d["learning_rate"])
         if "env_state_dict" in d and hasattr(self.env, "load_state_dict"):
             self.env.load_state_dict(d["env_state_dict"])
-        if "rollout_draw_counter" in d and self.graphs is not None:
-            self.graphs.draws.fill_(d["rollout_draw_counter"])
+        if "rollout_draw_counter" in d:           # the sampler's Philox step word: applied now, or when enable_graphs() creates the rollout
+            if self.graphs is not None:
+                self.graphs.draws.fill_(d["rollout_draw_counter"])
+            else:
+                self._pending_draw_counter = int(d["rollout_draw_counter"])
 
     def load(self, path, load_optimizer=True):
         d = torch.load(path, map_location=self.device, weights_only=False)   # holds optimizer state and plain-python extras
@@ -246,6 +266,10 @@ class HIMOnPolicyRunner:
         if load_optimizer:
             self.alg.optimizer.load_state_dict(d["optimizer_state_dict"])
             self.alg.actor_critic.estimator.optimizer.load_state_dict(d["estimator_optimizer_state_dict"])
+            for opt in (self.alg.optimizer, self.alg.actor_critic.estimator.optimizer):
+                for g in opt.param_groups:            # a portable checkpoint (or the reference's) carries no backend flags: keep this optimiser's own
+                    for k, v in opt.defaults.items():
+                        g.setdefault(k, v)
             self.alg._relink_lr()
         self.current_learning_iteration = d["iter"]
         self._load_extra_checkpoint_state(d)

@@ -254,6 +254,19 @@ def test_checkpoint_round_trip_restores_env_curricula(tmp_path):
     for k, v in run.alg.actor_critic.state_dict().items():
         assert torch.equal(v, run2.alg.actor_critic.state_dict()[k])
     run2.learn(1)                                           # and training continues from there
+    # the checkpoint is portable: plain-float learning rates, no backend flag, CPU-loadable by the reference's runner.load
+    for key in ("optimizer_state_dict", "estimator_optimizer_state_dict"):
+        for g in d[key]["param_groups"]:
+            assert isinstance(g["lr"], float) and "fused" not in g
+    cpu_opt = torch.optim.Adam([torch.nn.Parameter(torch.zeros_like(p, device="cpu")) for p in run.alg.actor_critic.parameters()], lr=1e-3)
+    cpu_opt.load_state_dict(d["optimizer_state_dict"])      # what the reference's load(load_optimizer=True) does (HIMR:246-247)
+    # a load BEFORE enable_graphs() keeps the sampler's counter and applies it when the fused rollout is created
+    env3, run3 = _make(seed=11)
+    run3.load(path)
+    assert run3.graphs is None and run3._pending_draw_counter == int(run.graphs.draws)
+    run3.enable_graphs()
+    assert int(run3.graphs.draws) == int(run.graphs.draws)
+    run3.learn(1)
 
 
 @pytest.mark.parametrize("N", [4096, 37])
