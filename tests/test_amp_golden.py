@@ -97,3 +97,22 @@ def test_hybrid_ppo_update_matches_reference():
         np.testing.assert_allclose(v, fx["hy_ac/" + k], rtol=1e-4, atol=1e-5, err_msg=k)
     for k, v in _ck(disc).items():
         np.testing.assert_allclose(v, fx["hy_disc/" + k], rtol=1e-4, atol=1e-5, err_msg=k)
+
+
+def test_closed_form_gradient_penalty_equals_autograd():
+    """amp._GradPenFn (the GPU path of compute_grad_pen: the penalty and its gradients in closed form, no double backward) against the
+    reference's autograd statement (DISC:36-53) on the CPU: value and every parameter gradient"""
+    torch.manual_seed(0)
+    d = amp.AMPDiscriminator(60, 0.01, [64, 32], "cpu", 0.3)
+    s, ns = torch.randn(50, 30), torch.randn(50, 30)
+    ref = d.compute_grad_pen(s, ns, 10)                     # CPU: autograd.grad(create_graph=True) + backward
+    ref.backward()
+    want = {n: (p.grad.clone() if p.grad is not None else torch.zeros_like(p)) for n, p in d.named_parameters()}
+    d.zero_grad()
+    l1, l2 = d.trunk[0], d.trunk[2]
+    v = amp._GradPenFn.apply(torch.cat([s, ns], -1), l1.weight, l1.bias, l2.weight, l2.bias, d.amp_linear.weight, 10.0)
+    v.backward()
+    assert abs(float(v.detach()) - float(ref.detach())) < 1e-6 * max(1.0, abs(float(ref.detach())))
+    for n, p in d.named_parameters():
+        got = p.grad if p.grad is not None else torch.zeros_like(p)
+        torch.testing.assert_close(got, want[n], rtol=1e-5, atol=1e-7, msg=n)
