@@ -36,10 +36,29 @@ def sites():
         cands = [b for k, b in base.items() if (b if k == 0 else b + 48) <= i]
         return cands[-1]
     for i, l in enumerate(src, 1):
-        m = re.search(r"LS_(PHASE|COLLECTIVE)\((.*)\);", l)
+        m = re.search(r"LS_(PHASE|COLLECTIVE)\((.*)\);", l) or re.search(r"(LS_)(TORQUES_KINEMATICS|KINEMATICS)\(\);", l)
         if m and not l.lstrip().startswith("#") and base and i > min(base.values()):
             out[(i - base_for(i)) & 63] = m.group(2)[:70]
     return out
+
+
+# lanes with work in each phase, by construction of the lane roles (ls_physics.h / ls_post.h headers); "R" = one lane per constraint row
+# (3 per contact + 1 per joint-limit row: 12-36), "P" = one lane per collision point of the model (64 for Aliengo)
+NOMINAL_LANES = [("KINEMATICS", "48 (12 matrix elements x 4 legs)"), ("ph_torques", "12"), ("ph_body_inertia", "17"), ("ph_leg_composite", "24"),
+                 ("ph_leg_block", "36"), ("ph_leg_schur", "24"), ("ph_base_assemble", "42"), ("ph_base_factor", "6"), ("ph_free_leg", "4 + 6"),
+                 ("ph_free_base", "6"), ("ph_free_finish", "18 + P"), ("ph_collide", "P"), ("wc_compact_contacts", "P + 12"), ("ph_rows", "R"),
+                 ("wc_delassus_pgs", "R"), ("ph_apply_impulses", "18 + 17"), ("ph_contact_forces", "17"), ("ph_integrate", "13"),
+                 ("ph_body_states_all", "17"), ("ph_store_sim_state", "51"), ("ph_load_a", "64"), ("ph_post_state", "8"), ("ph_callback", "3"),
+                 ("ph_heights", "64 (187 + 63 points)"), ("ph_termination", "1"), ("ph_reward_terms", "one per active term (21)"),
+                 ("ph_reward_total", "1"), ("ph_build_obs", "64"), ("ph_term_outputs", "64"), ("ph_load_b", "64"), ("ph_b_store", "64"),
+                 ("ph_b_reset", "16"), ("ph_b_episode_stats", "51"), ("ph_b_housekeeping", "53 (env 0 only)")]
+
+
+def nominal_lanes(text):
+    for key, lanes in NOMINAL_LANES:
+        if key in text:
+            return lanes
+    return "?"
 
 
 if __name__ == "__main__":
@@ -75,4 +94,5 @@ if __name__ == "__main__":
     for s in range(64):
         if c[s]:
             tot = tot_a if s < 48 else tot_b
-            print(f"site {s:2d} calls/step {c[s] / (K * N):4.1f} ticks/step {t[s] / (K * N):8.0f} {100.0 * t[s] / tot:5.1f}%  {names.get(s, '?')}")
+            nm = names.get(s, "?")
+            print(f"site {s:2d} calls/step {c[s] / (K * N):4.1f} ticks/step {t[s] / (K * N):8.0f} {100.0 * t[s] / tot:5.1f}%  busy lanes {nominal_lanes(nm):<28s} {nm}")
