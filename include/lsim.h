@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LSIM_ABI_VERSION 1
+#define LSIM_ABI_VERSION 2   /* 2: LSIM_BUF_CONTACT_COUNT, fixed-point words in LSIM_BUF_STATS (round 2) */
 
 /* ---- fixed sizes of the robot family on this path (12-DoF quadrupeds) ---- */
 #define LSIM_NUM_DOF 12
