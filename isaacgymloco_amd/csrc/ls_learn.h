@@ -348,8 +348,13 @@ void lsim_k_linear_wgrad_tiled(const float* __restrict__ x, long ldx, const floa
     // register rotation and waits hide behind the other's MFMAs)
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));                                // wave-uniform: scalar loop control
-    const long slice = (long)blockIdx.x / tiles;
-    const int tile = (int)((long)blockIdx.x - slice * tiles);
+    // XCD-aware order: the dispatcher deals consecutive blocks round-robin to the 8 XCDs, each with its own L2.  Renumber so that XCD x owns
+    // a CONTIGUOUS range of (slice, tile) pairs: all tiles of a slice then read that slice's rows of x / g through one L2 (fetched over
+    // the fabric once instead of once per XCD that holds one of its tiles).  v is a bijection of [0, gridDim.x) for any block count.
+    const int total = (int)gridDim.x, xcd = (int)blockIdx.x & 7;
+    const long v = (long)xcd * (total >> 3) + (xcd < (total & 7) ? xcd : (total & 7)) + ((long)blockIdx.x >> 3);
+    const long slice = v / tiles;
+    const int tile = (int)(v - slice * tiles);
     const int nb = tile / k_blocks, kb = tile - nb * k_blocks;
     const int n_base = nb * 64, k_base = kb * 64 * KG;
     const int sub = lane >> 4, col = lane & 15;
