@@ -143,7 +143,11 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    forced = world == 1 and os.environ.get("LSIM_DEBUG_FORCE_COLLECTIVES") == "1"   # debugging aid: a 1-rank RCCL group, every collective issued
+    if forced:
+        for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_PORT", "29533")):
+            os.environ.setdefault(k, v)
+    if world > 1 or forced:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if single_dev:
             dist.init_process_group(backend="gloo")
@@ -162,7 +166,7 @@ def main():
     N, K, W = args.envs, args.steps, args.warmup
 
     def barrier():
-        if world > 1:
+        if world > 1 or forced:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -203,7 +207,7 @@ def main():
         actions_src = "policy"
 
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    if world > 1:
+    if world > 1 or forced:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
@@ -257,7 +261,7 @@ def main():
         import atexit, shutil
         src = os.environ["PYTORCH_TUNABLEOP_FILENAME"].replace(".csv", f"{local_rank}.csv")
         atexit.register(lambda: os.path.exists(src) and shutil.copy(src, os.path.join(ROOT, "gpurun_out", "tunableop_new.csv")))
-    if world > 1:
+    if world > 1 or forced:
         dist.destroy_process_group()
 
 

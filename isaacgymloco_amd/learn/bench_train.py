@@ -82,8 +82,8 @@ def run_train_bench(env, cfg, args, dev, rank, world, barrier):
     ka = sum(ms_a[i] for i in range(n.value)) / max(n.value, 1)
     kb = sum(ms_b[i] for i in range(n.value)) / max(n.value, 1)
     digest = weights_digest(runner.alg.actor_critic)
-    if world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    if dist.is_initialized():               # N > 1, or the 1-rank RCCL group of LSIM_DEBUG_FORCE_COLLECTIVES
         d = torch.tensor(digest, device=dev, dtype=torch.float64)
         all_d = [torch.zeros_like(d) for _ in range(world)]
         dist.all_gather(all_d, d)

@@ -6,6 +6,8 @@ Data parallel (not in the reference): `dist_ctx` averages gradient
 all-reduce per optimiser step (RCCL over xGMI; latency-bound payload of 2.2 MB), synchronises the KL estimate before
 the lr decision and the advantage statistics, so every rank takes identical optimiser steps.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -18,7 +20,10 @@ class DistCtx:
     def __init__(self):
         import torch.distributed as dist
         self.dist = dist
-        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        # LSIM_DEBUG_FORCE_COLLECTIVES=1: issue every collective even in a group of one rank (bench.py then opens a 1-rank RCCL group), so that
+        # the RCCL calls of the N > 1 path can be exercised on a box with a single GPU
+        forced = os.environ.get("LSIM_DEBUG_FORCE_COLLECTIVES") == "1"
+        self.enabled = dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or forced)
         self.world = dist.get_world_size() if self.enabled else 1
 
     def average_grads(self, params):

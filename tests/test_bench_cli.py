@@ -67,3 +67,18 @@ def test_two_ranks_on_the_fused_gpu_path_stay_in_lockstep():
     assert j["ppo_updates_timed"] >= 1
     assert len(j["weights_digest_by_rank"]) == 2 and j["ranks_in_lockstep"] is True
     assert abs(j["value"] - 2 * 256 * j["timed_env_steps"] / (j["ppo_iteration_wall_s"] * j["ppo_updates_timed"])) / j["value"] < 0.02
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("task", ["aliengo", "aliengo_amp"])
+def test_rccl_collectives_of_the_multi_rank_path_run_on_one_gpu(task):
+    """the RCCL calls of the N > 1 path (gradient buckets, KL mean, advantage / normaliser moments, parameter broadcast, barrier, timing
+    max) on real hardware: a 1-rank `nccl` group with every collective issued (LSIM_DEBUG_FORCE_COLLECTIVES); the 2-rank test above can
+    only use gloo because RCCL refuses two ranks on one device"""
+    r = _run(["--gpus", "1", "--steps", "20", "--warmup", "5", "--envs", "256", "--task", task, "--no-cpu-baseline"],
+             env={"LSIM_DEBUG_FORCE_COLLECTIVES": "1", "MASTER_PORT": "29541"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 1 and j["ppo_updates_timed"] >= 1 and j["ranks_in_lockstep"] is True

@@ -16,6 +16,8 @@ timeout 300 python bench.py --mode env --envs 64 --steps 500 --warmup 50 --no-cp
 for t in aliengo_stairs aliengo_amp go1; do timeout 900 python bench.py --task $t --no-cpu-baseline > $O/bench_$t.log 2>&1; tail -1 $O/bench_$t.log > $O/bench_$t.json; done
 LSIM_DEBUG_SINGLE_DEVICE=1 timeout 600 python bench.py --gpus 2 --no-cpu-baseline > $O/bench_2ranks_debug.log 2>&1; tail -1 $O/bench_2ranks_debug.log > $O/bench_2ranks_debug.json
 LSIM_DEBUG_SINGLE_DEVICE=1 timeout 600 python bench.py --gpus 2 --mixed-robots --no-cpu-baseline > $O/bench_2ranks_mixed_debug.log 2>&1; tail -1 $O/bench_2ranks_mixed_debug.log > $O/bench_2ranks_mixed_debug.json
+# the RCCL calls of the N > 1 path on one GPU: a 1-rank group with every collective issued, started the way the driver starts N ranks
+LSIM_DEBUG_FORCE_COLLECTIVES=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_rccl_1rank.log 2>&1; tail -1 $O/bench_rccl_1rank.log > $O/bench_rccl_1rank.json
 timeout 120 tools/micro/valu_peak > $O/valu_peak.json 2>/dev/null
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_env -o env -- python3 bench.py --mode env --steps 100 --warmup 20 --no-cpu-baseline > $O/prof_env.log 2>&1
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_train -o train -- python3 bench.py --no-cpu-baseline > $O/prof_train.log 2>&1

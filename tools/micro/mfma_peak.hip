@@ -135,6 +135,51 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int j = 0; j < 8; ++j) for (int t = 0; t < 8; ++t) s += acc[j][t][0] + acc[j][t][1] + acc[j][t][2] + acc[j][t][3];
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
+
+// the same 64 x 128 tile through v_mfma_f32_32x32x2_f32 (half the MFMA instructions, 16-pass): per 2-row step one 8-byte load (A: 64
+// columns) and one 16-byte load (B: 128 columns) and 8 MFMAs; three register stages, loads spread between the MFMAs
+typedef float v16f __attribute__((ext_vector_type(16)));
+template <int PRIO, int LOADS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k32(const float* __restrict__ src, float* out, int iters, int mask) {
+    v16f acc[2][4];
+    for (int j = 0; j < 2; ++j) for (int t = 0; t < 4; ++t) for (int e = 0; e < 16; ++e) acc[j][t][e] = 0.f;
+    const float4* p = (const float4*)src + threadIdx.x;
+    const float2* p2 = (const float2*)src + threadIdx.x;
+    float2 a0, a1, a2; float4 x0, x1, x2;
+    a0 = a1 = a2 = p2[0]; x0 = x1 = x2 = p[0];
+#define SB() __builtin_amdgcn_sched_barrier(0)
+#define MF(A, X, J) do { const float av = (J) == 0 ? A.x : A.y; const float bv[4] = {X.x, X.y, X.z, X.w};                    \
+        if (PRIO) __builtin_amdgcn_s_setprio(1);                                                                                 \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) acc[J][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[J][t], 0, 0, 0);  \
+        if (PRIO) __builtin_amdgcn_s_setprio(0); } while (0)
+#define STEP(CA, CX, LA, LX, I) do { const int o = ((I) * 512) & mask;                                                       \
+        MF(CA, CX, 0); SB(); if (LOADS) { LA = p2[2 * o]; } SB(); MF(CA, CX, 1); SB(); if (LOADS) { LX = p[o + 256]; } SB(); } while (0)
+    int i = blockIdx.x;
+    for (int it = 0; it < iters; it += 3, i += 3) {
+        STEP(a0, x0, a2, x2, i + 2);
+        STEP(a1, x1, a0, x0, i + 3);
+        STEP(a2, x2, a1, x1, i + 4);
+    }
+#undef STEP
+#undef MF
+#undef SB
+    float s = 0.f;
+    for (int j = 0; j < 2; ++j) for (int t = 0; t < 4; ++t) for (int e = 0; e < 16; ++e) s += acc[j][t][e];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+template <int PRIO, int LOADS> void run32(int blocks, int iters, int mask, const char* what) {
+    float *out, *src; hipMalloc(&out, (size_t)blocks * 256 * 4); hipMalloc(&src, ((size_t)mask + 1024) * 16 + (1 << 20)); hipMemset(src, 0, ((size_t)mask + 1024) * 16 + (1 << 20));
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((k32<PRIO, LOADS>), dim3(blocks), dim3(256), 0, 0, (const float*)src, out, iters, mask);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((k32<PRIO, LOADS>), dim3(blocks), dim3(256), 0, 0, (const float*)src, out, iters, mask);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    double flop = (double)blocks * 4 * iters * 8 * 2.0 * 32 * 32 * 2;
+    printf("%s: %.3f ms, %.1f TFLOP/s\n", what, ms, flop / ms / 1e9);
+    hipFree(out); hipFree(src);
+}
 void runbig(int blocks, int iters, int mask, const char* what) {
     float *out, *src; hipMalloc(&out, (size_t)blocks * 256 * 4); hipMalloc(&src, ((size_t)mask + 2048) * 16 + (1 << 20)); hipMemset(src, 0, ((size_t)mask + 2048) * 16 + (1 << 20));
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -223,6 +268,11 @@ int main() {
     runspread<0>(512, 3999, 0xfffff, "  3 loads per step SPREAD between the MFMAs, 16 MB window");
     runspread<1>(512, 3999, 0x3ff, "  spread + s_setprio(1) around each MFMA group, 16 KB window");
     runspread<1>(512, 3999, 0xfffff, "  spread + s_setprio(1) around each MFMA group, 16 MB window");
+    run32<0, 0>(512, 7998, 0x3ff, "  32x32x2: 8 MFMAs per 2-row step, no loads");
+    run32<0, 1>(512, 7998, 0x3ff, "  32x32x2: 8 MFMAs + 2 loads per 2-row step, 16 KB window");
+    run32<0, 1>(512, 7998, 0xfffff, "  32x32x2: 8 MFMAs + 2 loads per 2-row step, 16 MB window");
+    run32<1, 1>(512, 7998, 0x3ff, "  32x32x2 + s_setprio, 16 KB window");
+    run32<1, 1>(512, 7998, 0xfffff, "  32x32x2 + s_setprio, 16 MB window");
     runbig(256, 3999, 0xfffff, "  1 wave/SIMD, 128 x 128 tile: 4 loads spread over 64 MFMAs per step, 16 MB window");
     return 0;
 }
