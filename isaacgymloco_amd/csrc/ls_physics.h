@@ -699,9 +699,9 @@ static inline void wc_pgs(WaveShared& sh, LaneRegs* L, int iters) {
             if (kind == 0) nl = fmaxf(nl, 0.0f);
             else if (kind == 3) nl = fmaxf(nl, 0.0f) + fminf(nl + L[r].row_rng / L[r].wdiag, 0.0f);   // boxed: lower bound pushes up, upper bound down
             else { float lim = sh.mu * lam[r - kind]; nl = clampf(nl, -lim, lim); }
-            float delta = nl - lam[r];
+            const float old = lam[r];
             lam[r] = nl;
-            for (int i = 0; i < R; ++i) if (ls_slot_active(sh, i)) w[i] += L[i].W[r] * delta;
+            for (int i = 0; i < R; ++i) if (ls_slot_active(sh, i)) w[i] = fmaf(L[i].W[r], nl, fmaf(-L[i].W[r], old, w[i]));   // the GPU form's two FMAs
         }
     for (int i = 0; i < R; ++i) if (ls_slot_active(sh, i)) sh.lam[i] = lam[i];
 }
@@ -713,44 +713,54 @@ LS_FN float ls_readlane(float v, int srclane) {  // srclane is wave-uniform
 template <int LANE> __device__ __forceinline__ void ls_writelane(float& v, float s) {
     asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(s), "n"(LANE));
 }
-// One Gauss-Seidel relaxation of slot R.  Every lane evaluates its own candidate; only lane R's is real: readlane broadcasts it and
-// its delta, lane R keeps it (v_writelane with an immediate lane).  The clamp is specialised by the slot's static row type:
-//   normal    lam >= 0, and its impulse is handed to its two friction rows (their box is +-mu * lam_n)
-//   friction  |lam| <= mu * lam_n
+// One Gauss-Seidel relaxation of slot R.  The impulses are wave-uniform data and live in SCALAR registers (sl[R]); a lane only owns the
+// residual w of its row.  Every lane evaluates the candidate of slot R from its own w (only lane R's is real), readlane broadcasts it,
+// and all residuals move by W[R] * (new - old) as two FMAs: - W[R] * old before the broadcast, + W[R] * new after it.  5-6 vector
+// instructions per row (a per-lane impulse register with readlane / writelane hand-offs needed 7-9; at four waves per SIMD the
+// sweep's time is its instruction count).  The clamp is specialised by the slot's static row type:
+//   normal    lam >= 0
+//   friction  |lam| <= mu * lam_n, lam_n = sl[first slot of the contact]
 //   limit     two-sided velocity interval [L, L + rng]: lam = raw - clamp(raw, -rng / d, 0)   (push up at L, push down at the upper bound)
 enum { LS_ROW_NORMAL = 0, LS_ROW_FRICTION = 1, LS_ROW_LIMIT = 3 };
-template <int R, int KIND> __device__ __forceinline__ void ls_pgs_row(const float (&W)[LS_MAXR], float cf, float inv_d, float neg_rng_d,
-                                                                     float& lam, float& lam_n, float& w) {
-    const float raw = fmaf(-w, inv_d, lam);
+template <int R, int KIND> __device__ __forceinline__ void ls_pgs_row(const float (&W)[LS_MAXR], float (&sl)[LS_MAXR], float fric_box, float inv_d,
+                                                                     float neg_rng_d, float& w) {
+    const float old = sl[R];
+    const float raw = fmaf(-w, inv_d, old);
+    w = fmaf(-W[R], old, w);
     float nl;
     if constexpr (KIND == LS_ROW_NORMAL) nl = fmaxf(raw, 0.0f);
-    else if constexpr (KIND == LS_ROW_FRICTION) { const float t = cf * lam_n; nl = __builtin_amdgcn_fmed3f(raw, -t, t); }
+    else if constexpr (KIND == LS_ROW_FRICTION) nl = __builtin_amdgcn_fmed3f(raw, -fric_box, fric_box);
     else nl = raw - __builtin_amdgcn_fmed3f(raw, neg_rng_d, 0.0f);
-    const float d = nl - lam;
-    const float s_nl = ls_readlane(nl, R), s_d = ls_readlane(d, R);
-    ls_writelane<R>(lam, s_nl);
-    if constexpr (KIND == LS_ROW_NORMAL) {
-        ls_writelane<R + 1>(lam_n, s_nl);
-        ls_writelane<R + 2>(lam_n, s_nl);
-    }
-    w = fmaf(W[R], s_d, w);
+    const float s_nl = ls_readlane(nl, R);
+    sl[R] = s_nl;
+    w = fmaf(W[R], s_nl, w);
 }
 // contacts K0 .. nc-1 (three slots each), then limit rows I0 .. nlim-1: compile-time recursion, one uniform branch per contact / limit row
-template <int K0> __device__ __forceinline__ void ls_pgs_contacts(int nc, const float (&W)[LS_MAXR], float cf, float inv_d, float& lam, float& lam_n, float& w) {
+template <int K0> __device__ __forceinline__ void ls_pgs_contacts(int nc, const float (&W)[LS_MAXR], float (&sl)[LS_MAXR], float cf, float inv_d, float& w) {
     if constexpr (K0 < LS_MAXC) {
         if (K0 < nc) {
-            ls_pgs_row<3 * K0, LS_ROW_NORMAL>(W, cf, inv_d, 0.0f, lam, lam_n, w);
-            ls_pgs_row<3 * K0 + 1, LS_ROW_FRICTION>(W, cf, inv_d, 0.0f, lam, lam_n, w);
-            ls_pgs_row<3 * K0 + 2, LS_ROW_FRICTION>(W, cf, inv_d, 0.0f, lam, lam_n, w);
-            ls_pgs_contacts<K0 + 1>(nc, W, cf, inv_d, lam, lam_n, w);
+            ls_pgs_row<3 * K0, LS_ROW_NORMAL>(W, sl, 0.0f, inv_d, 0.0f, w);
+            const float box = cf * sl[3 * K0];
+            ls_pgs_row<3 * K0 + 1, LS_ROW_FRICTION>(W, sl, box, inv_d, 0.0f, w);
+            ls_pgs_row<3 * K0 + 2, LS_ROW_FRICTION>(W, sl, box, inv_d, 0.0f, w);
+            ls_pgs_contacts<K0 + 1>(nc, W, sl, cf, inv_d, w);
         }
     }
 }
-template <int I0> __device__ __forceinline__ void ls_pgs_limits(int nlim, const float (&W)[LS_MAXR], float inv_d, float neg_rng_d, float& lam, float& lam_n, float& w) {
+template <int I0> __device__ __forceinline__ void ls_pgs_limits(int nlim, const float (&W)[LS_MAXR], float (&sl)[LS_MAXR], float inv_d, float neg_rng_d, float& w) {
     if constexpr (I0 < LSIM_NUM_DOF) {
         if (I0 < nlim) {
-            ls_pgs_row<LS_LIM0 + I0, LS_ROW_LIMIT>(W, 0.0f, inv_d, neg_rng_d, lam, lam_n, w);
-            ls_pgs_limits<I0 + 1>(nlim, W, inv_d, neg_rng_d, lam, lam_n, w);
+            ls_pgs_row<LS_LIM0 + I0, LS_ROW_LIMIT>(W, sl, 0.0f, inv_d, neg_rng_d, w);
+            ls_pgs_limits<I0 + 1>(nlim, W, sl, inv_d, neg_rng_d, w);
+        }
+    }
+}
+// the scalar impulses back into lane R's register (slots J0 .. END-1 while J0 < cnt)
+template <int J0, int END> __device__ __forceinline__ void ls_pgs_collect(int cnt, const float (&sl)[LS_MAXR], float& lam) {
+    if constexpr (J0 < END) {
+        if (J0 < cnt) {
+            ls_writelane<J0>(lam, sl[J0]);
+            ls_pgs_collect<J0 + 1, END>(cnt, sl, lam);
         }
     }
 }
@@ -785,14 +795,18 @@ LS_FN void wc_delassus_pgs(WaveShared& sh, const LaneRegs& rg, int lane, int ite
     float wd = 1.0f;
     ls_delassus_rows<0, LS_LIM0>(sh, 3 * nc, lane, lo, jb, jl0, jl1, jl2, W, wd);
     ls_delassus_rows<LS_LIM0, LS_MAXR>(sh, LS_LIM0 + nlim, lane, lo, jb, jl0, jl1, jl2, W, wd);
-    float lam = 0.0f, lam_n = 0.0f, w = act ? rg.brow : 0.0f;
+    float w = act ? rg.brow : 0.0f;
     const float inv_d = act ? ls_rcp(wd) : 0.0f;
     const float cf = sh.mu;                                                 // only the friction slots use it
     const float neg_rng_d = act ? -(rg.row_rng * inv_d) : 0.0f;            // only the limit slots use it (their range is finite)
+    float sl[LS_MAXR] = {};                                                 // the impulses: wave-uniform, scalar registers
     for (int it = 0; it < iters; ++it) {
-        ls_pgs_contacts<0>(nc, W, cf, inv_d, lam, lam_n, w);
-        ls_pgs_limits<0>(nlim, W, inv_d, neg_rng_d, lam, lam_n, w);
+        ls_pgs_contacts<0>(nc, W, sl, cf, inv_d, w);
+        ls_pgs_limits<0>(nlim, W, sl, inv_d, neg_rng_d, w);
     }
+    float lam = 0.0f;
+    ls_pgs_collect<0, LS_LIM0>(3 * nc, sl, lam);
+    ls_pgs_collect<LS_LIM0, LS_MAXR>(LS_LIM0 + nlim, sl, lam);
     if (act) sh.lam[lane] = lam;
 }
 #endif
