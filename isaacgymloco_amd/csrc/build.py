@@ -15,7 +15,7 @@ HEADERS = ["ls_math.h", "ls_shared.h", "ls_physics.h", "ls_post.h", "ls_kernels.
 # -fno-hip-fp32-correctly-rounded-divide-sqrt: the dynamics is VALU-issue bound and ~150 divisions per sub-step cost ~12
 # instructions each when IEEE-rounded; quotients that must be exact use ls_div_exact (ls_math.h)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-pass-failed",
-         "-fno-hip-fp32-correctly-rounded-divide-sqrt"]
+         "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-fno-slp-vectorize"]
 
 
 def stale():

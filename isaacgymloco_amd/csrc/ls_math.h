@@ -29,6 +29,14 @@
 #define LS_STRIDED(k, lane, N) _Pragma("unroll") for (int it_ = 0, k = (lane); it_ < ((N) + 63) / 64; ++it_, k += 64) if (k < (N))
 #endif
 
+// a value every lane of the wave holds identically (read from LDS, so the compiler cannot know): moved to a scalar register, which turns
+// branches and loop bounds on it into scalar compares instead of per-lane compares with hoisted lane masks
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LS_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+#else
+#define LS_UNIFORM(x) (x)
+#endif
+
 struct alignas(8) LsF2 { float x, y; };   // one 8-byte global store
 
 struct V3 {

@@ -783,7 +783,7 @@ template <int J0, int END> __device__ __forceinline__ void ls_delassus_rows(cons
 // GPU form: Delassus row and sweep fused so that the 36-entry row lives in registers only between here and the end of
 // the sweep (written unconditionally: no liveness across sub-steps); rows relaxed in slot order, impulse broadcast by readlane.
 LS_FN void wc_delassus_pgs(WaveShared& sh, const LaneRegs& rg, int lane, int iters) {
-    const int nc = sh.nc, nlim = sh.nlim;
+    const int nc = LS_UNIFORM(sh.nc), nlim = LS_UNIFORM(sh.nlim);
     const bool act = ls_slot_active(sh, lane);
     const int leg = rg.row_leg;
     const int lo = (act && leg >= 0) ? 6 + 3 * leg : 6;
@@ -801,8 +801,12 @@ LS_FN void wc_delassus_pgs(WaveShared& sh, const LaneRegs& rg, int lane, int ite
     const float neg_rng_d = act ? -(rg.row_rng * inv_d) : 0.0f;            // only the limit slots use it (their range is finite)
     float sl[LS_MAXR] = {};                                                 // the impulses: wave-uniform, scalar registers
     for (int it = 0; it < iters; ++it) {
-        ls_pgs_contacts<0>(nc, W, sl, cf, inv_d, w);
-        ls_pgs_limits<0>(nlim, W, sl, inv_d, neg_rng_d, w);
+        // the counts are re-materialised every sweep: loop-invariant, the 20 branch conditions on them would be hoisted out of the loop
+        // as 20 lane masks in 40 scalar registers, which pushes the impulses out of the scalar file (spills through v_readlane)
+        int nc_it = nc, nlim_it = nlim;
+        asm volatile("" : "+s"(nc_it), "+s"(nlim_it));
+        ls_pgs_contacts<0>(nc_it, W, sl, cf, inv_d, w);
+        ls_pgs_limits<0>(nlim_it, W, sl, inv_d, neg_rng_d, w);
     }
     float lam = 0.0f;
     ls_pgs_collect<0, LS_LIM0>(3 * nc, sl, lam);
@@ -817,8 +821,9 @@ LS_FN void wc_delassus_pgs(WaveShared& sh, const LaneRegs& rg, int lane, int ite
 LS_FN void ph_apply_impulses(WaveShared& sh, int lane) {
     if (lane >= LS_NV) return;
     float acc = 0.0f;
-    for (int r = 0; r < 3 * sh.nc; ++r) acc += sh.u.c.Y[r][lane] * sh.lam[r];
-    for (int r = LS_LIM0; r < LS_LIM0 + sh.nlim; ++r) acc += sh.u.c.Y[r][lane] * sh.lam[r];
+    const int nc = LS_UNIFORM(sh.nc), nlim = LS_UNIFORM(sh.nlim);
+    for (int r = 0; r < 3 * nc; ++r) acc += sh.u.c.Y[r][lane] * sh.lam[r];
+    for (int r = LS_LIM0; r < LS_LIM0 + nlim; ++r) acc += sh.u.c.Y[r][lane] * sh.lam[r];
     if (lane < 6) sh.ab[lane] = acc;
     sh.vnew[lane] = sh.vfree[lane] + acc;
 }
@@ -828,7 +833,8 @@ LS_FN void ph_contact_forces(WaveShared& sh, int lane, float dt) {
     if (lane >= LS_NB) return;
     V3 f = v3(0, 0, 0);
     const float idt = ls_rcp(dt);
-    for (int k = 0; k < sh.nc; ++k)
+    const int nc = LS_UNIFORM(sh.nc);
+    for (int k = 0; k < nc; ++k)
         if (sh.cbody[k] == lane)
             for (int a = 0; a < 3; ++a) f = f + v3p(sh.u.c.dirs[3 * k + a]) * (sh.lam[3 * k + a] * idt);
     v3st(sh.cf[lane], f);
