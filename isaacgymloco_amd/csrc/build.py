@@ -12,10 +12,15 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 LIB = os.path.join(HERE, "liblsim.so")
 SOURCES = ["lsim_hip.hip"]
 HEADERS = ["ls_math.h", "ls_shared.h", "ls_physics.h", "ls_post.h", "ls_kernels.h", "ls_api_impl.h", "ls_rollout.h", "ls_learn.h", "ls_policy.h"]
-# -fno-hip-fp32-correctly-rounded-divide-sqrt: the dynamics is VALU-issue bound and ~150 divisions per sub-step cost ~12
-# instructions each when IEEE-rounded; quotients that must be exact use ls_div_exact (ls_math.h)
+# The simulator kernels' time is their vector instruction count, so the flags are chosen for that:
+# -fno-hip-fp32-correctly-rounded-divide-sqrt: ~150 divisions per sub-step cost ~12 instructions each when IEEE-rounded; quotients that
+#   must be exact use ls_div_exact (ls_math.h)
+# -fgpu-flush-denormals-to-zero: with fp32 denormals kept, every sqrtf / fast division carries a frexp / ldexp range-scaling sequence
+#   (5-8 instructions instead of 1-2; 360 of kernel A's 7 400 static vector instructions); nothing in the path lives near 1e-38
+# -fno-slp-vectorize: the SLP vectoriser pairs independent fp32 FMAs into v_pk_fma_f32 and pays two v_mov_b32 per pair to pack the
+#   operands: more instructions than the scalar form it replaces (kernel A: 7 626 -> 7 401 static, 0.1245 -> 0.116 ms)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-pass-failed",
-         "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-fno-slp-vectorize"]
+         "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-fgpu-flush-denormals-to-zero", "-fno-slp-vectorize"]
 
 
 def stale():
