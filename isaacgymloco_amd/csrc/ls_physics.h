@@ -791,7 +791,7 @@ LS_FN void wc_delassus_pgs(WaveShared& sh, const LaneRegs& rg, int lane, int ite
     const float jl0 = has_leg ? rg.Jl[0] : 0.0f, jl1 = has_leg ? rg.Jl[1] : 0.0f, jl2 = has_leg ? rg.Jl[2] : 0.0f;
     float jb[6];
     for (int k = 0; k < 6; ++k) jb[k] = act ? rg.Jb[k] : 0.0f;
-    float W[LS_MAXR] = {};
+    float W[LS_MAXR];                   // entries of inactive slots stay unset: the sweep never touches them (36 zero-fills saved per sub-step)
     float wd = 1.0f;
     ls_delassus_rows<0, LS_LIM0>(sh, 3 * nc, lane, lo, jb, jl0, jl1, jl2, W, wd);
     ls_delassus_rows<LS_LIM0, LS_MAXR>(sh, LS_LIM0 + nlim, lane, lo, jb, jl0, jl1, jl2, W, wd);
