@@ -180,6 +180,12 @@ extern "C" int LS_API(create)(const lsim_config* cfg, const lsim_robot_model* mo
     h.num_active = 0;
     for (int id = 0; id < LSIM_NUM_REWARD_TERMS; ++id)
         if (id != LSIM_R_TERMINATION && c.reward_scales[id] != 0.0f) h.active_terms[h.num_active++] = id;
+    for (int ai = 0; ai < h.num_active; ++ai) {       // the (term, part) items of ph_reward_parts, whole terms while the table has room
+        const int id = h.active_terms[ai], n = ls_reward_num_parts(id);
+        if (n == 0 || h.num_part_items + n > LS_MAX_PART_ITEMS) continue;
+        for (int j = 0; j < n; ++j) h.part_items[h.num_part_items++] = (uint16_t)((id << 10) | (ai << 4) | j);
+        h.parted_mask |= 1ull << ai;
+    }
     if (lsbk_malloc((void**)&s->dev_ctx, sizeof(LsCtx)) != 0) bad = 1;
     else bad |= lsbk_h2d(s->dev_ctx, &h, sizeof(LsCtx));
     if (bad) { if (s->owns_arena) lsbk_free(s->arena); if (s->dev_ctx) lsbk_free(s->dev_ctx); free(s); return LSIM_E_HIP; }

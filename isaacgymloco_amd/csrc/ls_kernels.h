@@ -46,8 +46,15 @@ __device__ unsigned long long g_ls_phase_calls[64];
 #define LS_TICK_INIT() do { } while (0)
 #define LS_TICK_FLUSH() do { } while (0)
 #endif
-#define LS_PHASE(call) do { { const int lane = ls_opaque_lane(lane0); call; } __syncthreads(); LS_TICK(__LINE__ - ls_line0); } while (0)
-#define LS_COLLECTIVE(gpu_call, emu_call) do { { const int lane = ls_opaque_lane(lane0); gpu_call; } __syncthreads(); LS_TICK(__LINE__ - ls_line0); } while (0)
+#if defined(LS_PHASE_MARKS)    // diagnostics only (tools/phase_static.py): a comment in the assembly behind every phase site
+#define LS_STR2(x) #x
+#define LS_STR(x) LS_STR2(x)
+#define LS_MARK() asm volatile("; LS_MARK " LS_STR(__LINE__))
+#else
+#define LS_MARK() do { } while (0)
+#endif
+#define LS_PHASE(call) do { { const int lane = ls_opaque_lane(lane0); call; } __syncthreads(); LS_MARK(); LS_TICK(__LINE__ - ls_line0); } while (0)
+#define LS_COLLECTIVE(gpu_call, emu_call) do { { const int lane = ls_opaque_lane(lane0); gpu_call; } __syncthreads(); LS_MARK(); LS_TICK(__LINE__ - ls_line0); } while (0)
 #define LS_KINEMATICS() LS_COLLECTIVE(wc_kinematics(sh, lane), (void)0)
 #define LS_TORQUES_KINEMATICS() LS_COLLECTIVE(ph_torques(cx, sh, lane, env, sub); wc_kinematics(sh, lane), (void)0)
 #define LS_ATOMIC_ADD(ptr, v) atomicAdd((ptr), (v))
@@ -97,7 +104,10 @@ LS_FN void ph_load_a(const LsCtx& cx, WaveShared& sh, LaneRegs& rg, int lane, in
     const unsigned int v_lc = LSB(cx, LSIM_BUF_LAST_CONTACTS, unsigned int)[env];
     const int v_level = (int)LSB(cx, LSIM_BUF_TERRAIN_LEVELS, int64_t)[env];
     const float v_es = LSB(cx, LSIM_BUF_EPISODE_SUMS, float)[env * LSIM_NUM_REWARD_TERMS + (lane < LSIM_NUM_REWARD_TERMS ? lane : 0)];
+    uint16_t v_items[LS_MAX_PART_ITEMS / 64];
+    for (int it = 0; it < LS_MAX_PART_ITEMS / 64; ++it) v_items[it] = cx.part_items[lane + 64 * it];
     // ---- LDS writes
+    for (int it = 0; it < LS_MAX_PART_ITEMS / 64; ++it) sh.items[lane + 64 * it] = v_items[it];
     if (lane < 13) sh.root[lane] = v_root;
     if (lane < 12) {
         sh.q[lane] = v_q;
@@ -265,7 +275,7 @@ LS_WAVE_FN void ls_wave_step_a(const LsCtx& cx, const LsStepArgs& a, const int e
     LS_PHASE(ph_post_state(cx, sh, lane, env));
     LS_PHASE(ph_callback(cx, sh, lane, env, a, sh.ranges));
     LS_PHASE(if (c.measure_heights) ph_heights(cx, sh, lane, env, true); ph_base_height_pts(cx, sh, lane));
-    LS_PHASE(ph_termination(cx, sh, lane, env));
+    LS_PHASE(ph_termination(cx, sh, lane, env); ph_reward_parts(cx, sh, lane, env));
     LS_PHASE(ph_reward_terms(cx, sh, lane, env));
     LS_PHASE(ph_reward_total(cx, sh, lane, env));
     LS_PHASE(if (sh.reset) ph_build_obs(cx, sh, lane, env, (uint32_t)a.step_counter, LSIM_RNG_TERM_NOISE, sh.cur));

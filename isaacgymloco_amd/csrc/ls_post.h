@@ -179,48 +179,40 @@ struct LsRewCtx {
 LS_FN float ls_up(const WaveShared& sh) { return clampf(-sh.grav[2], 0.0f, 1.0f); }
 LS_FN float ls_cmd_norm(const WaveShared& sh) { return sqrtf(sh.cmd[0] * sh.cmd[0] + sh.cmd[1] * sh.cmd[1]); }
 
-LS_FN float ls_foot_slide_like(const LsCtx& cx, const WaveShared& sh, const LsRewCtx& x, bool with_height) {  // LR:1610-1619 / LR:1682-1698
-    float acc = 0.0f;
-    for (int f = 0; f < 4; ++f) {
-        const float* bs = sh.feet[f];
-        V3 vb = quat_rotate_inverse(sh.root + 3, v3(bs[3] - sh.root[7], bs[4] - sh.root[8], bs[5] - sh.root[9]));
-        float lat = sqrtf(vb.x * vb.x + vb.y * vb.y);
-        if (with_height) {
-            V3 pb = quat_rotate_inverse(sh.root + 3, v3(bs[0] - sh.root[0], bs[1] - sh.root[1], bs[2] - sh.root[2]));
-            float he = pb.z - cx.cfg.foot_height_target_base;
-            acc += (he * he) * lat;
-        } else acc += (x.filt[f] ? 1.0f : 0.0f) * lat;
+// ---- reward terms that are sums over joints / legs / feet / height samples are evaluated in two steps: their summands ("parts") by one lane
+//      each (ph_reward_parts: lane = (term, part) pair from a host-built item table), then the term's lane adds them up IN THE ORDER of the
+//      reference's torch.sum and applies the term's factor (ph_reward_terms).  One lane per term alone ran all 21 term bodies one after the
+//      other -- 12-joint loops on a single lane each -- a tenth of kernel A's instructions.
+LS_FN float ls_foot_slide_part(const LsCtx& cx, const WaveShared& sh, const LsRewCtx& x, bool with_height, int f) {  // LR:1610-1619 / LR:1682-1698
+    const float* bs = sh.feet[f];
+    V3 vb = quat_rotate_inverse(sh.root + 3, v3(bs[3] - sh.root[7], bs[4] - sh.root[8], bs[5] - sh.root[9]));
+    float lat = sqrtf(vb.x * vb.x + vb.y * vb.y);
+    if (with_height) {
+        V3 pb = quat_rotate_inverse(sh.root + 3, v3(bs[0] - sh.root[0], bs[1] - sh.root[1], bs[2] - sh.root[2]));
+        float he = pb.z - cx.cfg.foot_height_target_base;
+        return (he * he) * lat;
     }
-    return acc;
+    return (x.filt[f] ? 1.0f : 0.0f) * lat;
 }
-LS_FN float ls_foot_clearance_terrain(const LsCtx& cx, const WaveShared& sh, int shifts) {  // LR:1717-1743 incl. quirk 3 (in-place += border)
+LS_FN float ls_foot_clearance_terrain_part(const LsCtx& cx, const WaveShared& sh, int shifts, int f) {  // LR:1717-1743 incl. quirk 3 (in-place += border)
     const lsim_config& c = cx.cfg;
-    float acc = 0.0f;
-    for (int f = 0; f < 4; ++f) {
-        const float* bs = sh.feet[f];
-        float fh;
-        if (c.mesh_type == 0) fh = bs[2];
-        else {
-            float px = bs[0], py = bs[1], pz = bs[2];
-            for (int s = 0; s < shifts; ++s) { px += c.border_size; py += c.border_size; pz += c.border_size; }
-            int ix = (int)ls_div_exact(px, c.horizontal_scale), iy = (int)ls_div_exact(py, c.horizontal_scale);
-            ix = ix < 0 ? 0 : (ix > c.grid_rows - 2 ? c.grid_rows - 2 : ix);
-            iy = iy < 0 ? 0 : (iy > c.grid_cols - 2 ? c.grid_cols - 2 : iy);
-            LS_GLOBAL const int16_t* g = LSB(cx, LSIM_BUF_HEIGHT_GRID, const int16_t);
-            int16_t h1 = g[ix * c.grid_cols + iy], h2 = g[(ix + 1) * c.grid_cols + iy], h3 = g[ix * c.grid_cols + iy + 1];
-            int16_t h = h1 < h2 ? h1 : h2; h = h < h3 ? h : h3;
-            fh = pz - (float)h * c.vertical_scale;
-        }
-        float lat = sqrtf(bs[3] * bs[3] + bs[4] * bs[4]);
-        float d = fh - c.foot_height_target_terrain;
-        acc += lat * (d * d);
+    const float* bs = sh.feet[f];
+    float fh;
+    if (c.mesh_type == 0) fh = bs[2];
+    else {
+        float px = bs[0], py = bs[1], pz = bs[2];
+        for (int s = 0; s < shifts; ++s) { px += c.border_size; py += c.border_size; pz += c.border_size; }
+        int ix = (int)ls_div_exact(px, c.horizontal_scale), iy = (int)ls_div_exact(py, c.horizontal_scale);
+        ix = ix < 0 ? 0 : (ix > c.grid_rows - 2 ? c.grid_rows - 2 : ix);
+        iy = iy < 0 ? 0 : (iy > c.grid_cols - 2 ? c.grid_cols - 2 : iy);
+        LS_GLOBAL const int16_t* g = LSB(cx, LSIM_BUF_HEIGHT_GRID, const int16_t);
+        int16_t h1 = g[ix * c.grid_cols + iy], h2 = g[(ix + 1) * c.grid_cols + iy], h3 = g[ix * c.grid_cols + iy + 1];
+        int16_t h = h1 < h2 ? h1 : h2; h = h < h3 ? h : h3;
+        fh = pz - (float)h * c.vertical_scale;
     }
-    return acc;
-}
-LS_FN float ls_sum_abs_dev(const LsCtx& cx, const LsRewCtx& x, int first) {
-    float acc = 0.0f;
-    for (int l = 0; l < 4; ++l) { int j = 3 * l + first; acc += fabsf(x.dof[2 * j] - cx.cfg.default_dof_pos[j]); }
-    return acc;
+    float lat = sqrtf(bs[3] * bs[3] + bs[4] * bs[4]);
+    float d = fh - c.foot_height_target_terrain;
+    return lat * (d * d);
 }
 LS_FN float ls_stumble(const LsCtx& cx, const WaveShared& sh, int env, float ratio) {  // LR:1589-1608
     const lsim_config& c = cx.cfg;
@@ -242,10 +234,87 @@ LS_FN float ls_var12(const float* v) {
     return a / 11.0f;
 }
 
-// one `_reward_<name>()` (LR:1444-1770)
-LS_FN float ls_reward_term(const LsCtx& cx, WaveShared& sh, const LsRewCtx& x, int id, int env, int fct_shifts) {
+// part j of term id: one summand of the `_reward_<name>()` (LR:1444-1770)
+LS_FN float ls_reward_part(const LsCtx& cx, WaveShared& sh, const LsRewCtx& x, int id, int j, int env, int fct_shifts) {
     const lsim_config& c = cx.cfg;
     const float dt = c.sim_dt * (float)c.decimation;
+    switch (id) {
+        case LSIM_R_DOF_VEL: return x.dof[2 * j + 1] * x.dof[2 * j + 1];
+        case LSIM_R_DOF_ACC: { float a = (x.last_dof_vel[j] - x.dof[2 * j + 1]) / dt; return a * a; }
+        case LSIM_R_DOF_VEL_LIMITS: return clampf(fabsf(x.dof[2 * j + 1]) - cx.model.dof_vel_limit[j] * c.soft_dof_vel_limit, 0.0f, 1.0f);
+        case LSIM_R_DOF_POS_DIF: { float d = x.last_dof_pos[j] - x.dof[2 * j]; return d * d; }
+        case LSIM_R_DOF_POS_LIMITS: {
+            float lo = cx.model.dof_pos_lower[j], hi = cx.model.dof_pos_upper[j];
+            float m = (lo + hi) / 2.0f, r = hi - lo;
+            float slo = m - 0.5f * r * c.soft_dof_pos_limit, shi = m + 0.5f * r * c.soft_dof_pos_limit;
+            float q = x.dof[2 * j];
+            float o = -fminf(q - slo, 0.0f);
+            o += fmaxf(q - shi, 0.0f);
+            return o;
+        }
+        case LSIM_R_ACTION_RATE: { float d = x.last_act[j] - x.act[j]; return d * d; }
+        case LSIM_R_SMOOTHNESS: { float d = x.act[j] - x.last_act[j] - x.last_act[j] + x.last_last_act[j]; return d * d; }
+        case LSIM_R_TORQUES: return x.tau[j] * x.tau[j];
+        case LSIM_R_TORQUES_DISTRIBUTION: return fabsf(x.tau[j]);
+        case LSIM_R_TORQUES_DIF: { float d = x.tau[j] - x.last_tau[j]; return d * d; }
+        case LSIM_R_TORQUE_LIMITS: return fmaxf(fabsf(x.tau[j]) - c.torque_limits[j] * c.soft_torque_limit, 0.0f);
+        case LSIM_R_JOINT_POWER: return fabsf(x.dof[2 * j + 1]) * fabsf(x.tau[j]);
+        case LSIM_R_POWER: return fabsf(x.tau[j] * x.dof[2 * j + 1]);
+        case LSIM_R_POWER_DISTRIBUTION: return fabsf(x.tau[j] * x.dof[2 * j + 1]);
+        case LSIM_R_STAND_STILL:
+        case LSIM_R_STAND_NICE: return fabsf(x.dof[2 * j] - c.default_dof_pos[j]);
+        case LSIM_R_BASE_HEIGHT:
+        case LSIM_R_BASE_HEIGHT_UP: {
+            float s = 0.0f;
+            if (c.mesh_type != 0) for (int k = 0; k < LSIM_NUM_BASE_HEIGHT_PTS / LS_BH_PARTS; ++k) s += sh.bh[(LSIM_NUM_BASE_HEIGHT_PTS / LS_BH_PARTS) * j + k];
+            return s;
+        }
+        case LSIM_R_HIP_ACTION_MAGNITUDE: { float m = fmaxf(fabsf(x.act[3 * j]) - 1.0f, 0.0f); return m * m; }
+        case LSIM_R_HIP_POS: case LSIM_R_HIP_POS_UP: return fabsf(x.dof[2 * (3 * j)] - c.default_dof_pos[3 * j]);
+        case LSIM_R_THIGH_POSE: case LSIM_R_THIGH_POSE_UP: return fabsf(x.dof[2 * (3 * j + 1)] - c.default_dof_pos[3 * j + 1]);
+        case LSIM_R_CALF_POSE: case LSIM_R_CALF_POSE_UP: return fabsf(x.dof[2 * (3 * j + 2)] - c.default_dof_pos[3 * j + 2]);
+        case LSIM_R_FEET_AIR_TIME: {  // LR:1459-1470 (mutates last_contacts and feet_air_time)
+            // quirk 2: the reference recomputes contact | last_contacts here AFTER post_physics_step already set last_contacts = contact
+            // (LR:207-209), so the filter of this term is the raw contact flag and rewriting last_contacts changes nothing
+            const bool contact = sh.cf[cx.model.feet_bodies[j]][2] > 1.0f;
+            float a = sh.pre_air[j];
+            const float first = (a > 0.0f && contact) ? 1.0f : 0.0f;
+            a += dt;
+            LSB(cx, LSIM_BUF_FEET_AIR_TIME, float)[4 * env + j] = a * (contact ? 0.0f : 1.0f);
+            return (a - 0.5f) * first;
+        }
+        case LSIM_R_FEET_CONTACT_FORCES: { V3 F = v3p(sh.cf[cx.model.feet_bodies[j]]); return fmaxf(sqrtf(dot(F, F)) - c.max_contact_force, 0.0f); }
+        case LSIM_R_FEET_SLIDE: case LSIM_R_FEET_SLIDE_UP: return ls_foot_slide_part(cx, sh, x, false, j);
+        case LSIM_R_FOOT_CLEARANCE_BASE: case LSIM_R_FOOT_CLEARANCE_BASE_UP: return ls_foot_slide_part(cx, sh, x, true, j);
+        case LSIM_R_FOOT_CLEARANCE_TERRAIN: case LSIM_R_FOOT_CLEARANCE_TERRAIN_UP: return ls_foot_clearance_terrain_part(cx, sh, fct_shifts, j);
+        default: return 0.0f;
+    }
+}
+// a term with parts from its n parts p[0..n) (added in index order: the order of the reference's reductions)
+LS_FN float ls_reward_finish(const LsCtx& cx, const WaveShared& sh, int id, const float* p, int n) {
+    const lsim_config& c = cx.cfg;
+    if (id == LSIM_R_TORQUES_DISTRIBUTION || id == LSIM_R_POWER_DISTRIBUTION) return ls_var12(p);
+    float acc = 0.0f;
+    for (int j = 0; j < n; ++j) acc += p[j];
+    switch (id) {
+        case LSIM_R_BASE_HEIGHT:
+        case LSIM_R_BASE_HEIGHT_UP: {
+            const float bh = c.mesh_type == 0 ? sh.root[2] : acc / 63.0f;
+            const float d = bh - c.base_height_target;
+            return id == LSIM_R_BASE_HEIGHT ? d * d : d * d * ls_up(sh);
+        }
+        case LSIM_R_STAND_STILL: return acc * ((ls_cmd_norm(sh) < 0.1f) ? 1.0f : 0.0f);
+        case LSIM_R_STAND_NICE: return acc * ((ls_cmd_norm(sh) < 0.1f) ? 1.0f : 0.0f) * (1.0f - sh.grav[2]);
+        case LSIM_R_FEET_AIR_TIME: return acc * ((ls_cmd_norm(sh) > 0.1f) ? 1.0f : 0.0f);
+        case LSIM_R_HIP_POS_UP: case LSIM_R_THIGH_POSE_UP: case LSIM_R_CALF_POSE_UP: case LSIM_R_FEET_SLIDE_UP:
+        case LSIM_R_FOOT_CLEARANCE_BASE_UP: case LSIM_R_FOOT_CLEARANCE_TERRAIN_UP:
+            return acc * ls_up(sh);
+        default: return acc;
+    }
+}
+// a scalar `_reward_<name>()` (LR:1444-1770)
+LS_FN float ls_reward_scalar(const LsCtx& cx, WaveShared& sh, const LsRewCtx& x, int id, int env) {
+    const lsim_config& c = cx.cfg;
     float acc = 0.0f;
     switch (id) {
         case LSIM_R_TRACKING_LIN_VEL: {
@@ -254,22 +323,6 @@ LS_FN float ls_reward_term(const LsCtx& cx, WaveShared& sh, const LsRewCtx& x, i
             return expf(-(ex * ex + ey * ey) / c.tracking_sigma);
         }
         case LSIM_R_TRACKING_ANG_VEL: { float e = sh.cmd[2] - sh.bav[2]; return expf(-(e * e) / c.tracking_sigma); }
-        case LSIM_R_FEET_AIR_TIME: {  // LR:1459-1470 (mutates last_contacts and feet_air_time)
-            // quirk 2: the reference recomputes contact | last_contacts here AFTER post_physics_step already set last_contacts = contact
-            // (LR:207-209), so the filter of this term is the raw contact flag and rewriting last_contacts changes nothing
-            LS_GLOBAL float* air = LSB(cx, LSIM_BUF_FEET_AIR_TIME, float) + 4 * env;
-            float r = 0.0f;
-            for (int f = 0; f < 4; ++f) {
-                const bool contact = sh.cf[cx.model.feet_bodies[f]][2] > 1.0f;
-                float a = sh.pre_air[f];
-                float first = (a > 0.0f && contact) ? 1.0f : 0.0f;
-                a += dt;
-                r += (a - 0.5f) * first;
-                air[f] = a * (contact ? 0.0f : 1.0f);
-            }
-            r *= (ls_cmd_norm(sh) > 0.1f) ? 1.0f : 0.0f;
-            return r;
-        }
         case LSIM_R_UPWARD: return 1.0f - sh.grav[2];
         case LSIM_R_HAS_CONTACT: {
             float n = 0.0f;
@@ -282,55 +335,14 @@ LS_FN float ls_reward_term(const LsCtx& cx, WaveShared& sh, const LsRewCtx& x, i
         case LSIM_R_ANG_VEL_XY_UP: return (sh.bav[0] * sh.bav[0] + sh.bav[1] * sh.bav[1]) * ls_up(sh);
         case LSIM_R_ORIENTATION: return sh.grav[0] * sh.grav[0] + sh.grav[1] * sh.grav[1];
         case LSIM_R_ORIENTATION_UP: return (sh.grav[0] * sh.grav[0] + sh.grav[1] * sh.grav[1]) * ls_up(sh);
-        case LSIM_R_BASE_HEIGHT:
-        case LSIM_R_BASE_HEIGHT_UP: {
-            float bh;
-            if (c.mesh_type == 0) bh = sh.root[2];
-            else { float s = 0.0f; for (int k = 0; k < LSIM_NUM_BASE_HEIGHT_PTS; ++k) s += sh.bh[k]; bh = s / 63.0f; }
-            float d = bh - c.base_height_target;
-            return id == LSIM_R_BASE_HEIGHT ? d * d : d * d * ls_up(sh);
-        }
-        case LSIM_R_DOF_VEL: for (int j = 0; j < 12; ++j) acc += x.dof[2 * j + 1] * x.dof[2 * j + 1]; return acc;
-        case LSIM_R_DOF_ACC: for (int j = 0; j < 12; ++j) { float a = (x.last_dof_vel[j] - x.dof[2 * j + 1]) / dt; acc += a * a; } return acc;
-        case LSIM_R_DOF_VEL_LIMITS:
-            for (int j = 0; j < 12; ++j) acc += clampf(fabsf(x.dof[2 * j + 1]) - cx.model.dof_vel_limit[j] * c.soft_dof_vel_limit, 0.0f, 1.0f);
-            return acc;
-        case LSIM_R_DOF_POS_DIF: for (int j = 0; j < 12; ++j) { float d = x.last_dof_pos[j] - x.dof[2 * j]; acc += d * d; } return acc;
-        case LSIM_R_DOF_POS_LIMITS:
-            for (int j = 0; j < 12; ++j) {
-                float lo = cx.model.dof_pos_lower[j], hi = cx.model.dof_pos_upper[j];
-                float m = (lo + hi) / 2.0f, r = hi - lo;
-                float slo = m - 0.5f * r * c.soft_dof_pos_limit, shi = m + 0.5f * r * c.soft_dof_pos_limit;
-                float q = x.dof[2 * j];
-                float o = -fminf(q - slo, 0.0f);
-                o += fmaxf(q - shi, 0.0f);
-                acc += o;
-            }
-            return acc;
-        case LSIM_R_ACTION_RATE: for (int j = 0; j < 12; ++j) { float d = x.last_act[j] - x.act[j]; acc += d * d; } return acc;
-        case LSIM_R_SMOOTHNESS:
-            for (int j = 0; j < 12; ++j) { float d = x.act[j] - x.last_act[j] - x.last_act[j] + x.last_last_act[j]; acc += d * d; }
-            return acc;
-        case LSIM_R_TORQUES: for (int j = 0; j < 12; ++j) acc += x.tau[j] * x.tau[j]; return acc;
-        case LSIM_R_TORQUES_DISTRIBUTION: { float v[12]; for (int j = 0; j < 12; ++j) v[j] = fabsf(x.tau[j]); return ls_var12(v); }
-        case LSIM_R_TORQUES_DIF: for (int j = 0; j < 12; ++j) { float d = x.tau[j] - x.last_tau[j]; acc += d * d; } return acc;
-        case LSIM_R_TORQUE_LIMITS: for (int j = 0; j < 12; ++j) acc += fmaxf(fabsf(x.tau[j]) - c.torque_limits[j] * c.soft_torque_limit, 0.0f); return acc;
-        case LSIM_R_JOINT_POWER: for (int j = 0; j < 12; ++j) acc += fabsf(x.dof[2 * j + 1]) * fabsf(x.tau[j]); return acc;
-        case LSIM_R_POWER: for (int j = 0; j < 12; ++j) acc += fabsf(x.tau[j] * x.dof[2 * j + 1]); return acc;
-        case LSIM_R_POWER_DISTRIBUTION: { float v[12]; for (int j = 0; j < 12; ++j) v[j] = fabsf(x.tau[j] * x.dof[2 * j + 1]); return ls_var12(v); }
         case LSIM_R_COLLISION:
         case LSIM_R_COLLISION_UP:
             for (int b = 0; b < LS_NB; ++b)
                 if ((cx.model.penalised_body_mask >> b) & 1u) { V3 f = v3p(sh.cf[b]); acc += (sqrtf(dot(f, f)) > 0.1f) ? 1.0f : 0.0f; }
             return id == LSIM_R_COLLISION ? acc : acc * ls_up(sh);
         case LSIM_R_TERMINATION: return (sh.reset && !sh.timeout) ? 1.0f : 0.0f;
-        case LSIM_R_FEET_CONTACT_FORCES:
-            for (int f = 0; f < 4; ++f) { V3 F = v3p(sh.cf[cx.model.feet_bodies[f]]); acc += fmaxf(sqrtf(dot(F, F)) - c.max_contact_force, 0.0f); }
-            return acc;
         case LSIM_R_FEET_STUMBLE: return ls_stumble(cx, sh, env, 5.0f);
         case LSIM_R_FEET_STUMBLE_UP: return ls_stumble(cx, sh, env, 4.0f) * ls_up(sh);
-        case LSIM_R_FEET_SLIDE: return ls_foot_slide_like(cx, sh, x, false);
-        case LSIM_R_FEET_SLIDE_UP: return ls_foot_slide_like(cx, sh, x, false) * ls_up(sh);
         case LSIM_R_FEET_MIRROR:
         case LSIM_R_FEET_MIRROR_UP: {
             const float* d = x.dof;
@@ -338,31 +350,12 @@ LS_FN float ls_reward_term(const LsCtx& cx, WaveShared& sh, const LsRewCtx& x, i
             float r = 0.5f * ((a1 * a1 + a2 * a2) + (b1 * b1 + b2 * b2));
             return id == LSIM_R_FEET_MIRROR ? r : r * ls_up(sh);
         }
-        case LSIM_R_STAND_STILL:
-        case LSIM_R_STAND_NICE:
-            for (int j = 0; j < 12; ++j) acc += fabsf(x.dof[2 * j] - c.default_dof_pos[j]);
-            acc *= (ls_cmd_norm(sh) < 0.1f) ? 1.0f : 0.0f;
-            return id == LSIM_R_STAND_STILL ? acc : acc * (1.0f - sh.grav[2]);
         case LSIM_R_STUCK: return ((fabsf(sh.blv[0]) < 0.1f) && (fabsf(sh.cmd[0]) > 0.1f)) ? 1.0f : 0.0f;
-        case LSIM_R_HIP_ACTION_MAGNITUDE: for (int l = 0; l < 4; ++l) { float m = fmaxf(fabsf(x.act[3 * l]) - 1.0f, 0.0f); acc += m * m; } return acc;
-        case LSIM_R_HIP_POS: return ls_sum_abs_dev(cx, x, 0);
-        case LSIM_R_HIP_POS_UP: return ls_sum_abs_dev(cx, x, 0) * ls_up(sh);
-        case LSIM_R_THIGH_POSE: return ls_sum_abs_dev(cx, x, 1);
-        case LSIM_R_THIGH_POSE_UP: return ls_sum_abs_dev(cx, x, 1) * ls_up(sh);
-        case LSIM_R_CALF_POSE: return ls_sum_abs_dev(cx, x, 2);
-        case LSIM_R_CALF_POSE_UP: return ls_sum_abs_dev(cx, x, 2) * ls_up(sh);
-        case LSIM_R_FOOT_CLEARANCE_BASE: return ls_foot_slide_like(cx, sh, x, true);
-        case LSIM_R_FOOT_CLEARANCE_BASE_UP: return ls_foot_slide_like(cx, sh, x, true) * ls_up(sh);
-        case LSIM_R_FOOT_CLEARANCE_TERRAIN: return ls_foot_clearance_terrain(cx, sh, fct_shifts);
-        case LSIM_R_FOOT_CLEARANCE_TERRAIN_UP: return ls_foot_clearance_terrain(cx, sh, fct_shifts) * ls_up(sh);
         default: return 0.0f;
     }
 }
 
-// ---- Q5: compute_reward (LR:363-380).  Lane i evaluates active term i; lane 0 then accumulates in the reference's order.
-LS_FN void ph_reward_terms(const LsCtx& cx, WaveShared& sh, int lane, int env) {
-    if (lane >= cx.num_active) return;
-    const int id = cx.active_terms[lane];
+LS_FN LsRewCtx ls_rew_ctx(const WaveShared& sh) {
     LsRewCtx x;
     x.dof = sh.dofs;
     x.act = sh.act;
@@ -373,10 +366,40 @@ LS_FN void ph_reward_terms(const LsCtx& cx, WaveShared& sh, int lane, int env) {
     x.tau = sh.tau;
     x.last_tau = sh.pre_ltau;
     x.filt = sh.filt;
-    // quirk 3: each earlier active foot_clearance_terrain* term has already shifted self.feet_pos by +border
-    int shifts = 1;
-    if (id == LSIM_R_FOOT_CLEARANCE_TERRAIN_UP && cx.cfg.reward_scales[LSIM_R_FOOT_CLEARANCE_TERRAIN] != 0.0f) shifts = 2;
-    float v = ls_reward_term(cx, sh, x, id, env, shifts) * cx.cfg.reward_scales[id];
+    return x;
+}
+// quirk 3: each earlier active foot_clearance_terrain* term has already shifted self.feet_pos by +border
+LS_FN int ls_fct_shifts(const LsCtx& cx, int id) {
+    return (id == LSIM_R_FOOT_CLEARANCE_TERRAIN_UP && cx.cfg.reward_scales[LSIM_R_FOOT_CLEARANCE_TERRAIN] != 0.0f) ? 2 : 1;
+}
+// ---- Q5a: the parts of the terms that have them.  Item = (term id << 10) | (term's index in the active list << 4) | part, built by the host
+//      (ls_api_impl.h) and staged in LDS by ph_load_a; same-term items are neighbours, so a pass of 64 lanes runs only a few term bodies.
+LS_FN void ph_reward_parts(const LsCtx& cx, WaveShared& sh, int lane, int env) {
+    const LsRewCtx x = ls_rew_ctx(sh);
+    for (int it = 0; it < (LS_MAX_PART_ITEMS + 63) / 64; ++it) {
+        const int k = lane + 64 * it;
+        if (64 * it >= cx.num_part_items) break;
+        if (k >= cx.num_part_items) continue;
+        const int item = sh.items[k];
+        const int id = item >> 10, ai = (item >> 4) & 63, j = item & 15;
+        sh.u.r.rj[ai][j] = ls_reward_part(cx, sh, x, id, j, env, ls_fct_shifts(cx, id));
+    }
+}
+// ---- Q5b: compute_reward (LR:363-380).  Lane i owns active term i; lane 0 then accumulates in the reference's order.
+LS_FN void ph_reward_terms(const LsCtx& cx, WaveShared& sh, int lane, int env) {
+    if (lane >= cx.num_active) return;
+    const int id = cx.active_terms[lane];
+    const LsRewCtx x = ls_rew_ctx(sh);
+    const int n = ls_reward_num_parts(id);
+    float v;
+    if (n == 0) v = ls_reward_scalar(cx, sh, x, id, env);
+    else {
+        float* p = sh.u.r.rj[lane];
+        if (!((cx.parted_mask >> lane) & 1ull))      // more parts than the item table holds (every term switched on): this lane does its own
+            for (int j = 0; j < n; ++j) p[j] = ls_reward_part(cx, sh, x, id, j, env, ls_fct_shifts(cx, id));
+        v = ls_reward_finish(cx, sh, id, p, n);
+    }
+    v *= cx.cfg.reward_scales[id];
     sh.rewv[lane] = v;
     const float es = sh.pre_es[id] + v;
     sh.pre_es[id] = es;

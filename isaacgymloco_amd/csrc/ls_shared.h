@@ -17,6 +17,28 @@
 #define LS_MAXC LSIM_MAX_CONTACTS
 #define LS_MAXR (3 * LSIM_MAX_CONTACTS + LSIM_NUM_DOF)  // 60 <= 64 lanes
 
+#define LS_MAX_PART_ITEMS 192          // three passes of 64 lanes
+#define LS_REW_MAX_PARTS 12
+#define LS_BH_PARTS 9                // the 63 base-height samples: 9 parts of 7
+// number of parts of a term; 0 = a scalar term (ls_reward_scalar)
+LS_FN int ls_reward_num_parts(int id) {
+    switch (id) {
+        case LSIM_R_DOF_VEL: case LSIM_R_DOF_ACC: case LSIM_R_DOF_VEL_LIMITS: case LSIM_R_DOF_POS_DIF: case LSIM_R_DOF_POS_LIMITS:
+        case LSIM_R_ACTION_RATE: case LSIM_R_SMOOTHNESS: case LSIM_R_TORQUES: case LSIM_R_TORQUES_DISTRIBUTION: case LSIM_R_TORQUES_DIF:
+        case LSIM_R_TORQUE_LIMITS: case LSIM_R_JOINT_POWER: case LSIM_R_POWER: case LSIM_R_POWER_DISTRIBUTION:
+        case LSIM_R_STAND_STILL: case LSIM_R_STAND_NICE:
+            return 12;
+        case LSIM_R_BASE_HEIGHT: case LSIM_R_BASE_HEIGHT_UP:
+            return LS_BH_PARTS;
+        case LSIM_R_HIP_ACTION_MAGNITUDE:
+        case LSIM_R_HIP_POS: case LSIM_R_HIP_POS_UP: case LSIM_R_THIGH_POSE: case LSIM_R_THIGH_POSE_UP: case LSIM_R_CALF_POSE: case LSIM_R_CALF_POSE_UP:
+        case LSIM_R_FEET_AIR_TIME: case LSIM_R_FEET_CONTACT_FORCES: case LSIM_R_FEET_SLIDE: case LSIM_R_FEET_SLIDE_UP:
+        case LSIM_R_FOOT_CLEARANCE_BASE: case LSIM_R_FOOT_CLEARANCE_BASE_UP: case LSIM_R_FOOT_CLEARANCE_TERRAIN: case LSIM_R_FOOT_CLEARANCE_TERRAIN_UP:
+            return 4;
+        default: return 0;
+    }
+}
+
 // constant per simulator instance; lives in device global memory, read through uniform (scalar) loads
 struct LsCtx {
     lsim_config cfg;
@@ -25,6 +47,10 @@ struct LsCtx {
     float* accum;                     // [2][LSIM_STATS_SIZE] ping-pong per-step reductions (== buf[LSIM_BUF_STATS])
     int32_t active_terms[LSIM_NUM_REWARD_TERMS];
     int32_t num_active;
+    // (term, part) work items of the reward terms that are sums (ls_post.h: ph_reward_parts): (id << 10) | (active index << 4) | part
+    uint16_t part_items[LS_MAX_PART_ITEMS];
+    int32_t num_part_items;
+    uint64_t parted_mask;             // bit i: the parts of active term i are in the item table
     float cmd_span_init[4];
 };
 
@@ -62,6 +88,7 @@ struct WaveShared {
     unsigned int pre_lc;                                         // last_contacts: 4 bytes
     float pre_es[LSIM_NUM_REWARD_TERMS];                         // episode_sums row
     unsigned char filt[4];                                       // contact_filt of this step (LR:207-209)
+    uint16_t items[LS_MAX_PART_ITEMS];                           // LsCtx::part_items
     // ---- kinematics / dynamics of the current sub-step (world axes, positions relative to the base origin), overlaid
     //      with the post-physics scratch that is only used once the last sub-step is over (keeps the block <= 10 KB so
     //      that 16 robots per CU -- all 4096 of a 256-CU launch -- are resident at once)
@@ -92,6 +119,7 @@ struct WaveShared {
             float Y[LS_MAXR][LS_NV];
             float dirs[3 * LS_MAXC][3];      // contact rows only
         } c;
+        struct { float rj[LSIM_NUM_REWARD_TERMS][12]; } r;   // post-physics: parts of the reward terms (ls_post.h)
     } u;
     float Mbl[4][18];        // 6x3: columns F_hip, F_thigh, F_calf
     float G[4][18];          // 3x6: Mll^-1 Mlb^T
