@@ -747,36 +747,47 @@ template <int K0> __device__ __forceinline__ void ls_pgs_contacts(int nc, const 
         }
     }
 }
+// joint-limit rows come in triples (wc_limits gives all three joints of a leg their rows together): one branch per leg
 template <int I0> __device__ __forceinline__ void ls_pgs_limits(int nlim, const float (&W)[LS_MAXR], float (&sl)[LS_MAXR], float inv_d, float neg_rng_d, float& w) {
     if constexpr (I0 < LSIM_NUM_DOF) {
         if (I0 < nlim) {
             ls_pgs_row<LS_LIM0 + I0, LS_ROW_LIMIT>(W, sl, 0.0f, inv_d, neg_rng_d, w);
-            ls_pgs_limits<I0 + 1>(nlim, W, sl, inv_d, neg_rng_d, w);
+            ls_pgs_row<LS_LIM0 + I0 + 1, LS_ROW_LIMIT>(W, sl, 0.0f, inv_d, neg_rng_d, w);
+            ls_pgs_row<LS_LIM0 + I0 + 2, LS_ROW_LIMIT>(W, sl, 0.0f, inv_d, neg_rng_d, w);
+            ls_pgs_limits<I0 + 3>(nlim, W, sl, inv_d, neg_rng_d, w);
         }
     }
 }
 // the scalar impulses back into lane R's register (slots J0 .. END-1 while J0 < cnt)
 template <int J0, int END> __device__ __forceinline__ void ls_pgs_collect(int cnt, const float (&sl)[LS_MAXR], float& lam) {
     if constexpr (J0 < END) {
-        if (J0 < cnt) {
-            ls_writelane<J0>(lam, sl[J0]);
-            ls_pgs_collect<J0 + 1, END>(cnt, sl, lam);
+        if (J0 < cnt) {      // slots come in threes (a contact's rows, a leg's limit rows)
+            ls_writelane<J0>(lam, sl[J0]); ls_writelane<J0 + 1>(lam, sl[J0 + 1]); ls_writelane<J0 + 2>(lam, sl[J0 + 2]);
+            ls_pgs_collect<J0 + 3, END>(cnt, sl, lam);
         }
     }
 }
 // W[j] = a_lane . z_j + Jl_lane . y_j[leg_lane] for slots j = J0 .. END-1 while j < cnt (compile-time recursion; the active slots of a
 // range are contiguous); y_j is zero on every leg but row j's own, so no leg comparison is needed
+template <int J0> __device__ __forceinline__ void ls_delassus_row(const WaveShared& sh, int lane, int lo, const float (&jb)[6], float jl0, float jl1, float jl2,
+                                                                  float (&W)[LS_MAXR], float& wd) {
+    const float* Y = sh.u.c.Y[J0];
+    float w = 0.0f;
+    for (int k = 0; k < 6; ++k) w += jb[k] * Y[k];
+    w += jl0 * Y[lo] + jl1 * Y[lo + 1] + jl2 * Y[lo + 2];
+    if (J0 == lane) { w += 1e-6f; wd = w; }   // constraint-force mixing keeps the diagonal positive
+    W[J0] = w;
+}
+// three slots per branch (a contact's rows, a leg's limit rows: the slot counts are multiples of three), so that the LDS reads of three
+// rows are in flight together instead of one round trip per row
 template <int J0, int END> __device__ __forceinline__ void ls_delassus_rows(const WaveShared& sh, int cnt, int lane, int lo, const float (&jb)[6],
                                                                            float jl0, float jl1, float jl2, float (&W)[LS_MAXR], float& wd) {
     if constexpr (J0 < END) {
         if (J0 < cnt) {
-            const float* Y = sh.u.c.Y[J0];
-            float w = 0.0f;
-            for (int k = 0; k < 6; ++k) w += jb[k] * Y[k];
-            w += jl0 * Y[lo] + jl1 * Y[lo + 1] + jl2 * Y[lo + 2];
-            if (J0 == lane) { w += 1e-6f; wd = w; }   // constraint-force mixing keeps the diagonal positive
-            W[J0] = w;
-            ls_delassus_rows<J0 + 1, END>(sh, cnt, lane, lo, jb, jl0, jl1, jl2, W, wd);
+            ls_delassus_row<J0>(sh, lane, lo, jb, jl0, jl1, jl2, W, wd);
+            ls_delassus_row<J0 + 1>(sh, lane, lo, jb, jl0, jl1, jl2, W, wd);
+            ls_delassus_row<J0 + 2>(sh, lane, lo, jb, jl0, jl1, jl2, W, wd);
+            ls_delassus_rows<J0 + 3, END>(sh, cnt, lane, lo, jb, jl0, jl1, jl2, W, wd);
         }
     }
 }
