@@ -1,6 +1,6 @@
 // ls_policy.h -- fused rollout-time forward of the HIM policy (include/lsim.h, lsim_policy_forward): estimator encoder
 // (history -> velocity + latent), L2-normalise, actor, critic -- eleven Linear layers, eight ELUs and the glue between them in ONE
-// kernel instead of 29 launches (HAC:136-163, HES:64-68).  A workgroup owns 16 environments; activations never leave LDS.
+// kernel instead of 29 launches (HAC:136-163, HES:64-68).  A workgroup owns 32 environments (16 for small batches); activations never leave LDS.
 //
 // Layer = Y[16 x N] = act(X[16 x K] W^T + b) on v_mfma_f32_16x16x4_f32 with A = W tile (16 outputs x 4 k) read straight from
 // global memory (the weights, 2.2 MB, stay L2 resident) and B = X (4 k x 16 rows) from LDS.  Both operands are fetched as 16-byte
@@ -11,9 +11,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#define LS_POL_ROWS 16
-#define LS_POL_WAVES 8            // 512 threads: <= 4 output tiles per wave keeps the layer routine under 128 VGPRs (2 blocks per CU)
-#define LS_POL_PAD 4              // floats of row padding in LDS (spreads the 16 rows over the banks)
+#define LS_POL_PAD 4              // floats of row padding in LDS (spreads the rows over the banks)
 #define LS_POL_MAX_HIDDEN 512
 #define LS_POL_MAX_IN 272
 
@@ -21,19 +19,22 @@ extern __shared__ float ls_pol_lds[];
 
 __device__ __forceinline__ float ls_elu(float x) { return x > 0.0f ? x : expm1f(x); }
 
-// one layer for this wave's NTW output tiles [tile0, tile0 + valid)
-template <int NTW>
+// one layer for this wave's NTW output tiles [tile0, tile0 + valid) and all RH * 16 rows of the block: every weight vector fetched from
+// L2 feeds RH MFMAs (one per 16-row half), so a block of 32 environments streams half the weight bytes per environment of a block of 16
+template <int NTW, int RH>
 __device__ __noinline__ void ls_pol_layer(const float* __restrict__ W, const float* __restrict__ bias, int k_pad, int x_off, int x_stride,
                                           int y_off, int y_stride, int tile0, int valid, int elu, int lane) {
     const int i = lane & 15, q = lane >> 4;
-    ls_v4f acc[NTW];
+    ls_v4f acc[NTW][RH];
 #pragma unroll
-    for (int t = 0; t < NTW; ++t) acc[t] = (ls_v4f){0.0f, 0.0f, 0.0f, 0.0f};
+    for (int t = 0; t < NTW; ++t)
+#pragma unroll
+        for (int h = 0; h < RH; ++h) acc[t][h] = (ls_v4f){0.0f, 0.0f, 0.0f, 0.0f};
     if (valid > 0) {
-        const float* xrow = ls_pol_lds + x_off + i * x_stride + 4 * q;            // B operand: row i of the tile, k group q
+        const float* xrow = ls_pol_lds + x_off + i * x_stride + 4 * q;            // B operand: row i (+ 16 h) of the block, k group q
         const float* wrow = W + (size_t)(tile0 * 16 + i) * k_pad + 4 * q;         // A operand: output tile0*16 + i, k group q
         // weight vectors of the current k chunk and of the next two (register triple buffer: the loads issued in an iteration are
-        // consumed two iterations later; a block keeps only one or two waves per SIMD, so this is what hides the L2 latency)
+        // consumed two iterations later; a block keeps only a few waves per SIMD, so this is what hides the L2 latency)
         float4 w0[NTW], w1[NTW], w2[NTW];
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
@@ -47,14 +48,19 @@ __device__ __noinline__ void ls_pol_layer(const float* __restrict__ W, const flo
                 for (int t = 0; t < NTW; ++t)
                     if (t < valid) w2[t] = *(const float4*)(wrow + (size_t)t * 16 * k_pad + kc + 32);
             }
-            const float4 x = *(const float4*)(xrow + kc);
+            float4 x[RH];
+#pragma unroll
+            for (int h = 0; h < RH; ++h) x[h] = *(const float4*)(xrow + 16 * h * x_stride + kc);
 #pragma unroll
             for (int t = 0; t < NTW; ++t) {
                 if (t < valid) {
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[t].x, x.x, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[t].y, x.y, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[t].z, x.z, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[t].w, x.w, acc[t], 0, 0, 0);
+#pragma unroll
+                    for (int h = 0; h < RH; ++h) {
+                        acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[t].x, x[h].x, acc[t][h], 0, 0, 0);
+                        acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[t].y, x[h].y, acc[t][h], 0, 0, 0);
+                        acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[t].z, x[h].z, acc[t][h], 0, 0, 0);
+                        acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[t].w, x[h].w, acc[t][h], 0, 0, 0);
+                    }
                 }
             }
 #pragma unroll
@@ -64,64 +70,73 @@ __device__ __noinline__ void ls_pol_layer(const float* __restrict__ W, const flo
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
         if (t < valid) {
-            const int n = (tile0 + t) * 16 + 4 * q;                               // D[n .. n+3][row i]
+            const int n = (tile0 + t) * 16 + 4 * q;                               // D[n .. n+3][row i + 16 h]
             const float4 b = *(const float4*)(bias + n);
-            float4 y = make_float4(acc[t][0] + b.x, acc[t][1] + b.y, acc[t][2] + b.z, acc[t][3] + b.w);
-            if (elu) { y.x = ls_elu(y.x); y.y = ls_elu(y.y); y.z = ls_elu(y.z); y.w = ls_elu(y.w); }
-            *(float4*)(ls_pol_lds + y_off + i * y_stride + n) = y;
+#pragma unroll
+            for (int h = 0; h < RH; ++h) {
+                float4 y = make_float4(acc[t][h][0] + b.x, acc[t][h][1] + b.y, acc[t][h][2] + b.z, acc[t][h][3] + b.w);
+                if (elu) { y.x = ls_elu(y.x); y.y = ls_elu(y.y); y.z = ls_elu(y.z); y.w = ls_elu(y.w); }
+                *(float4*)(ls_pol_lds + y_off + (i + 16 * h) * y_stride + n) = y;
+            }
         }
     }
 }
 
+template <int ROWS, int WAVES>
 __device__ __forceinline__ void ls_pol_run_layer(const lsim_mlp_layer& L, int x_off, int x_stride, int y_off, int y_stride, int elu, int wave, int lane) {
+    constexpr int RH = ROWS / 16;
     const int tiles = L.n_pad >> 4;
-    const int per = (tiles + LS_POL_WAVES - 1) / LS_POL_WAVES;                 // output tiles per wave (<= 4 for 512-wide layers)
+    const int per = (tiles + WAVES - 1) / WAVES;                               // output tiles per wave
     const int tile0 = wave * per;
     int valid = tiles - tile0;
     if (valid > per) valid = per;
     if (valid < 0) valid = 0;
-    if (per > 2) ls_pol_layer<4>(L.weight, L.bias, L.k_pad, x_off, x_stride, y_off, y_stride, tile0, valid, elu, lane);
-    else if (per > 1) ls_pol_layer<2>(L.weight, L.bias, L.k_pad, x_off, x_stride, y_off, y_stride, tile0, valid, elu, lane);
-    else ls_pol_layer<1>(L.weight, L.bias, L.k_pad, x_off, x_stride, y_off, y_stride, tile0, valid, elu, lane);
+    if constexpr (32 / WAVES > 2) { if (per > 2) { ls_pol_layer<4, RH>(L.weight, L.bias, L.k_pad, x_off, x_stride, y_off, y_stride, tile0, valid, elu, lane); __syncthreads(); return; } }
+    if (per > 1) ls_pol_layer<2, RH>(L.weight, L.bias, L.k_pad, x_off, x_stride, y_off, y_stride, tile0, valid, elu, lane);
+    else ls_pol_layer<1, RH>(L.weight, L.bias, L.k_pad, x_off, x_stride, y_off, y_stride, tile0, valid, elu, lane);
     __syncthreads();
 }
 
-__global__ __launch_bounds__(64 * LS_POL_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void lsim_k_policy_forward(lsim_him_policy p, const float* __restrict__ obs, const float* __restrict__ priv,
+// ROWS environments per workgroup of WAVES waves: (16, 8) -- two blocks per CU, 68 KB of LDS each -- or (32, 16): one block per CU (137 KB),
+// the same four waves per SIMD, half the weight traffic per environment
+template <int ROWS, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void lsim_k_policy_forward(lsim_him_policy p, const float* __restrict__ obs, const float* __restrict__ priv,
                                                              long num_envs, float* __restrict__ mean_out, float* __restrict__ values_out) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long r0 = (long)blockIdx.x * LS_POL_ROWS;
+    const long r0 = (long)blockIdx.x * ROWS;
     // blockIdx.y = 0: estimator encoder + actor on the observation history; 1: critic on the privileged observation.  The two halves are
-    // independent, so a CU hosts one block of each (2 x ~67 KB of LDS): twice the waves per SIMD and half the serial layer chain.
+    // independent: separate blocks halve the serial layer chain.
     // LDS map (floats): input rows | buffer A (<= 512 wide) | buffer B (<= 272 wide)
     const bool critic = blockIdx.y != 0;
     const lsim_mlp_layer& first = critic ? p.critic[0] : p.encoder[0];
     const int n_in = critic ? p.num_priv_obs : p.num_obs;
     const float* __restrict__ src = critic ? priv : obs;
     const int s_in = first.k_pad + LS_POL_PAD, s_a = LS_POL_MAX_HIDDEN + LS_POL_PAD, s_b = LS_POL_MAX_IN + LS_POL_PAD;
-    const int o_in = 0, o_a = o_in + LS_POL_ROWS * (LS_POL_MAX_IN + LS_POL_PAD), o_b = o_a + LS_POL_ROWS * s_a;
-    for (int e = tid; e < LS_POL_ROWS * first.k_pad; e += 64 * LS_POL_WAVES) {
+    const int o_in = 0, o_a = o_in + ROWS * (LS_POL_MAX_IN + LS_POL_PAD), o_b = o_a + ROWS * s_a;
+    for (int e = tid; e < ROWS * first.k_pad; e += 64 * WAVES) {
         const int r = e / first.k_pad, c = e - r * first.k_pad;
         const long env = r0 + r;
         ls_pol_lds[o_in + r * s_in + c] = (env < num_envs && c < n_in) ? src[env * n_in + c] : 0.0f;
     }
     __syncthreads();
+#define LS_RUN(L, XO, XS, YO, YS, ELU) ls_pol_run_layer<ROWS, WAVES>(L, XO, XS, YO, YS, ELU, wave, lane)
     if (critic) {
         // ---- critic (HAC:82-95)
-        ls_pol_run_layer(p.critic[0], o_in, s_in, o_a, s_a, 1, wave, lane);
-        ls_pol_run_layer(p.critic[1], o_a, s_a, o_b, s_b, 1, wave, lane);
-        ls_pol_run_layer(p.critic[2], o_b, s_b, o_a, s_a, 1, wave, lane);
-        ls_pol_run_layer(p.critic[3], o_a, s_a, o_b, s_b, 0, wave, lane);
-        if (tid < LS_POL_ROWS && r0 + tid < num_envs) values_out[r0 + tid] = ls_pol_lds[o_b + tid * s_b];
+        LS_RUN(p.critic[0], o_in, s_in, o_a, s_a, 1);
+        LS_RUN(p.critic[1], o_a, s_a, o_b, s_b, 1);
+        LS_RUN(p.critic[2], o_b, s_b, o_a, s_a, 1);
+        LS_RUN(p.critic[3], o_a, s_a, o_b, s_b, 0);
+        if (tid < ROWS && r0 + tid < num_envs) values_out[r0 + tid] = ls_pol_lds[o_b + tid * s_b];
         return;
     }
     // ---- estimator encoder (HES:64-68): history -> (velocity 3, latent 16)
-    ls_pol_run_layer(p.encoder[0], o_in, s_in, o_a, s_a, 1, wave, lane);
-    ls_pol_run_layer(p.encoder[1], o_a, s_a, o_b, s_b, 1, wave, lane);
-    ls_pol_run_layer(p.encoder[2], o_b, s_b, o_a, s_a, 0, wave, lane);
+    LS_RUN(p.encoder[0], o_in, s_in, o_a, s_a, 1);
+    LS_RUN(p.encoder[1], o_a, s_a, o_b, s_b, 1);
+    LS_RUN(p.encoder[2], o_b, s_b, o_a, s_a, 0);
     // ---- actor input (HAC:136-141): [current one-step observation, velocity estimate, L2-normalised latent] -> buffer B
     {
         const int n1 = p.num_one_step_obs, nl = p.encoder[2].n_out - 3, kin = p.actor[0].k_pad;
-        for (int e = tid; e < LS_POL_ROWS * kin; e += 64 * LS_POL_WAVES) {
+        for (int e = tid; e < ROWS * kin; e += 64 * WAVES) {
             const int r = e / kin, c = e - r * kin;
             float v = 0.0f;
             if (c < n1) v = ls_pol_lds[o_in + r * s_in + c];
@@ -136,11 +151,12 @@ __global__ __launch_bounds__(64 * LS_POL_WAVES) __attribute__((amdgpu_waves_per_
         __syncthreads();
     }
     // ---- actor (HAC:66-80)
-    ls_pol_run_layer(p.actor[0], o_b, s_b, o_a, s_a, 1, wave, lane);
-    ls_pol_run_layer(p.actor[1], o_a, s_a, o_b, s_b, 1, wave, lane);
-    ls_pol_run_layer(p.actor[2], o_b, s_b, o_a, s_a, 1, wave, lane);
-    ls_pol_run_layer(p.actor[3], o_a, s_a, o_b, s_b, 0, wave, lane);
-    for (int e = tid; e < LS_POL_ROWS * p.num_actions; e += 64 * LS_POL_WAVES) {
+    LS_RUN(p.actor[0], o_b, s_b, o_a, s_a, 1);
+    LS_RUN(p.actor[1], o_a, s_a, o_b, s_b, 1);
+    LS_RUN(p.actor[2], o_b, s_b, o_a, s_a, 1);
+    LS_RUN(p.actor[3], o_a, s_a, o_b, s_b, 0);
+#undef LS_RUN
+    for (int e = tid; e < ROWS * p.num_actions; e += 64 * WAVES) {
         const int r = e / p.num_actions, c = e - r * p.num_actions;
         if (r0 + r < num_envs) mean_out[(r0 + r) * p.num_actions + c] = ls_pol_lds[o_b + r * s_b + c];
     }
@@ -171,15 +187,20 @@ extern "C" int lsim_policy_forward(const lsim_him_policy* p, const float* obs, c
     if (p->encoder[1].n_pad > LS_POL_MAX_IN || p->actor[1].n_pad > LS_POL_MAX_IN || p->actor[3].n_pad > LS_POL_MAX_IN ||
         p->critic[1].n_pad > LS_POL_MAX_IN || p->critic[3].n_pad > LS_POL_MAX_IN) bad = 1;
     if (bad) return LSIM_E_UNSUPPORTED;
-    const size_t lds = (size_t)LS_POL_ROWS * (2 * (LS_POL_MAX_IN + LS_POL_PAD) + (LS_POL_MAX_HIDDEN + LS_POL_PAD)) * sizeof(float);
-    static size_t configured[64] = {0};          // per device: the attribute belongs to the device's copy of the kernel
+    // 32 environments per block once that still fills the chip's 256 CUs with one block each; 16 per block (two blocks per CU) below that
+    const bool wide = num_envs >= 2048 && getenv("LSIM_POLICY_ROWS16") == nullptr;
+    const int rows = wide ? 32 : 16;
+    const size_t lds = (size_t)rows * (2 * (LS_POL_MAX_IN + LS_POL_PAD) + (LS_POL_MAX_HIDDEN + LS_POL_PAD)) * sizeof(float);
+    static size_t configured[2][64] = {{0}};     // per kernel and device: the attribute belongs to the device's copy of the kernel
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LSIM_E_HIP;
-    if (lds > configured[dev]) {
-        if (hipFuncSetAttribute((const void*)lsim_k_policy_forward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return LSIM_E_HIP;
-        configured[dev] = lds;
+    const void* fn = wide ? (const void*)lsim_k_policy_forward<32, 16> : (const void*)lsim_k_policy_forward<16, 8>;
+    if (lds > configured[wide][dev]) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return LSIM_E_HIP;
+        configured[wide][dev] = lds;
     }
-    const int blocks = (int)((num_envs + LS_POL_ROWS - 1) / LS_POL_ROWS);
-    hipLaunchKernelGGL(lsim_k_policy_forward, dim3(blocks, 2), dim3(64 * LS_POL_WAVES), lds, (hipStream_t)stream, *p, obs, priv_obs, (long)num_envs, mean_out, values_out);
+    const int blocks = (int)((num_envs + rows - 1) / rows);
+    if (wide) hipLaunchKernelGGL((lsim_k_policy_forward<32, 16>), dim3(blocks, 2), dim3(64 * 16), lds, (hipStream_t)stream, *p, obs, priv_obs, (long)num_envs, mean_out, values_out);
+    else hipLaunchKernelGGL((lsim_k_policy_forward<16, 8>), dim3(blocks, 2), dim3(64 * 8), lds, (hipStream_t)stream, *p, obs, priv_obs, (long)num_envs, mean_out, values_out);
     return hipGetLastError() == hipSuccess ? LSIM_OK : LSIM_E_HIP;
 }
