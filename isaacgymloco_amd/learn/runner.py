@@ -141,6 +141,11 @@ class HIMOnPolicyRunner:
             learn_time = time.time() - start
             self.last_perf = dict(collection_time=collection_time, learn_time=learn_time,
                                   fps=self.num_steps_per_env * env.num_envs / (collection_time + learn_time))
+            if it == self.current_learning_iteration and self.graphs is not None:
+                # the update is launch-bound (~2 200 launches in 78 ms); a full pass of Python's cyclic collector over everything the set-up
+                # left behind stalls it for ~60 ms every few iterations.  Collect once, then park the survivors in the permanent generation.
+                import gc
+                gc.collect(); gc.freeze()
             if self.log_dir is not None:
                 f = fin.tolist()
                 if f[0] > 0:
