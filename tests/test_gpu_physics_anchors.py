@@ -5,7 +5,8 @@ of this is reference parity; these tests bound the discretisation and solver err
   * the 8-contact cap: how often it binds at BASELINE size on the stairs task (histogram from LSIM_BUF_CONTACT_COUNT);
   * BASELINE-size (N = 4096) invariants for the stairs and AMP configurations (the flat one is in test_gpu_parity.py);
   * mechanical energy of a passive robot in free flight, evaluated from the published body states and the model table alone: first-order drift;
-  * the response to joint torques against M^-1 tau with the mass matrix M assembled from kinetic energies of the published body states.
+  * the response to joint torques against M^-1 tau with the mass matrix M assembled from kinetic energies of the published body states;
+  * impulse-momentum: the reported net contact forces account for the change of the linear momentum through an impact, a skid and stance.
 The configuration being replaced is legged_robot_config.py:238-255 (dt 5 ms, TGS, 4 position iterations)."""
 import numpy as np
 import pytest
@@ -304,3 +305,64 @@ def test_torque_response_against_a_mass_matrix_built_from_the_kinematic_outputs(
     err = np.abs(dv - ref).max(axis=1) / np.abs(ref).max(axis=1)
     print(f"generalised acceleration under joint torques vs M^-1 tau with M from the kinematic outputs: max relative error {err.max():.2e}")
     assert err.max() < 1e-4          # measured 9e-7
+
+
+def _linear_momentum(env):
+    import json, os
+    from helpers import ROOT
+    bodies = json.load(open(os.path.join(ROOT, "isaacgymloco_amd", "robots", "tables", "aliengo.json")))["bodies"]
+    s = env.rigid_body_states.view(env.num_envs, 17, 13).double().cpu().numpy()
+    P = np.zeros((env.num_envs, 3))
+    for b, bd in enumerate(bodies):
+        q, v, w = s[:, b, 3:7], s[:, b, 7:10], s[:, b, 10:13]
+        x, y, z, ww = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+        R = np.stack([np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * ww), 2 * (x * z + y * ww)], -1),
+                      np.stack([2 * (x * y + z * ww), 1 - 2 * (x * x + z * z), 2 * (y * z - x * ww)], -1),
+                      np.stack([2 * (x * z - y * ww), 2 * (y * z + x * ww), 1 - 2 * (x * x + y * y)], -1)], 1)
+        c = np.einsum("nij,j->ni", R, np.asarray(bd["com"], dtype=np.float64))
+        P += bd["mass"] * (v + np.cross(w, c))
+    return P
+
+
+def _momentum_run(dt, seconds=0.8):
+    cfg = quiet_cfg()
+    cfg.sim.dt = dt
+    cfg.control.decimation = 1
+    cfg.termination.fall_down = False
+    cfg.init_state.pos = [0.0, 0.0, 0.55]
+    cfg.domain_rand.base_init_vel_range = dict(x=[0.8, 0.8], y=[-0.4, -0.4], z=[0.0, 0.0], roll=[0.0, 0.0], pitch=[0.0, 0.0], yaw=[0.5, 0.5])
+    cfg.control.stiffness = {"joint": 20.0}          # soft gains: no velocity-limit rows (they act inside the robot and cancel anyway)
+    cfg.control.damping = {"joint": 0.5}
+    env = _env(cfg, 8)
+    env.reset()
+    zero = torch.zeros(8, 12, device=DEV)
+    env.step_device(zero)
+    P = _linear_momentum(env)
+    W = np.array([0.0, 0.0, -_total_mass() * 9.81])
+    resid, force = [], []
+    for k in range(int(round(seconds / dt))):        # free fall, impact on four feet, skid to rest
+        env.step_device(zero)
+        Pn = _linear_momentum(env)
+        F = env.contact_forces.double().cpu().numpy().sum(1)          # (N, 3) total of the per-body net contact forces of this sub-step
+        resid.append(np.abs((Pn - P) - (F + W) * dt).max(axis=1))
+        force.append(np.abs(F).max(axis=1))
+        P = Pn
+    env.close()
+    return np.array(resid), np.array(force)
+
+
+def test_reported_contact_forces_account_for_the_change_of_momentum():
+    """impulse-momentum theorem on the published tensors (P5, LR:943-944): with one sub-step per control step every sub-step's net contact
+    forces are visible, and the robot's linear momentum -- from the body states and the model table -- must change per step by
+    (sum of the reported contact forces + weight) * dt: landing impact, sliding friction and steady stance alike."""
+    r1, f1 = _momentum_run(0.005)
+    r2, f2 = _momentum_run(0.0025)
+    k = int(np.argmax(r1.max(axis=1)))
+    s1, s2 = r1.sum(0).max(), r2.sum(0).max()
+    print(f"peak total contact force {f1.max():.0f} N; worst per-step momentum residual {r1.max():.2e} N s at 5 ms (step {k}, impulse "
+          f"{f1[k].max() * 0.005:.1f} N s), {r2.max():.2e} at 2.5 ms; residuals summed over 0.8 s: {s1:.2f} N s at 5 ms, {s2:.2f} at 2.5 ms")
+    assert f1.max() > 400.0 and (f1.max(axis=1) > 50.0).sum() > 60          # the scenario really lands and stands
+    # the solver's velocity update is exactly M^-1 J^T lambda; what is left is the configuration moving under the same generalised velocity
+    # within a step (first-order integrator): a few per cent of the impact step's impulse, and it halves with the step
+    assert r1.max() < 0.04 * f1[k].max() * 0.005
+    assert s2 < 0.65 * s1
