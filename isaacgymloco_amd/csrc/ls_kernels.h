@@ -53,8 +53,13 @@ __device__ unsigned long long g_ls_phase_calls[64];
 #else
 #define LS_MARK() do { } while (0)
 #endif
-#define LS_PHASE(call) do { { const int lane = ls_opaque_lane(lane0); call; } __syncthreads(); LS_MARK(); LS_TICK(__LINE__ - ls_line0); } while (0)
-#define LS_COLLECTIVE(gpu_call, emu_call) do { { const int lane = ls_opaque_lane(lane0); gpu_call; } __syncthreads(); LS_MARK(); LS_TICK(__LINE__ - ls_line0); } while (0)
+#if defined(LS_EXP_TWICE)      // diagnostics only (tools/phase_cost.py): the phase at source line LS_EXP_TWICE runs twice -- its marginal cost is the
+#define LS_AGAIN(call) do { if (__LINE__ == LS_EXP_TWICE) { { const int lane = ls_opaque_lane(lane0); call; } __syncthreads(); } } while (0)   /* change of the kernel time (idempotent phases only) */
+#else
+#define LS_AGAIN(call) do { } while (0)
+#endif
+#define LS_PHASE(call) do { { const int lane = ls_opaque_lane(lane0); call; } __syncthreads(); LS_AGAIN(call); LS_MARK(); LS_TICK(__LINE__ - ls_line0); } while (0)
+#define LS_COLLECTIVE(gpu_call, emu_call) do { { const int lane = ls_opaque_lane(lane0); gpu_call; } __syncthreads(); LS_AGAIN(gpu_call); LS_MARK(); LS_TICK(__LINE__ - ls_line0); } while (0)
 #define LS_KINEMATICS() LS_COLLECTIVE(wc_kinematics(sh, lane), (void)0)
 #define LS_TORQUES_KINEMATICS() LS_COLLECTIVE(ph_torques(cx, sh, lane, env, sub); wc_kinematics(sh, lane), (void)0)
 #define LS_ATOMIC_ADD(ptr, v) atomicAdd((ptr), (v))
@@ -257,10 +262,10 @@ LS_WAVE_FN void ls_wave_step_a(const LsCtx& cx, const LsStepArgs& a, const int e
 #if defined(LS_EMU)
         LS_PHASE(ph_delassus(sh, rg, lane));
         wc_pgs(sh, L, c.solver_iterations);
-#else
-        LS_PHASE(wc_delassus_pgs(sh, rg, lane, c.solver_iterations));
-#endif
         LS_PHASE(ph_apply_impulses(sh, lane); ph_contact_forces(sh, lane, dt));
+#else
+        LS_PHASE(wc_delassus_pgs(sh, rg, lane, c.solver_iterations, dt));      // rows, sweep, constrained velocity, contact forces
+#endif
         LS_PHASE(ph_integrate(cx, sh, lane, dt));
     }
     if (!skip) {

@@ -758,15 +758,6 @@ template <int I0> __device__ __forceinline__ void ls_pgs_limits(int nlim, const 
         }
     }
 }
-// the scalar impulses back into lane R's register (slots J0 .. END-1 while J0 < cnt)
-template <int J0, int END> __device__ __forceinline__ void ls_pgs_collect(int cnt, const float (&sl)[LS_MAXR], float& lam) {
-    if constexpr (J0 < END) {
-        if (J0 < cnt) {      // slots come in threes (a contact's rows, a leg's limit rows)
-            ls_writelane<J0>(lam, sl[J0]); ls_writelane<J0 + 1>(lam, sl[J0 + 1]); ls_writelane<J0 + 2>(lam, sl[J0 + 2]);
-            ls_pgs_collect<J0 + 3, END>(cnt, sl, lam);
-        }
-    }
-}
 // W[j] = a_lane . z_j + Jl_lane . y_j[leg_lane] for slots j = J0 .. END-1 while j < cnt (compile-time recursion; the active slots of a
 // range are contiguous); y_j is zero on every leg but row j's own, so no leg comparison is needed
 template <int J0> __device__ __forceinline__ void ls_delassus_row(const WaveShared& sh, int lane, int lo, const float (&jb)[6], float jl0, float jl1, float jl2,
@@ -791,9 +782,34 @@ template <int J0, int END> __device__ __forceinline__ void ls_delassus_rows(cons
         }
     }
 }
+// sum over slots [R0, R0 + N) of Y[r][lane] * lam_r in slot order, every read issued before the first use; lanes past the 18 velocities idle
+template <int R0, int N> __device__ __forceinline__ float ls_apply_rows(const WaveShared& sh, const float (&sl)[LS_MAXR], int lane, float acc) {
+    if (lane >= LS_NV) return acc;
+    float y[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) y[i] = sh.u.c.Y[R0 + i][lane];
+#pragma unroll
+    for (int i = 0; i < N; ++i) acc += y[i] * sl[R0 + i];
+    return acc;
+}
+// net contact force on body `lane`: contacts K0 .. nc-1, one uniform branch per contact (compile-time recursion); within a contact the three
+// axes are selects, no branch on the body test
+template <int K0> __device__ __forceinline__ void ls_contact_force(const WaveShared& sh, const float (&sl)[LS_MAXR], int nc, int lane, float idt, V3& f) {
+    if constexpr (K0 < LS_MAXC) {
+        if (K0 < nc) {
+            const bool mine = sh.cbody[K0] == lane;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const V3 g = f + v3p(sh.u.c.dirs[3 * K0 + a]) * (sl[3 * K0 + a] * idt);
+                f.x = mine ? g.x : f.x; f.y = mine ? g.y : f.y; f.z = mine ? g.z : f.z;      // per component: a select of whole structs goes through memory
+            }
+            ls_contact_force<K0 + 1>(sh, sl, nc, lane, idt, f);
+        }
+    }
+}
 // GPU form: Delassus row and sweep fused so that the 36-entry row lives in registers only between here and the end of
 // the sweep (written unconditionally: no liveness across sub-steps); rows relaxed in slot order, impulse broadcast by readlane.
-LS_FN void wc_delassus_pgs(WaveShared& sh, const LaneRegs& rg, int lane, int iters) {
+LS_FN void wc_delassus_pgs(WaveShared& sh, const LaneRegs& rg, int lane, int iters, float dt) {
     const int nc = LS_UNIFORM(sh.nc), nlim = LS_UNIFORM(sh.nlim);
     const bool act = ls_slot_active(sh, lane);
     const int leg = rg.row_leg;
@@ -819,14 +835,37 @@ LS_FN void wc_delassus_pgs(WaveShared& sh, const LaneRegs& rg, int lane, int ite
         ls_pgs_contacts<0>(nc_it, W, sl, cf, inv_d, w);
         ls_pgs_limits<0>(nlim_it, W, sl, inv_d, neg_rng_d, w);
     }
-    float lam = 0.0f;
-    ls_pgs_collect<0, LS_LIM0>(3 * nc, sl, lam);
-    ls_pgs_collect<LS_LIM0, LS_MAXR>(LS_LIM0 + nlim, sl, lam);
-    if (act) sh.lam[lane] = lam;
+    // ---- v+ = vfree + M^-1 J^T lam (lane = generalized velocity index) and the net contact force per body (lane = body, LR:944), here at the
+    //      end of the solver phase with the impulses still in scalar registers: no impulse array in LDS, no extra phase, and one straight-line
+    //      block per contact / limit-row count, so that all the LDS reads of a block are in flight together (a loop over the active rows paid
+    //      one LDS round trip per remainder row: 7.8 us of kernel A for two dozen FMAs)
+    const float idt = ls_rcp(dt);
+    float acc = 0.0f;
+    V3 f = v3(0, 0, 0);
+    switch (nc) {
+#define LS_C(N) case N: acc = ls_apply_rows<0, 3 * N>(sh, sl, lane, acc); break;
+        LS_C(1) LS_C(2) LS_C(3) LS_C(4) LS_C(5) LS_C(6) LS_C(7) LS_C(8)
+#undef LS_C
+        default: break;
+    }
+    if (lane < LS_NB) ls_contact_force<0>(sh, sl, nc, lane, idt, f);
+    switch (nlim) {
+#define LS_L(N) case N: acc = ls_apply_rows<LS_LIM0, N>(sh, sl, lane, acc); break;
+        LS_L(3) LS_L(6) LS_L(9) LS_L(12)
+#undef LS_L
+        default: break;
+    }
+    static_assert(LS_MAXC == 8 && LSIM_NUM_DOF == 12, "cases above");
+    if (lane < LS_NV) {
+        if (lane < 6) sh.ab[lane] = acc;
+        sh.vnew[lane] = sh.vfree[lane] + acc;
+    }
+    if (lane < LS_NB) v3st(sh.cf[lane], f);
 }
 #endif
 
-// ---- phase V: constrained velocity v+ = vfree + M^-1 J^T lam from the stored rows (lane = generalized velocity index): the base part
+// ---- phase V (lane emulator; the GPU does this at the end of wc_delassus_pgs): constrained velocity v+ = vfree + M^-1 J^T lam from the
+//      stored rows (lane = generalized velocity index): the base part
 //      dvb = sum_r z_r lam_r is final here (and parked in sh.ab, dead since ph_free_finish); a joint gets its own-leg part here and the
 //      coupling term - G_l dvb in ph_integrate, once dvb is complete
 LS_FN void ph_apply_impulses(WaveShared& sh, int lane) {
@@ -839,7 +878,7 @@ LS_FN void ph_apply_impulses(WaveShared& sh, int lane) {
     sh.vnew[lane] = sh.vfree[lane] + acc;
 }
 
-// ---- phase B: net contact force per body, world frame (LR:944) (lane = body)
+// ---- phase B (lane emulator; GPU: end of wc_delassus_pgs): net contact force per body, world frame (LR:944) (lane = body)
 LS_FN void ph_contact_forces(WaveShared& sh, int lane, float dt) {
     if (lane >= LS_NB) return;
     V3 f = v3(0, 0, 0);
