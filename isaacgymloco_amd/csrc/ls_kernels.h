@@ -267,6 +267,9 @@ LS_WAVE_FN void ls_wave_step_a(const LsCtx& cx, const LsStepArgs& a, const int e
         LS_PHASE(wc_delassus_pgs(sh, rg, lane, c.solver_iterations, dt));      // rows, sweep, constrained velocity, contact forces
 #endif
         LS_PHASE(ph_integrate(cx, sh, lane, dt));
+#if defined(LS_EXP_TWICE) && LS_EXP_TWICE == 9001      // cost probe: the integrator again with a zero step (leaves the state where it is)
+        LS_PHASE(ph_integrate(cx, sh, lane, 0.0f));
+#endif
     }
     if (!skip) {
         LS_KINEMATICS();
@@ -279,9 +282,15 @@ LS_WAVE_FN void ls_wave_step_a(const LsCtx& cx, const LsStepArgs& a, const int e
     LS_PHASE(ph_store_root_cmd_ranges(cx, sh, lane, env, a));
     LS_PHASE(ph_post_state(cx, sh, lane, env));
     LS_PHASE(ph_callback(cx, sh, lane, env, a, sh.ranges));
+#if defined(LS_EXP_TWICE) && LS_EXP_TWICE == 9003      // cost probe: counter-based draws, so a second pass writes the same values
+    LS_PHASE(ph_callback(cx, sh, lane, env, a, sh.ranges));
+#endif
     LS_PHASE(if (c.measure_heights) ph_heights(cx, sh, lane, env, true); ph_base_height_pts(cx, sh, lane));
     LS_PHASE(ph_termination(cx, sh, lane, env); ph_reward_parts(cx, sh, lane, env));
     LS_PHASE(ph_reward_terms(cx, sh, lane, env));
+#if defined(LS_EXP_TWICE) && LS_EXP_TWICE == 9002      // cost probe (adds the step's rewards to the episode sums twice: statistics only)
+    LS_PHASE(ph_reward_terms(cx, sh, lane, env));
+#endif
     LS_PHASE(ph_reward_total(cx, sh, lane, env));
     LS_PHASE(if (sh.reset) ph_build_obs(cx, sh, lane, env, (uint32_t)a.step_counter, LSIM_RNG_TERM_NOISE, sh.cur));
     LS_PHASE(ph_term_outputs(cx, sh, lane, env, a));

@@ -28,6 +28,8 @@ def sites():
             break
         if PAT.search(l) and not l.lstrip().startswith("#") and not l.lstrip().startswith("//"):
             out.append((i, l.strip()[:90]))
+    # phases that are not idempotent as written have explicit probes in ls_kernels.h (second pass with a zero step / harmless double write)
+    out += [(9001, "ph_integrate (probe: second pass with dt = 0)"), (9002, "ph_reward_terms (probe)"), (9003, "ph_callback (probe)")]
     return out
 
 
