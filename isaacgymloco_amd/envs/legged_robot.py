@@ -172,6 +172,29 @@ class LeggedRobot:
         return self.buf["rigid_body_states"][:, self.feet_indices, 7:10]
 
     @property
+    def height_samples(self):                  # LR:1084 / LR:1098: the int16 height grid on the device
+        return self.buf["height_grid"]
+
+    def _get_feet_heights(self, env_ids=None):
+        """Height of every foot above the terrain under it (LR:1400-1441): feet xy + border, / horizontal_scale, truncated, clipped to the grid,
+        MEAN of the three samples (x, y), (x+1, y), (x, y+1) -- the other samplers take their minimum -- times vertical_scale; `plane`
+        terrain returns the feet z.  No reward or observation of the reference calls it; it is part of the task's surface, so it exists,
+        as device-side torch ops on the simulator's buffers."""
+        mesh = self.cfg.terrain.mesh_type
+        if mesh == "plane":
+            return self.feet_pos[:, :, 2].clone()
+        if mesh == "none":
+            raise NameError("Can't measure height with terrain mesh type 'none'")
+        feet = self.feet_pos if env_ids is None else self.feet_pos[env_ids]
+        points = ((feet + self.cfg.terrain.border_size) / self.cfg.terrain.horizontal_scale).long()
+        grid = self.height_samples
+        px = torch.clip(points[:, :, 0].reshape(-1), 0, grid.shape[0] - 2)
+        py = torch.clip(points[:, :, 1].reshape(-1), 0, grid.shape[1] - 2)
+        heights = (grid[px, py] + grid[px + 1, py] + grid[px, py + 1]) / 3         # int16 sums promote to float on the division, as in the reference
+        heights = heights.view(feet.shape[0], -1) * self.cfg.terrain.vertical_scale
+        return feet[:, :, 2] - heights
+
+    @property
     def disturbance(self):
         """self.disturbance (LR:1017), (N, 17, 3): the body-local force applied to every body in the next simulate().  Only row 0 (the base)
         is ever written (LR:843) and the reference zeroes the whole buffer at the end of each step (LR:235), so what a caller can observe

@@ -301,3 +301,31 @@ def test_hip_handles_are_independent_and_stream_ordered():
     torch.cuda.synchronize()
     assert torch.equal(tmp, ref[2])
     L.lsim_destroy(h)
+
+
+@pytest.mark.gpu
+def test_feet_heights_surface_method_matches_a_numpy_restatement():
+    """LeggedRobot._get_feet_heights (LR:1400-1441; the reference never calls it): mean of three grid samples under each foot"""
+    import numpy as np
+    import torch
+    from helpers import C
+    from isaacgymloco_amd.envs.legged_robot import LeggedRobot
+    cfg = C.TASKS["aliengo_stairs"][0]()
+    cfg.env.num_envs = 64
+    env = LeggedRobot(cfg, sim_device="cuda:0", seed=1)
+    env.reset()
+    for _ in range(20):
+        env.step_device(torch.randn(64, 12, device="cuda:0"))
+    got = env._get_feet_heights().cpu().numpy()
+    feet = env.feet_pos.cpu().numpy().astype(np.float32)
+    grid = env.height_samples.cpu().numpy()
+    hs, vs, border = np.float32(cfg.terrain.horizontal_scale), np.float32(cfg.terrain.vertical_scale), np.float32(cfg.terrain.border_size)
+    p = ((feet + border) / hs).astype(np.int64)                      # truncation toward zero, as .long()
+    px = np.clip(p[:, :, 0], 0, grid.shape[0] - 2)
+    py = np.clip(p[:, :, 1], 0, grid.shape[1] - 2)
+    mean3 = (grid[px, py].astype(np.float32) + grid[px + 1, py] + grid[px, py + 1]) / np.float32(3)
+    want = feet[:, :, 2] - mean3 * vs
+    assert got.shape == (64, 4) and np.allclose(got, want, atol=1e-5)
+    sub = env._get_feet_heights(torch.tensor([3, 7], device="cuda:0")).cpu().numpy()
+    assert np.allclose(sub, want[[3, 7]], atol=1e-5)
+    env.close()
