@@ -709,10 +709,6 @@ static inline void wc_pgs(WaveShared& sh, LaneRegs* L, int iters) {
 LS_FN float ls_readlane(float v, int srclane) {  // srclane is wave-uniform
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), srclane));
 }
-// v[lane_imm] = s  (v_writelane_b32 with an immediate lane: one instruction instead of a lane compare + select)
-template <int LANE> __device__ __forceinline__ void ls_writelane(float& v, float s) {
-    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(s), "n"(LANE));
-}
 // One Gauss-Seidel relaxation of slot R.  The impulses are wave-uniform data and live in SCALAR registers (sl[R]); a lane only owns the
 // residual w of its row.  Every lane evaluates the candidate of slot R from its own w (only lane R's is real), readlane broadcasts it,
 // and all residuals move by W[R] * (new - old) as two FMAs: - W[R] * old before the broadcast, + W[R] * new after it.  5-6 vector
