@@ -112,6 +112,10 @@ LS_FN void ph_load_a(const LsCtx& cx, WaveShared& sh, LaneRegs& rg, int lane, in
     uint16_t v_items[LS_MAX_PART_ITEMS / 64];
     for (int it = 0; it < LS_MAX_PART_ITEMS / 64; ++it) v_items[it] = cx.part_items[lane + 64 * it];
     // ---- LDS writes
+    // the tail of the row array Y that no spatial inertia ever overlays (ls_shared.h, union u): the solver reads whole triples of limit slots,
+    // i.e. up to two slots that hold no row yet, and multiplies what it finds by a zero impulse -- harmless only if it is finite
+    static_assert(sizeof(sh.u.c.Y) - sizeof(sh.u.I6) == 2 * LS_NV * sizeof(float), "rows of Y beyond the inertias");
+    if (lane < 2 * LS_NV) (&sh.u.c.Y[LS_MAXR - 2][0])[lane] = 0.0f;
     for (int it = 0; it < LS_MAX_PART_ITEMS / 64; ++it) sh.items[lane + 64 * it] = v_items[it];
     if (lane < 13) sh.root[lane] = v_root;
     if (lane < 12) {

@@ -549,13 +549,16 @@ LS_FN void wc_compact_contacts(WaveShared& sh, LaneRegs& r, int lane) {
 
 // ---- phase: joint position AND velocity limits as ONE two-sided ("boxed") row per joint: L <= qd_j <= U with
 //      [L, U] = [-vmax, vmax]  cut by  qd >= -gap_lo / dt (within 0.1 rad of the lower stop)  /  qd <= gap_hi / dt (upper stop); a
-//      penetrated stop pushes back with erp, capped at 1 rad/s.  A joint needs its row when the free velocity violates a bound or
-//      comes within LS_LIMIT_MARGIN of the velocity limit of it; because the limit impulses of one joint move its neighbours on the same leg by
-//      tens of rad/s, all three joints of a leg get rows as soon as one of them needs one.  [Clamping the joint velocity after the
-//      solve instead leaves the reaction of a saturated motor torque on the base and spins up a robot in free flight.]
+//      penetrated stop pushes back with erp, capped at 1 rad/s.  A joint gets its row when its free velocity violates a bound or comes within
+//      LS_LIMIT_MARGIN of the velocity limit of it; because the limit impulses of one joint move its neighbours on the same leg by tens of
+//      rad/s, a joint that VIOLATES a bound -- whose row will carry an impulse -- also gives its two neighbours on the leg their rows.
+//      [Until round 2 a joint merely within the margin did that too: 4.6 of 5.3 limit rows per solve never carried an impulse.  Rows for the
+//      needing joints alone fail tests/test_physics_invariants.py's saturated-motor case: the kicked neighbours run into the 1.5 x safety clamp,
+//      which is not momentum-neutral.]  [Clamping the joint velocity after the solve instead leaves the reaction of a saturated motor torque
+//      on the base and spins up a robot in free flight.]
 //      GPU: lane = joint, ordered compaction by ballot; lane emulator: lane 0 walks the joints (same order, same result)
 #define LS_LIMIT_MARGIN 0.2f    // a joint "needs" its row when the free velocity is within this fraction of vmax of a bound (or beyond it)
-LS_FN bool ls_joint_limit_bounds(const LsCtx& cx, const WaveShared& sh, int j, float dt, float& Lb, float& Ub) {
+LS_FN bool ls_joint_limit_bounds(const LsCtx& cx, const WaveShared& sh, int j, float dt, float& Lb, float& Ub, bool& violates) {
     const float idt = ls_rcp(dt);
     const float lo = sh.q[j] - cx.model.dof_pos_lower[j], hi = cx.model.dof_pos_upper[j] - sh.q[j];
     const float vmax = cx.model.dof_vel_limit[j], vf = sh.vfree[6 + j];
@@ -563,15 +566,16 @@ LS_FN bool ls_joint_limit_bounds(const LsCtx& cx, const WaveShared& sh, int j, f
     if (lo < 0.1f) Lb = fmaxf(Lb, lo >= 0.0f ? -lo * idt : fminf(1.0f, cx.cfg.erp * (-lo) * idt));
     if (hi < 0.1f) Ub = fminf(Ub, hi >= 0.0f ? hi * idt : -fminf(1.0f, cx.cfg.erp * (-hi) * idt));
     if (Ub < Lb) Ub = Lb;                                   // both stops violated at once cannot happen; keep the box well formed
+    violates = fminf(vf - Lb, Ub - vf) < 0.0f;
     return fminf(vf - Lb, Ub - vf) < LS_LIMIT_MARGIN * vmax;
 }
 #if !defined(LS_EMU)
 LS_FN void wc_limits(const LsCtx& cx, WaveShared& sh, int lane, float dt) {
-    bool need = false;
+    bool need = false, viol = false;
     float Lb = 0.0f, Ub = 0.0f;
-    if (lane < 12) need = ls_joint_limit_bounds(cx, sh, lane, dt, Lb, Ub);
-    const unsigned long long mneed = __ballot(need);
-    const bool has = lane < 12 && ((mneed >> (3 * (lane / 3))) & 7ull) != 0ull;     // any joint of this leg
+    if (lane < 12) need = ls_joint_limit_bounds(cx, sh, lane, dt, Lb, Ub, viol);
+    const unsigned long long mviol = __ballot(viol);
+    const bool has = need || (lane < 12 && ((mviol >> (3 * (lane / 3))) & 7ull) != 0ull);     // own need, or a violating joint on this leg
     const unsigned long long m = __ballot(has);
     if (has) {
         const int rank = __popcll(m & ((1ull << lane) - 1ull));
@@ -585,10 +589,12 @@ LS_FN void ph_limits(const LsCtx& cx, WaveShared& sh, int lane, float dt) {
     int n = 0;
     for (int leg = 0; leg < 4; ++leg) {
         float Lb[3], Ub[3];
-        bool any = false;
-        for (int k = 0; k < 3; ++k) any = ls_joint_limit_bounds(cx, sh, 3 * leg + k, dt, Lb[k], Ub[k]) || any;
-        if (!any) continue;
-        for (int k = 0; k < 3; ++k) { sh.limdof[n] = 3 * leg + k; sh.limvt[n] = Lb[k]; sh.limrng[n] = Ub[k] - Lb[k]; ++n; }
+        bool need[3], viol[3], any_viol = false;
+        for (int k = 0; k < 3; ++k) { need[k] = ls_joint_limit_bounds(cx, sh, 3 * leg + k, dt, Lb[k], Ub[k], viol[k]); any_viol = any_viol || viol[k]; }
+        for (int k = 0; k < 3; ++k) {
+            if (!(need[k] || any_viol)) continue;
+            sh.limdof[n] = 3 * leg + k; sh.limvt[n] = Lb[k]; sh.limrng[n] = Ub[k] - Lb[k]; ++n;
+        }
     }
     sh.nlim = n;
     sh.nrows = 3 * sh.nc + n;
@@ -743,7 +749,8 @@ template <int K0> __device__ __forceinline__ void ls_pgs_contacts(int nc, const 
         }
     }
 }
-// joint-limit rows come in triples (wc_limits gives all three joints of a leg their rows together): one branch per leg
+// joint-limit slots three per branch; a slot past nlim in the last triple is relaxed too, which is a no-op: its lane holds w = 0, 1/d = 0 and
+// an impulse of 0, so the candidate is 0 and every residual moves by W * 0 (W of a stale slot is finite: see ph_load_a on the row array's tail)
 template <int I0> __device__ __forceinline__ void ls_pgs_limits(int nlim, const float (&W)[LS_MAXR], float (&sl)[LS_MAXR], float inv_d, float neg_rng_d, float& w) {
     if constexpr (I0 < LSIM_NUM_DOF) {
         if (I0 < nlim) {
@@ -845,9 +852,9 @@ LS_FN void wc_delassus_pgs(WaveShared& sh, const LaneRegs& rg, int lane, int ite
         default: break;
     }
     if (lane < LS_NB) ls_contact_force<0>(sh, sl, nc, lane, idt, f);
-    switch (nlim) {
-#define LS_L(N) case N: acc = ls_apply_rows<LS_LIM0, N>(sh, sl, lane, acc); break;
-        LS_L(3) LS_L(6) LS_L(9) LS_L(12)
+    switch ((nlim + 2) / 3) {       // whole triples: the impulse of a slot past nlim is 0 and its stale row finite
+#define LS_L(T) case T: acc = ls_apply_rows<LS_LIM0, 3 * T>(sh, sl, lane, acc); break;
+        LS_L(1) LS_L(2) LS_L(3) LS_L(4)
 #undef LS_L
         default: break;
     }
