@@ -503,6 +503,8 @@ int lsim_linear_wgrad(const float* x, int64_t ldx, const float* g, int64_t ldg, 
  * pre-activation  grad_pre = grad_out * (z > 0 ? 1 : z + 1)  (torch's elu_backward on the saved OUTPUT) is formed on the fly as the MFMA
  * operand of the weight-gradient kernel and written once -- [batch, n_out] contiguous -- for the caller's input-gradient GEMM
  * (grad_pre @ W); dw / db as lsim_linear_wgrad.  One pass over grad_out and z instead of elu_backward + column sum + wgrad.
+ * grad_pre may be NULL when no input gradient will be formed (the first layer of a network): the gradient of the pre-activation is then
+ * only used inside the kernel and never written.
  * Same workspace as lsim_linear_wgrad; LSIM_E_UNSUPPORTED for shapes lsim_linear_wgrad handles in its single-wave form (<= 4096 outputs). */
 int lsim_linear_elu_wgrad(const float* x, int64_t ldx, const float* grad_out, int64_t ldg, const float* elu_out, int64_t ldz, int64_t batch,
                           int k_in, int n_out, float* dw, float* db, float* grad_pre, void* workspace, size_t workspace_bytes, void* stream);

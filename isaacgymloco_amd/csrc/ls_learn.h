@@ -375,14 +375,14 @@ void lsim_k_linear_wgrad_tiled(const float* __restrict__ x, long ldx, const floa
     const long safe = b0 < batch ? b0 : batch - 1;          // an existing row for the masked loads of rows past the slice
     {
         const bool live1 = KG == 1 || k_base + 64 < k_in;
-        const bool wgy = FZ && kb == 0, wgy_vec = (n_out & 3) == 0 && n_base + 64 <= n_out;
+        const bool wgy = FZ && kb == 0 && gy != nullptr, wgy_vec = (n_out & 3) == 0 && n_base + 64 <= n_out;      // gy == NULL: nobody needs grad_pre (a network's first layer)
 #define LS_L3(LIVE1, WGY) b0 = ls_wgrad_tile_loop3<VX, VG, KG, FZ, LIVE1, WGY>(x, ldx, g, ldg, z, ldz, gy, b0, b1, full, n_base, k_base, n_out, k_in, sub, col, acc, dbacc)
         if (!wgy) { if (live1) LS_L3(true, false); else LS_L3(false, false); }
         else if (wgy_vec) { if (live1) LS_L3(true, true); else LS_L3(false, true); }
         // (g_y rows of an edge n tile: everything goes through the guarded loop below)
 #undef LS_L3
     }
-    ls_wgrad_tile_loop<VX, VG, KG, false, FZ>(x, ldx, g, ldg, z, ldz, gy, kb == 0, b0, b1, safe, n_base, k_base, n_out, k_in, sub, col, acc, dbacc);   // the last < 12 rows
+    ls_wgrad_tile_loop<VX, VG, KG, false, FZ>(x, ldx, g, ldg, z, ldz, gy, kb == 0 && gy != nullptr, b0, b1, safe, n_base, k_base, n_out, k_in, sub, col, acc, dbacc);   // the last < 12 rows
     // block reduction: wave 0 stores its accumulators to LDS (lane-major, 16-byte vectors: no bank conflicts), waves 1-3 add theirs in
     // turn; wave 3 ends up with the block's sums and writes the partial tile
     __shared__ float4 red[4 * 4 * KG][64];
@@ -514,7 +514,7 @@ static int ls_linear_wgrad_impl(const float* x, int64_t ldx, const float* g, int
     const size_t need = (size_t)p.partials * ((size_t)n_out * k_in + n_out) * sizeof(float);
     if (workspace_bytes < need || ldx < k_in || ldg < n_out) return LSIM_E_INVALID;
     const bool fz = z != nullptr;
-    if (fz && (p.small || !gy || ldz < n_out)) return p.small ? LSIM_E_UNSUPPORTED : LSIM_E_INVALID;
+    if (fz && (p.small || ldz < n_out)) return p.small ? LSIM_E_UNSUPPORTED : LSIM_E_INVALID;
     float* pdw = (float*)workspace;
     float* pdb = db ? pdw + (size_t)p.partials * n_out * k_in : nullptr;
     hipStream_t s = (hipStream_t)stream;
@@ -559,7 +559,7 @@ extern "C" int lsim_linear_wgrad(const float* x, int64_t ldx, const float* g, in
 
 extern "C" int lsim_linear_elu_wgrad(const float* x, int64_t ldx, const float* grad_out, int64_t ldg, const float* elu_out, int64_t ldz, int64_t batch,
                                      int k_in, int n_out, float* dw, float* db, float* grad_pre, void* workspace, size_t workspace_bytes, void* stream) {
-    if (!elu_out || !grad_pre) return LSIM_E_INVALID;
+    if (!elu_out) return LSIM_E_INVALID;
     return ls_linear_wgrad_impl(x, ldx, grad_out, ldg, elu_out, ldz, grad_pre, batch, k_in, n_out, dw, db, workspace, workspace_bytes, stream);
 }
 

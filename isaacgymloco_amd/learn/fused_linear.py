@@ -106,11 +106,12 @@ class _LinearEluFn(torch.autograd.Function):
             _workspaces[x.device] = ws
         dw = torch.empty(n_out, k_in, device=x.device, dtype=torch.float32)
         db = torch.empty(n_out, device=x.device, dtype=torch.float32) if ctx.has_bias else None
-        g_pre = torch.empty(batch, n_out, device=x.device, dtype=torch.float32)
+        # the gradient of the pre-activation is written out only where an input gradient follows (not for a network's first layer: 210 MB per call)
+        g_pre = torch.empty(batch, n_out, device=x.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
         lib.check(L.lsim_linear_elu_wgrad(x.data_ptr(), x.stride(0), g.data_ptr(), g.stride(0), z.data_ptr(), z.stride(0), batch, k_in, n_out,
-                                          dw.data_ptr(), db.data_ptr() if db is not None else None, g_pre.data_ptr(), ws.data_ptr(), ws.numel(),
-                                          torch.cuda.current_stream(x.device).cuda_stream), what="lsim_linear_elu_wgrad")
-        gx = g_pre @ weight if ctx.needs_input_grad[0] else None
+                                          dw.data_ptr(), db.data_ptr() if db is not None else None, g_pre.data_ptr() if g_pre is not None else None,
+                                          ws.data_ptr(), ws.numel(), torch.cuda.current_stream(x.device).cuda_stream), what="lsim_linear_elu_wgrad")
+        gx = g_pre @ weight if g_pre is not None else None
         return gx, dw, db
 
 

@@ -419,6 +419,11 @@ def test_fused_linear_elu_backward_matches_torch(k_in, n_out):
         scale = float(p1.grad.abs().max())
         torch.testing.assert_close(p2.grad, p1.grad, rtol=2e-4, atol=2e-5 * scale, msg=n1)
     torch.testing.assert_close(xb.grad, xa.grad, rtol=2e-4, atol=2e-5 * float(xa.grad.abs().max()))
+    # a first layer: the input needs no gradient, so the kernel is called with grad_pre = NULL and never writes it -- same parameter gradients
+    fus.zero_grad()
+    (fus(xb.detach()) * w).sum().backward()
+    for (n1, p1), (n2, p2) in zip(ref.named_parameters(), fus.named_parameters()):
+        torch.testing.assert_close(p2.grad, p1.grad, rtol=2e-4, atol=2e-5 * float(p1.grad.abs().max()), msg=n1 + " (no input gradient)")
 
 
 def test_reference_style_step_tuple_and_strict_runner_path():
