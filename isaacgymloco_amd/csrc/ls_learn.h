@@ -1284,10 +1284,29 @@ __global__ __launch_bounds__(256) void lsim_k_actor_input(const float* __restric
     out[idx] = v;
 }
 
+// the same for the usual 64-wide input (45 + 3 + 16) with a 16-wide latent: one wavefront per row, lane = column -- no index division per element,
+// and the latent's norm is one sum over the 16-lane DPP row that holds it instead of 16 loads in each of 16 threads (60 -> 17 us at 102 400 rows)
+__global__ __launch_bounds__(256) void lsim_k_actor_input64(const float* __restrict__ obs, long ld_obs, int n_one, const float* __restrict__ enc, long ld_enc,
+                                                            long batch, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= batch) return;
+    float v = lane < n_one ? obs[row * ld_obs + lane] : enc[row * ld_enc + (lane - n_one)];
+    float ss = lane >= 48 ? v * v : 0.0f;                      // lanes 48..63 = the latent (n_one + 3 == 48)
+    ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64); ss += __shfl_xor(ss, 8, 64);
+    if (lane >= 48) v = v / fmaxf(sqrtf(ss), 1e-12f);          // F.normalize(p=2, eps=1e-12)
+    out[row * 64 + lane] = v;
+}
+
 extern "C" int lsim_actor_input(const float* obs, int64_t ld_obs, int num_one_step_obs, const float* enc_out, int64_t ld_enc, int latent,
                                 int64_t batch, float* out, void* stream) {
     if (!obs || !enc_out || !out || batch <= 0 || num_one_step_obs <= 0 || latent <= 0 || ld_obs < num_one_step_obs || ld_enc < 3 + latent)
         return LSIM_E_INVALID;
+    if (num_one_step_obs == 45 && latent == 16) {
+        hipLaunchKernelGGL(lsim_k_actor_input64, dim3((unsigned)((batch + 3) / 4)), dim3(256), 0, (hipStream_t)stream, obs, (long)ld_obs, num_one_step_obs,
+                           enc_out, (long)ld_enc, (long)batch, out);
+        return hipGetLastError() == hipSuccess ? LSIM_OK : LSIM_E_HIP;
+    }
     const long total = (long)batch * (num_one_step_obs + 3 + latent);
     hipLaunchKernelGGL(lsim_k_actor_input, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, obs, (long)ld_obs, num_one_step_obs,
                        enc_out, (long)ld_enc, latent, (long)batch, out);
