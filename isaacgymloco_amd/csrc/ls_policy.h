@@ -188,7 +188,8 @@ extern "C" int lsim_policy_forward(const lsim_him_policy* p, const float* obs, c
         p->critic[1].n_pad > LS_POL_MAX_IN || p->critic[3].n_pad > LS_POL_MAX_IN) bad = 1;
     if (bad) return LSIM_E_UNSUPPORTED;
     // 32 environments per block once that still fills the chip's 256 CUs with one block each; 16 per block (two blocks per CU) below that
-    const bool wide = num_envs >= 2048 && getenv("LSIM_POLICY_ROWS16") == nullptr;
+    static const bool force16 = getenv("LSIM_POLICY_ROWS16") != nullptr;      // A/B switch (tools/policy_time.py), read once
+    const bool wide = num_envs >= 2048 && !force16;
     const int rows = wide ? 32 : 16;
     const size_t lds = (size_t)rows * (2 * (LS_POL_MAX_IN + LS_POL_PAD) + (LS_POL_MAX_HIDDEN + LS_POL_PAD)) * sizeof(float);
     static size_t configured[2][64] = {{0}};     // per kernel and device: the attribute belongs to the device's copy of the kernel
