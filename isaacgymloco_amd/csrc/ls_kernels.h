@@ -151,7 +151,7 @@ LS_FN void ph_load_a(const LsCtx& cx, WaveShared& sh, LaneRegs& rg, int lane, in
         for (int k = 0; k < 3; ++k) { o.com[k] = b.com[k]; o.jpos[k] = b.joint_pos[k]; o.axis[k] = b.joint_axis[k]; }
         for (int k = 0; k < 6; ++k) o.inertia[k] = b.inertia[k];
     }
-    if (lane < 48) sh.pre_lla[lane] = v_pre;            // pre_lla .. pre_ltau are contiguous
+    if (lane < 48) sh.pre4[lane] = v_pre;               // pre_lla .. pre_ltau
     else if (lane < 52) sh.pre_cmd[lane - 48] = v_cmd;
     else if (lane < 56) sh.pre_air[lane - 52] = v_air;
     else if (lane == 56) sh.pre_eplen = v_eplen;

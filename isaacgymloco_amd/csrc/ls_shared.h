@@ -82,7 +82,10 @@ struct WaveShared {
     LsBodyLds body[LS_NB];
     // ---- inputs of the post-physics stack, fetched by ph_load_a before the kernel has any store in flight: a global load issued after
     //      stores waits for every one of them (vmcnt is in order), so nothing after the physics loop reads global state buffers
-    float pre_lla[12], pre_ldp[12], pre_ldv[12], pre_ltau[12];   // last_last_actions, last_dof_pos, last_dof_vel, last_torques (contiguous)
+    union {
+        struct { float pre_lla[12], pre_ldp[12], pre_ldv[12], pre_ltau[12]; };   // last_last_actions, last_dof_pos, last_dof_vel, last_torques
+        float pre4[48];                                                           // the same 48 floats as one array (filled by lanes 0..47 of the load phase)
+    };
     float pre_cmd[4], pre_air[4];                                // commands, feet_air_time
     int pre_eplen, pre_level;                                    // episode_length_buf, terrain_levels (low words)
     unsigned int pre_lc;                                         // last_contacts: 4 bytes
