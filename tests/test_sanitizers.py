@@ -32,12 +32,17 @@ def _build():
     subprocess.check_call(["g++", "-std=c++17", "-Wno-unknown-pragmas"] + flags + src + objs + ["-lm", "-o", SAN])
 
 
-@pytest.mark.parametrize("task,using_amp", [("aliengo", False), ("aliengo_stairs", False), ("aliengo_amp", True)])
+@pytest.mark.parametrize("task,using_amp", [("aliengo", False), ("aliengo_stairs", False), ("aliengo_amp", True), ("aliengo_allterms", False), ("go1", False)])
 def test_emulator_and_oracle_run_clean_under_asan_and_ubsan(task, using_amp, tmp_path):
     _build()
+    from helpers import abi
     from isaacgymloco_amd.envs.legged_robot import build_robot_model
-    cfg = C.TASKS[task][0]()
-    if task != "aliengo_stairs":
+    allterms = task == "aliengo_allterms"
+    cfg = C.TASKS["aliengo_stairs" if allterms else task][0]()
+    if allterms:                                       # every one of the 51 reward terms switched on: more parts than the item table holds
+        for name in abi.REWARD_IDS:
+            setattr(cfg.rewards.scales, name, -0.01)
+    elif task != "aliengo_stairs":
         cfg.rewards.scales.termination = -1.0          # one more active term: touches the termination-reward path as well
     N, steps = 24, 60
     ter = T.Terrain(cfg.terrain, N, seed=1)
