@@ -48,7 +48,7 @@ def test_hip_physics_matches_oracle(quiet):
 def test_hip_stairs_wall_contacts_match_oracle():
     """Stairs (slope-corrected mesh with vertical risers, TER:72-75): robots dropped all over the staircases.  States are
     re-synchronised every step; float-vs-double decisions at triangle edges may differ for single env-steps, so the bar is
-    >= 97 % of env-steps with identical termination flag AND state within the fp32 tolerance."""
+    >= 99 % of env-steps with identical termination flag AND state within the fp32 tolerance (measured: 1276 of 1280)."""
     from hip_backend import HipBackend
     N = 32
     cfg = C.TASKS["aliengo_stairs"][0]()
@@ -77,7 +77,8 @@ def test_hip_stairs_wall_contacts_match_oracle():
         lat = np.linalg.norm(feet[..., :2], axis=-1)
         if (lat > 5).any():
             lateral = max(lateral, float((lat / (np.abs(feet[..., 2]) + 1e-6))[lat > 5].max()))
-    assert ok >= 0.97 * tot, (ok, tot)
+    print(f"stairs: {ok} of {tot} env-steps within tolerance")
+    assert ok >= 0.99 * tot, (ok, tot)
     assert lateral > 5.0, "risers must be able to produce mostly-horizontal foot forces (feet_stumble, LR:1589-1599)"
 
 

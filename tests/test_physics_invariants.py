@@ -206,7 +206,8 @@ def test_emu_stairs_wall_contacts_match_oracle():
         ok += int((same & (e_root < 2e-3) & (e_dof < 2e-2)).sum()); tot += N
         feet = orc.buf["contact_forces"][:, [4, 8, 12, 16], :]
         walls += int((np.linalg.norm(feet[..., :2], axis=-1) > 2.0 * np.abs(feet[..., 2]) + 1.0).sum())
-    assert ok >= 0.97 * tot, (ok, tot)
+    print(f"stairs (emulator): {ok} of {tot} env-steps within tolerance")
+    assert ok >= 0.99 * tot, (ok, tot)          # measured: 479 of 480
     assert walls > 0, "the scenario must exercise riser (mostly horizontal) foot contacts"
 
 
