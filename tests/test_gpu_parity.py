@@ -25,7 +25,7 @@ def test_hip_matches_reference_step(name):
 @pytest.mark.parametrize("quiet", [True, False])
 def test_hip_physics_matches_oracle(quiet):
     """Dynamics: structured fp32 wave solver (HIP) vs dense fp64 oracle on the same seeds/actions.  fp32 tolerance:
-    states agree to 2e-3 abs over 12 steps (48 sub-steps) of contact-rich motion; contact forces to 0.5 N (~0.2 %)."""
+    states agree to 3e-4 abs (joints 3e-3) over 12 steps (48 sub-steps) of contact-rich motion; contact forces to 0.15 N (< 0.1 %)."""
     from hip_backend import HipBackend
     N = 16
     cfg = quiet_cfg("aliengo") if quiet else C.TASKS["aliengo"][0]()
@@ -38,11 +38,12 @@ def test_hip_physics_matches_oracle(quiet):
         a = rs.normal(0, 1, (N, 12)).astype(np.float32)
         orc.step(a); be.step(a)
         np.testing.assert_array_equal(be.get("reset"), orc.buf["reset"], err_msg=f"step {t}")
-        np.testing.assert_allclose(be.get("root_states"), orc.buf["root_states"], atol=2e-3, rtol=1e-3, err_msg=f"step {t}")
-        np.testing.assert_allclose(be.get("dof_state"), orc.buf["dof_state"], atol=5e-3, rtol=1e-3, err_msg=f"step {t}")
-        np.testing.assert_allclose(be.get("contact_forces"), orc.buf["contact_forces"], atol=0.5, rtol=5e-3, err_msg=f"step {t}")
-        np.testing.assert_allclose(be.get("rew"), orc.buf["rew"], atol=1e-3, rtol=1e-3, err_msg=f"step {t}")
-        np.testing.assert_allclose(be.get("obs"), orc.buf["obs"], atol=5e-3, rtol=1e-3, err_msg=f"step {t}")
+        # bars ~ 5 x the errors measured on MI355X (round 2: root 4.6e-5, joints 7.3e-4, contact forces 0.032 N, reward 6e-7, observations 3.6e-5)
+        np.testing.assert_allclose(be.get("root_states"), orc.buf["root_states"], atol=3e-4, rtol=1e-4, err_msg=f"step {t}")
+        np.testing.assert_allclose(be.get("dof_state"), orc.buf["dof_state"], atol=3e-3, rtol=1e-3, err_msg=f"step {t}")
+        np.testing.assert_allclose(be.get("contact_forces"), orc.buf["contact_forces"], atol=0.15, rtol=2e-3, err_msg=f"step {t}")
+        np.testing.assert_allclose(be.get("rew"), orc.buf["rew"], atol=1e-5, rtol=1e-4, err_msg=f"step {t}")
+        np.testing.assert_allclose(be.get("obs"), orc.buf["obs"], atol=3e-4, rtol=1e-4, err_msg=f"step {t}")
 
 
 def test_hip_stairs_wall_contacts_match_oracle():
