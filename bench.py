@@ -109,6 +109,13 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_ranks(args.gpus)             # never returns
 
+    # The contract is ONE JSON line on stdout.  RCCL prints a five-line banner (version, host, library path) to the C stdout of every process that
+    # opens a communicator, flushed at exit -- i.e. AFTER the JSON line.  Keep a private handle on the real stdout for the result and point file
+    # descriptor 1 at stderr for everything else (libraries included).
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -256,7 +263,7 @@ def main():
         out.update({k: v for k, v in extra.items() if k not in out})
         if cpu is not None:
             out["cpu_baseline"] = cpu
-        print(json.dumps(out), flush=True)
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if os.environ.get("LSIM_TUNE") == "1" and rank == 0:   # keep the freshly tuned table (written at interpreter exit)
         import atexit, shutil
         src = os.environ["PYTORCH_TUNABLEOP_FILENAME"].replace(".csv", f"{local_rank}.csv")
