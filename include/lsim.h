@@ -460,6 +460,15 @@ int lsim_rollout_act(const lsim_rollout_storage* st, const int64_t* step_idx_dev
 int lsim_rollout_post(const lsim_rollout_storage* st, int64_t* step_idx_dev, int64_t* draw_counter_dev,
                       const uint8_t* dones, const uint8_t* time_outs, const float* rewards, const float* values,
                       const float* priv_obs, const float* term_priv_obs, float gamma, void* stream);
+/* lsim_rollout_act / lsim_rollout_post with the storage row and the sampler's counter passed BY VALUE (a host-driven rollout loop knows
+ * both): same kernels, same results, and no second launch to advance device-side counters -- the caller advances its own.
+ * LSIM_E_INVALID when step_idx is outside [0, num_steps). */
+int lsim_rollout_act_at(const lsim_rollout_storage* st, int64_t step_idx, int64_t draw_counter,
+                        const float* mean, const float* std, const float* values, const float* obs, const float* priv_obs,
+                        uint32_t seed, uint32_t rank, float* actions_out, void* stream);
+int lsim_rollout_post_at(const lsim_rollout_storage* st, int64_t step_idx, const uint8_t* dones, const uint8_t* time_outs,
+                         const float* rewards, const float* values, const float* priv_obs, const float* term_priv_obs, float gamma,
+                         void* stream);
 /* GAE(lambda) reverse sweep of HIMRolloutStorage.compute_returns (HST:113-123), one thread per env over the T stored steps:
  *   delta = r_t + (1 - done_t) * gamma * V_{t+1} - V_t;   A_t = delta + (1 - done_t) * gamma * lam * A_{t+1};   returns_t = A_t + V_t
  * with V_T = last_values [N, 1].  Writes returns [T, N, 1] and the raw advantages returns - values [T, N, 1]; the batch

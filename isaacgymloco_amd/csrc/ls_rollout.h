@@ -5,14 +5,16 @@
 
 struct LsRolloutActArgs {
     lsim_rollout_storage st;
-    const int64_t* step_idx; const int64_t* draw_counter;
+    const int64_t* step_idx; const int64_t* draw_counter;      // device-side counters, or NULL: the values below (lsim_rollout_act_at)
+    int64_t step_val, draw_val;
     const float* mean; const float* std; const float* values; const float* obs; const float* priv;
     uint32_t seed, rank;
     float* actions_out;
 };
 struct LsRolloutPostArgs {
     lsim_rollout_storage st;
-    int64_t* step_idx; int64_t* draw_counter;
+    int64_t* step_idx; int64_t* draw_counter;                  // device-side counters, or NULL: step_val (lsim_rollout_post_at)
+    int64_t step_val;
     const uint8_t* dones; const uint8_t* time_outs; const float* rewards; const float* values;
     const float* priv; const float* term_priv;
     float gamma;
@@ -29,7 +31,7 @@ __global__ __launch_bounds__(256) void lsim_k_rollout_act(LsRolloutActArgs a) {
     const int env = blockIdx.x * 4 + (threadIdx.x >> 6);
     const lsim_rollout_storage& st = a.st;
     if (env >= st.num_envs) return;
-    const int64_t t = *a.step_idx;
+    const int64_t t = a.step_idx ? *a.step_idx : a.step_val;
     if (t < 0 || t >= st.num_steps) return;                     // a full storage is the caller's error (HST:93-94 raises)
     const size_t row = (size_t)t * st.num_envs + env;
     ls_copy_row2(st.observations + row * st.num_obs, a.obs + (size_t)env * st.num_obs, st.num_obs, lane);
@@ -39,7 +41,7 @@ __global__ __launch_bounds__(256) void lsim_k_rollout_act(LsRolloutActArgs a) {
     if (lane < A) {
         const float mu = a.mean[(size_t)env * A + lane], sd = a.std[lane];
         float u[4];
-        ls_u01x4(a.seed, a.rank, (uint32_t)env, (uint32_t)*a.draw_counter, LSIM_RNG_POLICY, (uint32_t)(lane >> 1), u);
+        ls_u01x4(a.seed, a.rank, (uint32_t)env, (uint32_t)(a.draw_counter ? *a.draw_counter : a.draw_val), LSIM_RNG_POLICY, (uint32_t)(lane >> 1), u);
         const float u1 = 1.0f - u[2 * (lane & 1)], u2 = u[2 * (lane & 1) + 1];   // u1 in (0, 1]
         const float z = sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
         const float act = fmaf(sd, z, mu);
@@ -62,7 +64,7 @@ __global__ __launch_bounds__(256) void lsim_k_rollout_post(LsRolloutPostArgs a) 
     const int env = blockIdx.x * 4 + (threadIdx.x >> 6);
     const lsim_rollout_storage& st = a.st;
     if (env >= st.num_envs) return;
-    const int64_t t = *a.step_idx;
+    const int64_t t = a.step_idx ? *a.step_idx : a.step_val;
     if (t < 0 || t >= st.num_steps) return;
     const size_t row = (size_t)t * st.num_envs + env;
     const uint8_t done = a.dones[env];
@@ -94,9 +96,37 @@ extern "C" int lsim_rollout_act(const lsim_rollout_storage* st, const int64_t* s
     if (rc != LSIM_OK) return rc;
     if (!step_idx_dev || !draw_counter_dev || !mean || !std || !values || !obs || !priv_obs || !actions_out) return LSIM_E_INVALID;
     LsRolloutActArgs a;
-    a.st = *st; a.step_idx = step_idx_dev; a.draw_counter = draw_counter_dev; a.mean = mean; a.std = std; a.values = values;
+    a.st = *st; a.step_idx = step_idx_dev; a.draw_counter = draw_counter_dev; a.step_val = 0; a.draw_val = 0; a.mean = mean; a.std = std; a.values = values;
     a.obs = obs; a.priv = priv_obs; a.seed = seed; a.rank = rank; a.actions_out = actions_out;
     hipLaunchKernelGGL(lsim_k_rollout_act, dim3((st->num_envs + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? LSIM_OK : LSIM_E_HIP;
+}
+
+// the same two kernels with the storage row and the sampler's counter passed by value: a host-driven rollout loop knows both, and the
+// one-thread kernel that advances the device-side counters (a whole launch slot per step) disappears
+extern "C" int lsim_rollout_act_at(const lsim_rollout_storage* st, int64_t step_idx, int64_t draw_counter,
+                                   const float* mean, const float* std, const float* values, const float* obs, const float* priv_obs,
+                                   uint32_t seed, uint32_t rank, float* actions_out, void* stream) {
+    int rc = ls_rollout_check(st);
+    if (rc != LSIM_OK) return rc;
+    if (!mean || !std || !values || !obs || !priv_obs || !actions_out || step_idx < 0 || step_idx >= st->num_steps) return LSIM_E_INVALID;
+    LsRolloutActArgs a;
+    a.st = *st; a.step_idx = nullptr; a.draw_counter = nullptr; a.step_val = step_idx; a.draw_val = draw_counter; a.mean = mean; a.std = std; a.values = values;
+    a.obs = obs; a.priv = priv_obs; a.seed = seed; a.rank = rank; a.actions_out = actions_out;
+    hipLaunchKernelGGL(lsim_k_rollout_act, dim3((st->num_envs + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? LSIM_OK : LSIM_E_HIP;
+}
+
+extern "C" int lsim_rollout_post_at(const lsim_rollout_storage* st, int64_t step_idx, const uint8_t* dones, const uint8_t* time_outs,
+                                    const float* rewards, const float* values, const float* priv_obs, const float* term_priv_obs, float gamma,
+                                    void* stream) {
+    int rc = ls_rollout_check(st);
+    if (rc != LSIM_OK) return rc;
+    if (!dones || !rewards || !values || !priv_obs || !term_priv_obs || step_idx < 0 || step_idx >= st->num_steps) return LSIM_E_INVALID;
+    LsRolloutPostArgs a;
+    a.st = *st; a.step_idx = nullptr; a.draw_counter = nullptr; a.step_val = step_idx; a.dones = dones; a.time_outs = time_outs;
+    a.rewards = rewards; a.values = values; a.priv = priv_obs; a.term_priv = term_priv_obs; a.gamma = gamma;
+    hipLaunchKernelGGL(lsim_k_rollout_post, dim3((st->num_envs + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? LSIM_OK : LSIM_E_HIP;
 }
 
@@ -107,7 +137,7 @@ extern "C" int lsim_rollout_post(const lsim_rollout_storage* st, int64_t* step_i
     if (rc != LSIM_OK) return rc;
     if (!step_idx_dev || !draw_counter_dev || !dones || !rewards || !values || !priv_obs || !term_priv_obs) return LSIM_E_INVALID;
     LsRolloutPostArgs a;
-    a.st = *st; a.step_idx = step_idx_dev; a.draw_counter = draw_counter_dev; a.dones = dones; a.time_outs = time_outs;
+    a.st = *st; a.step_idx = step_idx_dev; a.draw_counter = draw_counter_dev; a.step_val = 0; a.dones = dones; a.time_outs = time_outs;
     a.rewards = rewards; a.values = values; a.priv = priv_obs; a.term_priv = term_priv_obs; a.gamma = gamma;
     hipLaunchKernelGGL(lsim_k_rollout_post, dim3((st->num_envs + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
     hipLaunchKernelGGL(lsim_k_rollout_advance, dim3(1), dim3(1), 0, (hipStream_t)stream, step_idx_dev, draw_counter_dev);

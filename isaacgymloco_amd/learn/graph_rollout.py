@@ -12,7 +12,9 @@ work).  Here
     lsim_rollout_post (HIP)    :  storage[idx] <- (where(done, termination_obs, critic_obs), reward + gamma * value * time_out,
                                    done);  idx += 1
 
-The storage index and the sampler's draw counter live in device memory, so nothing in the loop reads back to the host.
+With the fused policy kernel the launches are direct, so the storage row and the sampler's draw counter go by value (lsim_rollout_*_at);
+when torch's forward is replayed from a captured graph they live in device memory and a one-thread kernel advances them.  Either way
+nothing in the loop reads back to the host.
 The sampler is the library's counter-based Philox (keyed like the simulator by (seed, rank)), not torch's generator: the
 action distribution is the reference's N(mean, std); the draws are not torch's draws.
 """
@@ -32,6 +34,7 @@ class GraphedRollout:
         N, A = self.env.num_envs, self.env.num_actions
         self.idx = torch.zeros(1, dtype=torch.long, device=self.dev)       # storage row of the current step (device resident)
         self.draws = torch.zeros(1, dtype=torch.long, device=self.dev)     # Philox step word of the action sampler
+        self._draw_host = 0                                                # the same counter on the host (fused-policy path: counters go by value)
         self.actions = torch.zeros(N, A, device=self.dev)
         self.values = torch.zeros(N, 1, device=self.dev)
         self.mean = torch.zeros(N, A, device=self.dev)
@@ -41,6 +44,7 @@ class GraphedRollout:
         # preferred: the library's fused policy kernel (11 Linear + 8 ELU + glue in one launch); otherwise capture torch's forward
         from .fused_policy import PackedHimPolicy
         self.packed = PackedHimPolicy(self.alg.actor_critic) if PackedHimPolicy.supported(self.alg.actor_critic) else None
+        self.by_value = self.packed is not None         # captured graphs need device-side counters; the direct launches do not
         if self.packed is None:
             self._capture()
         self._weights_stale = True
@@ -56,6 +60,12 @@ class GraphedRollout:
             self.mean.copy_(ac.action_mean)
             self.values.copy_(ac.evaluate(env.privileged_obs_buf))
         s = torch.cuda.current_stream(self.dev).cuda_stream
+        if self.by_value:       # host-driven loop: storage row and draw counter by value, no device-side counters to advance
+            lib.check(self._L.lsim_rollout_act_at(ctypes.byref(self._S), int(self.storage.step), self._draw_host, self.mean.data_ptr(),
+                                                  ac.std.data_ptr(), self.values.data_ptr(), env.obs_buf.data_ptr(),
+                                                  env.privileged_obs_buf.data_ptr(), self._seed, self._rank, self.actions.data_ptr(), s),
+                      what="lsim_rollout_act_at")
+            return
         lib.check(self._L.lsim_rollout_act(ctypes.byref(self._S), self.idx.data_ptr(), self.draws.data_ptr(), self.mean.data_ptr(),
                                            ac.std.data_ptr(), self.values.data_ptr(), env.obs_buf.data_ptr(),
                                            env.privileged_obs_buf.data_ptr(), self._seed, self._rank, self.actions.data_ptr(), s),
@@ -67,6 +77,13 @@ class GraphedRollout:
         to = env.extras.get("time_outs")
         rewards = env.rew_buf if rewards is None else rewards
         s = torch.cuda.current_stream(self.dev).cuda_stream
+        if self.by_value:
+            lib.check(self._L.lsim_rollout_post_at(ctypes.byref(self._S), int(self.storage.step), env.reset_buf.data_ptr(),
+                                                   to.data_ptr() if to is not None else None, rewards.data_ptr(), self.values.data_ptr(),
+                                                   env.privileged_obs_buf.data_ptr(), env.termination_privileged_obs_buf.data_ptr(),
+                                                   float(self.alg.gamma), s), what="lsim_rollout_post_at")
+            self._draw_host += 1
+            return
         lib.check(self._L.lsim_rollout_post(ctypes.byref(self._S), self.idx.data_ptr(), self.draws.data_ptr(), env.reset_buf.data_ptr(),
                                             to.data_ptr() if to is not None else None, rewards.data_ptr(), self.values.data_ptr(),
                                             env.privileged_obs_buf.data_ptr(), env.termination_privileged_obs_buf.data_ptr(),
@@ -100,6 +117,14 @@ class GraphedRollout:
         with lib.roctx_range("rollout_post"):
             self._post()
         self.storage.step += 1
+
+    def get_draw_counter(self):
+        """Philox step word of the action sampler (checkpointed by the runner)"""
+        return self._draw_host if self.by_value else int(self.draws.item())
+
+    def set_draw_counter(self, v):
+        self._draw_host = int(v)
+        self.draws.fill_(int(v))
 
     def _sync_weights(self):
         if self._weights_stale and self.packed is not None:

@@ -55,7 +55,7 @@ class HIMOnPolicyRunner:
             if self.graphs is not None:
                 self.alg.enable_device_lr()
                 if self._pending_draw_counter is not None:
-                    self.graphs.draws.fill_(self._pending_draw_counter)
+                    self.graphs.set_draw_counter(self._pending_draw_counter)
                     self._pending_draw_counter = None
         return self.graphs is not None
 
@@ -249,7 +249,7 @@ class HIMOnPolicyRunner:
         if hasattr(self.env, "state_dict"):
             out["env_state_dict"] = self.env.state_dict()
         if self.graphs is not None:
-            out["rollout_draw_counter"] = int(self.graphs.draws.item())
+            out["rollout_draw_counter"] = self.graphs.get_draw_counter()
         elif self._pending_draw_counter is not None:
             out["rollout_draw_counter"] = int(self._pending_draw_counter)
         return out
@@ -261,7 +261,7 @@ class HIMOnPolicyRunner:
             self.env.load_state_dict(d["env_state_dict"])
         if "rollout_draw_counter" in d:           # the sampler's Philox step word: applied now, or when enable_graphs() creates the rollout
             if self.graphs is not None:
-                self.graphs.draws.fill_(d["rollout_draw_counter"])
+                self.graphs.set_draw_counter(d["rollout_draw_counter"])
             else:
                 self._pending_draw_counter = int(d["rollout_draw_counter"])
 

@@ -250,7 +250,7 @@ def test_checkpoint_round_trip_restores_env_curricula(tmp_path):
     run2.load(path)
     st2 = env2.state_dict()
     assert st2["step_counter"] == st["step_counter"] and torch.equal(st2["terrain_levels"], st["terrain_levels"])
-    assert torch.equal(st2["command_ranges"], st["command_ranges"]) and int(run2.graphs.draws) == int(run.graphs.draws)
+    assert torch.equal(st2["command_ranges"], st["command_ranges"]) and run2.graphs.get_draw_counter() == run.graphs.get_draw_counter()
     for k, v in run.alg.actor_critic.state_dict().items():
         assert torch.equal(v, run2.alg.actor_critic.state_dict()[k])
     run2.learn(1)                                           # and training continues from there
@@ -263,9 +263,9 @@ def test_checkpoint_round_trip_restores_env_curricula(tmp_path):
     # a load BEFORE enable_graphs() keeps the sampler's counter and applies it when the fused rollout is created
     env3, run3 = _make(seed=11)
     run3.load(path)
-    assert run3.graphs is None and run3._pending_draw_counter == int(run.graphs.draws)
+    assert run3.graphs is None and run3._pending_draw_counter == run.graphs.get_draw_counter()
     run3.enable_graphs()
-    assert int(run3.graphs.draws) == int(run.graphs.draws)
+    assert run3.graphs.get_draw_counter() == run.graphs.get_draw_counter()
     run3.learn(1)
 
 
