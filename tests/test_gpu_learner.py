@@ -153,6 +153,18 @@ def test_fused_rollout_kernels_match_torch():
     assert torch.equal(st["actions"], before)
     assert L.lsim_rollout_act(None, idx.data_ptr(), draws.data_ptr(), mean.data_ptr(), std.data_ptr(), values.data_ptr(), obs.data_ptr(),
                               priv.data_ptr(), 5, 0, acts.data_ptr(), s) == abi.E_INVALID
+    # ---- the by-value forms (lsim_rollout_act_at / _post_at): row 0 with counter 7 must reproduce what the device-counter form wrote into row 1
+    by_val = torch.zeros_like(acts)
+    assert L.lsim_rollout_act_at(ctypes.byref(S), 0, 7, mean.data_ptr(), std.data_ptr(), values.data_ptr(), obs.data_ptr(), priv.data_ptr(), 5, 0,
+                                 by_val.data_ptr(), s) == 0
+    assert L.lsim_rollout_post_at(ctypes.byref(S), 0, dones.data_ptr(), touts.data_ptr(), rew.data_ptr(), values.data_ptr(), priv.data_ptr(),
+                                  term.data_ptr(), ctypes.c_float(0.99), s) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(by_val, acts)
+    for k in ("observations", "privileged_observations", "next_privileged_observations", "actions", "values", "actions_log_prob", "mu", "sigma", "rewards", "dones"):
+        assert torch.equal(st[k][0], st[k][1]), k
+    assert L.lsim_rollout_act_at(ctypes.byref(S), T, 7, mean.data_ptr(), std.data_ptr(), values.data_ptr(), obs.data_ptr(), priv.data_ptr(), 5, 0,
+                                 by_val.data_ptr(), s) == abi.E_INVALID                     # row past the storage
 
 
 def test_fused_gae_matches_torch_sweep():
