@@ -497,6 +497,13 @@ typedef struct lsim_him_policy {
 int lsim_policy_forward(const lsim_him_policy* p, const float* obs, const float* priv_obs, int64_t num_envs, float* mean_out,
                         float* values_out, void* stream);
 
+/* lsim_policy_forward and lsim_rollout_act_at in ONE launch: the blocks that evaluate the networks also copy the observation rows into
+ * storage row step_idx, sample the actions (same Philox draws, same log-probability sums as lsim_rollout_act) and store actions, values,
+ * log-prob, mu, sigma.  num_envs = st->num_envs; the storage's observation widths and action count must equal the policy's. */
+int lsim_policy_act_at(const lsim_him_policy* p, const lsim_rollout_storage* st, int64_t step_idx, int64_t draw_counter,
+                       const float* obs, const float* priv_obs, const float* std, uint32_t seed, uint32_t rank,
+                       float* mean_out, float* values_out, float* actions_out, void* stream);
+
 /* ---- learner-side kernel: weight / bias gradient of a small Linear layer over a tall minibatch,
  *   dw[n, k] = sum_b g[b, n] * x[b, k],   db[n] = sum_b g[b, n]      (torch.nn.Linear backward: grad_weight = g^T x, grad_bias = g.sum(0))
  * for ceil(n_out / 16) * ceil(k_in / 16) <= 32 (each <= 8): the heads and narrow layers of HAC:66-95 / HES:36-54 / DISC:18-25, whose

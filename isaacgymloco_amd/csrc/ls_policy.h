@@ -99,9 +99,19 @@ __device__ __forceinline__ void ls_pol_run_layer(const lsim_mlp_layer& L, int x_
 
 // ROWS environments per workgroup of WAVES waves: (16, 8) -- two blocks per CU, 68 KB of LDS each -- or (32, 16): one block per CU (137 KB),
 // the same four waves per SIMD, half the weight traffic per environment
-template <int ROWS, int WAVES>
+// ACT: the rollout's sampling / storage step (lsim_rollout_act: HIMP:90-103, HST:92-106) done by the same blocks -- the observation rows
+// go to the storage while they are staged, the actor block samples the actions from the means it holds in LDS, the critic block stores the
+// values: one launch less per rollout step, same Philox draws and the same summation order of the log-probability as lsim_k_rollout_act
+struct LsPolActArgs {
+    lsim_rollout_storage st;
+    int64_t step, draw;
+    const float* std;
+    uint32_t seed, rank;
+    float* actions_out;
+};
+template <int ROWS, int WAVES, bool ACT>
 __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void lsim_k_policy_forward(lsim_him_policy p, const float* __restrict__ obs, const float* __restrict__ priv,
-                                                             long num_envs, float* __restrict__ mean_out, float* __restrict__ values_out) {
+                                                             long num_envs, float* __restrict__ mean_out, float* __restrict__ values_out, LsPolActArgs act) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long r0 = (long)blockIdx.x * ROWS;
     // blockIdx.y = 0: estimator encoder + actor on the observation history; 1: critic on the privileged observation.  The two halves are
@@ -116,7 +126,12 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4
     for (int e = tid; e < ROWS * first.k_pad; e += 64 * WAVES) {
         const int r = e / first.k_pad, c = e - r * first.k_pad;
         const long env = r0 + r;
-        ls_pol_lds[o_in + r * s_in + c] = (env < num_envs && c < n_in) ? src[env * n_in + c] : 0.0f;
+        const float v = (env < num_envs && c < n_in) ? src[env * n_in + c] : 0.0f;
+        ls_pol_lds[o_in + r * s_in + c] = v;
+        if (ACT && env < num_envs && c < n_in) {
+            float* dst = critic ? act.st.privileged_observations : act.st.observations;
+            dst[((size_t)act.step * act.st.num_envs + env) * n_in + c] = v;
+        }
     }
     __syncthreads();
 #define LS_RUN(L, XO, XS, YO, YS, ELU) ls_pol_run_layer<ROWS, WAVES>(L, XO, XS, YO, YS, ELU, wave, lane)
@@ -126,7 +141,11 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4
         LS_RUN(p.critic[1], o_a, s_a, o_b, s_b, 1);
         LS_RUN(p.critic[2], o_b, s_b, o_a, s_a, 1);
         LS_RUN(p.critic[3], o_a, s_a, o_b, s_b, 0);
-        if (tid < ROWS && r0 + tid < num_envs) values_out[r0 + tid] = ls_pol_lds[o_b + tid * s_b];
+        if (tid < ROWS && r0 + tid < num_envs) {
+            const float v = ls_pol_lds[o_b + tid * s_b];
+            values_out[r0 + tid] = v;
+            if (ACT) act.st.values[(size_t)act.step * act.st.num_envs + r0 + tid] = v;
+        }
         return;
     }
     // ---- estimator encoder (HES:64-68): history -> (velocity 3, latent 16)
@@ -160,6 +179,36 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4
         const int r = e / p.num_actions, c = e - r * p.num_actions;
         if (r0 + r < num_envs) mean_out[(r0 + r) * p.num_actions + c] = ls_pol_lds[o_b + r * s_b + c];
     }
+    if constexpr (ACT) {
+        const int A = p.num_actions;                    // <= 16 (checked by the host)
+        float* lp_lds = ls_pol_lds + o_a;               // buffer A is free again: 16 log-probability terms per row
+        for (int e = tid; e < ROWS * 16; e += 64 * WAVES) {
+            const int r = e >> 4, c = e & 15;
+            const long env = r0 + r;
+            float lp = 0.0f;
+            if (c < A && env < num_envs) {
+                const float mu = ls_pol_lds[o_b + r * s_b + c], sd = act.std[c];
+                const float a = ls_sample_action(act.seed, act.rank, (uint32_t)env, (uint32_t)act.draw, c, mu, sd);
+                const size_t row = (size_t)act.step * act.st.num_envs + env;
+                act.actions_out[env * A + c] = a;
+                act.st.actions[row * A + c] = a;
+                act.st.mu[row * A + c] = mu;
+                act.st.sigma[row * A + c] = sd;
+                lp = ls_normal_log_prob(a - mu, sd);
+            }
+            lp_lds[e] = lp;
+        }
+        __syncthreads();
+        if (tid < ROWS && r0 + tid < num_envs) {        // the pairwise tree of lsim_k_rollout_act's shuffle reduction, so that the sums agree bit for bit
+            const float* l = lp_lds + 16 * tid;
+            float t8[8], t4[4];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t8[i] = l[i] + l[i + 8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) t4[i] = t8[i] + t8[i + 4];
+            act.st.actions_log_prob[(size_t)act.step * act.st.num_envs + r0 + tid] = (t4[0] + t4[2]) + (t4[1] + t4[3]);
+        }
+    }
 }
 
 static int ls_pol_check_layer(const lsim_mlp_layer* L, int k_in_expected) {
@@ -170,9 +219,13 @@ static int ls_pol_check_layer(const lsim_mlp_layer* L, int k_in_expected) {
     return 0;
 }
 
-extern "C" int lsim_policy_forward(const lsim_him_policy* p, const float* obs, const float* priv_obs, int64_t num_envs, float* mean_out,
-                                   float* values_out, void* stream) {
+static int ls_policy_launch(const lsim_him_policy* p, const float* obs, const float* priv_obs, int64_t num_envs, float* mean_out,
+                            float* values_out, const LsPolActArgs* act_args, void* stream) {
     if (!p || !obs || !priv_obs || !mean_out || !values_out || num_envs <= 0) return LSIM_E_INVALID;
+    const bool act = act_args != nullptr;
+    LsPolActArgs aa;
+    memset(&aa, 0, sizeof(aa));
+    if (act) aa = *act_args;
     if (p->num_obs > LS_POL_MAX_IN || p->num_priv_obs > LS_POL_MAX_IN || p->num_actions <= 0 || p->num_actions > 16) return LSIM_E_UNSUPPORTED;
     int bad = 0, k = p->num_obs;
     for (int l = 0; l < 3; ++l) { bad |= ls_pol_check_layer(&p->encoder[l], k); k = p->encoder[l].n_out; }
@@ -192,16 +245,39 @@ extern "C" int lsim_policy_forward(const lsim_him_policy* p, const float* obs, c
     const bool wide = num_envs >= 2048 && !force16;
     const int rows = wide ? 32 : 16;
     const size_t lds = (size_t)rows * (2 * (LS_POL_MAX_IN + LS_POL_PAD) + (LS_POL_MAX_HIDDEN + LS_POL_PAD)) * sizeof(float);
-    static size_t configured[2][64] = {{0}};     // per kernel and device: the attribute belongs to the device's copy of the kernel
+    static size_t configured[4][64] = {{0}};     // per kernel and device: the attribute belongs to the device's copy of the kernel
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LSIM_E_HIP;
-    const void* fn = wide ? (const void*)lsim_k_policy_forward<32, 16> : (const void*)lsim_k_policy_forward<16, 8>;
-    if (lds > configured[wide][dev]) {
+    const void* fn = wide ? (act ? (const void*)lsim_k_policy_forward<32, 16, true> : (const void*)lsim_k_policy_forward<32, 16, false>)
+                          : (act ? (const void*)lsim_k_policy_forward<16, 8, true> : (const void*)lsim_k_policy_forward<16, 8, false>);
+    const int slot = 2 * (int)wide + (int)act;
+    if (lds > configured[slot][dev]) {
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return LSIM_E_HIP;
-        configured[wide][dev] = lds;
+        configured[slot][dev] = lds;
     }
     const int blocks = (int)((num_envs + rows - 1) / rows);
-    if (wide) hipLaunchKernelGGL((lsim_k_policy_forward<32, 16>), dim3(blocks, 2), dim3(64 * 16), lds, (hipStream_t)stream, *p, obs, priv_obs, (long)num_envs, mean_out, values_out);
-    else hipLaunchKernelGGL((lsim_k_policy_forward<16, 8>), dim3(blocks, 2), dim3(64 * 8), lds, (hipStream_t)stream, *p, obs, priv_obs, (long)num_envs, mean_out, values_out);
+#define LS_POL_LAUNCH(R, W, A) hipLaunchKernelGGL((lsim_k_policy_forward<R, W, A>), dim3(blocks, 2), dim3(64 * W), lds, (hipStream_t)stream, *p, obs, priv_obs, \
+                                                 (long)num_envs, mean_out, values_out, aa)
+    if (wide) { if (act) LS_POL_LAUNCH(32, 16, true); else LS_POL_LAUNCH(32, 16, false); }
+    else { if (act) LS_POL_LAUNCH(16, 8, true); else LS_POL_LAUNCH(16, 8, false); }
+#undef LS_POL_LAUNCH
     return hipGetLastError() == hipSuccess ? LSIM_OK : LSIM_E_HIP;
+}
+
+extern "C" int lsim_policy_forward(const lsim_him_policy* p, const float* obs, const float* priv_obs, int64_t num_envs, float* mean_out,
+                                   float* values_out, void* stream) {
+    return ls_policy_launch(p, obs, priv_obs, num_envs, mean_out, values_out, nullptr, stream);
+}
+
+extern "C" int lsim_policy_act_at(const lsim_him_policy* p, const lsim_rollout_storage* st, int64_t step_idx, int64_t draw_counter,
+                                  const float* obs, const float* priv_obs, const float* std, uint32_t seed, uint32_t rank,
+                                  float* mean_out, float* values_out, float* actions_out, void* stream) {
+    if (!p || !st || !std || !actions_out) return LSIM_E_INVALID;
+    int rc = ls_rollout_check(st);
+    if (rc != LSIM_OK) return rc;
+    if (step_idx < 0 || step_idx >= st->num_steps || st->num_obs != p->num_obs || st->num_priv_obs != p->num_priv_obs ||
+        st->num_actions != p->num_actions) return LSIM_E_INVALID;
+    LsPolActArgs a;
+    a.st = *st; a.step = step_idx; a.draw = draw_counter; a.std = std; a.seed = seed; a.rank = rank; a.actions_out = actions_out;
+    return ls_policy_launch(p, obs, priv_obs, st->num_envs, mean_out, values_out, &a, stream);
 }

@@ -26,6 +26,18 @@ __device__ __forceinline__ void ls_copy_row2(float* dst, const float* src, int n
     for (int k = lane; k < (n >> 1); k += 64) d2[k] = s2[k];
 }
 
+// action j of env: mean + std * z, z ~ N(0,1) by Box-Muller on the Philox block (env, draw counter, LSIM_RNG_POLICY, j / 2)
+__device__ __forceinline__ float ls_sample_action(uint32_t seed, uint32_t rank, uint32_t env, uint32_t draw, int j, float mu, float sd) {
+    float u[4];
+    ls_u01x4(seed, rank, env, draw, LSIM_RNG_POLICY, (uint32_t)(j >> 1), u);
+    const float u1 = 1.0f - u[2 * (j & 1)], u2 = u[2 * (j & 1) + 1];   // u1 in (0, 1]
+    const float z = sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+    return fmaf(sd, z, mu);
+}
+__device__ __forceinline__ float ls_normal_log_prob(float d, float sd) {      // torch.distributions.Normal.log_prob of mean + d
+    return -(d * d) / (2.0f * sd * sd) - logf(sd) - 0.9189385332046727f;
+}
+
 __global__ __launch_bounds__(256) void lsim_k_rollout_act(LsRolloutActArgs a) {
     const int lane = threadIdx.x & 63;
     const int env = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -40,17 +52,13 @@ __global__ __launch_bounds__(256) void lsim_k_rollout_act(LsRolloutActArgs a) {
     float lp = 0.0f;
     if (lane < A) {
         const float mu = a.mean[(size_t)env * A + lane], sd = a.std[lane];
-        float u[4];
-        ls_u01x4(a.seed, a.rank, (uint32_t)env, (uint32_t)(a.draw_counter ? *a.draw_counter : a.draw_val), LSIM_RNG_POLICY, (uint32_t)(lane >> 1), u);
-        const float u1 = 1.0f - u[2 * (lane & 1)], u2 = u[2 * (lane & 1) + 1];   // u1 in (0, 1]
-        const float z = sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
-        const float act = fmaf(sd, z, mu);
+        const float act = ls_sample_action(a.seed, a.rank, (uint32_t)env, (uint32_t)(a.draw_counter ? *a.draw_counter : a.draw_val), lane, mu, sd);
         a.actions_out[(size_t)env * A + lane] = act;
         st.actions[row * A + lane] = act;
         st.mu[row * A + lane] = mu;
         st.sigma[row * A + lane] = sd;
         const float d = act - mu;
-        lp = -(d * d) / (2.0f * sd * sd) - logf(sd) - 0.9189385332046727f;      // torch.distributions.Normal.log_prob
+        lp = ls_normal_log_prob(d, sd);
     }
     for (int off = 16; off > 0; off >>= 1) lp += __shfl_down(lp, off, 64);       // A <= 32
     if (lane == 0) {

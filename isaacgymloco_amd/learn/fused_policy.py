@@ -61,3 +61,9 @@ class PackedHimPolicy:
         n = obs.shape[0]
         lib.check(self._L.lsim_policy_forward(ctypes.byref(self._P), obs.data_ptr(), priv_obs.data_ptr(), n, mean_out.data_ptr(), values_out.data_ptr(),
                                               torch.cuda.current_stream(self.dev).cuda_stream), what="lsim_policy_forward")
+
+    def forward_act(self, storage_struct, step, draw, obs, priv_obs, std, seed, rank, mean_out, values_out, actions_out):
+        """lsim_policy_act_at: the networks, the action sample and the storage row of rollout step `step` in one launch"""
+        lib.check(self._L.lsim_policy_act_at(ctypes.byref(self._P), ctypes.byref(storage_struct), int(step), int(draw), obs.data_ptr(), priv_obs.data_ptr(),
+                                             std.data_ptr(), seed, rank, mean_out.data_ptr(), values_out.data_ptr(), actions_out.data_ptr(),
+                                             torch.cuda.current_stream(self.dev).cuda_stream), what="lsim_policy_act_at")

@@ -5,9 +5,9 @@ log-prob, the time-out bootstrap, eleven storage copies, HIMR:110-127 + HIMP:90-
 a few microseconds on the GPU but ~10 us of host dispatch, so collection is host-bound (1.2 ms/step against 0.76 ms of GPU
 work).  Here
 
-    lsim_policy_forward (HIP)  :  encoder + normalise + actor + critic in one MFMA kernel (learn/fused_policy.py)  ->  mean, values
-                                  [other network topologies: torch's forward, captured once in a HIP graph]
-    lsim_rollout_act   (HIP)   :  a = mean + std * z, log-prob, storage[idx] <- (obs, critic_obs, actions, values, log-prob, mu, sigma)
+    lsim_policy_act_at (HIP)   :  encoder + normalise + actor + critic in one MFMA kernel (learn/fused_policy.py) whose blocks also do
+                                  a = mean + std * z, log-prob, storage[idx] <- (obs, critic_obs, actions, values, log-prob, mu, sigma)
+                                  [other network topologies: torch's forward, captured once in a HIP graph, then lsim_rollout_act]
     env.step_device(actions)      (HIP kernels A + B, not captured: per-call arguments)
     lsim_rollout_post (HIP)    :  storage[idx] <- (where(done, termination_obs, critic_obs), reward + gamma * value * time_out,
                                    done);  idx += 1
@@ -53,6 +53,10 @@ class GraphedRollout:
     # ---- HIMP:90-103 written against static tensors; the elementwise tail is one HIP kernel --------------------------
     def _act(self):
         env, ac = self.env, self.alg.actor_critic
+        if self.by_value:           # networks + sample + storage row in one launch (lsim_policy_act_at)
+            self.packed.forward_act(self._S, self.storage.step, self._draw_host, env.obs_buf, env.privileged_obs_buf, ac.std, self._seed, self._rank,
+                                    self.mean, self.values, self.actions)
+            return
         if self.packed is not None:
             self.packed.forward(env.obs_buf, env.privileged_obs_buf, self.mean, self.values)
         else:
@@ -60,12 +64,6 @@ class GraphedRollout:
             self.mean.copy_(ac.action_mean)
             self.values.copy_(ac.evaluate(env.privileged_obs_buf))
         s = torch.cuda.current_stream(self.dev).cuda_stream
-        if self.by_value:       # host-driven loop: storage row and draw counter by value, no device-side counters to advance
-            lib.check(self._L.lsim_rollout_act_at(ctypes.byref(self._S), int(self.storage.step), self._draw_host, self.mean.data_ptr(),
-                                                  ac.std.data_ptr(), self.values.data_ptr(), env.obs_buf.data_ptr(),
-                                                  env.privileged_obs_buf.data_ptr(), self._seed, self._rank, self.actions.data_ptr(), s),
-                      what="lsim_rollout_act_at")
-            return
         lib.check(self._L.lsim_rollout_act(ctypes.byref(self._S), self.idx.data_ptr(), self.draws.data_ptr(), self.mean.data_ptr(),
                                            ac.std.data_ptr(), self.values.data_ptr(), env.obs_buf.data_ptr(),
                                            env.privileged_obs_buf.data_ptr(), self._seed, self._rank, self.actions.data_ptr(), s),

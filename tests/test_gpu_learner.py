@@ -311,6 +311,48 @@ def test_fused_policy_forward_matches_torch(N):
     torch.testing.assert_close(mean, ac.action_mean, rtol=2e-4, atol=2e-5 * float(ac.action_mean.abs().max()))
 
 
+def test_policy_act_in_one_launch_equals_forward_then_act():
+    """lsim_policy_act_at (networks + sample + storage row in one kernel) against lsim_policy_forward followed by lsim_rollout_act_at:
+    identical means / values / actions / storage rows, bit for bit (same Philox draws, same log-probability summation tree)"""
+    import ctypes
+    from isaacgymloco_amd import abi, lib
+    from isaacgymloco_amd.learn import modules as M
+    from isaacgymloco_amd.learn.fused_policy import PackedHimPolicy
+    L = lib.load()
+    dev = "cuda:0"
+    for N in (4096, 37):                        # the 32-row and the 16-row kernels
+        torch.manual_seed(N)
+        ac = M.HIMActorCritic(270, 238, 45, 12).to(dev)
+        pk = PackedHimPolicy(ac)
+        T, A, O, P = 3, 12, 270, 238
+
+        def storage():
+            st = {k: torch.zeros(T, N, d, device=dev) for k, d in (("observations", O), ("privileged_observations", P),
+                  ("next_privileged_observations", P), ("actions", A), ("values", 1), ("actions_log_prob", 1), ("mu", A), ("sigma", A), ("rewards", 1))}
+            st["dones"] = torch.zeros(T, N, 1, device=dev, dtype=torch.uint8)
+            S = abi.LsimRolloutStorage()
+            for k, t in st.items():
+                setattr(S, k, t.data_ptr())
+            S.num_steps, S.num_envs, S.num_obs, S.num_priv_obs, S.num_actions = T, N, O, P, A
+            return st, S
+        obs, priv = torch.randn(N, O, device=dev), torch.randn(N, P, device=dev)
+        std = torch.rand(A, device=dev) + 0.3
+        s = torch.cuda.current_stream().cuda_stream
+        st1, S1 = storage()
+        m1, v1, a1 = torch.zeros(N, A, device=dev), torch.zeros(N, 1, device=dev), torch.zeros(N, A, device=dev)
+        pk.forward(obs, priv, m1, v1)
+        assert L.lsim_rollout_act_at(ctypes.byref(S1), 2, 11, m1.data_ptr(), std.data_ptr(), v1.data_ptr(), obs.data_ptr(), priv.data_ptr(), 5, 1,
+                                     a1.data_ptr(), s) == 0
+        st2, S2 = storage()
+        m2, v2, a2 = torch.zeros(N, A, device=dev), torch.zeros(N, 1, device=dev), torch.zeros(N, A, device=dev)
+        pk.forward_act(S2, 2, 11, obs, priv, std, 5, 1, m2, v2, a2)
+        torch.cuda.synchronize()
+        assert torch.equal(m2, m1) and torch.equal(v2, v1) and torch.equal(a2, a1)
+        for k in st1:
+            assert torch.equal(st2[k], st1[k]), (N, k)
+        assert st2["actions"][2].abs().sum() > 0 and st2["observations"][0].abs().sum() == 0
+
+
 @pytest.mark.parametrize("clipped", [True, False])
 def test_fused_ppo_loss_matches_torch_autograd(clipped):
     """lsim_ppo_loss (forward + backward + KL in one pass) against the torch statement of HIMP:136-176 and its autograd gradients"""
