@@ -504,6 +504,16 @@ int lsim_policy_act_at(const lsim_him_policy* p, const lsim_rollout_storage* st,
                        const float* obs, const float* priv_obs, const float* std, uint32_t seed, uint32_t rank,
                        float* mean_out, float* values_out, float* actions_out, void* stream);
 
+/* lsim_policy_act_at that also performs the PREVIOUS step's lsim_rollout_post_at (prev_step < 0: none): the privileged observation the critic
+ * blocks stage for this step is the previous step's next critic observation (termination rows patched in from prev_term_priv_obs where
+ * prev_dones), and values_out still holds the previous step's values when they form  r + gamma * V * time_out.  The caller stores the last
+ * step of a rollout with lsim_rollout_post_at.  Same results as the separate calls. */
+int lsim_policy_act_post_at(const lsim_him_policy* p, const lsim_rollout_storage* st, int64_t step_idx, int64_t draw_counter,
+                            const float* obs, const float* priv_obs, const float* std, uint32_t seed, uint32_t rank,
+                            float* mean_out, float* values_out, float* actions_out,
+                            int64_t prev_step, const uint8_t* prev_dones, const uint8_t* prev_time_outs, const float* prev_rewards,
+                            const float* prev_term_priv_obs, float gamma, void* stream);
+
 /* ---- learner-side kernel: weight / bias gradient of a small Linear layer over a tall minibatch,
  *   dw[n, k] = sum_b g[b, n] * x[b, k],   db[n] = sum_b g[b, n]      (torch.nn.Linear backward: grad_weight = g^T x, grad_bias = g.sum(0))
  * for ceil(n_out / 16) * ceil(k_in / 16) <= 32 (each <= 8): the heads and narrow layers of HAC:66-95 / HES:36-54 / DISC:18-25, whose

@@ -108,6 +108,12 @@ struct LsPolActArgs {
     const float* std;
     uint32_t seed, rank;
     float* actions_out;
+    // the PREVIOUS step's post-step store (lsim_rollout_post: HIMP:105-118, HST:92-106), done by the critic blocks while they stage the new
+    // privileged observation -- which IS the previous step's next critic observation -- and before they overwrite values_out; prev_step < 0: none
+    int64_t prev_step;
+    const uint8_t* prev_dones; const uint8_t* prev_time_outs;
+    const float* prev_rewards; const float* prev_term_priv;
+    float gamma;
 };
 template <int ROWS, int WAVES, bool ACT>
 __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void lsim_k_policy_forward(lsim_him_policy p, const float* __restrict__ obs, const float* __restrict__ priv,
@@ -131,7 +137,18 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4
         if (ACT && env < num_envs && c < n_in) {
             float* dst = critic ? act.st.privileged_observations : act.st.observations;
             dst[((size_t)act.step * act.st.num_envs + env) * n_in + c] = v;
+            if (critic && act.prev_step >= 0)       // next critic observation of the previous step, termination rows patched in (HIMR:119-121)
+                act.st.next_privileged_observations[((size_t)act.prev_step * act.st.num_envs + env) * n_in + c] =
+                    act.prev_dones[env] ? act.prev_term_priv[env * n_in + c] : v;
         }
+    }
+    if (ACT && critic && act.prev_step >= 0 && tid < ROWS && r0 + tid < num_envs) {
+        const long env = r0 + tid;
+        const size_t row = (size_t)act.prev_step * act.st.num_envs + env;
+        float r = act.prev_rewards[env];
+        if (act.prev_time_outs) r += act.gamma * (values_out[env] * (float)act.prev_time_outs[env]);      // HIMP:110-111, with the previous step's value
+        act.st.rewards[row] = r;
+        act.st.dones[row] = act.prev_dones[env];
     }
     __syncthreads();
 #define LS_RUN(L, XO, XS, YO, YS, ELU) ls_pol_run_layer<ROWS, WAVES>(L, XO, XS, YO, YS, ELU, wave, lane)
@@ -278,6 +295,27 @@ extern "C" int lsim_policy_act_at(const lsim_him_policy* p, const lsim_rollout_s
     if (step_idx < 0 || step_idx >= st->num_steps || st->num_obs != p->num_obs || st->num_priv_obs != p->num_priv_obs ||
         st->num_actions != p->num_actions) return LSIM_E_INVALID;
     LsPolActArgs a;
+    memset(&a, 0, sizeof(a));
     a.st = *st; a.step = step_idx; a.draw = draw_counter; a.std = std; a.seed = seed; a.rank = rank; a.actions_out = actions_out;
+    a.prev_step = -1;
+    return ls_policy_launch(p, obs, priv_obs, st->num_envs, mean_out, values_out, &a, stream);
+}
+
+extern "C" int lsim_policy_act_post_at(const lsim_him_policy* p, const lsim_rollout_storage* st, int64_t step_idx, int64_t draw_counter,
+                                       const float* obs, const float* priv_obs, const float* std, uint32_t seed, uint32_t rank,
+                                       float* mean_out, float* values_out, float* actions_out,
+                                       int64_t prev_step, const uint8_t* prev_dones, const uint8_t* prev_time_outs, const float* prev_rewards,
+                                       const float* prev_term_priv_obs, float gamma, void* stream) {
+    if (!p || !st || !std || !actions_out) return LSIM_E_INVALID;
+    int rc = ls_rollout_check(st);
+    if (rc != LSIM_OK) return rc;
+    if (step_idx < 0 || step_idx >= st->num_steps || st->num_obs != p->num_obs || st->num_priv_obs != p->num_priv_obs ||
+        st->num_actions != p->num_actions) return LSIM_E_INVALID;
+    if (prev_step >= st->num_steps || (prev_step >= 0 && (!prev_dones || !prev_rewards || !prev_term_priv_obs))) return LSIM_E_INVALID;
+    LsPolActArgs a;
+    memset(&a, 0, sizeof(a));
+    a.st = *st; a.step = step_idx; a.draw = draw_counter; a.std = std; a.seed = seed; a.rank = rank; a.actions_out = actions_out;
+    a.prev_step = prev_step < 0 ? -1 : prev_step; a.prev_dones = prev_dones; a.prev_time_outs = prev_time_outs; a.prev_rewards = prev_rewards;
+    a.prev_term_priv = prev_term_priv_obs; a.gamma = gamma;
     return ls_policy_launch(p, obs, priv_obs, st->num_envs, mean_out, values_out, &a, stream);
 }

@@ -62,8 +62,17 @@ class PackedHimPolicy:
         lib.check(self._L.lsim_policy_forward(ctypes.byref(self._P), obs.data_ptr(), priv_obs.data_ptr(), n, mean_out.data_ptr(), values_out.data_ptr(),
                                               torch.cuda.current_stream(self.dev).cuda_stream), what="lsim_policy_forward")
 
-    def forward_act(self, storage_struct, step, draw, obs, priv_obs, std, seed, rank, mean_out, values_out, actions_out):
-        """lsim_policy_act_at: the networks, the action sample and the storage row of rollout step `step` in one launch"""
-        lib.check(self._L.lsim_policy_act_at(ctypes.byref(self._P), ctypes.byref(storage_struct), int(step), int(draw), obs.data_ptr(), priv_obs.data_ptr(),
-                                             std.data_ptr(), seed, rank, mean_out.data_ptr(), values_out.data_ptr(), actions_out.data_ptr(),
-                                             torch.cuda.current_stream(self.dev).cuda_stream), what="lsim_policy_act_at")
+    def forward_act(self, storage_struct, step, draw, obs, priv_obs, std, seed, rank, mean_out, values_out, actions_out, prev=None):
+        """lsim_policy_act_at: the networks, the action sample and the storage row of rollout step `step` in one launch; with
+        prev = (step, dones, time_outs or None, rewards, term_priv_obs, gamma) also the previous step's post-step store (lsim_policy_act_post_at)"""
+        s = torch.cuda.current_stream(self.dev).cuda_stream
+        if prev is None:
+            lib.check(self._L.lsim_policy_act_at(ctypes.byref(self._P), ctypes.byref(storage_struct), int(step), int(draw), obs.data_ptr(), priv_obs.data_ptr(),
+                                                 std.data_ptr(), seed, rank, mean_out.data_ptr(), values_out.data_ptr(), actions_out.data_ptr(), s),
+                      what="lsim_policy_act_at")
+            return
+        pstep, dones, touts, rewards, term, gamma = prev
+        lib.check(self._L.lsim_policy_act_post_at(ctypes.byref(self._P), ctypes.byref(storage_struct), int(step), int(draw), obs.data_ptr(), priv_obs.data_ptr(),
+                                                  std.data_ptr(), seed, rank, mean_out.data_ptr(), values_out.data_ptr(), actions_out.data_ptr(),
+                                                  int(pstep), dones.data_ptr(), touts.data_ptr() if touts is not None else None, rewards.data_ptr(),
+                                                  term.data_ptr(), float(gamma), s), what="lsim_policy_act_post_at")

@@ -35,6 +35,7 @@ class GraphedRollout:
         self.idx = torch.zeros(1, dtype=torch.long, device=self.dev)       # storage row of the current step (device resident)
         self.draws = torch.zeros(1, dtype=torch.long, device=self.dev)     # Philox step word of the action sampler
         self._draw_host = 0                                                # the same counter on the host (fused-policy path: counters go by value)
+        self._pending_post = None                                          # post-step store deferred into the next policy launch
         self.actions = torch.zeros(N, A, device=self.dev)
         self.values = torch.zeros(N, 1, device=self.dev)
         self.mean = torch.zeros(N, A, device=self.dev)
@@ -53,9 +54,10 @@ class GraphedRollout:
     # ---- HIMP:90-103 written against static tensors; the elementwise tail is one HIP kernel --------------------------
     def _act(self):
         env, ac = self.env, self.alg.actor_critic
-        if self.by_value:           # networks + sample + storage row in one launch (lsim_policy_act_at)
+        if self.by_value:           # networks + sample + storage row (+ the previous step's post-step store) in one launch
+            prev, self._pending_post = self._pending_post, None
             self.packed.forward_act(self._S, self.storage.step, self._draw_host, env.obs_buf, env.privileged_obs_buf, ac.std, self._seed, self._rank,
-                                    self.mean, self.values, self.actions)
+                                    self.mean, self.values, self.actions, prev=prev)
             return
         if self.packed is not None:
             self.packed.forward(env.obs_buf, env.privileged_obs_buf, self.mean, self.values)
@@ -76,11 +78,13 @@ class GraphedRollout:
         rewards = env.rew_buf if rewards is None else rewards
         s = torch.cuda.current_stream(self.dev).cuda_stream
         if self.by_value:
-            lib.check(self._L.lsim_rollout_post_at(ctypes.byref(self._S), int(self.storage.step), env.reset_buf.data_ptr(),
-                                                   to.data_ptr() if to is not None else None, rewards.data_ptr(), self.values.data_ptr(),
-                                                   env.privileged_obs_buf.data_ptr(), env.termination_privileged_obs_buf.data_ptr(),
-                                                   float(self.alg.gamma), s), what="lsim_rollout_post_at")
             self._draw_host += 1
+            if self.storage.step + 1 < self.storage.num_transitions_per_env:
+                # not the rollout's last step: the next step's policy launch does this store (its critic blocks stage the same privileged
+                # observation, and the buffers read here stay untouched until the simulator steps again); flush() forces it
+                self._pending_post = (int(self.storage.step), env.reset_buf, to, rewards, env.termination_privileged_obs_buf, float(self.alg.gamma))
+                return
+            self._post_now(int(self.storage.step), env.reset_buf, to, rewards, env.termination_privileged_obs_buf, float(self.alg.gamma))
             return
         lib.check(self._L.lsim_rollout_post(ctypes.byref(self._S), self.idx.data_ptr(), self.draws.data_ptr(), env.reset_buf.data_ptr(),
                                             to.data_ptr() if to is not None else None, rewards.data_ptr(), self.values.data_ptr(),
@@ -116,6 +120,17 @@ class GraphedRollout:
             self._post()
         self.storage.step += 1
 
+    def _post_now(self, step, dones, to, rewards, term, gamma):
+        lib.check(self._L.lsim_rollout_post_at(ctypes.byref(self._S), step, dones.data_ptr(), to.data_ptr() if to is not None else None,
+                                               rewards.data_ptr(), self.values.data_ptr(), self.env.privileged_obs_buf.data_ptr(), term.data_ptr(),
+                                               gamma, torch.cuda.current_stream(self.dev).cuda_stream), what="lsim_rollout_post_at")
+
+    def flush(self):
+        """write a post-step store that is still waiting for the next policy launch (callers that read the storage in the middle of a rollout)"""
+        if getattr(self, "_pending_post", None) is not None:
+            p, self._pending_post = self._pending_post, None
+            self._post_now(*p)
+
     def get_draw_counter(self):
         """Philox step word of the action sampler (checkpointed by the runner)"""
         return self._draw_host if self.by_value else int(self.draws.item())
@@ -132,6 +147,7 @@ class GraphedRollout:
     def end_iteration(self):
         """after compute_returns (callers rewind before or after update()): rewind the device-side step index.  The packed weights of
         the fused policy kernel are re-copied lazily at the first step of the next rollout, i.e. always AFTER the optimiser steps."""
+        self.flush()
         self.idx.zero_()
         self._weights_stale = True
 

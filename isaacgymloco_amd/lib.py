@@ -46,6 +46,8 @@ def load():
     L.lsim_rollout_act_at.argtypes = [ctypes.POINTER(abi.LsimRolloutStorage), ctypes.c_int64, ctypes.c_int64, vp, vp, vp, vp, vp, u32, u32, vp, vp]
     L.lsim_rollout_post_at.argtypes = [ctypes.POINTER(abi.LsimRolloutStorage), ctypes.c_int64, vp, vp, vp, vp, vp, vp, f32, vp]
     L.lsim_policy_act_at.argtypes = [vp, ctypes.POINTER(abi.LsimRolloutStorage), ctypes.c_int64, ctypes.c_int64, vp, vp, vp, u32, u32, vp, vp, vp, vp]
+    L.lsim_policy_act_post_at.argtypes = [vp, ctypes.POINTER(abi.LsimRolloutStorage), ctypes.c_int64, ctypes.c_int64, vp, vp, vp, u32, u32, vp, vp, vp,
+                                          ctypes.c_int64, vp, vp, vp, vp, f32, vp]
     L.lsim_rollout_gae.argtypes = [ctypes.POINTER(abi.LsimRolloutStorage), vp, f32, f32, vp, vp, vp]
     L.lsim_linear_wgrad_workspace.argtypes = [ctypes.c_long, i32, i32, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(i32)]
     L.lsim_linear_wgrad.argtypes = [vp, i64, vp, i64, i64, i32, i32, vp, vp, vp, ctypes.c_size_t, vp]

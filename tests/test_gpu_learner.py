@@ -43,6 +43,7 @@ def test_graph_rollout_matches_eager_storage():
             obs, crit = o.clone(), p.clone()
             nxt = torch.where(d.unsqueeze(1), env_e.termination_privileged_obs_buf, crit)
             run_e.alg.process_env_step(r, d, env_e.extras, nxt)
+    run_g.graphs.flush()                # the last step's post-step store waits for the next policy launch
     torch.cuda.synchronize()
     se, sg = run_e.alg.storage, run_g.alg.storage
     for name in ("observations", "privileged_observations", "next_privileged_observations", "actions", "rewards", "dones", "values",

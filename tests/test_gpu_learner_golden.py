@@ -204,6 +204,7 @@ def test_hybrid_fused_rollout_matches_eager_storage():
             rew = alg.discriminator.predict_amp_reward(amp_obs, nxt_amp, r, normalizer=alg.amp_normalizer)[0]
             alg.process_env_step(rew, d, env_e.extras, nxt_amp, nxt_crit)
             amp_obs = next_amp
+    run_g.graphs.flush()                # the last step's post-step store waits for the next policy launch
     torch.cuda.synchronize()
     assert saw_reset
     se, sg = run_e.alg.storage, run_g.alg.storage
