@@ -352,6 +352,25 @@ def test_policy_act_in_one_launch_equals_forward_then_act():
         for k in st1:
             assert torch.equal(st2[k], st1[k]), (N, k)
         assert st2["actions"][2].abs().sum() > 0 and st2["observations"][0].abs().sum() == 0
+        # ---- the previous step's post-step store folded into the next launch (lsim_policy_act_post_at) against the separate calls
+        obs_n, priv_n, term = torch.randn(N, O, device=dev), torch.randn(N, P, device=dev), torch.randn(N, P, device=dev)
+        dones = torch.rand(N, device=dev) < 0.3
+        touts = dones & (torch.rand(N, device=dev) < 0.5)
+        rew = torch.randn(N, device=dev)
+        stA, SA = storage(); stB, SB = storage()
+        mA, vA, aA = torch.zeros(N, A, device=dev), torch.zeros(N, 1, device=dev), torch.zeros(N, A, device=dev)
+        mB, vB, aB = torch.zeros(N, A, device=dev), torch.zeros(N, 1, device=dev), torch.zeros(N, A, device=dev)
+        pk.forward_act(SA, 0, 3, obs, priv, std, 5, 1, mA, vA, aA)
+        assert L.lsim_rollout_post_at(ctypes.byref(SA), 0, dones.data_ptr(), touts.data_ptr(), rew.data_ptr(), vA.data_ptr(), priv_n.data_ptr(),
+                                      term.data_ptr(), ctypes.c_float(0.99), s) == 0
+        pk.forward_act(SA, 1, 4, obs_n, priv_n, std, 5, 1, mA, vA, aA)
+        pk.forward_act(SB, 0, 3, obs, priv, std, 5, 1, mB, vB, aB)
+        pk.forward_act(SB, 1, 4, obs_n, priv_n, std, 5, 1, mB, vB, aB, prev=(0, dones, touts, rew, term, 0.99))
+        torch.cuda.synchronize()
+        assert torch.equal(vB, vA) and torch.equal(aB, aA)
+        for k in stA:
+            assert torch.equal(stB[k], stA[k]), (N, k)
+        assert stB["dones"][0].sum() > 0 and stB["next_privileged_observations"][0].abs().sum() > 0 and stB["rewards"][1].abs().sum() == 0
 
 
 @pytest.mark.parametrize("clipped", [True, False])
