@@ -1,16 +1,17 @@
-"""hipGraph-captured rollout step for HIMOnPolicyRunner: one graph replay + the simulator launch + one fused storage launch.
+"""Device-side rollout step for HIMOnPolicyRunner: three launches per step (policy + sample + storage, simulator kernels A and B).
 
 The eager rollout step issues ~100 tiny torch kernels (policy / estimator / critic forward at batch N, Gaussian sampling,
 log-prob, the time-out bootstrap, eleven storage copies, HIMR:110-127 + HIMP:90-118 + HST:92-106).  At N = 4096 each takes
 a few microseconds on the GPU but ~10 us of host dispatch, so collection is host-bound (1.2 ms/step against 0.76 ms of GPU
 work).  Here
 
-    lsim_policy_act_at (HIP)   :  encoder + normalise + actor + critic in one MFMA kernel (learn/fused_policy.py) whose blocks also do
-                                  a = mean + std * z, log-prob, storage[idx] <- (obs, critic_obs, actions, values, log-prob, mu, sigma)
-                                  [other network topologies: torch's forward, captured once in a HIP graph, then lsim_rollout_act]
-    env.step_device(actions)      (HIP kernels A + B, not captured: per-call arguments)
-    lsim_rollout_post (HIP)    :  storage[idx] <- (where(done, termination_obs, critic_obs), reward + gamma * value * time_out,
-                                   done);  idx += 1
+    lsim_policy_act_post_at    :  encoder + normalise + actor + critic in one MFMA kernel (learn/fused_policy.py) whose blocks also do
+                                  a = mean + std * z, log-prob, storage[t] <- (obs, critic_obs, actions, values, log-prob, mu, sigma)
+                                  and the PREVIOUS step's post-step store: storage[t - 1] <- (where(done, termination_obs, critic_obs),
+                                  reward + gamma * value * time_out, done) -- the critic input of step t is that next critic observation
+    env.step_device(actions)      (HIP kernels A + B)
+    lsim_rollout_post_at       :  the post-step store of the rollout's LAST step only (and of flush())
+    [other network topologies: torch's forward, captured once in a HIP graph, then lsim_rollout_act / lsim_rollout_post with device-side counters]
 
 With the fused policy kernel the launches are direct, so the storage row and the sampler's draw counter go by value (lsim_rollout_*_at);
 when torch's forward is replayed from a captured graph they live in device memory and a one-thread kernel advances them.  Either way
