@@ -7,7 +7,7 @@ One "step" = one LeggedRobot.step() over the whole batch of envs of a rank (4 ph
 reset + observations), driven the way the reference's runner drives it (HIMR:105-157).  Prints ONE JSON line from rank 0.
 
 --mode train (default) is the reference's `Perf/total_fps` (HIMR:179): value = N * T * iterations / (collection + learn).  The timed
-region always consists of WHOLE PPO iterations -- ceil(K / T) of them, T = num_steps_per_env = 100 -- each one = T x {policy
+region always consists of WHOLE PPO iterations -- max(5, ceil(K / T)) of them, T = num_steps_per_env = 100 -- each one = T x {policy
 inference + step + storage} + compute_returns + update(); `steps` echoes the request, `timed_env_steps` says what was timed.
 --mode env times step() back-to-back with pre-generated actions (exactly K steps), no learner.
 
@@ -25,7 +25,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 ALGO_BYTES_PER_ENV_STEP = 6900.0   # 3.07 KB read + 3.79 KB written per env-step (fused design)
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s spec

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LSIM_ABI_VERSION 2   /* 2: LSIM_BUF_CONTACT_COUNT, fixed-point words in LSIM_BUF_STATS (round 2) */
+#define LSIM_ABI_VERSION 3   /* 2: LSIM_BUF_CONTACT_COUNT, fixed-point words in LSIM_BUF_STATS (round 2); 3: LSIM_BUF_SUBSTEP_TORQUES (round 3) */
 
 /* ---- fixed sizes of the robot family on this path (12-DoF quadrupeds) ---- */
 #define LSIM_NUM_DOF 12
@@ -328,6 +328,9 @@ enum lsim_buffer_id {
     LSIM_BUF_DELAY_STEPS,        /* i32 [N]       last drawn action delay (LR:134) */
     LSIM_BUF_CONTACT_COUNT,      /* i32 [N,2]     diagnostic: collision points within contact_offset of the terrain BEFORE the cap of
                                                   LSIM_MAX_CONTACTS -- [0] maximum over the sub-steps of this step, [1] last sub-step */
+    LSIM_BUF_SUBSTEP_TORQUES,    /* f32 [N,decimation,12] diagnostic, written only under LSIM_STEP_RECORD_SUBSTEPS: the torques of EVERY sub-step
+                                                  (LR:146 keeps only the last), i.e. _compute_torques(delayed_actions[:, i]) of LR:138-146 -- what
+                                                  makes the action-delay model observable from outside */
     LSIM_BUF_STATS,              /* f32 [2,LSIM_STATS_SIZE] device-side per-step reductions, see below */
     LSIM_BUF_HEIGHT_GRID,        /* i16 [rows,cols] */
     LSIM_BUF_TERRAIN_ORIGINS,    /* f32 [levels,types,3] */
@@ -347,7 +350,7 @@ enum lsim_buffer_id {
  *   [2+T .. 10+T)            command_ranges[4][2] live values (LR:877-880)
  *   [10+T]                   reserved (the tracking sum of LR:875 is kept in fixed point, below)
  *   [11+T]                   reserved
- *   [LSIM_STATS_FIX ..)      internal, not for the host: int64 fixed-point (2^-40) accumulators of [1 .. 1+T) and of the sum over reset envs of
+ *   [LSIM_STATS_FIX ..)      internal, not for the host: int64 fixed-point (2^-32, each addend clamped to +-2^20) accumulators of [1 .. 1+T) and of the sum over reset envs of
  *                            episode_sums[tracking_lin_vel] (LR:875), and a ticket counter.  Waves add to them with integer atomics, so the sums
  *                            -- extras["episode"] and the command-curriculum decision -- do not depend on the order the waves arrive in; the last
  *                            resetting wave of a step converts [1 .. 1+T) to fp32.
@@ -369,6 +372,7 @@ enum lsim_buffer_id {
 #define LSIM_STEP_SKIP_PHYSICS 1u   /* test hook: use ROOT/DOF/RIGID_BODY/CONTACT buffers as injected by the caller
                                        instead of simulating; still computes torques (E3) for the 4 sub-steps */
 #define LSIM_STEP_NO_RESET 2u       /* test hook: compute reset_buf but do not reset_idx */
+#define LSIM_STEP_RECORD_SUBSTEPS 4u /* test hook: also write LSIM_BUF_SUBSTEP_TORQUES (one 48-byte store per sub-step and robot) */
 
 typedef struct lsim_sim* lsim_handle;
 

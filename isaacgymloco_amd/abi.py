@@ -109,6 +109,7 @@ E_INVALID, E_NOMEM, E_HIP, E_UNSUPPORTED, E_ABI = (DEFINES[k] for k in ("LSIM_E_
 ABI_VERSION = DEFINES["LSIM_ABI_VERSION"]
 STEP_SKIP_PHYSICS = DEFINES["LSIM_STEP_SKIP_PHYSICS"]
 STEP_NO_RESET = DEFINES["LSIM_STEP_NO_RESET"]
+STEP_RECORD_SUBSTEPS = DEFINES["LSIM_STEP_RECORD_SUBSTEPS"]
 STATS = {k[len("LSIM_STATS_"):].lower(): v for k, v in DEFINES.items() if k.startswith("LSIM_STATS_")}
 
 

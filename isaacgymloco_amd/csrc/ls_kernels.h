@@ -17,7 +17,7 @@
 #define LS_PHASE(call) do { for (int lane = 0; lane < 64; ++lane) { LaneRegs& rg = L[lane]; (void)rg; call; } } while (0)
 #define LS_COLLECTIVE(gpu_call, emu_call) do { emu_call; } while (0)
 #define LS_KINEMATICS() LS_PHASE(ph_kinematics(sh, lane))
-#define LS_TORQUES_KINEMATICS() LS_PHASE(ph_torques(cx, sh, lane, env, sub); ph_kinematics(sh, lane))
+#define LS_TORQUES_KINEMATICS() LS_PHASE(ph_torques(cx, sh, lane, env, sub, a.flags); ph_kinematics(sh, lane))
 #define LS_ATOMIC_ADD(ptr, v) (*(ptr) += (v))
 #define LS_ATOMIC_ADD_I64(ptr, v) (*(ptr) += (v))
 #define LS_ATOMIC_FETCH_ADD_I64(ptr, v) ls_emu_fetch_add((ptr), (v))
@@ -61,7 +61,7 @@ __device__ unsigned long long g_ls_phase_calls[64];
 #define LS_PHASE(call) do { { const int lane = ls_opaque_lane(lane0); call; } __syncthreads(); LS_AGAIN(call); LS_MARK(); LS_TICK(__LINE__ - ls_line0); } while (0)
 #define LS_COLLECTIVE(gpu_call, emu_call) do { { const int lane = ls_opaque_lane(lane0); gpu_call; } __syncthreads(); LS_AGAIN(gpu_call); LS_MARK(); LS_TICK(__LINE__ - ls_line0); } while (0)
 #define LS_KINEMATICS() LS_COLLECTIVE(wc_kinematics(sh, lane), (void)0)
-#define LS_TORQUES_KINEMATICS() LS_COLLECTIVE(ph_torques(cx, sh, lane, env, sub); wc_kinematics(sh, lane), (void)0)
+#define LS_TORQUES_KINEMATICS() LS_COLLECTIVE(ph_torques(cx, sh, lane, env, sub, a.flags); wc_kinematics(sh, lane), (void)0)
 #define LS_ATOMIC_ADD(ptr, v) atomicAdd((ptr), (v))
 // 64-bit integer atomics on the fixed-point accumulators (device scope: they are performed at the memory side, coherent across the XCDs)
 #define LS_ATOMIC_ADD_I64(ptr, v) ((void)atomicAdd((unsigned long long*)(ptr), (unsigned long long)(v)))
@@ -72,10 +72,13 @@ __device__ unsigned long long g_ls_phase_calls[64];
 #endif
 
 // Order-independent reductions over waves (float atomics made extras["episode"] and the command-curriculum decision depend on the
-// arrival order of the waves): values are added as 2^-40 fixed-point int64, integer addition being associative.  |v| < 2^23 by construction
-// (episode sums of rewards); the conversion error 2^-41 is far below fp32 resolution of the sums that are reported.
-LS_FN long long ls_to_fix(float v) { return (long long)llrintf(v * 1099511627776.0f); }
-LS_FN float ls_from_fix(long long f) { return (float)((double)f * (1.0 / 1099511627776.0)); }
+// arrival order of the waves): values are added as 2^-32 fixed-point int64, integer addition being associative.  One value is clamped to
+// +-2^20 (an episode sum of a million is not a reward any more), so a single conversion cannot overflow and the int64 sum holds
+// 2^63 / 2^52 = 2048 envs AT the clamp, or every env of a 2^22-env batch at |sum| <= 512 -- round 2's 2^-40 scale left a factor 1.6 at
+// N = 262 144 with |sum| = 20.  The conversion error 2^-33 is far below the fp32 resolution of the sums that are reported.
+#define LS_FIX_SCALE 4294967296.0f
+LS_FN long long ls_to_fix(float v) { return (long long)llrintf(fminf(fmaxf(v, -1048576.0f), 1048576.0f) * LS_FIX_SCALE); }
+LS_FN float ls_from_fix(long long f) { return (float)((double)f * (1.0 / 4294967296.0)); }
 LS_FN long long* ls_fix_row(const LsCtx& cx, int row) { return (long long*)(cx.accum + row * LSIM_STATS_SIZE + LSIM_STATS_FIX); }
 
 // ---- load the robot's state into LDS, clip the actions (LR:129-130), draw the action delay (LR:134)
@@ -163,7 +166,7 @@ LS_FN void ph_load_a(const LsCtx& cx, WaveShared& sh, LaneRegs& rg, int lane, in
 }
 
 // ---- LeggedRobot._compute_torques (LR:658-688) with the delayed action of sub-step `sub` (LR:138); lane = dof
-LS_FN void ph_torques(const LsCtx& cx, WaveShared& sh, int lane, int env, int sub) {
+LS_FN void ph_torques(const LsCtx& cx, WaveShared& sh, int lane, int env, int sub, uint32_t flags) {
     if (lane >= 12) return;
     const lsim_config& c = cx.cfg;
     float act = sh.act[lane], last = sh.last_act[lane];
@@ -176,7 +179,9 @@ LS_FN void ph_torques(const LsCtx& cx, WaveShared& sh, int lane, int env, int su
     if (c.control_type == 0) t = c.p_gains[lane] * sh.kpf * (target - q) - c.d_gains[lane] * sh.kdf * qd;
     else if (c.control_type == 1) t = c.p_gains[lane] * (as - qd) - c.d_gains[lane] * (qd - sh.pre_ldv[lane]) / c.sim_dt;
     else t = as;
-    sh.tau[lane] = clampf(t, -c.torque_limits[lane], c.torque_limits[lane]);
+    t = clampf(t, -c.torque_limits[lane], c.torque_limits[lane]);
+    sh.tau[lane] = t;
+    if (flags & LSIM_STEP_RECORD_SUBSTEPS) LSB(cx, LSIM_BUF_SUBSTEP_TORQUES, float)[12 * (c.decimation * env + sub) + lane] = t;   // test hook (wave-uniform branch)
 }
 
 // ---- after the last sub-step: publish the simulator state tensors (LR:187-190 refresh_* equivalents)
@@ -248,7 +253,7 @@ LS_WAVE_FN void ls_wave_step_a(const LsCtx& cx, const LsStepArgs& a, const int e
     LS_TICK_INIT();
     LS_PHASE(ph_load_a(cx, sh, rg, lane, env, a));
     for (int sub = 0; sub < c.decimation; ++sub) {
-        if (skip) { LS_PHASE(ph_torques(cx, sh, lane, env, sub)); continue; }
+        if (skip) { LS_PHASE(ph_torques(cx, sh, lane, env, sub, a.flags)); continue; }
         // phases that do not depend on each other share a barrier: (torques, kinematics), (free velocity, narrow phase),
         // (contact compaction, joint-limit rows), (apply impulses, contact forces)
         LS_TORQUES_KINEMATICS();

@@ -1,6 +1,7 @@
 // lsim_hip.hip -- the MI355X (gfx950) library behind include/lsim.h.
 // One wavefront (64-thread workgroup) per robot; per-robot scratch in LDS (WaveShared); XCD-aware block -> env map.
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC lsim_hip.hip -o liblsim.so   (see build.py)
+// This translation unit is the SIMULATOR (kernels A / B, the C-ABI of lsim_create .. lsim_destroy); the rollout / learner / policy kernels
+// are lsim_learn.hip, compiled with IEEE division / square root and denormals kept (build.py states both flag sets and why).
 #include <hip/hip_runtime.h>
 
 #define LS_API(name) lsim_##name
@@ -19,9 +20,6 @@ static void lsbk_prof_free(lsim_sim* s);
 
 #include "ls_api_impl.h"
 #include "ls_kernels.h"
-#include "ls_rollout.h"
-#include "ls_learn.h"
-#include "ls_policy.h"
 
 // Each XCD (8 per chip, block b is dispatched to XCD b % 8) works on one contiguous slice of the env range, so a
 // robot's state lines stay in one XCD's L2 and neighbouring robots do not false-share lines across XCD L2s.

@@ -220,9 +220,19 @@ class LeggedRobot:
     def get_amp_observations(self):
         return self.amp_obs_buf
 
+    def _external_call(self):
+        """a public entry point (step / reset / reset_idx) is about to overwrite the live buffers: let a device-side rollout that still holds
+        references to them (learn/graph_rollout.py: the deferred post-step store) finish first.  step_device() is the rollout's own entry."""
+        hook = getattr(self, "before_external_step", None)
+        if hook is not None:
+            hook()
+
     def reset_idx(self, env_ids):
+        """LR:288 with env_ids = all envs (BaseTask.reset, BT:113).  Partial id sets raise: in the reference only step() itself calls
+        reset_idx with a subset (LR:229), and that call lives inside kernel B here."""
         if len(env_ids) != self.num_envs:
             raise NotImplementedError("host-driven partial resets are not part of the path; resets happen inside step()")
+        self._external_call()
         lib.check(self._L.lsim_reset_all(self._h, self._stream()), self._h, "lsim_reset_all")
         self._refresh_extras(force_valid=True)
 
@@ -247,6 +257,7 @@ class LeggedRobot:
 
     def step(self, actions):
         """LeggedRobot.step (LR:122-176): same 7-tuple (8 with terminal AMP states when using_amp)."""
+        self._external_call()
         self.step_device(actions)
         env_ids = self.reset_buf.nonzero(as_tuple=False).flatten()   # the reference's own host sync (LR:225)
         self._refresh_extras(force_valid=len(env_ids) > 0)

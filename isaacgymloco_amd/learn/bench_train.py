@@ -2,8 +2,10 @@
 env-steps/s over collection (policy inference + LeggedRobot.step + storage) PLUS compute_returns + update().
 
 The unit of timing is one WHOLE PPO iteration (HIMR:105-157): T = num_steps_per_env rollout steps, then GAE, then
-HIMPPO.update().  `--steps K` asks for K env-steps; ceil(K / T) iterations are timed (never zero updates), `--warmup W`
-likewise runs ceil(W / T) untimed iterations (at least two: the first update carries lazy library initialisation)."""
+HIMPPO.update().  `--steps K` asks for K env-steps; max(5, ceil(K / T)) iterations are timed -- never fewer than five (0.5 s at the
+BASELINE size), so that one clock ramp or collector pause cannot move the line by several per cent -- and `--warmup W`
+likewise runs ceil(W / T) untimed iterations (at least two: the first update carries lazy library initialisation).  `value` stays
+whole-region throughput (all timed env-steps / barrier-to-barrier time); the per-iteration minimum / median / maximum are reported beside it."""
 import ctypes
 import os
 import time
@@ -12,6 +14,9 @@ import torch
 
 from ..envs import config as C
 from .runner import HIMOnPolicyRunner
+
+
+MIN_TIMED_ITERATIONS = 5
 
 
 def train_cfg_dict(task):
@@ -38,7 +43,7 @@ def run_train_bench(env, cfg, args, dev, rank, world, barrier):
         runner = HIMOnPolicyRunner(env, tc, log_dir=None, device=str(dev))
     use_graphs = os.environ.get("LSIM_NO_GRAPHS") != "1" and runner.enable_graphs()
     T = runner.num_steps_per_env
-    iters = max(1, -(-args.steps // T))
+    iters = max(MIN_TIMED_ITERATIONS, -(-args.steps // T))
     warm_iters = max(2, -(-args.warmup // T))
     env.episode_length_buf = torch.randint_like(env.episode_length_buf, high=int(env.max_episode_length))   # HIMR:90-91
     state = dict(obs=env.get_observations().clone(), critic=env.get_privileged_observations().clone())
@@ -89,19 +94,28 @@ def run_train_bench(env, cfg, args, dev, rank, world, barrier):
     ka = sum(ms_a[i] for i in range(n.value)) / max(n.value, 1)
     kb = sum(ms_b[i] for i in range(n.value)) / max(n.value, 1)
     digest = weights_digest(runner.alg.actor_critic)
+    # which robot this rank really simulated: total mass of the model table the simulator was created with (aliengo 24.9 kg, go1 11.3 kg)
+    mass = float(sum(b.mass for b in env.model.bodies))
     import torch.distributed as dist
     if dist.is_initialized():               # N > 1, or the 1-rank RCCL group of LSIM_DEBUG_FORCE_COLLECTIVES
-        d = torch.tensor(digest, device=dev, dtype=torch.float64)
+        d = torch.tensor(digest + [mass], device=dev, dtype=torch.float64)
         all_d = [torch.zeros_like(d) for _ in range(world)]
         dist.all_gather(all_d, d)
-        digests = [x.tolist() for x in all_d]
+        digests = [x.tolist()[:2] for x in all_d]
+        masses = [x.tolist()[2] for x in all_d]
     else:
-        digests = [digest]
+        digests, masses = [digest], [mass]
+    walls = sorted(c + l for c, l in per_iter)
+    med = walls[len(walls) // 2] if len(walls) % 2 else 0.5 * (walls[len(walls) // 2 - 1] + walls[len(walls) // 2])
     extra = {"kernel_a_ms": ka, "kernel_b_ms": kb, "timed_env_steps": iters * T, "ppo_updates_timed": iters, "warmup_iterations": warm_iters,
              "ppo_iteration_wall_s": elapsed / iters, "collection_s_per_iteration": coll / iters, "learn_s_per_update": learn / iters,
              "collection_env_steps_per_s": world * env.num_envs * iters * T / max(coll, 1e-9),
              "collection_learn_s_by_iteration": per_iter[:32], "rollout_hip_graphs": bool(use_graphs), "weights_digest_by_rank": digests,
-             "ranks_in_lockstep": all(x == digests[0] for x in digests)}
+             "ranks_in_lockstep": all(x == digests[0] for x in digests), "robot_mass_kg_by_rank": [round(m, 3) for m in masses],
+             # this rank's iterations: spread of the timed sample, and the throughput the median iteration gives (whole job, weak scaling)
+             "iteration_wall_s_min_median_max": [round(walls[0], 5), round(med, 5), round(walls[-1], 5)],
+             "iteration_spread_frac": (walls[-1] - walls[0]) / med,
+             "value_from_median_iteration": world * env.num_envs * T / med}
     alg = runner.alg
     workload = (f"{task}: {type(runner).__name__} loop, {iters} whole PPO iteration(s) timed, each = {T} x (policy inference + LeggedRobot.step + "
                 f"storage) + GAE + {type(alg).__name__}.update ({alg.num_learning_epochs} epochs x {alg.num_mini_batches} minibatches), "

@@ -51,6 +51,10 @@ class GraphedRollout:
             self._capture()
         self._weights_stale = True
         self.storage.step = 0
+        # the deferred post-step store keeps references to live simulator buffers: anything else that steps / resets the env (an evaluation
+        # rollout, env.reset()) or reads the storage in the middle of a rollout flushes it first
+        self.env.before_external_step = self.flush
+        self.storage.pending_store = lambda: self._pending_post is not None
 
     # ---- HIMP:90-103 written against static tensors; the elementwise tail is one HIP kernel --------------------------
     def _act(self):

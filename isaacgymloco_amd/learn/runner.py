@@ -224,6 +224,8 @@ class HIMOnPolicyRunner:
 
     # ------------------------------------------------------------------ checkpoints (HIMR:233-255)
     def save(self, path, infos=None):
+        if self.graphs is not None:
+            self.graphs.flush()
         if self.dist_ctx.enabled and self.dist_ctx.dist.get_rank() != 0:
             return
         os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
@@ -272,7 +274,10 @@ class HIMOnPolicyRunner:
             self.alg.optimizer.load_state_dict(d["optimizer_state_dict"])
             self.alg.actor_critic.estimator.optimizer.load_state_dict(d["estimator_optimizer_state_dict"])
             for opt in (self.alg.optimizer, self.alg.actor_critic.estimator.optimizer):
-                for g in opt.param_groups:            # a portable checkpoint (or the reference's) carries no backend flags: keep this optimiser's own
+                for g in opt.param_groups:            # a portable checkpoint (or the reference's) carries no backend flags: keep this optimiser's own.
+                    for k in ("fused", "foreach", "capturable", "differentiable"):   # ASSIGN them: Adam.__setstate__ (inside load_state_dict) has
+                        if k in opt.defaults:                                         # already filled the missing keys with None / False, so a
+                            g[k] = opt.defaults[k]                                    # setdefault() would leave a resumed run on the per-tensor Adam
                     for k, v in opt.defaults.items():
                         g.setdefault(k, v)
             self.alg._relink_lr()
@@ -281,6 +286,8 @@ class HIMOnPolicyRunner:
         return d["infos"]
 
     def get_inference_policy(self, device=None):
+        if self.graphs is not None:
+            self.graphs.flush()                    # a deferred post-step store must not see buffers an evaluation rollout is about to overwrite
         self.alg.actor_critic.eval()
         if device is not None:
             self.alg.actor_critic.to(device)

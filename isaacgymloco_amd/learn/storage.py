@@ -57,7 +57,13 @@ class HIMRolloutStorage:
         self.sigma[i].copy_(t.action_sigma)
         self.step += 1
 
+    def _no_pending_store(self):
+        """a device-side rollout may still owe this storage the post-step row of its latest step (learn/graph_rollout.py: flush())"""
+        pending = getattr(self, "pending_store", None)
+        assert pending is None or not pending(), "rollout storage read / rewound while a deferred post-step store is pending: call flush()"
+
     def clear(self):
+        self._no_pending_store()
         self.step = 0
 
     def c_struct(self):
@@ -80,6 +86,7 @@ class HIMRolloutStorage:
     def compute_returns(self, last_values, gamma, lam):
         """GAE(lambda) reverse sweep (HST:113-123) and advantage normalisation over the whole batch (HST:126-127)."""
         T = self.num_transitions_per_env
+        self._no_pending_store()
         if self.values.is_cuda and self.privileged_observations is not None:
             # one HIP launch (one thread per env walks the T steps) instead of ~8 torch kernels per step
             import ctypes
@@ -115,6 +122,7 @@ class HIMRolloutStorage:
         return (idx[1:] - idx[:-1]).float().mean(), self.rewards.mean()
 
     def mini_batch_generator(self, num_mini_batches, num_epochs=8):
+        self._no_pending_store()
         batch = self.num_envs * self.num_transitions_per_env
         mb = batch // num_mini_batches
         perm = torch.randperm(num_mini_batches * mb, requires_grad=False, device=self.device)

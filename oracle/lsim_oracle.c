@@ -850,6 +850,7 @@ int orc_step_ex(orc_sim* s, const float* actions, uint32_t flags) {
                 a[j] = c->delay ? last[j] + (act[j] - last[j]) * ((sub >= delay) ? 1.0f : 0.0f) : act[j]; /* LR:138 */
             compute_torques(s, e, a, tau);
             memcpy(ORC_F(s, LSIM_BUF_TORQUES) + N_DOF * e, tau, sizeof(tau));
+            if (flags & LSIM_STEP_RECORD_SUBSTEPS) memcpy(ORC_F(s, LSIM_BUF_SUBSTEP_TORQUES) + N_DOF * (c->decimation * e + sub), tau, sizeof(tau));
             if (!(flags & LSIM_STEP_SKIP_PHYSICS)) orc_physics_substep(s, e, tau, sub == 0);
         }
         if (!(flags & LSIM_STEP_SKIP_PHYSICS)) orc_refresh_body_states(s, e);

@@ -33,6 +33,31 @@ TWEAKS = {
 SCENARIOS = sorted(TWEAKS)
 
 
+def _all_terms_10(cfg):
+    _all_terms(cfg)
+    cfg.terrain.terrain_proportions = [0.5, 0.0, 0.0, 0.0, 0.2, 0.1, 0.0, 0.0, 0.1, 0.1]
+
+
+# BASELINE-size fixtures (N = 4096, tools/gen_golden.py: run_scenario_big): file step4096_<name>.npz
+BIG_TWEAKS = {
+    "aliengo": ("aliengo", _all_terms_10),
+    "aliengo_stairs": TWEAKS["aliengo_stairs"],
+    "aliengo_amp": ("aliengo_amp", _flat),
+}
+BIG_SCENARIOS = sorted(BIG_TWEAKS)
+
+
+def load_big(name):
+    return np.load(os.path.join(GOLDEN_DIR, f"step4096_{name}.npz"))
+
+
+def big_scenario_cfg(name):
+    task, tweak = BIG_TWEAKS[name]
+    cfg = C.TASKS[task][0]()
+    tweak(cfg)
+    return cfg
+
+
 def load(name):
     return np.load(os.path.join(GOLDEN_DIR, f"step_{name}.npz"))
 
@@ -73,43 +98,97 @@ def replay(fx, backend, get, put):
     """get(name) -> numpy copy of a backend buffer; put(name, array) writes one."""
     N = int(fx["num_envs"])
     feet = [4, 8, 12, 16]
+    big = "big" in fx.files
+    if big:   # the init-time draws that place the robots (LR:1221-1244) at BASELINE size, before anything has stepped
+        for k in ("terrain_levels", "terrain_types", "env_origins"):
+            np.testing.assert_array_equal(get(k), fx["init_" + k], err_msg=f"init {k} at N = {N}")
     backend.reset_all()
-    T = fx["in_actions"].shape[0]
+    T = len(fx["in_counter_before"])
     for t in range(T):
         backend.step_counter = int(fx["in_counter_before"][t])
-        put("episode_length", fx["in_ep_before"][t])
-        put("root_states", fx["in_root"][t])
-        put("dof_state", fx["in_dof"][t])
+        if big:   # injected state rebuilt from tests/big_inputs.py (the generator fed the same arrays to the reference; CRC in the fixture)
+            import big_inputs
+            inp = big_inputs.synth_step_inputs(N, t, get("env_origins"), int(fx["seed"]))
+            assert big_inputs.crc_of_inputs(inp) == fx["in_crc"][t], f"step {t}: synthetic inputs differ from the ones the fixture was generated with"
+            if int(fx["in_counter_before"][t]) + 1 == 1000:
+                inp["ep_before"][3] = 1000
+        else:
+            inp = {k: fx["in_" + k][t] for k in ("actions", "root", "dof", "body_feet", "contact", "ep_before")}
+        if big and t > 0:
+            put("terrain_levels", inp["terrain_levels"])
+        put("episode_length", inp["ep_before"])
+        put("root_states", inp["root"])
+        put("dof_state", inp["dof"])
         body = np.zeros((N, 17, 13), np.float32)
-        body[:, feet, :] = fx["in_body_feet"][t]
+        body[:, feet, :] = inp["body_feet"]
         put("rigid_body_states", body)
-        put("contact_forces", fx["in_contact"][t])
+        put("contact_forces", inp["contact"])
         if not np.isnan(fx["in_track_override"][t]):
             es = get("episode_sums")
             es[:, abi.REWARD_IDS["tracking_lin_vel"]] = fx["in_track_override"][t]
             put("episode_sums", es)
-        backend.step(fx["in_actions"][t], flags=abi.STEP_SKIP_PHYSICS)
-        yield t, {k[4:]: fx[k][t] for k in fx.files if k.startswith("out_")}
+        last_before = get("last_actions")
+        backend.step(inp["actions"], flags=abi.STEP_SKIP_PHYSICS | abi.STEP_RECORD_SUBSTEPS)
+        out = {k[4:]: fx[k][t] for k in fx.files if k.startswith("out_")}
+        out["last_actions_before"] = last_before
+        if big:
+            out["sel"] = fx["sel"]
+            out["red"] = {k[4:]: fx[k][t] for k in fx.files if k.startswith("red_")}
+        yield t, out
 
 
-def compare_step(t, ref, get, stats_row, dt=0.02):
-    """Assert one replayed step against the reference outputs; returns max abs errors for reporting."""
+def compare_step(t, ref, get_full, stats_row, dt=0.02):
+    """Assert one replayed step against the reference outputs; returns max abs errors for reporting.
+    BASELINE-size fixtures store the fat outputs for the rows ref["sel"] only, plus fp64 column sums over ALL envs (ref["red"])."""
     errs = {}
+    sel, red = ref.get("sel"), ref.get("red", {})
+    N = get_full("reset").shape[0]
+
+    def get(name, key=None):
+        """backend buffer, cut to the rows the fixture holds for `key`"""
+        got = get_full(name)
+        if sel is not None and key is not None and ref[key].shape[0] != N:
+            if "sum_" + key in red:   # every env contributes: |sum error| <= rtol * sum|x| + N * atol
+                atol = dict((k, a) for k, _, a in FLOAT_CHECKS).get(key, 2e-5)
+                s = got.astype(np.float64).sum(0)
+                bound = 2e-5 * red["abs_" + key] + N * max(atol, 1e-7)
+                assert np.all(np.abs(s - red["sum_" + key]) <= bound), f"step {t}: column sums of {key} over all {N} envs"
+            got = got[sel]
+        return got
     for key, name in EXACT_CHECKS:
-        got = get(name)
+        got = get(name, key)
         np.testing.assert_array_equal(got.astype(np.int64), ref[key].astype(np.int64), err_msg=f"step {t}: {key}")
     for key, name, atol in FLOAT_CHECKS:
-        got = get(name)
+        got = get(name, key)
         np.testing.assert_allclose(got, ref[key], rtol=2e-5, atol=atol, err_msg=f"step {t}: {key}")
         errs[key] = float(np.max(np.abs(got - ref[key]))) if got.size else 0.0
+    # E2, the action-delay model (LR:133-138) on EVERY sub-step: the drawn delay, the torques _compute_torques returned for each of the four
+    # delayed actions (only the last sub-step's action equals `actions` whatever the delay), and the delayed actions rebuilt from the
+    # backend's own buffers
+    delay = get("delay_steps")
+    np.testing.assert_array_equal(delay, ref["delay_steps"], err_msg=f"step {t}: delay_steps")
+    np.testing.assert_allclose(get("substep_torques", "substep_torques"), ref["substep_torques"], rtol=2e-5, atol=2e-4, err_msg=f"step {t}: per-sub-step torques")
+    act, last = get("actions"), ref["last_actions_before"]
+    if sel is not None:
+        act, last, delay = act[sel], last[sel], delay[sel]
+    sub = np.arange(ref["delayed_actions"].shape[1])
+    rebuilt = last[:, None, :] + (act - last)[:, None, :] * (sub[None, :, None] >= delay[:, None, None]).astype(np.float32)
+    np.testing.assert_allclose(rebuilt, ref["delayed_actions"], rtol=0, atol=1e-6, err_msg=f"step {t}: delayed_actions")
     mask = ref["term_mask"].astype(bool)
     np.testing.assert_array_equal(get("reset").astype(bool), mask, err_msg=f"step {t}: termination ids")
     if mask.any():
-        np.testing.assert_allclose(get("term_priv_obs")[mask], ref["term_priv_obs"][mask], rtol=2e-5, atol=2e-5, err_msg=f"step {t}: term_priv_obs")
+        msel = mask if sel is None else mask[sel]
+        gtp, gta = get_full("term_priv_obs"), get_full("term_amp_obs")
+        if sel is not None:
+            gtp, gta = gtp[sel], gta[sel]
+        np.testing.assert_allclose(gtp[msel], ref["term_priv_obs"][msel], rtol=2e-5, atol=2e-5, err_msg=f"step {t}: term_priv_obs")
         if np.abs(ref["term_amp"]).max() > 0:   # captured only when the reference ran with USING_AMP (LR:173)
-            np.testing.assert_allclose(get("term_amp_obs")[mask], ref["term_amp"][mask], rtol=2e-5, atol=1e-5, err_msg=f"step {t}: terminal AMP states")
-    es = get("episode_sums")
+            np.testing.assert_allclose(gta[msel], ref["term_amp"][msel], rtol=2e-5, atol=1e-5, err_msg=f"step {t}: terminal AMP states")
+    es = get("episode_sums", "episode_sums")
     np.testing.assert_allclose(es, ref["episode_sums"], rtol=2e-5, atol=2e-5, err_msg=f"step {t}: episode_sums")
+    if "stumble_sums" in ref:   # BASELINE-size fixtures: the two terms with index slices (LR:1597-1607), every env
+        ids = [abi.REWARD_IDS["feet_stumble"], abi.REWARD_IDS["feet_stumble_up"]]
+        np.testing.assert_allclose(get_full("episode_sums")[:, ids], ref["stumble_sums"], rtol=2e-5, atol=1e-6, err_msg=f"step {t}: stumble slices")
     st = get("stats")[stats_row]
     S = abi.STATS
     np.testing.assert_allclose(st[S["cmd_ranges"]:S["cmd_ranges"] + 8].reshape(4, 2), ref["command_ranges"], rtol=1e-6, atol=1e-6, err_msg=f"step {t}: command_ranges")

@@ -44,7 +44,9 @@ def test_driver_arguments_time_a_full_ppo_iteration():
     assert r.returncode == 0, r.stderr[-2000:]
     j = json.loads(r.stdout.strip().splitlines()[-1])
     assert j["n_gpus"] == 1 and j["steps"] == 20 and j["warmup"] == 5
-    assert j["ppo_updates_timed"] >= 1 and j["timed_env_steps"] == 100 * j["ppo_updates_timed"]
+    assert j["ppo_updates_timed"] >= 5 and j["timed_env_steps"] == 100 * j["ppo_updates_timed"]     # never a single-iteration sample
+    lo, med, hi = j["iteration_wall_s_min_median_max"]
+    assert 0 < lo <= med <= hi and len(j["collection_learn_s_by_iteration"]) == j["ppo_updates_timed"]
     assert j["learn_s_per_update"] > 0 and j["collection_s_per_iteration"] > 0 and j["ppo_iteration_wall_s"] > 0
     # value = N * T * iterations / (collection + learn), HIMR:179
     expect = 512 * j["timed_env_steps"] / (j["ppo_iteration_wall_s"] * j["ppo_updates_timed"])
@@ -67,6 +69,27 @@ def test_two_ranks_on_the_fused_gpu_path_stay_in_lockstep():
     assert j["ppo_updates_timed"] >= 1
     assert len(j["weights_digest_by_rank"]) == 2 and j["ranks_in_lockstep"] is True
     assert abs(j["value"] - 2 * 256 * j["timed_env_steps"] / (j["ppo_iteration_wall_s"] * j["ppo_updates_timed"])) / j["value"] < 0.02
+
+
+@pytest.mark.gpu
+def test_mixed_robots_two_ranks_share_one_policy():
+    """BASELINE config 5's mapping (`--mixed-robots`: the upper half of the ranks simulate the second robot, one asset per process as in the
+    reference, LR:1135) on the fused GPU path: rank 0 on the Aliengo table, rank 1 REALLY on the Go1 table (total model mass as created),
+    gradients all-reduced, bit-identical weights on both ranks.  Two ranks on one device, gloo (the 8-GPU RCCL run is the driver's)."""
+    r = _run(["--gpus", "2", "--steps", "100", "--warmup", "100", "--envs", "256", "--no-cpu-baseline", "--mixed-robots"],
+             env={"LSIM_DEBUG_SINGLE_DEVICE": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["mixed_robots"] is True and j["config"]["parallelism"] == "dp2"
+    m0, m1 = j["robot_mass_kg_by_rank"]
+    from isaacgymloco_amd.robots import aliengo, urdf
+    want0 = sum(b.mass for b in aliengo.build_model().bodies)
+    want1 = sum(b.mass for b in urdf.build_model_from_table("go1")[0].bodies)
+    assert abs(m0 - want0) < 1e-2 and abs(m1 - want1) < 1e-2 and abs(want0 - want1) > 5.0, (m0, m1, want0, want1)
+    assert len(j["weights_digest_by_rank"]) == 2 and j["ranks_in_lockstep"] is True
+    assert j["ppo_updates_timed"] >= 5
 
 
 @pytest.mark.gpu

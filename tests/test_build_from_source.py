@@ -11,8 +11,7 @@ from helpers import ROOT, abi
 def test_from_source_compile_exports_the_abi(tmp_path):
     from isaacgymloco_amd.csrc import build as B
     out = os.path.join(tmp_path, "liblsim_fresh.so")
-    cmd = [os.environ.get("HIPCC", "hipcc")] + B.FLAGS + [os.path.join(B.HERE, s) for s in B.SOURCES] + ["-o", out]
-    subprocess.check_call(cmd, cwd=str(tmp_path))
+    B.build_variant(out, workdir=str(tmp_path))      # both translation units from source, with the product's flag sets
     assert os.path.getsize(out) > 100_000
     L = ctypes.CDLL(out)                          # loading needs no GPU; no compute call is made
     missing = [f for f in abi.declared_functions() if not hasattr(L, f)]

@@ -8,10 +8,10 @@ import golden_replay as GR
 from helpers import LC, aliengo, make_oracle, quiet_cfg, abi
 
 
-def make_emu_from_fixture(name):
+def make_emu_from_fixture(name, big=False):
     import emu_binding
-    fx = GR.load(name)
-    cfg = GR.scenario_cfg(name)
+    fx = GR.load_big(name) if big else GR.load(name)
+    cfg = GR.big_scenario_cfg(name) if big else GR.scenario_cfg(name)
     N = int(fx["num_envs"])
     model = aliengo.build_model()
     ter = GR.FixtureTerrain(fx)
@@ -22,6 +22,19 @@ def make_emu_from_fixture(name):
 @pytest.mark.parametrize("name", GR.SCENARIOS)
 def test_emu_matches_reference_step(name):
     fx, sim = make_emu_from_fixture(name)
+
+    def get(n):
+        return np.array(sim.buf[n])
+
+    def put(n, a):
+        sim.buf[n][...] = a
+    for t, ref in GR.replay(fx, sim, get, put):
+        GR.compare_step(t, ref, get, sim.stats_row)
+
+
+@pytest.mark.parametrize("name", GR.BIG_SCENARIOS)
+def test_emu_matches_reference_step_at_baseline_size(name):
+    fx, sim = make_emu_from_fixture(name, big=True)
 
     def get(n):
         return np.array(sim.buf[n])

@@ -17,7 +17,7 @@ def test_element_parallel_kinematics_matches_per_leg_form():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import kin_check
     from isaacgymloco_amd.csrc import build as B
-    src_time = max(os.path.getmtime(os.path.join(B.HERE, f)) for f in B.SOURCES + B.HEADERS)
+    src_time = max(os.path.getmtime(f) for f in B.all_sources())
     if not os.path.exists(kin_check.OUT) or os.path.getmtime(kin_check.OUT) < src_time:
         kin_check.build()
     from isaacgymloco_amd.envs.legged_robot import LeggedRobot

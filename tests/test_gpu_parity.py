@@ -22,6 +22,22 @@ def test_hip_matches_reference_step(name):
     assert n == fx["in_actions"].shape[0]
 
 
+@pytest.mark.parametrize("name", GR.BIG_SCENARIOS)
+def test_hip_matches_reference_step_at_baseline_size(name):
+    """BASELINE size, N = 4096 (cfg 2-4) through the C-ABI: the reference's own outputs on the steps around the command-curriculum step
+    999 -> 1000 -- every env for rewards / commands / resets / terrain placement, 211+ selected envs (every 37th + bands around each index
+    boundary of LR:72-90, LR:649, LR:1234) for the observation rows, fp64 column sums over all envs for the rest."""
+    from hip_backend import HipBackend
+    fx = GR.load_big(name)
+    cfg = GR.big_scenario_cfg(name)
+    be = HipBackend(cfg, int(fx["num_envs"]), GR.FixtureTerrain(fx), seed=int(fx["seed"]))
+    n = 0
+    for t, ref in GR.replay(fx, be, be.get, be.put):
+        GR.compare_step(t, ref, be.get, be.stats_row)
+        n += 1
+    assert n == 3
+
+
 @pytest.mark.parametrize("quiet", [True, False])
 def test_hip_physics_matches_oracle(quiet):
     """Dynamics: structured fp32 wave solver (HIP) vs dense fp64 oracle on the same seeds/actions.  fp32 tolerance:

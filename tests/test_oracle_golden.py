@@ -7,10 +7,10 @@ import golden_replay as GR
 from helpers import LC, aliengo
 
 
-def make_oracle_from_fixture(name):
+def make_oracle_from_fixture(name, big=False):
     from oracle import oracle
-    fx = GR.load(name)
-    cfg = GR.scenario_cfg(name)
+    fx = GR.load_big(name) if big else GR.load(name)
+    cfg = GR.big_scenario_cfg(name) if big else GR.scenario_cfg(name)
     N = int(fx["num_envs"])
     model = aliengo.build_model()
     ter = GR.FixtureTerrain(fx)
@@ -37,3 +37,21 @@ def test_oracle_matches_reference_step(name):
         nsteps += 1
     assert nsteps == fx["in_actions"].shape[0]
     print(name, "max abs err:", {k: f"{v:.2e}" for k, v in worst.items()})
+
+
+@pytest.mark.parametrize("name", GR.BIG_SCENARIOS)
+def test_oracle_matches_reference_step_at_baseline_size(name):
+    """N = 4096 (BASELINE cfg 2-4): the index-dependent logic -- high-velocity commands of the first 20 % of the envs (LR:649), terrain columns
+    (LR:1234), the stumble slices (LR:72-90, 1597-1607) -- around the command-curriculum step 999 -> 1000, against the reference's own outputs."""
+    fx, sim = make_oracle_from_fixture(name, big=True)
+
+    def get(n):
+        return np.array(sim.buf[n])
+
+    def put(n, a):
+        sim.buf[n][...] = a
+    nsteps = 0
+    for t, ref in GR.replay(fx, sim, get, put):
+        GR.compare_step(t, ref, get, sim.stats_row)
+        nsteps += 1
+    assert nsteps == len(fx["in_counter_before"]) == 3

@@ -96,8 +96,12 @@ def patched_rand_like(t, **kw):
 def patched_randint(low, high, size, device=None, **kw):
     if not _planned():
         return _ORIG["randint"](low, high, size, **kw)
+    tag = CTX.plan[0][0]
     u = CTX.uniforms(size)
-    return (u * float(high - low)).to(torch.long) + low
+    r = (u * float(high - low)).to(torch.long) + low
+    if tag == TAG["delay"]:
+        CTX.last_delay = r.clone()     # LR:134 keeps delay_steps in a local: recorded here for the fixture
+    return r
 
 
 def patched_randint_like(t, high, **kw):
@@ -133,7 +137,17 @@ def install_rng_patches():
     def before_step(self, actions):
         CTX.stepw = self.common_step_counter + 1
         CTX.plan = [(TAG["delay"], 0, None)]
+        CTX.sub_torques = []
     wrap(LeggedRobot, "step", before=before_step)
+
+    orig_ct = LeggedRobot._compute_torques
+
+    def recording_compute_torques(self, actions):      # LR:146: one call per sub-step; the reference keeps only the last result
+        t = orig_ct(self, actions)
+        if CTX is not None and hasattr(CTX, "sub_torques"):
+            CTX.sub_torques.append(t.detach().clone().view(self.num_envs, -1))
+        return t
+    LeggedRobot._compute_torques = recording_compute_torques
 
     def before_resample(self, env_ids):
         tag = TAG["reset_cmd"] if CTX.in_reset else TAG["cmd"]
@@ -337,7 +351,7 @@ OUT_KEYS = ["obs", "priv_obs", "rew", "reset", "time_out", "extras_time_outs", "
             "commands", "torques", "base_lin_vel", "base_ang_vel", "projected_gravity", "feet_air_time", "last_contacts",
             "contact_filt", "measured_heights", "root_states", "dof_state", "terrain_levels", "env_origins", "episode_length",
             "kp_factors", "kd_factors", "friction", "last_actions", "last_last_actions", "last_dof_vel", "episode_sums",
-            "command_ranges", "ep_stats", "level_mean", "delayed_last_substep"]
+            "command_ranges", "ep_stats", "level_mean", "delayed_actions", "delay_steps", "substep_torques"]
 
 
 def capture(env, tensors, N):
@@ -371,7 +385,9 @@ def capture(env, tensors, N):
         last_last_actions=env.last_last_actions.numpy().copy(), last_dof_vel=env.last_dof_vel.numpy().copy(),
         episode_sums=es, ep_stats=ep, level_mean=level_mean, amp_obs=env.get_amp_observations().numpy().copy(),
         command_ranges=np.array([cr["lin_vel_x"], cr["lin_vel_y"], cr["ang_vel_yaw"], cr["heading"]], dtype=np.float64),
-        delayed_last_substep=env.delayed_actions[:, -1].numpy().copy(),
+        delayed_actions=env.delayed_actions.numpy().copy(),                                   # (N, 4, 12), LR:133-138
+        delay_steps=CTX.last_delay.numpy().reshape(N).astype(np.int32),                        # the draw of LR:134
+        substep_torques=torch.stack(CTX.sub_torques[-env.cfg.control.decimation:], dim=1).numpy().copy(),   # (N, 4, 12), LR:146 per sub-step
     )
 
 
@@ -477,6 +493,97 @@ def run_scenario(name, task, ref_cfg_cls, N, segments, seed=1, tweak=None, using
     print(f"wrote {path}: {len(steps)} steps, N={N}, resets={nres}, size={os.path.getsize(path) / 1e6:.2f} MB")
 
 
+# keys stored for ALL envs of a BASELINE-size fixture (cheap, and they carry the index-dependent logic: high-velocity commands of the first 20 % of the
+# envs LR:649, terrain columns LR:1234, the stumble slices LR:1597-1607 through `rew`); every other key is stored for the rows `sel` only
+BIG_FULL_KEYS = ["rew", "reset", "time_out", "extras_time_outs", "commands", "terrain_levels", "env_origins", "episode_length", "delay_steps",
+                 "kp_factors", "kd_factors", "friction", "term_mask", "command_ranges", "ep_stats", "level_mean", "stumble_sums"]
+
+
+def big_selection(env, N):
+    """every 37th env + a band of +-2 around every index boundary the reference's code has"""
+    cols = env.cfg.terrain.num_cols
+    bounds = {0, N - 1, int(N * 0.2)}                                        # LR:649: env_ids < num_envs * 0.2
+    bounds |= {int(k * N / cols) for k in range(1, cols)}                     # LR:1234: terrain_types = floor(i / (N / cols))
+    for nm in ("flat", "rough", "smoothslope", "roughslope", "stairsup", "stairsdown", "discreteobstacles", "steppingstones", "pit", "gap"):
+        bounds |= {int(getattr(env, nm + "_start_idx")), int(getattr(env, nm + "_end_idx"))}   # LR:72-90 -> LR:1597-1607
+    sel = set(range(0, N, 37))
+    for b in bounds:
+        sel |= {i for i in range(b - 2, b + 3) if 0 <= i < N}
+    return np.array(sorted(sel), dtype=np.int64)
+
+
+def run_scenario_big(name, task, ref_cfg_cls, N=4096, seed=1, tweak=None, using_amp=False, counters=(0, 999, 1000)):
+    """BASELINE-size fixture: reset + zero-action step, then steps at the given counters (999 -> 1000 fires the command
+    curriculum, LR:307).  Injected states come from tests/big_inputs.py (not stored); outputs are stored for all envs where cheap, else for `sel`."""
+    global CTX
+    import big_inputs
+    LRmod.USING_AMP = using_amp
+    cfg = C.TASKS[task][0]()
+    if tweak:
+        tweak(cfg)
+    orc, lc, model, terrain = make_oracle(cfg, N, seed=seed)          # init-time draws only
+    ref_cfg = ref_cfg_cls()
+    if tweak:
+        tweak(ref_cfg)
+    CTX = None
+    env, tensors = build_reference_env(ref_cfg, terrain, model, N)
+    sync_initial_state(env, tensors, orc)
+    init = dict(terrain_levels=env.terrain_levels.numpy().copy(), terrain_types=env.terrain_types.numpy().copy(), env_origins=env.env_origins.numpy().copy())
+    CTX = RngCtx(seed, 0, N)
+    CTX.stepw = 0
+    env.reset_idx(torch.arange(N))
+    sel = big_selection(env, N)
+    steps, crcs = [], []
+    for t, counter_before in enumerate(counters):
+        env.common_step_counter = counter_before
+        inp = big_inputs.synth_step_inputs(N, t, env.env_origins.numpy(), seed)
+        crcs.append(big_inputs.crc_of_inputs(inp))
+        if counter_before + 1 == 1000:
+            inp["ep_before"][3] = 1000                              # a reset on the curriculum step (LR:307)
+        env.episode_length_buf = torch.from_numpy(inp["ep_before"].copy())
+        if t > 0:
+            env.terrain_levels = torch.from_numpy(inp["terrain_levels"].copy())
+        body = np.zeros((N, 17, 13), np.float32)
+        body[:, list(model.feet_bodies), :] = inp["body_feet"]
+        track_override = np.float32(np.nan)
+        if counter_before + 1 == 1000:
+            track_override = np.float32(30.0)
+            if "tracking_lin_vel" in env.episode_sums:
+                env.episode_sums["tracking_lin_vel"][:] = float(track_override)
+        inject_state(tensors, inp["root"], inp["dof"], body, inp["contact"])
+        ret = env.step(torch.from_numpy(inp["actions"]))
+        out = capture(env, tensors, N)
+        out["stumble_sums"] = out["episode_sums"][:, [abi.REWARD_IDS["feet_stumble"], abi.REWARD_IDS["feet_stumble_up"]]].copy()
+        term_ids = ret[5].numpy().copy()
+        m = np.zeros(N, np.uint8); m[term_ids] = 1
+        out["term_mask"] = m
+        tp = np.zeros((N, 238), np.float32); tp[term_ids] = ret[6].numpy()
+        out["term_priv_obs"] = tp
+        ta = np.zeros((N, 30), np.float32)
+        if len(ret) > 7:
+            ta[term_ids] = ret[7].numpy()
+        out["term_amp"] = ta
+        steps.append(dict(counter_before=np.int64(counter_before), track_override=track_override, out=out))
+    pack = {"num_envs": np.int64(N), "seed": np.int64(seed), "task": np.array(task), "big": np.int64(1), "sel": sel,
+            "height_grid": terrain.heightsamples, "terrain_origins": terrain.env_origins.astype(np.float32),
+            "in_counter_before": np.array([s["counter_before"] for s in steps]), "in_track_override": np.array([s["track_override"] for s in steps]),
+            "in_crc": np.array(crcs, dtype=np.uint32)}
+    for k, v in init.items():
+        pack["init_" + k] = v
+    for k in steps[0]["out"]:
+        arrs = [s["out"][k] for s in steps]
+        if k not in BIG_FULL_KEYS:
+            # fat keys: the selected rows + full-batch reductions (fp64 sum and sum of magnitudes per column)
+            pack["red_sum_" + k] = np.stack([a.astype(np.float64).sum(0) for a in arrs])
+            pack["red_abs_" + k] = np.stack([np.abs(a.astype(np.float64)).sum(0) for a in arrs])
+            arrs = [a[sel] for a in arrs]
+        pack["out_" + k] = np.stack(arrs)
+    path = os.path.join(GOLDEN, f"step4096_{name}.npz")
+    np.savez_compressed(path, **pack)
+    print(f"wrote {path}: {len(steps)} steps, N={N}, |sel|={len(sel)}, resets={[int(s['out']['term_mask'].sum()) for s in steps]}, "
+          f"size={os.path.getsize(path) / 1e6:.2f} MB")
+
+
 def main():
     install_rng_patches()
 
@@ -496,6 +603,14 @@ def main():
         cfg.rewards.only_positive_rewards = True
     run_scenario("aliengo_allterms", "aliengo", aliengo_config.AlienGoRoughCfg, 16, [(0, 4), (795, 8)], tweak=all_terms)
     run_scenario("aliengo_amp", "aliengo_amp", aliengo_amp_config.AlienGoRoughCfg, 16, [(0, 4), (795, 8)], tweak=flat_only, using_amp=True)
+
+    # BASELINE size (cfg 2-4): the same three tasks at N = 4096.  `aliengo` runs with every reward term on so that the stumble slices are live.
+    def all_terms_10(cfg):   # 10-entry proportions of in-tree generators only (flat, stairs, pit, gap): the stairs-up / pit / gap slices of LR:1597-1607 are non-empty
+        all_terms(cfg)
+        cfg.terrain.terrain_proportions = [0.5, 0.0, 0.0, 0.0, 0.2, 0.1, 0.0, 0.0, 0.1, 0.1]
+    run_scenario_big("aliengo", "aliengo", aliengo_config.AlienGoRoughCfg, tweak=all_terms_10)
+    run_scenario_big("aliengo_stairs", "aliengo_stairs", aliengo_stairs_config.AlienGoStairsCfg, tweak=stairs_only)
+    run_scenario_big("aliengo_amp", "aliengo_amp", aliengo_amp_config.AlienGoRoughCfg, tweak=flat_only, using_amp=True)
 
 
 if __name__ == "__main__":

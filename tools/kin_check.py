@@ -15,7 +15,7 @@ OUT = os.path.join(ROOT, "isaacgymloco_amd", "csrc", "variants", "liblsim_kindeb
 def build():
     from isaacgymloco_amd.csrc import build as B
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    subprocess.check_call([os.environ.get("HIPCC", "hipcc")] + B.FLAGS + ["-DLS_DEBUG_KIN"] + [os.path.join(B.HERE, x) for x in B.SOURCES] + ["-o", OUT])
+    B.build_variant(OUT, ["-DLS_DEBUG_KIN"])
 
 
 if __name__ == "__main__":

@@ -59,13 +59,19 @@ static int run(int waves_per_simd, int iters, const char* what, bool last) {
     cyc /= blocks * 4; wall /= blocks * 4;                       // mean per wave
     const double insts_per_wave = (double)iters * 64.0;
     const double clock_hz = cyc / (wall / 100e6);
-    // every SIMD hosts waves_per_simd waves that all run for ~cyc cycles concurrently
-    const double ipc_simd = insts_per_wave * waves_per_simd / cyc;
+    // Headline: cycles per wave64 instruction per SIMD from the WALL rate of the whole launch (1024 SIMDs): independent of how the blocks
+    // were placed.  The in-wave tick figure assumes all waves_per_simd waves of a SIMD are co-resident for the whole `cyc`, which the
+    // dispatcher does not guarantee (round 2's table was off by ~2x at 4-8 waves where the blocks ran in two rounds): it is
+    // kept as "cycles_per_wave_inst_if_coresident" and is only meaningful where kernel_ms ~ cyc / clock.
     const double wall_rate = insts_per_wave * blocks * 4 / (ms * 1e-3);      // wave-instructions per second, whole chip
-    printf("  {\"test\": \"%s\", \"chains_per_lane\": %d, \"waves_per_simd\": %d, \"wave_insts_per_cycle_per_simd\": %.4f, "
-           "\"cycles_per_wave_inst\": %.3f, \"effective_clock_ghz\": %.3f, \"kernel_ms\": %.3f, \"chip_wave_insts_per_s\": %.4g, "
-           "\"fp32_tflops\": %.1f}%s\n",
-           what, NCHAIN, waves_per_simd, ipc_simd, 1.0 / ipc_simd, clock_hz * 1e-9, ms, wall_rate, wall_rate * 128.0 * 1e-12, last ? "" : ",");
+    const double cyc_wall = clock_hz * 1024.0 / wall_rate;
+    const double ipc_simd = insts_per_wave * waves_per_simd / cyc;
+    const double resident_frac = (cyc / clock_hz) / (ms * 1e-3);              // share of the launch one wave was alive for
+    printf("  {\"test\": \"%s\", \"chains_per_lane\": %d, \"waves_per_simd\": %d, \"cycles_per_wave_inst\": %.3f, "
+           "\"cycles_per_wave_inst_if_coresident\": %.3f, \"wave_alive_frac_of_launch\": %.3f, \"effective_clock_ghz\": %.3f, "
+           "\"kernel_ms\": %.3f, \"chip_wave_insts_per_s\": %.4g, \"fp32_tflops\": %.1f}%s\n",
+           what, NCHAIN, waves_per_simd, cyc_wall, 1.0 / ipc_simd, resident_frac, clock_hz * 1e-9, ms, wall_rate, wall_rate * 128.0 * 1e-12,
+           last ? "" : ",");
     CK(hipFree(out)); CK(hipFree(ticks));
     return 0;
 }

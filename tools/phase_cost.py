@@ -47,7 +47,7 @@ if __name__ == "__main__":
     if "--build" in sys.argv:
         for line, text in sites():
             out = os.path.join(VAR, f"liblsim_twice{line}.so")
-            subprocess.check_call([os.environ.get("HIPCC", "hipcc")] + B.FLAGS + [f"-DLS_EXP_TWICE={line}", os.path.join(B.HERE, "lsim_hip.hip"), "-o", out])
+            B.build_variant(out, [f"-DLS_EXP_TWICE={line}"])
             print("built", out, flush=True)
         sys.exit(0)
     base = min(bench(None), bench(None))

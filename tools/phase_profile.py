@@ -19,9 +19,7 @@ OUT = os.path.join(CSRC, "variants", "liblsim_phasetiming.so")
 def build():
     from isaacgymloco_amd.csrc import build as B
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    cmd = [os.environ.get("HIPCC", "hipcc")] + B.FLAGS + ["-DLS_PHASE_TIMING"] + [os.path.join(B.HERE, x) for x in B.SOURCES] + ["-o", OUT]
-    subprocess.check_call(cmd)
-    return OUT
+    return B.build_variant(OUT, ["-DLS_PHASE_TIMING"])
 
 
 def sites():

@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 from isaacgymloco_amd.csrc import build as B   # noqa: E402
 
 out = "/tmp/lsim_marks.s"
-flags = [f for f in B.FLAGS if f not in ("-shared", "-fPIC")]
+flags = [f for f in B.FLAGS + B.SIM_FLAGS if f not in ("-shared", "-fPIC")]
 subprocess.check_call([os.environ.get("HIPCC", "hipcc")] + flags + ["-DLS_PHASE_MARKS", "--cuda-device-only", "-S",
                                                                      os.path.join(B.HERE, "lsim_hip.hip"), "-o", out])
 src = open(os.path.join(B.HERE, "ls_kernels.h")).read().splitlines()
