@@ -52,15 +52,14 @@ LS_FN V3 operator*(float s, V3 a) { return v3(a.x * s, a.y * s, a.z * s); }
 LS_FN float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 LS_FN V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 LS_FN float clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
-// The library is built with -fno-hip-fp32-correctly-rounded-divide-sqrt (fast v_rcp/v_rsq based division in the dynamics);
-// quotients that feed an integer truncation of the reference (grid indices, LR:1343) must stay IEEE-exact.
-LS_FN float ls_div_exact(float a, float b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __fdiv_rn(a, b);
-#else
-    return a / b;
-#endif
-}
+// The simulator is built with -fno-hip-fp32-correctly-rounded-divide-sqrt (fast v_rcp / v_rsq based division in the dynamics);
+// quotients that feed an integer truncation of the reference (grid indices, LR:1343) must stay IEEE-exact.  Under that flag
+// __fdiv_rn / __fsqrt_rn are NOT exact either -- __clang_hip_math.h defines them as `x / y` and the native square root unless
+// OCML_BASIC_ROUNDED_OPERATIONS is set, which round 2 relied on by mistake (an N = 4096 step put ~1 of its 2.3 M height samples into the
+// neighbouring grid cell).  The fp64 operations are not affected by the flag, and the fp64 quotient / root of fp32 operands rounded to
+// fp32 IS the correctly rounded fp32 result (53 >= 2 * 24 + 2 bits: no double rounding).
+LS_FN float ls_div_exact(float a, float b) { return (float)((double)a / (double)b); }
+LS_FN float ls_sqrt_exact(float a) { return (float)sqrt((double)a); }
 
 // Hardware reciprocal / reciprocal square root (v_rcp_f32 / v_rsq_f32, 1 ulp) for the dynamics: a plain `a / b` compiles to an 8-instruction
 // range-safe sequence (frexp / rcp / ldexp) even with fast division enabled, and the physics does ~60 of them per sub-step.  The

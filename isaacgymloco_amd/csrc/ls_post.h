@@ -29,23 +29,42 @@ LS_FN float ls_sample_height_min3(const LsCtx& cx, float x, float y) {
     return (float)h * c.vertical_scale;
 }
 
-LS_FN V3 ls_yaw_point(const float* root, float px, float py) {
+// Height-sample points (LR:1336-1340: quat_apply_yaw(base_quat, points) + root position), evaluated so that every point lands in the SAME
+// grid cell as the reference's: IEEE-rounded square root / division for the yaw quaternion and no fused multiply-adds, term by term as
+// torch evaluates normalize() and quat_apply() (MTH:38-42; t = cross(xyz, b) * 2; b + w * t + cross(xyz, t) with xyz = (0, 0, qz)).
+// With the simulator's fast division / contraction the points moved by an ulp, and of the 2.3 M samples of an N = 4096 step about one per
+// step fell into the neighbouring cell -- a stair riser or a pit wall away (found by the N = 4096 golden fixture, round 3).
+struct LsYawQuat { float z, w; };
+LS_FN LsYawQuat ls_yaw_quat(const float* q) {
 #if defined(__clang__)
 #pragma clang fp contract(off)
 #endif
-    V3 w = quat_apply_yaw(root + 3, v3(px, py, 0.0f));
-    return v3(w.x + root[0], w.y + root[1], 0.0f);
+    float n = ls_sqrt_exact(q[2] * q[2] + q[3] * q[3]);
+    if (n < 1e-9f) n = 1e-9f;
+    LsYawQuat y;
+    y.z = ls_div_exact(q[2], n); y.w = ls_div_exact(q[3], n);
+    return y;
+}
+LS_FN V3 ls_yaw_point(const float* root, LsYawQuat y, float px, float py) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+    const float tx = (0.0f - y.z * py) * 2.0f, ty = (y.z * px) * 2.0f;
+    const float ux = 0.0f - y.z * ty, uy = y.z * tx;
+    const float wx = px + y.w * tx + ux, wy = py + y.w * ty + uy;
+    return v3(wx + root[0], wy + root[1], 0.0f);
 }
 
 // LeggedRobot._get_heights (LR:1318-1355): lanes stride over the 187 points
 LS_FN void ph_heights(const LsCtx& cx, WaveShared& sh, int lane, int env, bool store_global) {
     const lsim_config& c = cx.cfg;
     LS_GLOBAL float* mh = LSB(cx, LSIM_BUF_MEASURED_HEIGHTS, float) + LS_NHP * env;
+    const LsYawQuat yq = ls_yaw_quat(sh.root + 3);
     LS_STRIDED(k, lane, LS_NHP) {
         float h = 0.0f;
         if (c.mesh_type != 0) {
             int ix = k / c.num_points_y, iy = k - ix * c.num_points_y;
-            V3 w = ls_yaw_point(sh.root, c.measured_points_x[ix], c.measured_points_y[iy]);
+            V3 w = ls_yaw_point(sh.root, yq, c.measured_points_x[ix], c.measured_points_y[iy]);
             h = ls_sample_height_min3(cx, w.x, w.y);
         }
         sh.heights[k] = h;
@@ -62,7 +81,7 @@ LS_FN void ph_base_height_pts(const LsCtx& cx, WaveShared& sh, int lane) {
     const float xs[7] = {-0.15f, -0.1f, -0.05f, 0.f, 0.05f, 0.1f, 0.15f};
     const float ys[9] = {-0.2f, -0.15f, -0.1f, -0.05f, 0.f, 0.05f, 0.1f, 0.15f, 0.2f};
     px = xs[ix]; py = ys[iy];
-    V3 w = ls_yaw_point(sh.root, px, py);
+    V3 w = ls_yaw_point(sh.root, ls_yaw_quat(sh.root + 3), px, py);
     sh.bh[lane] = sh.root[2] - ls_sample_height_min3(cx, w.x, w.y);
 }
 
