@@ -590,6 +590,15 @@ int lsim_adam_clip_step(int count, const int64_t* numel, float* const* params, f
                         float* const* exp_avg_sq, float* const* steps, const float* lr_dev, float lr_host, float beta1, float beta2,
                         float eps, float max_grad_norm, float* grad_norm_out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* lsim_adam_clip_step for an optimiser with several parameter groups (HybridPPO, HYBP:86-92 + HYBP:270-273: one Adam over the actor-critic,
+ * the discriminator trunk with weight decay 1e-3 and its head with weight decay 1e-1, gradient clipping over the actor-critic's parameters
+ * only): weight_decay[i] >= 0 per tensor (torch.optim.Adam's L2 form, grad + weight_decay * param, applied after the clipping and not written
+ * back to the gradient; NULL = none), and only tensors [0, clip_count) enter the clipped norm and are rescaled.  grad_norm_out = that norm. */
+int lsim_adam_clip_step_ex(int count, const int64_t* numel, float* const* params, float* const* grads, float* const* exp_avg,
+                           float* const* exp_avg_sq, float* const* steps, const float* weight_decay, int clip_count,
+                           const float* lr_dev, float lr_host, float beta1, float beta2, float eps, float max_grad_norm,
+                           float* grad_norm_out, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Actor input of HIMActorCritic (HAC:136-141; HES:64-68 for the normalisation): out[b] = [ obs[b, :num_one_step_obs] | enc_out[b, :3] |
  * enc_out[b, 3:3+latent] / max(||.||, 1e-12) ], out [batch, num_one_step_obs + 3 + latent] contiguous; obs / enc_out with row strides
  * ld_obs / ld_enc (floats).  No gradient flows through this (the estimator's outputs are detached there). */

@@ -1171,7 +1171,9 @@ struct LsAdamTable {
     float* v[LS_ADAM_MAX_TENSORS];
     float* step[LS_ADAM_MAX_TENSORS];
     int n[LS_ADAM_MAX_TENSORS];
+    float wd[LS_ADAM_MAX_TENSORS];     // L2 weight decay of torch.optim.Adam (grad + wd * param), per tensor
     int count;
+    int clip_count;                    // tensors [0, clip_count) form the clipped-norm group (clip_grad_norm_ over a subset of the parameters)
 };
 
 __global__ __launch_bounds__(256) void lsim_k_adam_sumsq(LsAdamTable t, float* __restrict__ part /* [count][LS_ADAM_SLICES] */) {
@@ -1202,7 +1204,7 @@ __global__ __launch_bounds__(64) void lsim_k_adam_finish(LsAdamTable t, const fl
     __syncthreads();
     if (i == 0) {
         float s = 0.0f;
-        for (int k = 0; k < t.count; ++k) s += tot[k];
+        for (int k = 0; k < t.clip_count; ++k) s += tot[k];
         const float norm = sqrtf(s);
         scal[0] = max_norm > 0.0f ? fminf(max_norm / (norm + 1e-6f), 1.0f) : 1.0f;
         scal[1] = norm;
@@ -1219,14 +1221,15 @@ __global__ __launch_bounds__(256) void lsim_k_adam_apply(LsAdamTable t, const fl
     float* __restrict__ v = t.v[ti];
     // the bias correction uses THIS tensor's step count (already incremented by lsim_k_adam_finish), as torch's Adam does: a parameter that
     // received gradients on fewer steps (frozen layer, partially restored state) must not borrow tensor 0's counter
-    const float coef = scal[0], step = *t.step[ti], lr = lr_dev ? *lr_dev : lr_host;
+    const float coef = ti < t.clip_count ? scal[0] : 1.0f, step = *t.step[ti], lr = lr_dev ? *lr_dev : lr_host, wd = t.wd[ti];
     const float bc1 = 1.0f - powf(b1, step), bc2s = sqrtf(1.0f - powf(b2, step));
     const float step_size = lr / bc1;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += LS_ADAM_SLICES * 256) {
-        const float gi = g[i] * coef;
+        const float gc = g[i] * coef;                                  // what clip_grad_norm_ leaves in .grad
+        const float gi = wd != 0.0f ? gc + wd * p[i] : gc;             // grad.add(param, alpha=weight_decay): not written back
         const float mi = m[i] + (gi - m[i]) * (1.0f - b1);             // torch's lerp form
         const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
-        g[i] = gi; m[i] = mi; v[i] = vi;
+        g[i] = gc; m[i] = mi; v[i] = vi;
         p[i] -= step_size * mi / (sqrtf(vi) / bc2s + eps);
     }
 }
@@ -1237,22 +1240,37 @@ extern "C" int lsim_adam_clip_step_workspace(int count, size_t* bytes) {
     return LSIM_OK;
 }
 
+extern "C" int lsim_adam_clip_step_ex(int count, const int64_t* numel, float* const* params, float* const* grads, float* const* exp_avg,
+                                      float* const* exp_avg_sq, float* const* steps, const float* weight_decay, int clip_count,
+                                      const float* lr_dev, float lr_host, float beta1, float beta2, float eps, float max_grad_norm,
+                                      float* grad_norm_out, void* workspace, size_t workspace_bytes, void* stream);
 extern "C" int lsim_adam_clip_step(int count, const int64_t* numel, float* const* params, float* const* grads, float* const* exp_avg,
                                    float* const* exp_avg_sq, float* const* steps, const float* lr_dev, float lr_host, float beta1, float beta2,
                                    float eps, float max_grad_norm, float* grad_norm_out, void* workspace, size_t workspace_bytes, void* stream) {
+    return lsim_adam_clip_step_ex(count, numel, params, grads, exp_avg, exp_avg_sq, steps, nullptr, count, lr_dev, lr_host, beta1, beta2, eps,
+                                  max_grad_norm, grad_norm_out, workspace, workspace_bytes, stream);
+}
+
+extern "C" int lsim_adam_clip_step_ex(int count, const int64_t* numel, float* const* params, float* const* grads, float* const* exp_avg,
+                                      float* const* exp_avg_sq, float* const* steps, const float* weight_decay, int clip_count,
+                                      const float* lr_dev, float lr_host, float beta1, float beta2, float eps, float max_grad_norm,
+                                      float* grad_norm_out, void* workspace, size_t workspace_bytes, void* stream) {
     size_t need;
     int rc = lsim_adam_clip_step_workspace(count, &need);
     if (rc != LSIM_OK) return rc;
     if (!numel || !params || !grads || !exp_avg || !exp_avg_sq || !steps || !workspace || workspace_bytes < need || beta1 < 0.0f || beta1 >= 1.0f ||
-        beta2 < 0.0f || beta2 >= 1.0f || eps <= 0.0f)
+        beta2 < 0.0f || beta2 >= 1.0f || eps <= 0.0f || clip_count < 0 || clip_count > count)
         return LSIM_E_INVALID;
     LsAdamTable t;
     t.count = count;
+    t.clip_count = clip_count;
     for (int i = 0; i < count; ++i) {
         if (!params[i] || !grads[i] || !exp_avg[i] || !exp_avg_sq[i] || !steps[i] || numel[i] <= 0 || numel[i] > 0x7fffffffLL) return LSIM_E_INVALID;
         t.p[i] = params[i]; t.g[i] = grads[i]; t.m[i] = exp_avg[i]; t.v[i] = exp_avg_sq[i]; t.step[i] = steps[i]; t.n[i] = (int)numel[i];
+        t.wd[i] = weight_decay ? weight_decay[i] : 0.0f;
+        if (t.wd[i] < 0.0f) return LSIM_E_INVALID;
     }
-    for (int i = count; i < LS_ADAM_MAX_TENSORS; ++i) { t.p[i] = t.g[i] = t.m[i] = t.v[i] = t.step[i] = nullptr; t.n[i] = 0; }
+    for (int i = count; i < LS_ADAM_MAX_TENSORS; ++i) { t.p[i] = t.g[i] = t.m[i] = t.v[i] = t.step[i] = nullptr; t.n[i] = 0; t.wd[i] = 0.0f; }
     float* part = (float*)workspace;
     float* scal = part + (size_t)count * LS_ADAM_SLICES;
     hipStream_t s = (hipStream_t)stream;

@@ -122,8 +122,10 @@ def discrete_obstacles_terrain(t, rng, max_height, min_size, max_size, num_rects
 
 
 def stepping_stones_terrain(t, rng, stone_size, stone_distance, max_height, platform_size=1.0, depth=-10):
-    ss = max(int(stone_size / t.horizontal_scale), 1)
-    sd = max(int(stone_distance / t.horizontal_scale), 1)
+    ss = int(stone_size / t.horizontal_scale)
+    sd = int(stone_distance / t.horizontal_scale)      # 0 for the reference's `stone_distance=0.05` at difficulty 0 (TER:189): stones touch
+    if ss < 1:
+        raise ValueError("stone_size below one cell")    # (the published code fails in randint(0, 0) here)
     mh = int(max_height / t.vertical_scale)
     plat = int(platform_size / t.horizontal_scale)
     hr = np.arange(-mh - 1, mh, 1)

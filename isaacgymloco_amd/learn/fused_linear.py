@@ -245,31 +245,41 @@ def estimator_loss_supported(latent, K):
     return latent <= 32 and K <= 64
 
 
-def adam_clip_step_hip(optimizer, max_grad_norm):
-    """clip_grad_norm_(params, max_grad_norm) + optimizer.step() for a plain torch.optim.Adam through lsim_adam_clip_step (3 launches instead
-    of ~12): works on the optimizer's own parameter / state tensors, so state_dict() and checkpoints stay torch's.  Returns False when the
-    optimizer is not eligible (the caller then runs the torch statements): amsgrad / weight decay / maximize, non-fp32 or non-CUDA
-    parameters, more than 48 tensors, or a parameter that has a gradient but no state yet (first step: torch initialises it)."""
+def adam_clip_step_hip(optimizer, max_grad_norm, clip_params=None):
+    """clip_grad_norm_(clip_params or all params, max_grad_norm) + optimizer.step() for a plain torch.optim.Adam through lsim_adam_clip_step_ex
+    (3 launches instead of ~12): works on the optimizer's own parameter / state tensors, so state_dict() and checkpoints stay torch's.
+    Several parameter groups are fine as long as they share lr / betas / eps (HybridPPO: three groups that differ in weight decay only);
+    `clip_params` restricts the clipped norm to a subset (HybridPPO clips the actor-critic only, HYBP:270).  Returns False when the
+    optimizer is not eligible (the caller then runs the torch statements): amsgrad / maximize, non-fp32 or non-CUDA parameters, more than
+    48 tensors, groups with different hyper-parameters, or a parameter that has a gradient but no state yet (first step: torch
+    initialises it)."""
     from .. import lib
-    if len(optimizer.param_groups) != 1:
+    groups = optimizer.param_groups
+    g0 = groups[0]
+    for grp in groups:
+        if grp.get("amsgrad") or grp.get("maximize") or grp.get("differentiable") or grp.get("weight_decay", 0) < 0:
+            return False
+        same_lr = grp["lr"] is g0["lr"] or (not torch.is_tensor(grp["lr"]) and not torch.is_tensor(g0["lr"]) and grp["lr"] == g0["lr"])
+        if grp["betas"] != g0["betas"] or grp["eps"] != g0["eps"] or not same_lr:      # (no tensor comparison: that would be a host sync)
+            return False
+    clip_ids = None if clip_params is None else {id(p) for p in clip_params}
+    entries = [(p, float(grp.get("weight_decay", 0))) for grp in groups for p in grp["params"] if p.grad is not None]
+    if not entries or len(entries) > 48:
         return False
-    grp = optimizer.param_groups[0]
-    if grp.get("amsgrad") or grp.get("maximize") or grp.get("weight_decay", 0) != 0 or grp.get("differentiable"):
-        return False
-    ps = [p for p in grp["params"] if p.grad is not None]
-    if not ps or len(ps) > 48:
-        return False
+    if clip_ids is not None:       # the clipped tensors first
+        entries = [e for e in entries if id(e[0]) in clip_ids] + [e for e in entries if id(e[0]) not in clip_ids]
+    n_clip = len(entries) if clip_ids is None else sum(1 for e in entries if id(e[0]) in clip_ids)
     tabs = ([], [], [], [], [])
-    for p in ps:
+    for p, _ in entries:
         st = optimizer.state.get(p)
         if (not st or not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous()
                 or not torch.is_tensor(st.get("step")) or not st["step"].is_cuda or st["step"].dtype != torch.float32):
             return False
         for tab, t in zip(tabs, (p, p.grad, st["exp_avg"], st["exp_avg_sq"], st["step"])):
             tab.append(t.data_ptr())
-    n = len(ps)
+    n = len(entries)
     L = lib.load()
-    dev = ps[0].device
+    dev = entries[0][0].device
     need = ctypes.c_size_t()
     lib.check(L.lsim_adam_clip_step_workspace(n, ctypes.byref(need)), what="lsim_adam_clip_step_workspace")
     ws = _workspaces.get(("adam", dev, id(optimizer)))
@@ -277,12 +287,13 @@ def adam_clip_step_hip(optimizer, max_grad_norm):
         ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
         _workspaces[("adam", dev, id(optimizer))] = ws
     arr = lambda v: (ctypes.c_void_p * n)(*v)
-    numel = (ctypes.c_int64 * n)(*[p.numel() for p in ps])
-    lr = grp["lr"]
+    numel = (ctypes.c_int64 * n)(*[p.numel() for p, _ in entries])
+    wd = (ctypes.c_float * n)(*[w for _, w in entries])
+    lr = g0["lr"]
     lr_dev = lr.data_ptr() if torch.is_tensor(lr) and lr.is_cuda else None
     lr_host = 0.0 if lr_dev is not None else float(lr)
-    b1, b2 = grp["betas"]
-    lib.check(L.lsim_adam_clip_step(n, numel, arr(tabs[0]), arr(tabs[1]), arr(tabs[2]), arr(tabs[3]), arr(tabs[4]), lr_dev, lr_host, float(b1),
-                                    float(b2), float(grp["eps"]), float(max_grad_norm), None, ws.data_ptr(), ws.numel(),
-                                    torch.cuda.current_stream(dev).cuda_stream), what="lsim_adam_clip_step")
+    b1, b2 = g0["betas"]
+    lib.check(L.lsim_adam_clip_step_ex(n, numel, arr(tabs[0]), arr(tabs[1]), arr(tabs[2]), arr(tabs[3]), arr(tabs[4]), wd, n_clip, lr_dev, lr_host,
+                                       float(b1), float(b2), float(g0["eps"]), float(max_grad_norm), None, ws.data_ptr(), ws.numel(),
+                                       torch.cuda.current_stream(dev).cuda_stream), what="lsim_adam_clip_step_ex")
     return True

@@ -111,9 +111,10 @@ class HIMPPO:
 
     def _clip_and_step(self, optimizer, params, max_grad_norm):
         """clip_grad_norm_ + optimizer.step() (HIMP:183-184); on the device-lr fast path one C-ABI call of three launches"""
+        params = list(params)
         if self._lr_t is not None:
             from .fused_linear import adam_clip_step_hip
-            if adam_clip_step_hip(optimizer, max_grad_norm):
+            if adam_clip_step_hip(optimizer, max_grad_norm, clip_params=params):
                 return
         nn.utils.clip_grad_norm_(params, max_grad_norm)
         optimizer.step()

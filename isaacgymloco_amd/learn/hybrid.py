@@ -84,8 +84,7 @@ class HybridPPO(HIMPPO):
             loss.backward()
             if self.dist_ctx is not None:
                 self.dist_ctx.average_grads(list(ac.parameters()) + list(disc.parameters()))
-            nn.utils.clip_grad_norm_(ac.parameters(), self.max_grad_norm)
-            self.optimizer.step()
+            self._clip_and_step(self.optimizer, ac.parameters(), self.max_grad_norm)     # HYBP:270-273: clipping over the actor-critic only
             if self.min_std is not None:
                 ac.std.data = ac.std.data.clamp(min=self.min_std)
             if self.amp_normalizer is not None:

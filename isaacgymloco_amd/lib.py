@@ -59,6 +59,8 @@ def load():
     L.lsim_adam_clip_step_workspace.argtypes = [i32, ctypes.POINTER(ctypes.c_size_t)]
     pp = ctypes.POINTER(ctypes.c_void_p)
     L.lsim_adam_clip_step.argtypes = [i32, ctypes.POINTER(i64), pp, pp, pp, pp, pp, vp, f32, f32, f32, f32, f32, vp, vp, ctypes.c_size_t, vp]
+    L.lsim_adam_clip_step_ex.argtypes = [i32, ctypes.POINTER(i64), pp, pp, pp, pp, pp, ctypes.POINTER(ctypes.c_float), i32, vp, f32, f32, f32, f32, f32,
+                                         vp, vp, ctypes.c_size_t, vp]
     L.lsim_actor_input.argtypes = [vp, i64, i32, vp, i64, i32, i64, vp, vp]
     L.lsim_ppo_loss_workspace.argtypes = [ctypes.c_long, ctypes.POINTER(ctypes.c_size_t)]
     L.lsim_ppo_loss.argtypes = [vp] * 10 + [i64, i32, f32, f32, f32, i32, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]

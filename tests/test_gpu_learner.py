@@ -673,6 +673,79 @@ def test_fused_clip_adam_step_matches_torch():
         assert used == 5
 
 
+def test_fused_clip_adam_step_with_weight_decay_groups_matches_torch():
+    """lsim_adam_clip_step_ex as HybridPPO uses it (HYBP:86-92, 270-273): ONE Adam over three parameter groups that differ in weight decay,
+    gradient clipping over the first group only -- against clip_grad_norm_(first group) + torch.optim.Adam.step()"""
+    import copy
+    from isaacgymloco_amd.learn.fused_linear import adam_clip_step_hip
+    torch.manual_seed(0)
+    mk = lambda: torch.nn.ModuleList([torch.nn.Linear(64, 128), torch.nn.Linear(60, 256), torch.nn.Linear(256, 1)]).to("cuda:0")
+    net = mk()
+    ref = copy.deepcopy(net)
+    groups = lambda m: [{"params": m[0].parameters()}, {"params": m[1].parameters(), "weight_decay": 10e-4}, {"params": m[2].parameters(), "weight_decay": 10e-2}]
+    lr_a, lr_b = torch.tensor(1e-3, device="cuda:0"), torch.tensor(1e-3, device="cuda:0")
+    oa = torch.optim.Adam(groups(net), lr=lr_a, fused=True)
+    ob = torch.optim.Adam(groups(ref), lr=lr_b, fused=True)
+    g = torch.Generator(device="cuda:0").manual_seed(1)
+    used = 0
+    for it in range(5):
+        x1, x2 = torch.randn(4096, 64, device="cuda:0", generator=g), torch.randn(4096, 60, device="cuda:0", generator=g)
+        for m, o in ((net, oa), (ref, ob)):
+            o.zero_grad()
+            (m[0](x1).square().mean() * 30.0 + m[2](torch.relu(m[1](x2))).square().mean()).backward()
+        if adam_clip_step_hip(oa, 1.0, clip_params=list(net[0].parameters())):
+            used += 1
+        else:
+            torch.nn.utils.clip_grad_norm_(net[0].parameters(), 1.0)
+            oa.step()
+        torch.nn.utils.clip_grad_norm_(ref[0].parameters(), 1.0)
+        ob.step()
+        for pa, pb in zip(net.parameters(), ref.parameters()):
+            scale = float(pb.detach().abs().max())
+            assert float((pa.detach() - pb.detach()).abs().max()) < 2e-3 * scale
+            assert float((pa.detach() - pb.detach()).abs().gt(1e-4 * scale).float().mean()) < 0.02
+            torch.testing.assert_close(pa.grad, pb.grad, rtol=1e-4, atol=1e-7)       # clipped in place for group 0, untouched (no decay written) for the others
+            assert float(oa.state[pa]["step"]) == float(ob.state[pb]["step"]) == it + 1
+    assert used == 4
+    # the decay really acts: the head's weights shrink against a run without it
+    assert float(net[2].weight.norm()) < float(mk()[2].weight.norm()) * 1.5
+
+
+def test_amp_checkpoint_load_keeps_the_fused_optimiser_path(tmp_path):
+    """after load() the param groups must carry the optimiser's own backend flags again (Adam.__setstate__ fills a
+    portable checkpoint's missing `fused` with None) and the resumed AMP run must keep training"""
+    import numpy as np
+    from isaacgymloco_amd.envs import config as C
+    from isaacgymloco_amd.envs.legged_robot import LeggedRobot
+    from isaacgymloco_amd.learn.bench_train import train_cfg_dict
+    from isaacgymloco_amd.learn.hybrid import HybridPolicyRunner
+
+    def make(seed):
+        cfg = C.TASKS["aliengo_amp"][0]()
+        cfg.env.num_envs = 256
+        env = LeggedRobot(cfg, sim_device="cuda:0", seed=seed, using_amp=True)
+        tc = train_cfg_dict("aliengo_amp")
+        tc["runner"]["num_steps_per_env"] = 8
+        torch.manual_seed(0); np.random.seed(0)
+        return HybridPolicyRunner(env, tc, log_dir=None, device="cuda:0")
+    run = make(2)
+    assert run.enable_graphs()
+    run.learn(2, init_at_random_ep_len=True)
+    path = str(tmp_path / "model_2.pt")
+    run.save(path)
+    run2 = make(5)
+    assert run2.enable_graphs()
+    run2.load(path)
+    for opt in (run2.alg.optimizer, run2.alg.actor_critic.estimator.optimizer):
+        for g in opt.param_groups:
+            assert g["fused"] is True and torch.is_tensor(g["lr"]) and g["lr"].is_cuda
+    assert [g.get("weight_decay") for g in run2.alg.optimizer.param_groups] == [0, 10e-4, 10e-2]
+    for k, v in run.alg.discriminator.state_dict().items():
+        assert torch.equal(v, run2.alg.discriminator.state_dict()[k])
+    run2.learn(1)
+    assert all(torch.isfinite(v).all() for v in run2.alg.actor_critic.state_dict().values())
+
+
 def test_fused_actor_input_matches_torch():
     """lsim_actor_input against the torch statement of HAC:136-141 (slice, F.normalize, cat), contiguous and strided histories"""
     from isaacgymloco_amd.learn import modules as M
