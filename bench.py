@@ -234,18 +234,28 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "task": base_task, "envs_per_gpu": N, "mode": mode, "parallelism": f"dp{world}",
                        "mixed_robots": bool(args.mixed_robots and world > 1)},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                         "kernel": "lsim_k_step_a", "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * N,
-                         "kernel_avg_ms": ka,
-                         "real_limiter": "latency / VALU issue inside each wave, not HBM (DESIGN.md section 6)",
-                         "valu_issue_frac": valu_frac,
-                         "valu_cycles_per_wave_inst": VALU_CYCLES_PER_WAVE_INST,
-                         "pmc_source": ({k: pmc.get(k) for k in ("task", "envs_per_gpu", "mode", "actions", "effective_clock_hz", "file")} if pmc else None),
-                         "note": "the schema offers hbm|mfma; the path moves 6.9 KB per env-step and is bounded by per-wave dependency latency and VALU "
-                                 "issue, so frac is small by construction (SURVEY.md 8d); traffic and valu_issue_frac come from separate rocprofv3 --pmc "
-                                 "passes of the same workload (profiles/pmc_traffic.json) and are null when none matches task/size/mode/actions"},
+            "roofline": None,
         }
+        # Roofline of the dominant kernel (kernel A).  The task's schema offers hbm | mfma; kernel A is neither: it moves 6.9 KB per env-step
+        # (3 % of HBM) and has no matrix work worth MFMA (tools/micro/delassus_mfma).  Its real limiter is VALU issue /
+        # dependent-instruction latency, so when wave-instruction counts from a PMC pass of THIS workload are available the line says
+        # bound = "valu" with frac = share of the chip's VALU issue slots used; the HBM figures the schema asks for stay beside it.
+        hbm = {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None}
+        common = {"traffic": traffic, "kernel": "lsim_k_step_a", "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * N, "kernel_avg_ms": ka,
+                  "hbm": hbm, "valu_issue_frac": valu_frac, "valu_cycles_per_wave_inst": VALU_CYCLES_PER_WAVE_INST,
+                  "pmc_source": ({k: pmc.get(k) for k in ("task", "envs_per_gpu", "mode", "actions", "effective_clock_hz", "file")} if pmc else None)}
+        if valu_frac is not None:
+            clk = pmc.get("effective_clock_hz") or MAX_CLOCK_HZ
+            peak_rate = N_SIMD * clk / VALU_CYCLES_PER_WAVE_INST / 1e9                       # G wave64 VALU instructions per second, whole chip
+            out["roofline"] = dict(common, bound="valu", achieved=pmc["valu_wave_insts_per_launch"] / (ka * 1e-3) / 1e9, peak=peak_rate,
+                                   unit="G wave-inst/s", frac=valu_frac,
+                                   note="bound = VALU issue (1024 SIMDs x clock / 2 cycles per wave64 instruction); `hbm` holds the schema's HBM figures: "
+                                        "algorithmic bytes / kernel time against 8 TB/s; `traffic` = HBM bytes per launch from the PMC passes of "
+                                        "profiles/pmc_traffic.json (same task / size / mode / action source)")
+        else:
+            out["roofline"] = dict(common, bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=hbm["frac"],
+                                   note="no PMC pass matches this workload (task / size / mode / actions): only the HBM figures of the schema; the "
+                                        "kernel's real limiter is VALU issue, not HBM (DESIGN.md section 6)")
         # measured device-memory copy rate on this box (quote the datasheet peak AND a measurement): 1 GiB fp32 copy
         try:
             xs = torch.empty(1 << 28, device=dev); ys = torch.empty_like(xs)

@@ -71,7 +71,8 @@ def build_variant(out, extra_flags=(), workdir=None):
     """a diagnostics / from-source build of the whole library into `out`: both translation units compiled from source with `extra_flags`
     added (objects go to `workdir`, default next to `out`), never touching the in-tree objects or liblsim.so"""
     hipcc = os.environ.get("HIPCC", "hipcc")
-    workdir = workdir or os.path.dirname(os.path.abspath(out))
+    out = os.path.abspath(out)
+    workdir = os.path.abspath(workdir) if workdir else os.path.dirname(out)
     objs, procs = [], []
     for src, _, flags in UNITS:
         obj = os.path.join(workdir, os.path.basename(out) + "." + os.path.splitext(src)[0] + ".o")

@@ -810,6 +810,58 @@ template <int K0> __device__ __forceinline__ void ls_contact_force(const WaveSha
         }
     }
 }
+// ---- Delassus build on the matrix core (north star: "MFMA ... for the small dense Jacobian / mass-matrix contractions where rocprof shows it
+// wins over scalar FMA").  W = J' Y^T with J'_i = [a_i (6) | Jl_i in the slots of its own leg (12)] and Y_j in the same layout is a dense
+// R x 18 by 18 x R product.  With at most 4 contacts and 4 limit rows (slots 0..11 and LS_LIM0..LS_LIM0+3) the active rows fit ONE 16 x 16 tile:
+// five v_mfma_f32_16x16x4_f32 (inner dimension 18 padded to 20) replace up to 16 x 9 FMAs + as many LDS operand reads per lane.  Around
+// them: J' goes to LDS as dense 18-vectors (A operand: lane (i, k) reads J'[i][4 s + k]), Y is read where it is (B operand), and the D tile
+// returns through LDS so that lane = slot ends up with its row in registers, which is what the sweep consumes.  The scratch lives in the
+// kinematics arrays (R .. Fb), dead between ph_rows and the next sub-step's kinematics.  tools/micro/delassus_mfma.hip measures the two forms
+// side by side at kernel A's occupancy (profiles/r03_delassus_mfma.json: 1.8 vs 3.3-5.0 us per build for 6-16 rows); for more rows the
+// D tiles need 4-9 KB of LDS the kernel does not have at 16 robots per CU, so the FMA rows above stay for those (9 % of the sub-steps).
+#define LS_DELASSUS_MFMA_NC 4
+#if !defined(LS_EMU)
+typedef float ls_v4f_t __attribute__((ext_vector_type(4)));
+LS_FN int ls_tile_row_of_slot(int slot) { return slot < 12 ? slot : (slot >= LS_LIM0 && slot < LS_LIM0 + 4 ? 12 + slot - LS_LIM0 : -1); }
+__device__ __forceinline__ void ls_delassus_mfma16(WaveShared& sh, int lane, bool act, int leg, const float (&jb)[6], float jl0, float jl1, float jl2,
+                                                   float (&W)[LS_MAXR], float& wd) {
+    float* Jd = &sh.R[0][0];                 // [16][18]
+    float* Wt = Jd + 16 * 18;                // [16][17]
+    static_assert(sizeof(sh.R) + sizeof(sh.p) + sizeof(sh.S) + sizeof(sh.V) + sizeof(sh.Ab) + sizeof(sh.Fb) >= (16 * 18 + 16 * 17) * sizeof(float), "scratch of the MFMA Delassus build");
+    const int t = ls_tile_row_of_slot(lane);
+    if (t >= 0) {                            // jb / jl are zero for an inactive slot: its tile row is zero
+        float* d = Jd + 18 * t;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) d[k] = jb[k];
+#pragma unroll
+        for (int l = 0; l < 4; ++l) { d[6 + 3 * l] = leg == l ? jl0 : 0.0f; d[7 + 3 * l] = leg == l ? jl1 : 0.0f; d[8 + 3 * l] = leg == l ? jl2 : 0.0f; }
+    }
+    __syncthreads();
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int bslot = r16 < 12 ? r16 : LS_LIM0 + r16 - 12;          // B rows: Y of the slot that tile column r16 stands for
+    ls_v4f_t acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        const int k = 4 * s + kq;
+        const int kk = k < LS_NV ? k : 0;
+        const float a = Jd[18 * r16 + kk], b = sh.u.c.Y[bslot][kk];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(k < LS_NV ? a : 0.0f, k < LS_NV ? b : 0.0f, acc, 0, 0, 0);
+    }
+    // D[i = 4 kq + r][j = r16]; the constraint-force-mixing term on the diagonal
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Wt[17 * (4 * kq + r) + r16] = acc[r] + ((4 * kq + r) == r16 ? 1e-6f : 0.0f);
+    __syncthreads();
+    const float* row = Wt + 17 * (t >= 0 ? t : 0);
+#pragma unroll
+    for (int j = 0; j < 12; ++j) W[j] = row[j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) W[LS_LIM0 + j] = row[12 + j];
+    W[LS_LIM0 + 4] = 0.0f; W[LS_LIM0 + 5] = 0.0f;     // the sweep relaxes limit slots in triples: slots past nlim must hold something finite
+    if (act) wd = row[t];
+    __syncthreads();                          // the scratch is the next phase's to overwrite only after every lane has read its row
+}
+#endif
+
 // GPU form: Delassus row and sweep fused so that the 36-entry row lives in registers only between here and the end of
 // the sweep (written unconditionally: no liveness across sub-steps); rows relaxed in slot order, impulse broadcast by readlane.
 LS_FN void wc_delassus_pgs(WaveShared& sh, const LaneRegs& rg, int lane, int iters, float dt) {
@@ -823,8 +875,15 @@ LS_FN void wc_delassus_pgs(WaveShared& sh, const LaneRegs& rg, int lane, int ite
     for (int k = 0; k < 6; ++k) jb[k] = act ? rg.Jb[k] : 0.0f;
     float W[LS_MAXR];                   // entries of inactive slots stay unset: the sweep never touches them (36 zero-fills saved per sub-step)
     float wd = 1.0f;
-    ls_delassus_rows<0, LS_LIM0>(sh, 3 * nc, lane, lo, jb, jl0, jl1, jl2, W, wd);
-    ls_delassus_rows<LS_LIM0, LS_MAXR>(sh, LS_LIM0 + nlim, lane, lo, jb, jl0, jl1, jl2, W, wd);
+#if !defined(LS_NO_DELASSUS_MFMA)
+    if (nc <= LS_DELASSUS_MFMA_NC && nlim <= 4) {
+        ls_delassus_mfma16(sh, lane, act, leg, jb, jl0, jl1, jl2, W, wd);      // <= 16 rows (91 % of the sub-steps): one 16 x 16 MFMA tile
+    } else
+#endif
+    {
+        ls_delassus_rows<0, LS_LIM0>(sh, 3 * nc, lane, lo, jb, jl0, jl1, jl2, W, wd);
+        ls_delassus_rows<LS_LIM0, LS_MAXR>(sh, LS_LIM0 + nlim, lane, lo, jb, jl0, jl1, jl2, W, wd);
+    }
     float w = act ? rg.brow : 0.0f;
     const float inv_d = act ? ls_rcp(wd) : 0.0f;
     const float cf = sh.mu;                                                 // only the friction slots use it
