@@ -3,8 +3,14 @@ Same surface and update rule as rsl_rl.algorithms.HIMPPO (HIMP:38-198): act / pr
 update, value-clip, entropy bonus, KL-adaptive lr x/1.5 (HIMP:144-156), grad-clip, estimator stepped first with the PPO lr.
 
 Data parallel (not in the reference): `dist_ctx` averages gradients over ranks with ONE flattened
-all-reduce per optimiser step (RCCL over xGMI; latency-bound payload of 2.2 MB), synchronises the KL estimate before
-the lr decision and the advantage statistics, so every rank takes identical optimiser steps.
+all-reduce per optimiser step (RCCL over xGMI; latency-bound payloads of 0.24 MB and 2.2 MB), so every rank takes identical optimiser
+steps.  Two collectives per minibatch, 41 per PPO iteration (20 minibatches x 2 + the advantage statistics):
+  * the estimator's gradient bucket carries the KL estimate of the adaptive-lr rule in its last element (no separate scalar all-reduce)
+    and is reduced ASYNCHRONOUSLY while the PPO loss back-propagates -- the estimator step does not feed the PPO backward (the actor's
+    input features are detached and were computed before it, HAC:136-141), so moving it behind the PPO backward changes nothing;
+  * the PPO bucket starts right behind its backward and is in flight during the lr rule and the estimator's optimiser step; then it is
+    clipped (HIMP:183: clip AFTER the reduce) and stepped.  Gradients are reduced with ReduceOp.AVG and the parameters' .grad become views of
+    the reduced buffer: one concatenation per bucket, no scaling pass, no copy back.
 """
 import os
 
@@ -25,21 +31,48 @@ class DistCtx:
         forced = os.environ.get("LSIM_DEBUG_FORCE_COLLECTIVES") == "1"
         self.enabled = dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or forced)
         self.world = dist.get_world_size() if self.enabled else 1
+        self.collectives = 0            # number of collectives issued so far (tests / DESIGN.md section 8 count them per iteration)
 
     def average_grads(self, params):
-        """one flattened all-reduce per optimiser step: cat (1 kernel) -> all_reduce -> scale -> multi-tensor copy back (1-2 kernels)"""
+        """one flattened all-reduce per optimiser step: cat (1 kernel) -> all_reduce(AVG); the parameters' .grad become views of the reduced
+        buffer (no copy back, no scaling pass)"""
         if not self.enabled:
             return
-        grads = [p.grad for p in params if p.grad is not None]
-        flat = torch.cat([g.reshape(-1) for g in grads])
-        self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM)
-        flat.div_(self.world)
-        torch._foreach_copy_(grads, [v.view_as(g) for v, g in zip(flat.split([g.numel() for g in grads]), grads)])
+        self.finish_bucket(self.reduce_bucket_async([p for p in params if p.grad is not None]))
+
+    def reduce_bucket_async(self, params, extra=None):
+        """start the all-reduce of one flattened bucket [gradients of `params`..., extra] WITHOUT waiting for it: RCCL works on its own stream
+        (ordered behind what the compute stream has issued so far), kernels issued after this call overlap with it.  finish_bucket() waits."""
+        parts = [p.grad.reshape(-1) for p in params]
+        if extra is not None:
+            parts.append(extra.detach().reshape(-1).to(parts[0].dtype))
+        flat = torch.cat(parts)
+        self.collectives += 1
+        avg = self._avg_op(flat)
+        work = self.dist.all_reduce(flat, op=avg if avg is not None else self.dist.ReduceOp.SUM, async_op=True)
+        return flat, work, params, (extra.numel() if extra is not None else 0), avg is not None
+
+    def _avg_op(self, t):
+        """ReduceOp.AVG where the backend has it (RCCL / NCCL: the division happens inside the collective); gloo sums and we scale"""
+        return self.dist.ReduceOp.AVG if t.is_cuda and self.dist.get_backend() == "nccl" else None
+
+    def finish_bucket(self, handle):
+        """wait; every parameter's .grad becomes a view of its slice of the reduced buffer; returns the averaged `extra` values (or None)"""
+        flat, work, params, n_extra, averaged = handle
+        work.wait()
+        if not averaged:
+            flat.div_(self.world)
+        sizes = [p.grad.numel() for p in params]
+        pieces = flat.split(sizes + ([n_extra] if n_extra else []))
+        for p, v in zip(params, pieces):
+            p.grad = v.view_as(p.grad)
+        return pieces[-1] if n_extra else None
 
     def average_scalar(self, t):
         if not self.enabled:
             return t
         t = t.clone()
+        self.collectives += 1
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return t / self.world
 
@@ -47,6 +80,7 @@ class DistCtx:
         if not self.enabled:
             return a, b, c
         v = torch.stack((a, b, c)).to(torch.float64)
+        self.collectives += 1
         self.dist.all_reduce(v, op=self.dist.ReduceOp.SUM)
         v = v.to(torch.float32)
         return v[0], v[1], v[2]
@@ -56,6 +90,7 @@ class DistCtx:
         if not self.enabled:
             return a, b, c
         v = torch.cat((a.reshape(-1), b.reshape(-1), c.reshape(1))).to(torch.float64)
+        self.collectives += 1
         self.dist.all_reduce(v, op=self.dist.ReduceOp.SUM)
         n = a.numel()
         return v[:n].view_as(a), v[n:2 * n].view_as(b), v[2 * n]
@@ -166,10 +201,15 @@ class HIMPPO:
         last_values = self.actor_critic.evaluate(last_critic_obs).detach()
         self.storage.compute_returns(last_values, self.gamma, self.lam)
 
-    def _adapt_lr(self, mu, sigma, old_mu, old_sigma, kl_mean=None):
+    def _local_kl(self, mu, sigma, old_mu, old_sigma):
+        with torch.inference_mode():
+            kl = torch.sum(torch.log(sigma / old_sigma + 1.0e-5) + (torch.square(old_sigma) + torch.square(old_mu - mu)) / (2.0 * torch.square(sigma)) - 0.5, dim=-1)
+            return torch.mean(kl)
+
+    def _adapt_lr(self, mu, sigma, old_mu, old_sigma, kl_mean=None, already_global=False):
         if self._lr_t is not None and kl_mean is not None:        # device path: no host round trip
             from .. import lib
-            if self.dist_ctx is not None and self.dist_ctx.enabled:
+            if self.dist_ctx is not None and self.dist_ctx.enabled and not already_global:
                 kl_mean = self.dist_ctx.average_scalar(kl_mean)
             kl_mean = kl_mean.detach().reshape(1).contiguous()
             lib.check(lib.load().lsim_adaptive_lr(kl_mean.data_ptr(), float(self.desired_kl), 1e-5, 1e-2, 1.5, self._lr_t.data_ptr(),
@@ -177,9 +217,8 @@ class HIMPPO:
             return
         with torch.inference_mode():
             if kl_mean is None:
-                kl = torch.sum(torch.log(sigma / old_sigma + 1.0e-5) + (torch.square(old_sigma) + torch.square(old_mu - mu)) / (2.0 * torch.square(sigma)) - 0.5, dim=-1)
-                kl_mean = torch.mean(kl)
-            if self.dist_ctx is not None:
+                kl_mean = self._local_kl(mu, sigma, old_mu, old_sigma)
+            if self.dist_ctx is not None and not already_global:
                 kl_mean = self.dist_ctx.average_scalar(kl_mean)
             kl_mean = kl_mean.item()
         if kl_mean > self.desired_kl * 2.0:
@@ -209,6 +248,47 @@ class HIMPPO:
             value_loss = (returns - value).pow(2).mean()
         return surrogate_loss + self.value_loss_coef * value_loss - self.entropy_coef * entropy.mean(), surrogate_loss, value_loss, None
 
+    def _step_minibatch_data_parallel(self, ac, obs, next_critic_obs, loss, mu, sigma, old_mu, old_sigma, kl_mean, adaptive, more_params=()):
+        """the optimiser half of one minibatch on N > 1 ranks: same two optimiser steps as the single-rank order (lr rule -> estimator step -> PPO
+        step, HIMP:144-184), with the estimator's gradient all-reduce -- carrying the KL estimate in its tail -- in flight during the PPO
+        backward.  Returns the estimator's (estimation, swap) losses."""
+        ctx, est_mod = self.dist_ctx, ac.estimator
+        est_params = list(est_mod.parameters())
+        self.optimizer.zero_grad()                                   # every parameter of the optimiser, the estimator's included
+        est, swap, total = est_mod.losses(obs, next_critic_obs)
+        est_mod._primed = None
+        total.backward()
+        extra = None
+        if adaptive:
+            extra = kl_mean if kl_mean is not None else self._local_kl(mu, sigma, old_mu, old_sigma)
+        handle = ctx.reduce_bucket_async([p for p in est_params if p.grad is not None], extra=extra)
+        loss.backward()                                              # actor / critic / std gradients: overlaps with the all-reduce above
+        # the PPO bucket starts as soon as its backward is issued and is in flight during the lr rule and the estimator's optimiser step.
+        # `more_params`: parameters outside the actor-critic that the same optimiser steps (HybridPPO: the discriminator) -- reduced in the same
+        # bucket, not clipped (HYBP:270 clips the actor-critic only)
+        est_ids = {id(p) for p in est_params}
+        ppo_params = [p for p in ac.parameters() if p.grad is not None and id(p) not in est_ids]
+        handle_ppo = ctx.reduce_bucket_async(ppo_params + [p for p in more_params if p.grad is not None])
+        kl_global = ctx.finish_bucket(handle)
+        if adaptive:
+            self._adapt_lr(mu, sigma, old_mu, old_sigma, kl_global.reshape(()), already_global=True)
+        if self._lr_t is None:                                       # host learning rate: the estimator steps with the PPO rate (HIMP:158)
+            est_mod.learning_rate = self.learning_rate
+            for g in est_mod.optimizer.param_groups:
+                g["lr"] = self.learning_rate
+        stepped = False
+        if est_mod.fused_step:
+            from .fused_linear import adam_clip_step_hip
+            stepped = adam_clip_step_hip(est_mod.optimizer, est_mod.max_grad_norm)
+        if not stepped:
+            nn.utils.clip_grad_norm_(est_params, est_mod.max_grad_norm)
+            est_mod.optimizer.step()
+        for p in est_params:                                         # the PPO optimiser also holds these parameters: as in the reference
+            p.grad = None                                            # (zero_grad before the PPO backward) it must not step them
+        ctx.finish_bucket(handle_ppo)                                # clip AFTER the all-reduce (HIMP:183)
+        self._clip_and_step(self.optimizer, ppo_params, self.max_grad_norm)
+        return est.detach(), swap.detach()
+
     def update(self):
         ac = self.actor_critic
         sums = torch.zeros(4, device=self.device)
@@ -226,14 +306,16 @@ class HIMPPO:
             mu, sigma = ac.action_mean, ac.action_std
             loss, surrogate_loss, value_loss, kl_mean = self._ppo_loss(ac, mu, sigma, value, actions, old_logp, advantages, returns, target_values,
                                                                        old_mu, old_sigma)
-            if self.desired_kl is not None and self.schedule == "adaptive":
-                self._adapt_lr(mu, sigma, old_mu, old_sigma, kl_mean)
-            est, swap = ac.estimator.update(obs, next_critic_obs, lr=None if self._lr_t is not None else self.learning_rate)
-            self.optimizer.zero_grad()
-            loss.backward()
-            if self.dist_ctx is not None:
-                self.dist_ctx.average_grads(list(ac.parameters()))   # clip AFTER the all-reduce (HIMP:183)
-            self._clip_and_step(self.optimizer, ac.parameters(), self.max_grad_norm)
+            adaptive = self.desired_kl is not None and self.schedule == "adaptive"
+            if self.dist_ctx is not None and self.dist_ctx.enabled:
+                est, swap = self._step_minibatch_data_parallel(ac, obs, next_critic_obs, loss, mu, sigma, old_mu, old_sigma, kl_mean, adaptive)
+            else:
+                if adaptive:
+                    self._adapt_lr(mu, sigma, old_mu, old_sigma, kl_mean)
+                est, swap = ac.estimator.update(obs, next_critic_obs, lr=None if self._lr_t is not None else self.learning_rate)
+                self.optimizer.zero_grad()
+                loss.backward()
+                self._clip_and_step(self.optimizer, ac.parameters(), self.max_grad_norm)
             sums += torch.stack((value_loss.detach(), surrogate_loss.detach(), est, swap))
             last_est, last_swap = est, swap
         n = self.num_learning_epochs * self.num_mini_batches

@@ -66,9 +66,12 @@ class HybridPPO(HIMPPO):
             mu, sigma = ac.action_mean, ac.action_std
             ppo_loss, surrogate_loss, value_loss, kl_mean = self._ppo_loss(ac, mu, sigma, value, actions, old_logp, advantages, returns, target_values,
                                                                            old_mu, old_sigma)
-            if self.desired_kl is not None and self.schedule == "adaptive":
-                self._adapt_lr(mu, sigma, old_mu, old_sigma, kl_mean)
-            est, swap = ac.estimator.update(obs, next_critic_obs, lr=None if self._lr_t is not None else self.learning_rate)
+            adaptive = self.desired_kl is not None and self.schedule == "adaptive"
+            dist_on = self.dist_ctx is not None and self.dist_ctx.enabled
+            if not dist_on:
+                if adaptive:
+                    self._adapt_lr(mu, sigma, old_mu, old_sigma, kl_mean)
+                est, swap = ac.estimator.update(obs, next_critic_obs, lr=None if self._lr_t is not None else self.learning_rate)
             exp_s, exp_ns = exp_s_raw, exp_ns_raw
             if self.amp_normalizer is not None:
                 with torch.no_grad():
@@ -80,11 +83,13 @@ class HybridPPO(HIMPPO):
                               torch.nn.functional.mse_loss(policy_d, -torch.ones_like(policy_d)))
             grad_pen = disc.compute_grad_pen(exp_s_raw, exp_ns_raw, lambda_=10)     # on the un-normalised expert pair (HYBP:262-263)
             loss = ppo_loss + amp_loss + grad_pen
-            self.optimizer.zero_grad()
-            loss.backward()
-            if self.dist_ctx is not None:
-                self.dist_ctx.average_grads(list(ac.parameters()) + list(disc.parameters()))
-            self._clip_and_step(self.optimizer, ac.parameters(), self.max_grad_norm)     # HYBP:270-273: clipping over the actor-critic only
+            if dist_on:      # two collectives per minibatch, the estimator's in flight during this backward (him_ppo.py)
+                est, swap = self._step_minibatch_data_parallel(ac, obs, next_critic_obs, loss, mu, sigma, old_mu, old_sigma, kl_mean, adaptive,
+                                                               more_params=list(disc.parameters()))
+            else:
+                self.optimizer.zero_grad()
+                loss.backward()
+                self._clip_and_step(self.optimizer, ac.parameters(), self.max_grad_norm)     # HYBP:270-273: clipping over the actor-critic only
             if self.min_std is not None:
                 ac.std.data = ac.std.data.clamp(min=self.min_std)
             if self.amp_normalizer is not None:

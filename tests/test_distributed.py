@@ -41,22 +41,28 @@ class FakeEnv:
         return self._r(self.num_envs, 270), self._r(self.num_envs, 238), self._r(self.num_envs), d, self.extras, ids, self._r(len(ids), 238)
 
 
-def _worker(rank, world, port, out_dir):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    sys.path.insert(0, ROOT)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+def _train_cfg():
     from isaacgymloco_amd.learn.bench_train import train_cfg_dict
-    from isaacgymloco_amd.learn.runner import HIMOnPolicyRunner
     tc = train_cfg_dict("aliengo")
     tc["runner"]["num_steps_per_env"] = 6
     tc["algorithm"]["num_learning_epochs"] = 2
     tc["algorithm"]["num_mini_batches"] = 2
-    torch.manual_seed(100 + rank)          # different initial weights per rank: the broadcast must fix that
-    runner = HIMOnPolicyRunner(FakeEnv(8, seed=7 + rank), tc, log_dir=None, device="cpu")
-    torch.manual_seed(5 + rank)
+    return tc
+
+
+def _worker(rank, world, port, out_dir, same_data=False):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from isaacgymloco_amd.learn.runner import HIMOnPolicyRunner
+    r = 0 if same_data else rank
+    torch.manual_seed(100 + r)             # different initial weights per rank: the broadcast must fix that
+    runner = HIMOnPolicyRunner(FakeEnv(8, seed=7 + r), _train_cfg(), log_dir=None, device="cpu")
+    torch.manual_seed(5 + r)
+    c0 = runner.dist_ctx.collectives
     runner.learn(2, init_at_random_ep_len=False)
     sd = {k: v.clone() for k, v in runner.alg.actor_critic.state_dict().items()}
-    torch.save({"sd": sd, "lr": runner.alg.learning_rate}, os.path.join(out_dir, f"rank{rank}.pt"))
+    torch.save({"sd": sd, "lr": runner.alg.learning_rate, "collectives": runner.dist_ctx.collectives - c0}, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.destroy_process_group()
 
 
@@ -68,6 +74,31 @@ def test_two_ranks_stay_in_lockstep(tmp_path):
     assert a["lr"] == b["lr"]
     for k in a["sd"]:
         torch.testing.assert_close(a["sd"][k], b["sd"][k], rtol=0, atol=0, msg=k)
+    # two collectives per minibatch (estimator bucket with the KL estimate in its tail, PPO bucket) + the advantage statistics per iteration
+    # (41 per iteration with the reference's 5 epochs x 4 minibatches; here 2 x 2 minibatches, 2 iterations)
+    assert a["collectives"] == b["collectives"] == 2 * (2 * 2 * 2 + 1)
+
+
+def test_data_parallel_order_equals_the_single_rank_order(tmp_path):
+    """the N > 1 path moves the estimator's step behind the PPO backward (its all-reduce is in flight meanwhile); with the SAME data on both
+    ranks the averaged gradients equal the local ones exactly ((g + g) / 2), so the two ranks must end where a single process running the
+    reference's order (lr rule -> estimator step -> PPO backward -> PPO step) ends, bit for bit -- given the same advantage statistics, i.e. the
+    single process normalises with the doubled sums the two ranks see (a batch that holds every sample twice)"""
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), True), nprocs=2, join=True)
+    from isaacgymloco_amd.learn.runner import HIMOnPolicyRunner
+    torch.manual_seed(100)
+    runner = HIMOnPolicyRunner(FakeEnv(8, seed=7), _train_cfg(), log_dir=None, device="cpu")
+    assert not runner.dist_ctx.enabled
+    runner.alg.storage.advantage_sync = lambda s1, s2, n: (2.0 * s1, 2.0 * s2, 2.0 * n)
+    torch.manual_seed(5)
+    runner.learn(2, init_at_random_ep_len=False)
+    single = runner.alg.actor_critic.state_dict()
+    for r in range(2):
+        d = torch.load(os.path.join(tmp_path, f"rank{r}.pt"))
+        assert d["lr"] == runner.alg.learning_rate
+        for k in single:
+            torch.testing.assert_close(d["sd"][k], single[k], rtol=0, atol=0, msg=k)
 
 
 def _grad_worker(rank, world, port, out_dir):
