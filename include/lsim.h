@@ -49,7 +49,9 @@ extern "C" {
 #define LSIM_NUM_PRIV_OBS 238   /* 45 + 3 + 3 + 187, LRC:53 */
 #define LSIM_NUM_AMP_OBS 30     /* LR:416 */
 #define LSIM_NUM_BASE_HEIGHT_PTS 63 /* 7 x 9, LR:1308-1312 */
+#ifndef LSIM_MAX_COLLISION_POINTS /* the CPU oracle can be compiled with a larger table: densely sampled TRUE collision shapes (tests/test_shape_variants.py) */
 #define LSIM_MAX_COLLISION_POINTS 64
+#endif
 #ifndef LSIM_MAX_CONTACTS      /* the CPU oracle can be compiled with a larger cap to measure what the cap costs (tests/test_contact_cap.py) */
 #define LSIM_MAX_CONTACTS 8
 #endif

@@ -26,12 +26,16 @@ def _strip_comments(text):
     return re.sub(r"//[^\n]*", "", text)
 
 
-def _parse(text):
+def _parse(text, overrides=None):
+    """`overrides`: values for the header's #ifndef-guarded defines, as a build with -DNAME=value sees them (test-only oracle variants)"""
     text = _strip_comments(text)
     defines = {}
     for m in re.finditer(r"^\s*#define\s+(\w+)\s+(.+?)\s*$", text, flags=re.M):
         name, expr = m.group(1), m.group(2)
         expr = re.sub(r"(\d+)u\b", r"\1", expr)
+        if overrides and name in overrides:
+            defines[name] = int(overrides[name])
+            continue
         try:
             defines[name] = int(eval(expr, {}, dict(defines)))  # only integer arithmetic on earlier defines
         except Exception:
@@ -113,6 +117,12 @@ STEP_RECORD_SUBSTEPS = DEFINES["LSIM_STEP_RECORD_SUBSTEPS"]
 STATS = {k[len("LSIM_STATS_"):].lower(): v for k, v in DEFINES.items() if k.startswith("LSIM_STATS_")}
 
 
+def structs_for(overrides):
+    """struct mirrors of a library compiled with -DNAME=value overrides of the header's guarded defines (oracle variants only)"""
+    with open(HEADER_PATH) as f:
+        return _parse(f.read(), overrides)[2]
+
+
 def declared_functions():
     """Names of every function the header declares (used by the 'exports every symbol' test)."""
     with open(HEADER_PATH) as f:
@@ -120,9 +130,10 @@ def declared_functions():
     return sorted(set(re.findall(r"\b(lsim_\w+)\s*\(", text)) - {"lsim_sim"})
 
 
-def check_abi(lib, prefix="lsim"):
+def check_abi(lib, prefix="lsim", structs=None):
     """Raise if the loaded library was built against a different struct layout."""
-    for what, struct in (("config", LsimConfig), ("model", LsimRobotModel)):
+    structs = structs or STRUCTS
+    for what, struct in (("config", structs["lsim_config"]), ("model", structs["lsim_robot_model"])):
         fn = getattr(lib, f"{prefix}_sizeof_{what}")
         fn.restype = ctypes.c_int
         got = fn()

@@ -38,13 +38,19 @@ def lib():
     return _lib
 
 
-def variant(name):
-    """another build of the same sources (oracle/Makefile target lib<name>.so), e.g. "orc_cap32": the contact cap lifted to 32"""
+def variant(name, defines=None):
+    """another build of the same sources (oracle/Makefile target lib<name>.so), e.g. "orc_cap32": the contact cap lifted to 32.
+    `defines`: the -D overrides of include/lsim.h's guarded sizes the target is compiled with, when they change a struct layout
+    (e.g. {"LSIM_MAX_COLLISION_POINTS": 768}); the matching model struct class is then `variant_structs(defines)["lsim_robot_model"]`."""
     path = os.path.join(_HERE, f"lib{name}.so")
     subprocess.check_call(["make", "-C", _HERE, f"lib{name}.so"], stdout=subprocess.DEVNULL)
     L = ctypes.CDLL(path)
-    abi.check_abi(L, prefix="orc")
+    abi.check_abi(L, prefix="orc", structs=abi.structs_for(defines) if defines else None)
     return L
+
+
+def variant_structs(defines):
+    return abi.structs_for(defines)
 
 
 class OracleSim:

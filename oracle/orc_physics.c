@@ -509,6 +509,81 @@ void orc_physics_substep(orc_sim* s, int e, const float tau_f[12], int apply_for
         dirs[R][0] = dirs[R][1] = dirs[R][2] = 0;
         ++R;
     }
+#if defined(ORC_SOLVER_TGS)
+    /* ---- variant (oracle/Makefile: liborc_tgs.so): PhysX's Temporal Gauss-Seidel scheme, the solver the reference actually configures
+     * (solver_type = 1, num_position_iterations = 4, num_velocity_iterations = 0: LRC:245-248), restated from its published description
+     * (Macklin, Storey, Lu, Terdiman, Chentanez, Jeschke, Mueller: "Small Steps in Physics Simulation", SCA 2019; PhysX SDK guide, "Temporal
+     * Gauss-Seidel"): the step is split into N = position-iterations sub-steps of h = dt / N; each sub-step integrates the unconstrained
+     * acceleration over h, relaxes every constraint ONCE against the positional error of the configuration reached so far (gaps and joint
+     * angles advance with the sub-steps; the articulation's response -- J, M^-1 J^T -- stays that of the start of the step), and advances the
+     * configuration by h.  Impulses accumulate over the step and are projected as totals (normal >= 0, friction box mu * normal).  No
+     * velocity iterations.  Used ONLY to measure how far the shipped solver (8 velocity-level sweeps over the whole step) sits from this
+     * scheme on the quantities the rewards read (tests/test_solver_variants.py); PhysX itself stays closed. */
+    {
+        const int NS = ORC_SOLVER_TGS;
+        const double hs = dt / NS;
+        double Y[MAXR][NV], Wd[MAXR], lam[MAXR], vv[NV], gap[MAXC], qs[12], dp[3] = {0, 0, 0}, qcur[4] = {qb[0], qb[1], qb[2], qb[3]};
+        for (int r = 0; r < R; ++r) {
+            memcpy(Y[r], J[r], sizeof(Y[r])); chol_solve(L, NV, Y[r]);
+            double a = 1e-6; for (int k = 0; k < NV; ++k) a += J[r][k] * Y[r][k];
+            Wd[r] = a; lam[r] = 0;
+        }
+        memcpy(vv, v, sizeof(vv));
+        for (int k = 0; k < nc; ++k) gap[k] = cdist[k];
+        for (int j = 0; j < 12; ++j) qs[j] = q[j];
+        for (int sub = 0; sub < NS; ++sub) {
+            for (int k = 0; k < NV; ++k) vv[k] += hs * rhs[k];
+            for (int r = 0; r < R; ++r) {
+                double tgt = 0, rng = 0;
+                if (rkind[r] == 0) {
+                    double d = gap[rcontact[r]];
+                    if (d >= 0) tgt = -d / hs;
+                    else { double pen = -d - c->contact_slop; if (pen < 0) pen = 0; tgt = fmin((double)c->max_depenetration_velocity, c->erp * pen / hs); }
+                } else if (rkind[r] == 3) {
+                    int j = -1; for (int k = 0; k < 12; ++k) if (J[r][6 + k] != 0) j = k;
+                    double lo = qs[j] - m->dof_pos_lower[j], hi = m->dof_pos_upper[j] - qs[j], vmax = m->dof_vel_limit[j];
+                    double Lb = -vmax, Ub = vmax;
+                    if (lo < 0.1) Lb = fmax(Lb, lo >= 0 ? -lo / hs : fmin(1.0, c->erp * (-lo) / hs));
+                    if (hi < 0.1) Ub = fmin(Ub, hi >= 0 ? hi / hs : -fmin(1.0, c->erp * (-hi) / hs));
+                    if (Ub < Lb) Ub = Lb;
+                    tgt = Lb; rng = Ub - Lb;
+                }
+                double w = -tgt; for (int k = 0; k < NV; ++k) w += J[r][k] * vv[k];
+                double nl = lam[r] - w / Wd[r];
+                if (rkind[r] == 0) { if (nl < 0) nl = 0; }
+                else if (rkind[r] == 3) { double up = nl + rng / Wd[r]; nl = (nl > 0 ? nl : 0) + (up < 0 ? up : 0); }   /* two-sided, as the shipped sweep */
+                else { double lim = mu * lam[r - rkind[r]]; if (nl > lim) nl = lim; if (nl < -lim) nl = -lim; }
+                double dl = nl - lam[r];
+                lam[r] = nl;
+                for (int k = 0; k < NV; ++k) vv[k] += Y[r][k] * dl;
+            }
+            /* advance the configuration by h: contact gaps along their normals, joints, base pose */
+            for (int r = 0; r < R; ++r) if (rkind[r] == 0) { double a = 0; for (int k = 0; k < NV; ++k) a += J[r][k] * vv[k]; gap[rcontact[r]] += hs * a; }
+            for (int j = 0; j < 12; ++j) qs[j] += hs * vv[6 + j];
+            {   /* vv[3..5] is the velocity of the point of the base that sat at the base origin at the start of the step */
+                double wxd[3], w3[3] = {vv[0], vv[1], vv[2]};
+                v3cross(w3, dp, wxd);
+                for (int k = 0; k < 3; ++k) dp[k] += hs * (vv[3 + k] + wxd[k]);
+                double dq[4] = { 0.5 * hs * ( w3[0] * qcur[3] + w3[1] * qcur[2] - w3[2] * qcur[1]),
+                                 0.5 * hs * (-w3[0] * qcur[2] + w3[1] * qcur[3] + w3[2] * qcur[0]),
+                                 0.5 * hs * ( w3[0] * qcur[1] - w3[1] * qcur[0] + w3[2] * qcur[3]),
+                                 0.5 * hs * (-w3[0] * qcur[0] - w3[1] * qcur[1] - w3[2] * qcur[2]) };
+                double nn = 0; for (int k = 0; k < 4; ++k) { qcur[k] += dq[k]; nn += qcur[k] * qcur[k]; }
+                nn = sqrt(nn); for (int k = 0; k < 4; ++k) qcur[k] /= nn;
+            }
+        }
+        double cf[NB][3];
+        memset(cf, 0, sizeof(cf));
+        for (int r = 0; r < R; ++r) if (rcontact[r] >= 0) for (int k = 0; k < 3; ++k) cf[cbody[rcontact[r]]][k] += lam[r] * dirs[r][k] / dt;
+        for (int i = 0; i < NB; ++i) for (int k = 0; k < 3; ++k) cfo[3 * i + k] = (float)cf[i][k];
+        for (int j = 0; j < 12; ++j) { dof[2 * j] = (float)qs[j]; dof[2 * j + 1] = (float)vv[6 + j]; }
+        double wxd[3], w3[3] = {vv[0], vv[1], vv[2]};
+        v3cross(w3, dp, wxd);
+        for (int k = 0; k < 3; ++k) { root[k] = (float)(p0[k] + dp[k]); root[7 + k] = (float)(vv[3 + k] + wxd[k]); root[10 + k] = (float)vv[k]; }
+        for (int k = 0; k < 4; ++k) root[3 + k] = (float)qcur[k];
+        (void)vt; (void)rrng; (void)vfree;
+    }
+#else
     /* 8. Delassus operator and projected Gauss-Seidel */
     static const double CFM = 1e-6;
     double Y[MAXR][NV], W[MAXR][MAXR], b[MAXR], lam[MAXR];
@@ -566,4 +641,5 @@ void orc_physics_substep(orc_sim* s, int e, const float tau_f[12], int apply_for
         root[10 + k] = (float)vn[k];
     }
     for (int k = 0; k < 4; ++k) root[3 + k] = (float)(qq[k] / nn);
+#endif
 }
