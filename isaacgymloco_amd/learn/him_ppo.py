@@ -144,6 +144,11 @@ class HIMPPO:
         est.fused_step = True
         return True
 
+    def _side_stream(self, device):
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=device)
+        return self._side
+
     def _clip_and_step(self, optimizer, params, max_grad_norm):
         """clip_grad_norm_ + optimizer.step() (HIMP:183-184); on the device-lr fast path one C-ABI call of three launches"""
         params = list(params)
@@ -253,6 +258,8 @@ class HIMPPO:
         step, HIMP:144-184), with the estimator's gradient all-reduce -- carrying the KL estimate in its tail -- in flight during the PPO
         backward.  Returns the estimator's (estimation, swap) losses."""
         ctx, est_mod = self.dist_ctx, ac.estimator
+        if ctx is not None and not ctx.enabled:
+            ctx = None                                               # single rank: same order, no collectives (the two-stream path of update())
         est_params = list(est_mod.parameters())
         self.optimizer.zero_grad()                                   # every parameter of the optimiser, the estimator's included
         est, swap, total = est_mod.losses(obs, next_critic_obs)
@@ -261,15 +268,15 @@ class HIMPPO:
         extra = None
         if adaptive:
             extra = kl_mean if kl_mean is not None else self._local_kl(mu, sigma, old_mu, old_sigma)
-        handle = ctx.reduce_bucket_async([p for p in est_params if p.grad is not None], extra=extra)
+        handle = ctx.reduce_bucket_async([p for p in est_params if p.grad is not None], extra=extra) if ctx is not None else None
         loss.backward()                                              # actor / critic / std gradients: overlaps with the all-reduce above
         # the PPO bucket starts as soon as its backward is issued and is in flight during the lr rule and the estimator's optimiser step.
         # `more_params`: parameters outside the actor-critic that the same optimiser steps (HybridPPO: the discriminator) -- reduced in the same
         # bucket, not clipped (HYBP:270 clips the actor-critic only)
         est_ids = {id(p) for p in est_params}
         ppo_params = [p for p in ac.parameters() if p.grad is not None and id(p) not in est_ids]
-        handle_ppo = ctx.reduce_bucket_async(ppo_params + [p for p in more_params if p.grad is not None])
-        kl_global = ctx.finish_bucket(handle)
+        handle_ppo = ctx.reduce_bucket_async(ppo_params + [p for p in more_params if p.grad is not None]) if ctx is not None else None
+        kl_global = ctx.finish_bucket(handle) if ctx is not None else extra
         if adaptive:
             self._adapt_lr(mu, sigma, old_mu, old_sigma, kl_global.reshape(()), already_global=True)
         if self._lr_t is None:                                       # host learning rate: the estimator steps with the PPO rate (HIMP:158)
@@ -285,7 +292,8 @@ class HIMPPO:
             est_mod.optimizer.step()
         for p in est_params:                                         # the PPO optimiser also holds these parameters: as in the reference
             p.grad = None                                            # (zero_grad before the PPO backward) it must not step them
-        ctx.finish_bucket(handle_ppo)                                # clip AFTER the all-reduce (HIMP:183)
+        if ctx is not None:
+            ctx.finish_bucket(handle_ppo)                            # clip AFTER the all-reduce (HIMP:183)
         self._clip_and_step(self.optimizer, ppo_params, self.max_grad_norm)
         return est.detach(), swap.detach()
 
@@ -295,6 +303,17 @@ class HIMPPO:
         last_est = last_swap = None
         for (obs, critic_obs, actions, next_critic_obs, target_values, advantages, returns, old_logp, old_mu, old_sigma) in \
                 self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs):
+            two_streams = obs.is_cuda and self._lr_t is not None and os.environ.get("LSIM_UPDATE_STREAMS", "1") != "0"
+            if two_streams:
+                # The critic chain (forward here, backward inside loss.backward(): autograd runs a node on the stream of its forward) goes to a
+                # side stream; encoder + actor + estimator stay on the main one.  The two halves carry about the same matrix work (858 k vs
+                # 771 k multiply-adds per sample over forward + backward), and their kernels interleave on the device: one chain's
+                # bandwidth-bound passes (ELU, stores) and tile-quantisation tails run under the other chain's MFMA-bound GEMMs.
+                cur = torch.cuda.current_stream(obs.device)
+                side = self._side_stream(obs.device)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    value = ac.evaluate(critic_obs)
             ac.estimator.prime(obs)        # one encoder forward serves the policy features and the estimator loss below
             # the reference calls act() here (HIMP:141) and throws the sample away; torch.normal(mean, std) validates std >= 0 with a
             # host read-back, i.e. one pipeline drain per minibatch on the GPU: only the distribution is needed
@@ -302,12 +321,16 @@ class HIMPPO:
                 ac.update_distribution(obs)
             else:
                 ac.act(obs)
-            value = ac.evaluate(critic_obs)
+            if two_streams:
+                cur.wait_stream(side)
+                value.record_stream(cur)
+            else:
+                value = ac.evaluate(critic_obs)
             mu, sigma = ac.action_mean, ac.action_std
             loss, surrogate_loss, value_loss, kl_mean = self._ppo_loss(ac, mu, sigma, value, actions, old_logp, advantages, returns, target_values,
                                                                        old_mu, old_sigma)
             adaptive = self.desired_kl is not None and self.schedule == "adaptive"
-            if self.dist_ctx is not None and self.dist_ctx.enabled:
+            if (self.dist_ctx is not None and self.dist_ctx.enabled) or two_streams:
                 est, swap = self._step_minibatch_data_parallel(ac, obs, next_critic_obs, loss, mu, sigma, old_mu, old_sigma, kl_mean, adaptive)
             else:
                 if adaptive:
