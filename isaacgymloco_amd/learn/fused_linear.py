@@ -17,6 +17,17 @@ _workspaces = {}
 _plans = {}
 
 
+def _workspace(kind, device, nbytes, floor=0):
+    """scratch buffer of one kernel family, PER STREAM: the update runs the actor / estimator chain and the critic chain on two streams
+    (him_ppo.py), and two weight-gradient kernels in flight at once must not share their partial-result buffers"""
+    key = (kind, device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(int(nbytes), int(floor)), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
 def _eligible(batch, k_in, n_out):
     """the library decides (lsim_linear_wgrad_workspace returns LSIM_E_UNSUPPORTED for shapes it leaves to BLAS)"""
     if batch < _MIN_BATCH:
@@ -43,10 +54,7 @@ def linear_wgrad(x, g, want_bias=True):
     n_out = g.shape[1]
     need, waves = ctypes.c_size_t(), ctypes.c_int()
     lib.check(L.lsim_linear_wgrad_workspace(batch, k_in, n_out, ctypes.byref(need), ctypes.byref(waves)), what="lsim_linear_wgrad_workspace")
-    ws = _workspaces.get(x.device)
-    if ws is None or ws.numel() < need.value:
-        ws = torch.empty(max(need.value, 1 << 20), dtype=torch.uint8, device=x.device)
-        _workspaces[x.device] = ws
+    ws = _workspace("wgrad", x.device, need.value, floor=1 << 20)
     dw = torch.empty(n_out, k_in, device=x.device, dtype=torch.float32)
     db = torch.empty(n_out, device=x.device, dtype=torch.float32) if want_bias else None
     lib.check(L.lsim_linear_wgrad(x.data_ptr(), x.stride(0), g.data_ptr(), g.stride(0), batch, k_in, n_out, dw.data_ptr(),
@@ -100,10 +108,7 @@ class _LinearEluFn(torch.autograd.Function):
         n_out = weight.shape[0]
         need, parts = ctypes.c_size_t(), ctypes.c_int()
         lib.check(L.lsim_linear_wgrad_workspace(batch, k_in, n_out, ctypes.byref(need), ctypes.byref(parts)), what="lsim_linear_wgrad_workspace")
-        ws = _workspaces.get(x.device)
-        if ws is None or ws.numel() < need.value:
-            ws = torch.empty(max(need.value, 1 << 20), dtype=torch.uint8, device=x.device)
-            _workspaces[x.device] = ws
+        ws = _workspace("wgrad", x.device, need.value, floor=1 << 20)
         dw = torch.empty(n_out, k_in, device=x.device, dtype=torch.float32)
         db = torch.empty(n_out, device=x.device, dtype=torch.float32) if ctx.has_bias else None
         # the gradient of the pre-activation is written out only where an input gradient follows (not for a network's first layer: 210 MB per call)
@@ -153,10 +158,7 @@ def sinkhorn_hip(scores, eps, iters):
     B, K = scores.shape
     need = ctypes.c_size_t()
     lib.check(L.lsim_sinkhorn_workspace(B, K, ctypes.byref(need)), what="lsim_sinkhorn_workspace")
-    ws = _workspaces.get(("sinkhorn", scores.device))
-    if ws is None or ws.numel() < need.value:
-        ws = torch.empty(need.value, dtype=torch.uint8, device=scores.device)
-        _workspaces[("sinkhorn", scores.device)] = ws
+    ws = _workspace("sinkhorn", scores.device, need.value)
     out = torch.empty(B, K, device=scores.device, dtype=torch.float32)
     lib.check(L.lsim_sinkhorn(scores.data_ptr(), scores.stride(0), B, K, float(eps), int(iters), out.data_ptr(), ws.data_ptr(), ws.numel(),
                               torch.cuda.current_stream(scores.device).cuda_stream), what="lsim_sinkhorn")
@@ -214,10 +216,7 @@ class _EstimatorLossFn(torch.autograd.Function):
         K = proto_.shape[0]
         need = ctypes.c_size_t()
         lib.check(L.lsim_estimator_loss_workspace(B, D, K, ctypes.byref(need)), what="lsim_estimator_loss_workspace")
-        ws = _workspaces.get(("estimator_loss", enc_.device))
-        if ws is None or ws.numel() < need.value:
-            ws = torch.empty(need.value, dtype=torch.uint8, device=enc_.device)
-            _workspaces[("estimator_loss", enc_.device)] = ws
+        ws = _workspace("estimator_loss", enc_.device, need.value)
         out = torch.empty(3, device=enc_.device)
         g_enc, g_tgt, g_proto = torch.empty(B, 3 + D, device=enc_.device), torch.empty(B, D, device=enc_.device), torch.empty_like(proto_)
         lib.check(L.lsim_estimator_loss(enc_.data_ptr(), enc_.stride(0), tgt_.data_ptr(), tgt_.stride(0), proto_.data_ptr(), vel_.data_ptr(),
@@ -282,10 +281,7 @@ def adam_clip_step_hip(optimizer, max_grad_norm, clip_params=None):
     dev = entries[0][0].device
     need = ctypes.c_size_t()
     lib.check(L.lsim_adam_clip_step_workspace(n, ctypes.byref(need)), what="lsim_adam_clip_step_workspace")
-    ws = _workspaces.get(("adam", dev, id(optimizer)))
-    if ws is None or ws.numel() < need.value:
-        ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
-        _workspaces[("adam", dev, id(optimizer))] = ws
+    ws = _workspace(("adam", id(optimizer)), dev, need.value)
     arr = lambda v: (ctypes.c_void_p * n)(*v)
     numel = (ctypes.c_int64 * n)(*[p.numel() for p, _ in entries])
     wd = (ctypes.c_float * n)(*[w for _, w in entries])

@@ -20,6 +20,47 @@ import torch.nn as nn
 from .storage import HIMRolloutStorage
 
 
+_two_stream_memo = {}
+
+
+def _two_streams_allowed(critic, rows):
+    """May the critic chain of the update run on a side stream, concurrently with the actor / estimator chain?  (LSIM_UPDATE_STREAMS = 0 / 1
+    forces it off / on.)  Two library GEMMs in flight at once are only safe when neither is a kernel whose workgroups wait for each other
+    (hipBLASLt's default heuristics pick such stream-K style kernels for some of these shapes: with TunableOp off, two concurrent GEMM streams
+    hung the device at N = 4096, round 3).  So the automatic answer is yes only when TunableOp is active in look-up mode AND every GEMM shape
+    of the critic chain at this minibatch size has an explicit (non-"Default") solution in the table -- which is the case for the shipped
+    gfx950 table at the BASELINE minibatch of 102 400 rows, the configuration the overlap was measured on (-1.6 % update time)."""
+    mode = os.environ.get("LSIM_UPDATE_STREAMS", "auto")
+    if mode in ("0", "1"):
+        return mode == "1"
+    if os.environ.get("PYTORCH_TUNABLEOP_ENABLED") != "1" or os.environ.get("PYTORCH_TUNABLEOP_TUNING", "1") != "0":
+        return False
+    dims = tuple((m.in_features, m.out_features) for m in critic if isinstance(m, nn.Linear))
+    key = (rows, dims, os.environ.get("PYTORCH_TUNABLEOP_FILENAME"))
+    if key not in _two_stream_memo:
+        ok = False
+        try:
+            base = os.environ.get("PYTORCH_TUNABLEOP_FILENAME", "")
+            paths = [base] + [base.replace(".csv", f"{d}.csv") for d in range(8)]
+            table = {}
+            for path in paths:
+                if path and os.path.exists(path):
+                    for line in open(path):
+                        f = line.strip().split(",")
+                        if len(f) >= 3 and not f[0].startswith("Validator"):
+                            table[f[1].split("_ld_")[0]] = f[2]
+            need = []
+            for i, (k, n) in enumerate(dims):
+                need.append(f"tn_{n}_{rows}_{k}")                      # forward  y = x W^T (+ bias)
+                if i > 0:
+                    need.append(f"nn_{k}_{rows}_{n}")                  # input gradient  g W
+            ok = bool(table) and all(table.get(s, "Default") != "Default" for s in need if not s.startswith("tn_1_"))
+        except Exception:
+            ok = False
+        _two_stream_memo[key] = ok
+    return _two_stream_memo[key]
+
+
 class DistCtx:
     """Thin helper around torch.distributed for gradient / scalar averaging (world_size 1 => no-ops)."""
 
@@ -303,7 +344,7 @@ class HIMPPO:
         last_est = last_swap = None
         for (obs, critic_obs, actions, next_critic_obs, target_values, advantages, returns, old_logp, old_mu, old_sigma) in \
                 self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs):
-            two_streams = obs.is_cuda and self._lr_t is not None and os.environ.get("LSIM_UPDATE_STREAMS", "1") != "0"
+            two_streams = obs.is_cuda and self._lr_t is not None and _two_streams_allowed(ac.critic, obs.shape[0])
             if two_streams:
                 # The critic chain (forward here, backward inside loss.backward(): autograd runs a node on the stream of its forward) goes to a
                 # side stream; encoder + actor + estimator stay on the main one.  The two halves carry about the same matrix work (858 k vs
