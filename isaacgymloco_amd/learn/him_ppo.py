@@ -23,7 +23,7 @@ from .storage import HIMRolloutStorage
 _two_stream_memo = {}
 
 
-def _two_streams_allowed(critic, rows):
+def _two_streams_allowed(critic, rows, multi_rank=False):
     """May the critic chain of the update run on a side stream, concurrently with the actor / estimator chain?  (LSIM_UPDATE_STREAMS = 0 / 1
     forces it off / on.)  Two library GEMMs in flight at once are only safe when neither is a kernel whose workgroups wait for each other
     (hipBLASLt's default heuristics pick such stream-K style kernels for some of these shapes: with TunableOp off, two concurrent GEMM streams
@@ -33,6 +33,12 @@ def _two_streams_allowed(critic, rows):
     mode = os.environ.get("LSIM_UPDATE_STREAMS", "auto")
     if mode in ("0", "1"):
         return mode == "1"
+    if multi_rank:
+        # Not with more than one rank: two rank processes sharing one GPU (LSIM_DEBUG_SINGLE_DEVICE, gloo) hang when the side stream and the
+        # asynchronous gradient buckets are both in play (two such processes WITHOUT collectives run fine side by side); the combination
+        # could not be run over RCCL between GPUs in the build environment, so it stays off there.  (A 1-rank RCCL group with every
+        # collective issued runs it: tests/test_bench_cli.py.)
+        return False
     if os.environ.get("PYTORCH_TUNABLEOP_ENABLED") != "1" or os.environ.get("PYTORCH_TUNABLEOP_TUNING", "1") != "0":
         return False
     dims = tuple((m.in_features, m.out_features) for m in critic if isinstance(m, nn.Linear))
@@ -344,7 +350,8 @@ class HIMPPO:
         last_est = last_swap = None
         for (obs, critic_obs, actions, next_critic_obs, target_values, advantages, returns, old_logp, old_mu, old_sigma) in \
                 self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs):
-            two_streams = obs.is_cuda and self._lr_t is not None and _two_streams_allowed(ac.critic, obs.shape[0])
+            multi_rank = self.dist_ctx is not None and self.dist_ctx.enabled and self.dist_ctx.world > 1
+            two_streams = obs.is_cuda and self._lr_t is not None and _two_streams_allowed(ac.critic, obs.shape[0], multi_rank)
             if two_streams:
                 # The critic chain (forward here, backward inside loss.backward(): autograd runs a node on the stream of its forward) goes to a
                 # side stream; encoder + actor + estimator stay on the main one.  The two halves carry about the same matrix work (858 k vs

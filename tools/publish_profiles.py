@@ -1,4 +1,4 @@
-"""Copy the judged summaries of one tools/gpu_round2.sh run (gpurun_out/<tag>/) into profiles/ under round-prefixed names.
+"""Copy the judged summaries of one tools/gpu_round3.sh (or gpu_round2.sh) run (gpurun_out/<tag>/) into profiles/ under round-prefixed names.
 usage: python tools/publish_profiles.py r02a r02"""
 import csv
 import os
@@ -12,7 +12,8 @@ for src, dst in (("bench_default", "bench_default_train"), ("bench_driver_args",
                  ("bench_aliengo_stairs", "bench_aliengo_stairs"), ("bench_aliengo_amp", "bench_aliengo_amp"), ("bench_go1", "bench_go1"),
                  ("bench_env_N262144", "bench_env_only_N262144"), ("bench_env_N64", "bench_env_only_N64"),
                  ("bench_env_zero_actions", "bench_env_only_zero_actions"), ("bench_2ranks_debug", "bench_2ranks_one_gpu_debug"),
-                 ("bench_2ranks_mixed_debug", "bench_2ranks_mixed_robots_one_gpu_debug"), ("valu_peak", "valu_peak")):
+                 ("bench_2ranks_mixed_debug", "bench_2ranks_mixed_robots_one_gpu_debug"), ("valu_peak", "valu_peak"),
+                 ("bench_rccl_1rank", "bench_rccl_1rank_forced_collectives"), ("delassus_mfma", "delassus_mfma")):
     f = os.path.join(O, src + ".json")
     if os.path.exists(f) and open(f).read().lstrip().startswith("{"):
         shutil.copy(f, os.path.join(P, f"{rnd}_{dst}.json"))
