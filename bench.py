@@ -29,8 +29,9 @@ sys.path.insert(0, ROOT)
 ALGO_BYTES_PER_ENV_STEP = 6900.0   # 3.07 KB read + 3.79 KB written per env-step (fused design)
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s spec
 N_SIMD = 1024                      # 256 CUs x 4 SIMD-32
-VALU_CYCLES_PER_WAVE_INST = 2.0    # MI355X_MICROARCH.md "Wave scheduling": a wave64 VALU instruction issues over 2 cycles on a SIMD-32
-                                   # (tools/micro/valu_peak.hip measures it: profiles/r02_valu_peak.json)
+VALU_CYCLES_PER_WAVE_INST = 2.0    # MI355X_MICROARCH.md "Wave scheduling": a wave64 VALU instruction issues over 2 cycles on a SIMD-32: the floor.
+                                   # tools/micro/valu_peak.hip measures 2.25-2.5 sustained (profiles/r03_valu_peak.json, wall-rate derived),
+                                   # so frac priced at 2.0 is conservative
 MAX_CLOCK_HZ = 2.4e9
 
 
