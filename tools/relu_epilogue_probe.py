@@ -16,7 +16,7 @@ for k, n in ((60, 1024), (1024, 512)):
         return torch._addmm_activation(lin.bias, x, lin.weight.t(), use_gelu=False)
     torch.testing.assert_close(plain(), fused(), rtol=1e-5, atol=1e-5)
     for name, fn in (("relu(linear)", plain), ("_addmm_activation", fused)):
-        for bwd in (False, True):
+        for bwd in ((False, True) if name.startswith("relu") else (False,)):     # (_addmm_activation has no autograd derivative: a custom Function would wrap it)
             for _ in range(3):
                 y = fn()
                 if bwd:
