@@ -136,7 +136,7 @@ def main():
     if os.environ.get("LSIM_TUNE") == "1" or os.path.exists(tuned):
         import shutil, tempfile
         tdir = tempfile.mkdtemp(prefix="lsim_tunableop_")
-        if os.path.exists(tuned):
+        if os.path.exists(tuned) and os.environ.get("LSIM_TUNE_FRESH") != "1":          # LSIM_TUNE_FRESH=1: tune every shape again from scratch
             shutil.copy(tuned, os.path.join(tdir, f"tuned{local_rank}.csv"))   # TunableOp appends the device ordinal to the name
         os.environ.setdefault("PYTORCH_TUNABLEOP_ENABLED", "1")
         os.environ.setdefault("PYTORCH_TUNABLEOP_FILENAME", os.path.join(tdir, "tuned.csv"))

@@ -5,6 +5,8 @@ import ctypes
 import os
 import subprocess
 
+import pytest
+
 from helpers import ROOT, abi
 
 
@@ -26,3 +28,44 @@ def test_build_rebuilds_when_the_artefact_is_missing(tmp_path, monkeypatch):
     from isaacgymloco_amd.csrc import build as B
     monkeypatch.setattr(B, "LIB", os.path.join(tmp_path, "absent.so"))
     assert B.stale()
+
+
+_DIGEST_SNIPPET = r"""
+import hashlib, sys, numpy as np, torch
+sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + "/tests")
+from helpers import C
+from hip_backend import HipBackend
+from isaacgymloco_amd.envs import terrain as T
+cfg = C.aliengo_cfg(); cfg.terrain.terrain_proportions = [0.5, 0.0, 0.0, 0.0, 0.25, 0.25]
+be = HipBackend(cfg, 64, T.Terrain(cfg.terrain, 64, seed=1), seed=7)
+be.reset_all()
+rs = np.random.RandomState(0)
+h = hashlib.sha256()
+for t in range(4):
+    be.step(rs.normal(0, 1, (64, 12)).astype(np.float32))
+    for k in ("obs", "priv_obs", "rew", "reset", "root_states", "dof_state", "contact_forces"):
+        h.update(be.get(k).tobytes())
+print("DIGEST", h.hexdigest())
+"""
+
+
+@pytest.mark.gpu
+def test_library_compiled_on_this_machine_reproduces_the_shipped_one(tmp_path):
+    """the GPU tests load a liblsim.so that travelled with the tree.  Here the library is compiled FROM SOURCE on the GPU box
+    (both translation units, the product's flags), loaded through LSIM_LIB in a fresh process, and four full-physics steps at N = 64 must
+    reproduce the shipped library's outputs bit for bit (same compiler, same flags: same code)."""
+    import subprocess
+    import sys
+    from isaacgymloco_amd.csrc import build as B
+    fresh = os.path.join(tmp_path, "liblsim_fresh.so")
+    B.build_variant(fresh, workdir=str(tmp_path))
+    code = _DIGEST_SNIPPET.format(root=ROOT)
+
+    def digest(env_extra):
+        env = dict(os.environ)
+        env.pop("LSIM_LIB", None)
+        env.update(env_extra)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return [l for l in r.stdout.splitlines() if l.startswith("DIGEST")][-1]
+    assert digest({"LSIM_LIB": fresh}) == digest({})
