@@ -347,3 +347,29 @@ def test_feet_heights_surface_method_matches_a_numpy_restatement():
     sub = env._get_feet_heights(torch.tensor([3, 7], device="cuda:0")).cpu().numpy()
     assert np.allclose(sub, want[[3, 7]], atol=1e-5)
     env.close()
+
+
+def test_hip_leg_kinematics_reproduce_the_reference_mocap_toe_positions():
+    """P1 on the device: the joint angles of the reference's Aliengo mocap frames (isaacgymloco_amd/data/mocap_aliengo.npz: the reference's
+    files re-packed unchanged) through kernel A's own kinematics -- one sub-step of 1 us, robots 5 m above the ground, so that the published
+    rigid_body_states are the forward kinematics of the injected joint angles to < 1e-6 -- against the toe positions in the base frame that
+    the reference's retargeting tool stored beside them (columns 19:31).  658 frames x 4 feet; CPU twin: tests/test_model.py."""
+    import os
+    from hip_backend import HipBackend
+    data = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "isaacgymloco_amd", "data", "mocap_aliengo.npz"), allow_pickle=True)
+    frames = np.concatenate([data[f"frames_{c}"] for c in range(int(data["num_clips"]))])
+    N = len(frames)
+    cfg = quiet_cfg("aliengo")
+    cfg.sim.dt = 1e-6
+    cfg.control.decimation = 1
+    be = HipBackend(cfg, N, T.Terrain(cfg.terrain, N, seed=1), seed=1)
+    be.reset_all()
+    root = np.zeros((N, 13), np.float32); root[:, 2] = 5.0; root[:, 6] = 1.0
+    dof = np.zeros((N, 12, 2), np.float32); dof[:, :, 0] = frames[:, 7:19]
+    be.put("root_states", root); be.put("dof_state", dof)
+    be.step(np.zeros((N, 12), np.float32), flags=abi.STEP_NO_RESET)
+    body = be.get("rigid_body_states")
+    feet = [4, 8, 12, 16]
+    got = body[:, feet, 0:3] - be.get("root_states")[:, None, 0:3]
+    want = frames[:, 19:31].reshape(N, 4, 3)
+    assert float(np.abs(got - want).max()) < 5e-5, float(np.abs(got - want).max())      # fp32 chain of three rotations at |p| ~ 0.4 m + 5 m offset

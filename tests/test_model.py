@@ -74,3 +74,38 @@ def test_urdf_loader_reproduces_tables():
         a, _, _ = urdf.build_model(URDF.replace("aliengo", robot))
         b, _, _ = urdf.build_model_from_table(robot)
         assert bytes(a) == bytes(b)
+
+
+def test_leg_kinematics_reproduce_the_reference_mocap_toe_positions():
+    """P1 pinned to reference DATA: every frame of the reference's Aliengo mocap clips (datasets/mocap_motions_aliengo/*.txt, re-packed
+    unchanged in isaacgymloco_amd/data/mocap_aliengo.npz: the 7 clips AGA:34-36 selects) stores the 12 joint angles AND the toe positions in the
+    base frame that the reference's retargeting tool computed from ITS kinematic model of the URDF (columns 7:19 and 19:31 of the 61,
+    motion_loader.py:26-48).  The forward kinematics of the build -- the model table (joint origins, axes, foot offsets) through the oracle's
+    body-state refresh, which the HIP kernels are compared with elsewhere -- must land on them: 658 frames x 4 feet, measured 7e-6 m.
+    (Leg slots of the files are FL, FR, RL, RR by the sign of the toes' y, i.e. already Isaac Gym's order.)"""
+    import ctypes
+    from helpers import make_oracle, quiet_cfg
+    data = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "isaacgymloco_amd", "data", "mocap_aliengo.npz"), allow_pickle=True)
+    frames = np.concatenate([data[f"frames_{c}"] for c in range(int(data["num_clips"]))])
+    assert frames.shape[1] == 61 and len(frames) > 600
+    N = 64
+    orc, lc, model, ter = make_oracle(quiet_cfg("aliengo"), N, seed=1)
+    L = orc._L
+    L.orc_refresh_body_states.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    feet = list(model.feet_bodies)
+    worst = 0.0
+    for i0 in range(0, len(frames), N):
+        chunk = frames[i0:i0 + N]
+        n = len(chunk)
+        root = np.zeros((N, 13), np.float32); root[:, 6] = 1.0            # base frame = world frame
+        orc.buf["root_states"][...] = root
+        dof = np.zeros((N, 12, 2), np.float32); dof[:n, :, 0] = chunk[:, 7:19]
+        orc.buf["dof_state"][...] = dof
+        for e in range(n):
+            L.orc_refresh_body_states(orc._h, e)
+        got = orc.buf["rigid_body_states"][:n][:, feet, 0:3]
+        want = chunk[:, 19:31].reshape(n, 4, 3)
+        assert np.all(np.sign(want[:, [0, 2], 1]) > 0) and np.all(np.sign(want[:, [1, 3], 1]) < 0)     # slots 0 / 2 are left legs
+        worst = max(worst, float(np.abs(got - want).max()))
+    orc.close()
+    assert worst < 3e-5, worst
