@@ -23,9 +23,10 @@ from isaacgymloco_amd.learn.runner import HIMOnPolicyRunner
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "gpurun_out", "train_curve.json")
 task = sys.argv[3] if len(sys.argv) > 3 else "aliengo"
+seed = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 cfg = C.TASKS[task][0]()
-env = LeggedRobot(cfg, sim_device="cuda:0", seed=1)
-torch.manual_seed(1)
+env = LeggedRobot(cfg, sim_device="cuda:0", seed=seed)
+torch.manual_seed(seed)
 runner = HIMOnPolicyRunner(env, train_cfg_dict(task), log_dir=None, device="cuda:0")
 runner.enable_graphs()
 runner.alg.actor_critic.train()
