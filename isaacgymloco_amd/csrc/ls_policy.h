@@ -16,6 +16,17 @@
 #define LS_POL_MAX_IN 272
 
 extern __shared__ float ls_pol_lds[];
+// The weight / bias pointers arrive inside a struct passed by value, so the compiler cannot tell their address space and emits FLAT loads --
+// which count in lgkmcnt as well as vmcnt: the `s_waitcnt lgkmcnt(0)` in front of every chunk's MFMAs (for the LDS operand reads) then also
+// waits for the weight vectors just issued for two chunks ahead, i.e. every chunk pays a full L2 round trip (MFMA pipe 42 % busy, round 3
+// PMC).  Explicit global address space = global_load, vmcnt only.
+#define LS_POL_GLOBAL __attribute__((address_space(1)))
+typedef const LS_POL_GLOBAL float* ls_pol_gptr;
+typedef float ls_pol_f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ls_pol_ld4(ls_pol_gptr p) {
+    const ls_pol_f4v v = *(const LS_POL_GLOBAL ls_pol_f4v*)p;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
 
 __device__ __forceinline__ float ls_elu(float x) { return x > 0.0f ? x : expm1f(x); }
 
@@ -32,21 +43,21 @@ __device__ __noinline__ void ls_pol_layer(const float* __restrict__ W, const flo
         for (int h = 0; h < RH; ++h) acc[t][h] = (ls_v4f){0.0f, 0.0f, 0.0f, 0.0f};
     if (valid > 0) {
         const float* xrow = ls_pol_lds + x_off + i * x_stride + 4 * q;            // B operand: row i (+ 16 h) of the block, k group q
-        const float* wrow = W + (size_t)(tile0 * 16 + i) * k_pad + 4 * q;         // A operand: output tile0*16 + i, k group q
+        ls_pol_gptr wrow = (ls_pol_gptr)W + (size_t)(tile0 * 16 + i) * k_pad + 4 * q;   // A operand: output tile0*16 + i, k group q
         // weight vectors of the current k chunk and of the next two (register triple buffer: the loads issued in an iteration are
         // consumed two iterations later; a block keeps only a few waves per SIMD, so this is what hides the L2 latency)
         float4 w0[NTW], w1[NTW], w2[NTW];
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
             const bool ok = t < valid;
-            w0[t] = ok ? *(const float4*)(wrow + (size_t)t * 16 * k_pad) : make_float4(0, 0, 0, 0);
-            w1[t] = (ok && 16 < k_pad) ? *(const float4*)(wrow + (size_t)t * 16 * k_pad + 16) : make_float4(0, 0, 0, 0);
+            w0[t] = ok ? ls_pol_ld4(wrow + (size_t)t * 16 * k_pad) : make_float4(0, 0, 0, 0);
+            w1[t] = (ok && 16 < k_pad) ? ls_pol_ld4(wrow + (size_t)t * 16 * k_pad + 16) : make_float4(0, 0, 0, 0);
         }
         for (int kc = 0; kc < k_pad; kc += 16) {
             if (kc + 32 < k_pad) {
 #pragma unroll
                 for (int t = 0; t < NTW; ++t)
-                    if (t < valid) w2[t] = *(const float4*)(wrow + (size_t)t * 16 * k_pad + kc + 32);
+                    if (t < valid) w2[t] = ls_pol_ld4(wrow + (size_t)t * 16 * k_pad + kc + 32);
             }
             float4 x[RH];
 #pragma unroll
@@ -71,7 +82,7 @@ __device__ __noinline__ void ls_pol_layer(const float* __restrict__ W, const flo
     for (int t = 0; t < NTW; ++t) {
         if (t < valid) {
             const int n = (tile0 + t) * 16 + 4 * q;                               // D[n .. n+3][row i + 16 h]
-            const float4 b = *(const float4*)(bias + n);
+            const float4 b = ls_pol_ld4((ls_pol_gptr)bias + n);
 #pragma unroll
             for (int h = 0; h < RH; ++h) {
                 float4 y = make_float4(acc[t][h][0] + b.x, acc[t][h][1] + b.y, acc[t][h][2] + b.z, acc[t][h][3] + b.w);
