@@ -402,6 +402,15 @@ int lsim_get_buffer(lsim_handle h, int buffer_id, void** dev_ptr, int64_t shape[
  * zero-action lsim_step to complete reset() (BT:114). */
 int lsim_reset_all(lsim_handle h, void* hip_stream);
 
+/* LeggedRobot.reset_idx(env_ids) (LR:290-361) called from outside a step (a play / evaluation script resetting some robots by hand):
+ * terrain curriculum per env, command curriculum over the reset set, dof / root / command / domain-randomisation redraws, buffer
+ * clears, extras["episode"] sums into the stats row, episode_length_buf = 0.  reset_mask_dev: device uint8 [N], nonzero = reset this env
+ * (the boolean form of env_ids; it is read by the kernels of this call only).  An all-zero mask is the reference's early return
+ * (LR:298): only the stats rows swap, with a reset count of 0.  As after lsim_reset_all, observations are not recomputed (the reference
+ * does not either): they are those of the next lsim_step.  Random draws are keyed by (env, common_step_counter), like the reset tail of
+ * a step: resetting the same env twice between two steps redraws the same state.  Asynchronous on hip_stream. */
+int lsim_reset_envs(lsim_handle h, const uint8_t* reset_mask_dev, void* hip_stream);
+
 /* LeggedRobot.step(actions) (LR:122-176): replaces set_dof_actuation_force_tensor/simulate/fetch_results/
  * refresh_* x4 (LR:146-152), refresh_* (LR:187-190), set_*_indexed (LR:714, LR:818), set_actor_root_state_tensor
  * (LR:828), apply_rigid_body_force_tensors (LR:844) and the whole post_physics_step (LR:178-247).

@@ -230,6 +230,18 @@ extern "C" int LS_API(reset_all)(lsim_sim* s, void* stream) {
     return LSIM_OK;
 }
 
+extern "C" int LS_API(reset_envs)(lsim_sim* s, const uint8_t* mask_dev, void* stream) {
+    if (!s || !mask_dev) return LSIM_E_INVALID;
+    LsStepArgs a;
+    memset(&a, 0, sizeof(a));
+    a.actions = nullptr; a.step_counter = s->step_counter; a.flags = 0; a.init_done = s->init_done;
+    a.row_in = s->stats_row; a.row_out = s->stats_row ^ 1; a.reset_all = 2; a.reset_mask = mask_dev;
+    s->stats_row = a.row_out;
+    if (lsbk_launch_reduce(s, a, stream) != 0) LS_FAIL(s, LSIM_E_HIP, "reduction kernel launch failed");
+    if (lsbk_launch_b(s, a, stream) != 0) LS_FAIL(s, LSIM_E_HIP, "reset kernel launch failed");
+    return LSIM_OK;
+}
+
 extern "C" int LS_API(get_step_counter)(lsim_sim* s, int64_t* out) { if (!s || !out) return LSIM_E_INVALID; *out = s->step_counter; return LSIM_OK; }
 extern "C" int LS_API(set_step_counter)(lsim_sim* s, int64_t v) { if (!s) return LSIM_E_INVALID; s->step_counter = v; return LSIM_OK; }
 extern "C" int LS_API(get_stats_row)(lsim_sim* s, int* row) { if (!s || !row) return LSIM_E_INVALID; *row = s->stats_row; return LSIM_OK; }

@@ -337,7 +337,7 @@ LS_FN void ph_load_b(const LsCtx& cx, WaveShared& sh, int lane, int env, const L
     const float v_track = ls_from_fix(LS_G(const long long, ls_fix_row(cx, a.row_out))[LSIM_STATS_FIX_TRACK]);
     float r[8];
     for (int k = 0; k < 8; ++k) r[k] = acc_in[LSIM_STATS_CMD_RANGES + k];
-    const int v_reset = LSB(cx, LSIM_BUF_RESET, uint8_t)[env];
+    const int v_reset = a.reset_all == 2 ? (LS_G(const uint8_t, a.reset_mask)[env] != 0) : LSB(cx, LSIM_BUF_RESET, uint8_t)[env];
     const int v_tout = LSB(cx, LSIM_BUF_TIME_OUT, uint8_t)[env];
     const int v_eplen = (int)LSB(cx, LSIM_BUF_EPISODE_LENGTH, int64_t)[env];
     // ---- LDS writes
@@ -367,10 +367,10 @@ LS_FN void ph_load_b(const LsCtx& cx, WaveShared& sh, int lane, int env, const L
         sh.reset = v_reset;
         sh.pre_lc = (unsigned int)v_tout;
         sh.eplen = v_eplen;
-        float nreset = a.reset_all ? (float)c.num_envs : v_nreset;
+        float nreset = a.reset_all == 1 ? (float)c.num_envs : v_nreset;     // reset_all == 2: counted by lsim_k_track_sum
         const bool no_reset = (a.flags & LSIM_STEP_NO_RESET) != 0;
-        sh.do_reset = a.reset_all || (v_reset && !no_reset);
-        sh.any_reset = a.reset_all || (!no_reset && nreset > 0.5f);
+        sh.do_reset = a.reset_all == 1 || (v_reset && !no_reset);
+        sh.any_reset = a.reset_all == 1 || (!no_reset && nreset > 0.5f);
         sh.flags64[1] = (unsigned int)nreset;          // number of envs that reset this step (the ticket of the last one is this minus 1)
         // command curriculum (LR:307-308, LR:868-880): every wave derives the same new ranges from the reduced sums
         if (sh.any_reset && c.commands_curriculum && (a.step_counter % c.max_episode_length == 0)) {
@@ -391,7 +391,7 @@ LS_FN void ph_b_housekeeping(const LsCtx& cx, WaveShared& sh, int lane, int env,
     if (env != 0) return;
     LS_GLOBAL float* out = LS_G(float, cx.accum) + a.row_out * LSIM_STATS_SIZE;
     if (lane < 8) out[LSIM_STATS_CMD_RANGES + lane] = sh.ranges[lane];
-    if (a.reset_all && lane == 8) out[LSIM_STATS_RESET_COUNT] = (float)cx.cfg.num_envs;
+    if (a.reset_all == 1 && lane == 8) out[LSIM_STATS_RESET_COUNT] = (float)cx.cfg.num_envs;
     LS_GLOBAL float* nxt = LS_G(float, cx.accum) + a.row_in * LSIM_STATS_SIZE;   // the next call accumulates into the row this call read
     if (lane == 9) nxt[LSIM_STATS_RESET_COUNT] = 0.0f;
     LS_GLOBAL long long* fnxt = LS_G(long long, ls_fix_row(cx, a.row_in));
@@ -552,10 +552,10 @@ LS_FN void ph_b_store(const LsCtx& cx, WaveShared& sh, int lane, int env, const 
     if (lane == 41 && sh.any_reset && c.send_timeouts)                                                        // LR:358-359
         LSB(cx, LSIM_BUF_EXTRAS_TIME_OUTS, uint8_t)[env] = (uint8_t)sh.pre_lc;
 }
-// tail of a bare reset_idx(all) (BT:113): no observation / last_* roll
+// tail of a bare reset_idx (BT:113 on all envs, LR:290 on a subset): no observation / last_* roll
 LS_FN void ph_b_store_reset_all(const LsCtx& cx, WaveShared& sh, int lane, int env, const LsStepArgs& a) {
-    if (lane == 40) LSB(cx, LSIM_BUF_EPISODE_LENGTH, int64_t)[env] = 0;
-    if (lane == 41 && cx.cfg.send_timeouts) LSB(cx, LSIM_BUF_EXTRAS_TIME_OUTS, uint8_t)[env] = (uint8_t)sh.pre_lc;
+    if (lane == 40 && sh.do_reset) LSB(cx, LSIM_BUF_EPISODE_LENGTH, int64_t)[env] = 0;                                             // LR:361
+    if (lane == 41 && sh.any_reset && cx.cfg.send_timeouts) LSB(cx, LSIM_BUF_EXTRAS_TIME_OUTS, uint8_t)[env] = (uint8_t)sh.pre_lc;  // LR:358-359
 }
 
 LS_WAVE_FN void ls_wave_step_b(const LsCtx& cx, const LsStepArgs& a, const int env, WaveShared& sh, LS_LANES_PARAM) {

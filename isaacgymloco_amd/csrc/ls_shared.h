@@ -62,7 +62,9 @@ struct LsStepArgs {
     int32_t init_done;        // LR:853
     int32_t row_in;           // accumulator row holding the previous step's command ranges
     int32_t row_out;          // accumulator row this step writes (step_counter & 1)
-    int32_t reset_all;        // kernel B only: BaseTask.reset's reset_idx(all) (BT:113)
+    int32_t reset_all;        // kernel B only.  0: the reset tail of a step; 1: a bare reset_idx(all) (BaseTask.reset, BT:113);
+                              // 2: a bare reset_idx(env_ids) (LR:290) on the envs flagged in reset_mask
+    const uint8_t* reset_mask; // reset_all == 2: u8 [num_envs] on the device, nonzero = reset this env
 };
 
 // body model entries staged in LDS once per kernel

@@ -47,21 +47,32 @@ __global__ __launch_bounds__(64) void lsim_k_step_b(const LsCtx* __restrict__ ct
     ls_wave_step_b(*ctx, a, env, sh, rg, (int)threadIdx.x);
 }
 
-// reset_idx(all): sum of episode_sums["tracking_lin_vel"] over all envs for the command curriculum (LR:875)
+// reset_idx outside a step: sum of episode_sums["tracking_lin_vel"] over the resetting envs for the command curriculum (LR:875) and, for a
+// subset (reset_all == 2), their number
 __global__ __launch_bounds__(256) void lsim_k_track_sum(const LsCtx* __restrict__ ctx, LsStepArgs a) {
     __shared__ float part[256];
+    __shared__ int count[256];
     const LsCtx& cx = *ctx;
     float acc = 0.0f;
-    for (int env = (int)(blockIdx.x * blockDim.x + threadIdx.x); env < cx.cfg.num_envs; env += (int)(gridDim.x * blockDim.x))
+    int n = 0;
+    for (int env = (int)(blockIdx.x * blockDim.x + threadIdx.x); env < cx.cfg.num_envs; env += (int)(gridDim.x * blockDim.x)) {
+        if (a.reset_all == 2 && !LS_G(const uint8_t, a.reset_mask)[env]) continue;
         acc += LSB(cx, LSIM_BUF_EPISODE_SUMS, float)[env * LSIM_NUM_REWARD_TERMS + LSIM_R_TRACKING_LIN_VEL];
+        n += 1;
+    }
     part[threadIdx.x] = acc;
+    count[threadIdx.x] = n;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+        if ((int)threadIdx.x < s) { part[threadIdx.x] += part[threadIdx.x + s]; count[threadIdx.x] += count[threadIdx.x + s]; }
         __syncthreads();
     }
     // block partials are formed in a fixed order; their fixed-point sum does not depend on the order the blocks arrive in
-    if (threadIdx.x == 0) LS_ATOMIC_ADD_I64(ls_fix_row(cx, a.row_out) + LSIM_STATS_FIX_TRACK, ls_to_fix(part[0]));
+    if (threadIdx.x == 0) {
+        LS_ATOMIC_ADD_I64(ls_fix_row(cx, a.row_out) + LSIM_STATS_FIX_TRACK, ls_to_fix(part[0]));
+        if (a.reset_all == 2 && count[0] > 0)     // integer-valued: exact in any order
+            LS_ATOMIC_ADD(LS_G(float, cx.accum) + a.row_out * LSIM_STATS_SIZE + LSIM_STATS_RESET_COUNT, (float)count[0]);
+    }
 }
 
 static int ls_grid(const lsim_sim* s) { return 8 * ((s->cfg.num_envs + 7) / 8); }

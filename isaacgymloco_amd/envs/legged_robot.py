@@ -228,12 +228,20 @@ class LeggedRobot:
             hook()
 
     def reset_idx(self, env_ids):
-        """LR:288 with env_ids = all envs (BaseTask.reset, BT:113).  Partial id sets raise: in the reference only step() itself calls
-        reset_idx with a subset (LR:229), and that call lives inside kernel B here."""
-        if len(env_ids) != self.num_envs:
-            raise NotImplementedError("host-driven partial resets are not part of the path; resets happen inside step()")
+        """LR:290-361 called from outside a step: BaseTask.reset's reset_idx(all envs) (BT:113), or a subset chosen by the caller (a play
+        script resetting some robots by hand).  The reset_idx that step() itself makes (LR:229) lives inside kernel B.  Like the
+        reference: an empty id list returns at once (LR:298); observations are not recomputed here."""
+        env_ids = torch.as_tensor(env_ids, device=self._arena.device, dtype=torch.long).flatten()
+        if env_ids.numel() == 0:
+            return
         self._external_call()
-        lib.check(self._L.lsim_reset_all(self._h, self._stream()), self._h, "lsim_reset_all")
+        mask = torch.zeros(self.num_envs, dtype=torch.uint8, device=self._arena.device)
+        mask[env_ids] = 1          # an id out of range raises here, as the reference's indexing would
+        if env_ids.numel() == self.num_envs and bool(mask.all()):
+            lib.check(self._L.lsim_reset_all(self._h, self._stream()), self._h, "lsim_reset_all")
+        else:
+            lib.check(self._L.lsim_reset_envs(self._h, mask.data_ptr(), self._stream()), self._h, "lsim_reset_envs")
+            self._reset_mask_ref = mask   # keep alive until the kernels ran
         self._refresh_extras(force_valid=True)
 
     def reset(self):

@@ -31,6 +31,7 @@ def load():
     L.lsim_create.argtypes = [ctypes.POINTER(abi.LsimConfig), ctypes.POINTER(abi.LsimRobotModel), vp, vp, vp, i32, ctypes.POINTER(vp)]
     L.lsim_get_buffer.argtypes = [vp, i32, ctypes.POINTER(vp), ctypes.POINTER(i64), ctypes.POINTER(i32), ctypes.POINTER(i32)]
     L.lsim_reset_all.argtypes = [vp, vp]
+    L.lsim_reset_envs.argtypes = [vp, vp, vp]
     L.lsim_step.argtypes = [vp, vp, vp]
     L.lsim_step_ex.argtypes = [vp, vp, u32, vp]
     L.lsim_get_step_counter.argtypes = [vp, ctypes.POINTER(i64)]

@@ -829,6 +829,19 @@ int orc_reset_all(orc_sim* s) { /* BT:113: reset_idx(arange(N)) */
     return LSIM_OK;
 }
 
+int orc_reset_envs(orc_sim* s, const uint8_t* mask) { /* LR:290: reset_idx(env_ids) called from outside a step; mask[e] != 0 <=> e in env_ids */
+    const int N = s->cfg.num_envs;
+    int n = 0;
+    for (int e = 0; e < N; ++e) n += mask[e] != 0;
+    s->stats_row ^= 1;
+    float* st = stats_row(s);
+    st[LSIM_STATS_RESET_COUNT] = 0.0f;
+    for (int k = 0; k < LSIM_NUM_REWARD_TERMS; ++k) st[LSIM_STATS_EPISODE_SUMS + k] = 0.0f;
+    refresh_stats_ranges(s);
+    reset_idx(s, mask, n, (uint32_t)s->step_counter);
+    return LSIM_OK;
+}
+
 int orc_step_ex(orc_sim* s, const float* actions, uint32_t flags) {
     const lsim_config* c = &s->cfg;
     const int N = c->num_envs;

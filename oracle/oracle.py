@@ -91,6 +91,11 @@ class OracleSim:
     def reset_all(self):
         assert self._L.orc_reset_all(self._h) == 0
 
+    def reset_envs(self, mask):
+        m = np.ascontiguousarray(mask, dtype=np.uint8)
+        assert m.shape == (self.cfg.num_envs,)
+        assert self._L.orc_reset_envs(self._h, m.ctypes.data_as(ctypes.c_void_p)) == 0
+
     @property
     def step_counter(self):
         v = ctypes.c_int64()

@@ -42,11 +42,17 @@ static int lsbk_launch_b(lsim_sim* s, const LsStepArgs& a, void*) {
     }
     return 0;
 }
-static int lsbk_launch_reduce(lsim_sim* s, const LsStepArgs& a, void*) {   // reset_all: track sum over all envs (LR:875)
+static int lsbk_launch_reduce(lsim_sim* s, const LsStepArgs& a, void*) {   // bare reset_idx: track sum (and count) over the resetting envs (LR:875)
     const LsCtx& cx = *s->dev_ctx;
     float acc = 0.0f;
-    for (int env = 0; env < s->cfg.num_envs; ++env) acc += LSB(cx, LSIM_BUF_EPISODE_SUMS, float)[env * LSIM_NUM_REWARD_TERMS + LSIM_R_TRACKING_LIN_VEL];
+    int n = 0;
+    for (int env = 0; env < s->cfg.num_envs; ++env) {
+        if (a.reset_all == 2 && !a.reset_mask[env]) continue;
+        acc += LSB(cx, LSIM_BUF_EPISODE_SUMS, float)[env * LSIM_NUM_REWARD_TERMS + LSIM_R_TRACKING_LIN_VEL];
+        n += 1;
+    }
     ls_fix_row(cx, a.row_out)[LSIM_STATS_FIX_TRACK] = ls_to_fix(acc);
+    if (a.reset_all == 2) cx.accum[a.row_out * LSIM_STATS_SIZE + LSIM_STATS_RESET_COUNT] = (float)n;
     return 0;
 }
 extern "C" int emu_sizeof_shared(void) { return (int)sizeof(WaveShared); }

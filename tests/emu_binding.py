@@ -59,6 +59,10 @@ class EmuSim:
     def reset_all(self):
         assert lib().emu_reset_all(self._h, None) == 0
 
+    def reset_envs(self, mask):
+        m = np.ascontiguousarray(mask, dtype=np.uint8)
+        assert lib().emu_reset_envs(self._h, m.ctypes.data_as(ctypes.c_void_p), None) == 0
+
     @property
     def stats_row(self):
         v = ctypes.c_int()

@@ -28,6 +28,13 @@ class HipBackend:
         self.env.reset_idx(torch.arange(self.env.num_envs))
         torch.cuda.synchronize()
 
+    def reset_envs(self, mask):
+        """the C entry point directly (LeggedRobot.reset_idx short-cuts an empty id list on the host)"""
+        m = torch.from_numpy(np.ascontiguousarray(mask, dtype=np.uint8)).to("cuda:0")
+        from isaacgymloco_amd import lib
+        lib.check(self.env._L.lsim_reset_envs(self.env._h, m.data_ptr(), None), self.env._h, "lsim_reset_envs")
+        torch.cuda.synchronize()
+
     @property
     def step_counter(self):
         import ctypes
