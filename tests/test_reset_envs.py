@@ -10,7 +10,7 @@ SYNC = ("root_states", "dof_state", "commands", "last_actions", "last_last_actio
         "episode_length", "terrain_levels", "env_origins", "kp_factors", "kd_factors", "motor_strength_factors", "friction", "restitution",
         "feet_air_time", "last_contacts", "episode_sums", "obs", "time_out", "reset", "measured_heights", "extras_time_outs")
 # what reset_idx writes; draws are pure functions of (seed, env, step, tag) and every value is a few fp32 operations: exact for the
-# lane-emulated sources (compiled without contraction, like the oracle), within an fp32 ulp for the HIP build (lo + u * (hi - lo) is one FMA there)
+# lane-emulated sources (compiled without contraction, like the oracle), within a few fp32 ulps for the HIP build (lo + u * (hi - lo) is one FMA there)
 EXACT = ("root_states", "dof_state", "commands", "last_actions", "last_last_actions", "last_dof_pos", "last_dof_vel", "last_torques",
          "episode_length", "terrain_levels", "env_origins", "kp_factors", "kd_factors", "motor_strength_factors", "friction", "restitution",
          "feet_air_time", "episode_sums", "reset", "extras_time_outs", "obs")
@@ -34,7 +34,7 @@ def _walk(orc, be, get, put, steps, seed):
         put(k, orc.buf[k])
 
 
-ULP = dict(rtol=3e-7, atol=3e-8)
+ULP = dict(rtol=2e-6, atol=2e-7)      # a few fp32 ulps: the yaw command goes through atan2 (LR:461-463)
 
 
 def _same(a, b, exact, msg):
