@@ -61,11 +61,17 @@ def _compare(orc, get, stats_row, mask, before, tag, exact=True):
 def _check(orc, be, get, put, stats_row, set_counter, exact=True):
     N = orc.cfg.num_envs
     c = orc.cfg
+
+    def snapshot():
+        """both sides start each case from the oracle's state, to the bit"""
+        for k in SYNC:
+            put(k, orc.buf[k])
+        return {k: orc.buf[k].copy() for k in SYNC}
     orc.reset_all(); be.reset_all()
     _walk(orc, be, get, put, 5, seed=0)
     # 1: a ragged subset, first and last env included
     mask = np.zeros(N, np.uint8); mask[[0, 3, 4, 11, N - 1]] = 1
-    before = {k: orc.buf[k].copy() for k in SYNC}
+    before = snapshot()
     orc.reset_envs(mask); be.reset_envs(mask)
     _compare(orc, get, stats_row, mask, before, "subset", exact)
     assert np.all(orc.buf["episode_length"][mask == 1] == 0) and np.all(orc.buf["episode_length"][mask == 0] == 5)
@@ -91,14 +97,14 @@ def _check(orc, be, get, put, stats_row, set_counter, exact=True):
     es[[2, 7], abi.REWARD_IDS["tracking_lin_vel"]] = 1.25 * bar
     orc.buf["episode_sums"][...] = es; put("episode_sums", es)
     mask = np.zeros(N, np.uint8); mask[[2, 7]] = 1
-    before = {k: orc.buf[k].copy() for k in SYNC}
+    before = snapshot()
     r0 = orc.buf["stats"][orc.stats_row][S["cmd_ranges"]:S["cmd_ranges"] + 8].copy()
     orc.reset_envs(mask); be.reset_envs(mask)
     _compare(orc, get, stats_row, mask, before, "curriculum", exact)
     r1 = get("stats")[stats_row()][S["cmd_ranges"]:S["cmd_ranges"] + 8]
     assert r1[1] == pytest.approx(min(r0[1] + 0.1, c.max_forward_curriculum)) and r1[1] > r0[1], (r0, r1)
     # 4: an empty id set is the reference's early return (LR:298)
-    before = {k: orc.buf[k].copy() for k in SYNC}
+    before = snapshot()
     mask = np.zeros(N, np.uint8)
     orc.reset_envs(mask); be.reset_envs(mask)
     _compare(orc, get, stats_row, mask, before, "empty", exact)
@@ -107,7 +113,7 @@ def _check(orc, be, get, put, stats_row, set_counter, exact=True):
     # 5: every env through the mask form equals reset_idx(all)
     orc.step_counter = c.max_episode_length + 1; set_counter(c.max_episode_length + 1)
     mask = np.ones(N, np.uint8)
-    before = {k: orc.buf[k].copy() for k in SYNC}
+    before = snapshot()
     orc.reset_envs(mask); be.reset_envs(mask)
     _compare(orc, get, stats_row, mask, before, "all through the mask", exact)
     snap = {k: get(k).copy() for k in EXACT}
