@@ -76,6 +76,30 @@ def test_urdf_loader_reproduces_tables():
         assert bytes(a) == bytes(b)
 
 
+def _fk_toe_error(cfg, joint_pos, toe_pos_base):
+    """largest |toe position by the build's forward kinematics - toe position stored in the reference's mocap frame| (m)"""
+    import ctypes
+    from helpers import make_oracle
+    N = 64
+    orc, lc, model, ter = make_oracle(cfg, N, seed=1)
+    L = orc._L
+    L.orc_refresh_body_states.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    feet = list(model.feet_bodies)
+    worst = 0.0
+    for i0 in range(0, len(joint_pos), N):
+        n = len(joint_pos[i0:i0 + N])
+        root = np.zeros((N, 13), np.float32); root[:, 6] = 1.0            # base frame = world frame
+        orc.buf["root_states"][...] = root
+        dof = np.zeros((N, 12, 2), np.float32); dof[:n, :, 0] = joint_pos[i0:i0 + n]
+        orc.buf["dof_state"][...] = dof
+        for e in range(n):
+            L.orc_refresh_body_states(orc._h, e)
+        got = orc.buf["rigid_body_states"][:n][:, feet, 0:3]
+        worst = max(worst, float(np.abs(got - toe_pos_base[i0:i0 + n].reshape(n, 4, 3)).max()))
+    orc.close()
+    return worst
+
+
 def test_leg_kinematics_reproduce_the_reference_mocap_toe_positions():
     """P1 pinned to reference DATA: every frame of the reference's Aliengo mocap clips (datasets/mocap_motions_aliengo/*.txt, re-packed
     unchanged in isaacgymloco_amd/data/mocap_aliengo.npz: the 7 clips AGA:34-36 selects) stores the 12 joint angles AND the toe positions in the
@@ -83,29 +107,26 @@ def test_leg_kinematics_reproduce_the_reference_mocap_toe_positions():
     motion_loader.py:26-48).  The forward kinematics of the build -- the model table (joint origins, axes, foot offsets) through the oracle's
     body-state refresh, which the HIP kernels are compared with elsewhere -- must land on them: 658 frames x 4 feet, measured 7e-6 m.
     (Leg slots of the files are FL, FR, RL, RR by the sign of the toes' y, i.e. already Isaac Gym's order.)"""
-    import ctypes
-    from helpers import make_oracle, quiet_cfg
+    from helpers import quiet_cfg
     data = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "isaacgymloco_amd", "data", "mocap_aliengo.npz"), allow_pickle=True)
     frames = np.concatenate([data[f"frames_{c}"] for c in range(int(data["num_clips"]))])
     assert frames.shape[1] == 61 and len(frames) > 600
-    N = 64
-    orc, lc, model, ter = make_oracle(quiet_cfg("aliengo"), N, seed=1)
-    L = orc._L
-    L.orc_refresh_body_states.argtypes = [ctypes.c_void_p, ctypes.c_int]
-    feet = list(model.feet_bodies)
-    worst = 0.0
-    for i0 in range(0, len(frames), N):
-        chunk = frames[i0:i0 + N]
-        n = len(chunk)
-        root = np.zeros((N, 13), np.float32); root[:, 6] = 1.0            # base frame = world frame
-        orc.buf["root_states"][...] = root
-        dof = np.zeros((N, 12, 2), np.float32); dof[:n, :, 0] = chunk[:, 7:19]
-        orc.buf["dof_state"][...] = dof
-        for e in range(n):
-            L.orc_refresh_body_states(orc._h, e)
-        got = orc.buf["rigid_body_states"][:n][:, feet, 0:3]
-        want = chunk[:, 19:31].reshape(n, 4, 3)
-        assert np.all(np.sign(want[:, [0, 2], 1]) > 0) and np.all(np.sign(want[:, [1, 3], 1]) < 0)     # slots 0 / 2 are left legs
-        worst = max(worst, float(np.abs(got - want).max()))
-    orc.close()
+    want = frames[:, 19:31].reshape(-1, 4, 3)
+    assert np.all(np.sign(want[:, [0, 2], 1]) > 0) and np.all(np.sign(want[:, [1, 3], 1]) < 0)     # slots 0 / 2 are left legs
+    worst = _fk_toe_error(quiet_cfg("aliengo"), frames[:, 7:19], frames[:, 19:31])
     assert worst < 3e-5, worst
+
+
+def test_a1_table_kinematics_reproduce_the_reference_a1_mocap_toe_positions():
+    """the same pin for a second model table (robots/tables/a1.json, from the reference's a1.urdf through the generic loader): every 4th frame
+    of the reference's 13 A1 clips (datasets/mocap_motions_a1, tests/golden/mocap_a1_frames.npz by tools/pack_mocap_fixture.py; 323 frames;
+    all 1274: the same 7e-6 m).  Catches a wrong hip / thigh / calf origin, axis or foot offset of the table."""
+    from helpers import quiet_cfg
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mocap_a1_frames.npz"))
+    assert fx["joint_pos"].shape == (323, 12) and len(set(fx["clip"].tolist())) == 13
+    cfg = quiet_cfg("go1")
+    cfg.asset.name = "a1"
+    worst = _fk_toe_error(cfg, fx["joint_pos"], fx["toe_pos_base"])
+    assert worst < 3e-5, worst
+    cfg.asset.name = "go1"      # negative control: Go1's table (8 mm shorter thighs, different hip offsets) does not fit A1's data
+    assert _fk_toe_error(cfg, fx["joint_pos"][:64], fx["toe_pos_base"][:64]) > 3e-3
