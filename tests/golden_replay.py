@@ -29,6 +29,7 @@ TWEAKS = {
     "aliengo_stairs": ("aliengo_stairs", lambda cfg: setattr(cfg.terrain, "terrain_proportions", [0.0, 0.0, 0.0, 0.0, 0.5, 0.5, 0.0, 0.0, 0.0, 0.0])),
     "aliengo_allterms": ("aliengo", _all_terms),
     "aliengo_amp": ("aliengo_amp", _flat),
+    "aliengo_reset_subset": ("aliengo", _flat),      # + the reference's reset_idx(env_ids) called by hand after the last step (fin_* keys)
 }
 SCENARIOS = sorted(TWEAKS)
 
@@ -204,3 +205,42 @@ def compare_step(t, ref, get_full, stats_row, dt=0.02):
         if not np.isnan(ref["level_mean"]):
             np.testing.assert_allclose(get("terrain_levels").astype(np.float32).mean(), ref["level_mean"], rtol=1e-6)
     return errs
+
+
+def replay_final_reset(fx, backend, get, put):
+    """after replay(): the by-hand reset_idx(env_ids) of the fixture (LR:290 called outside step()) through backend.reset_envs(mask)"""
+    N = int(fx["num_envs"])
+    assert backend.step_counter == int(fx["fin_counter"])
+    es = get("episode_sums")
+    es[:, abi.REWARD_IDS["tracking_lin_vel"]] = fx["fin_track"]
+    put("episode_sums", es)
+    mask = np.zeros(N, np.uint8)
+    mask[fx["fin_ids"]] = 1
+    backend.reset_envs(mask)
+    return mask
+
+
+def compare_final_reset(fx, mask, get, stats_row, dt=0.02):
+    """what the reference's by-hand reset_idx(env_ids) left behind, same tolerances as compare_step"""
+    atols = dict((k, a) for k, _, a in FLOAT_CHECKS)
+    for key in ("reset", "time_out", "extras_time_outs", "terrain_levels", "episode_length"):
+        np.testing.assert_array_equal(get(key).astype(np.int64), fx["fin_" + key].astype(np.int64), err_msg=f"by-hand reset: {key}")
+    for key in ("commands", "root_states", "dof_state", "env_origins", "kp_factors", "kd_factors", "friction", "last_actions", "last_last_actions",
+                "last_dof_vel", "feet_air_time", "measured_heights"):
+        np.testing.assert_allclose(get(key), fx["fin_" + key], rtol=2e-5, atol=atols[key], err_msg=f"by-hand reset: {key}")
+    np.testing.assert_allclose(get("episode_sums"), fx["fin_episode_sums"], rtol=2e-5, atol=2e-5, err_msg="by-hand reset: episode_sums")
+    st = get("stats")[stats_row]
+    S = abi.STATS
+    np.testing.assert_allclose(st[S["cmd_ranges"]:S["cmd_ranges"] + 8].reshape(4, 2), fx["fin_command_ranges"], rtol=1e-6, atol=1e-6, err_msg="by-hand reset: command_ranges")
+    assert int(st[S["reset_count"]]) == int(mask.sum())
+    mine = st[S["episode_sums"]:S["episode_sums"] + abi.NUM_REWARD_TERMS] / st[S["reset_count"]] / dt
+    valid = ~np.isnan(fx["fin_ep_stats"])
+    assert valid.any()
+    np.testing.assert_allclose(mine[valid], fx["fin_ep_stats"][valid], rtol=1e-4, atol=1e-5, err_msg="by-hand reset: extras[episode]")
+    if not np.isnan(fx["fin_level_mean"]):
+        np.testing.assert_allclose(get("terrain_levels").astype(np.float32).mean(), fx["fin_level_mean"], rtol=1e-6)
+    # the fixture is not vacuous: the chosen envs moved, the others did not, and the command curriculum fired on the SET's mean
+    moved = np.abs(fx["fin_root_states"] - fx["finb_root_states"]).max(1) > 0
+    np.testing.assert_array_equal(moved, mask.astype(bool))
+    assert np.all(fx["fin_episode_length"][mask == 1] == 0) and np.all(fx["fin_episode_length"][mask == 0] == fx["finb_episode_length"][mask == 0])
+    assert fx["fin_command_ranges"][0, 1] > fx["fin_ranges_before"][0, 1] or fx["fin_command_ranges"][0, 0] < fx["fin_ranges_before"][0, 0]

@@ -30,6 +30,9 @@ def test_emu_matches_reference_step(name):
         sim.buf[n][...] = a
     for t, ref in GR.replay(fx, sim, get, put):
         GR.compare_step(t, ref, get, sim.stats_row)
+    if "fin_ids" in fx.files:     # the reference's by-hand reset_idx(env_ids): kernel B's masked mode (lsim_reset_envs)
+        mask = GR.replay_final_reset(fx, sim, get, put)
+        GR.compare_final_reset(fx, mask, get, sim.stats_row)
 
 
 @pytest.mark.parametrize("name", GR.BIG_SCENARIOS)

@@ -20,6 +20,9 @@ def test_hip_matches_reference_step(name):
         GR.compare_step(t, ref, be.get, be.stats_row)
         n += 1
     assert n == fx["in_actions"].shape[0]
+    if "fin_ids" in fx.files:     # the reference's reset_idx(env_ids) called by hand after the last step (LR:290): lsim_reset_envs
+        mask = GR.replay_final_reset(fx, be, be.get, be.put)
+        GR.compare_final_reset(fx, mask, be.get, be.stats_row)
 
 
 @pytest.mark.parametrize("name", GR.BIG_SCENARIOS)

@@ -37,6 +37,9 @@ def test_oracle_matches_reference_step(name):
         nsteps += 1
     assert nsteps == fx["in_actions"].shape[0]
     print(name, "max abs err:", {k: f"{v:.2e}" for k, v in worst.items()})
+    if "fin_ids" in fx.files:     # the reference's reset_idx(env_ids) called by hand after the last step (LR:290): orc_reset_envs
+        mask = GR.replay_final_reset(fx, sim, get, put)
+        GR.compare_final_reset(fx, mask, get, sim.stats_row)
 
 
 @pytest.mark.parametrize("name", GR.BIG_SCENARIOS)

@@ -1,5 +1,7 @@
 """LeggedRobot.reset_idx(env_ids) called from outside a step (LR:290-361) on a subset of the robots: lsim_reset_envs against the oracle's
-reset_idx -- the same function the reference's step() calls on the terminated envs (LR:229), pinned there by the golden fixtures.
+reset_idx -- the same function the reference's step() calls on the terminated envs (LR:229), pinned there by the golden fixtures, and pinned
+for the by-hand call itself by tests/golden/step_aliengo_reset_subset.npz (the reference's own reset_idx(env_ids) after the last replayed step;
+test_oracle_golden / test_emu_golden / test_gpu_parity).  Here: more cases (ragged subset, empty set, mask of ones, curriculum over the set).
 CPU leg: the lane-emulated kernel sources; GPU leg: the HIP library through the C-ABI and through LeggedRobot.reset_idx."""
 import numpy as np
 import pytest

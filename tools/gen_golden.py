@@ -391,8 +391,9 @@ def capture(env, tensors, N):
     )
 
 
-def run_scenario(name, task, ref_cfg_cls, N, segments, seed=1, tweak=None, using_amp=False):
-    """segments: list of (start_counter, num_steps)."""
+def run_scenario(name, task, ref_cfg_cls, N, segments, seed=1, tweak=None, using_amp=False, final_reset_ids=None):
+    """segments: list of (start_counter, num_steps).  final_reset_ids: after the last step the reference's reset_idx(ids) is called BY HAND
+    (LR:290, outside step()) and what it left behind is stored under fin_* (the reference-side pin of lsim_reset_envs)."""
     global CTX
     LRmod.USING_AMP = using_amp   # LR:173: step() returns the 8-tuple with terminal AMP states
     cfg = C.TASKS[task][0]()
@@ -477,6 +478,26 @@ def run_scenario(name, task, ref_cfg_cls, N, segments, seed=1, tweak=None, using
     pack = {"num_envs": np.int64(N), "seed": np.int64(seed), "task": np.array(task),
             "height_grid": terrain.heightsamples, "terrain_origins": terrain.env_origins.astype(np.float32),
             "segments": np.array(segments, dtype=np.int64)}
+    if final_reset_ids is not None:
+        ids = np.asarray(final_reset_ids, dtype=np.int64)
+        # the command curriculum averages over the reset SET (LR:307-308, LR:875): only the chosen envs carry a tracking sum above the bar
+        track = np.zeros(N, np.float32)
+        track[ids] = 1.25 * 0.8 * float(env.reward_scales["tracking_lin_vel"]) * float(env.max_episode_length)
+        env.episode_sums["tracking_lin_vel"][:] = torch.from_numpy(track)
+        env.extras.pop("episode", None)
+        pack["fin_ids"] = ids
+        pack["fin_track"] = track
+        pack["fin_counter"] = np.int64(env.common_step_counter)
+        pack["fin_ranges_before"] = np.array([env.command_ranges[k] for k in ("lin_vel_x", "lin_vel_y", "ang_vel_yaw", "heading")], dtype=np.float64)
+        before = capture(env, tensors, N)
+        env.reset_idx(torch.from_numpy(ids))          # draws keyed by the step word of the last step (CTX.stepw), as lsim_reset_envs keys them
+        after = capture(env, tensors, N)
+        for k in ("commands", "root_states", "dof_state", "terrain_levels", "env_origins", "episode_length", "kp_factors", "kd_factors", "friction",
+                  "last_actions", "last_last_actions", "last_dof_vel", "feet_air_time", "reset", "extras_time_outs", "time_out", "episode_sums",
+                  "ep_stats", "level_mean", "command_ranges", "measured_heights"):
+            pack["fin_" + k] = after[k]
+        for k in ("root_states", "commands", "episode_length"):
+            pack["finb_" + k] = before[k]
     for k in steps[0]["inp"]:
         pack["in_" + k] = np.stack([s["inp"][k] for s in steps])
     for k in steps[0]["out"]:
@@ -589,6 +610,11 @@ def main():
 
     def flat_only(cfg):
         cfg.terrain.terrain_proportions = [1.0, 0.0, 0.0, 0.0]
+
+    if sys.argv[1:] == ["reset_subset"]:     # only the by-hand reset_idx(env_ids) fixture
+        run_scenario("aliengo_reset_subset", "aliengo", aliengo_config.AlienGoRoughCfg, 16, [(0, 3), (997, 3)], tweak=flat_only,
+                     final_reset_ids=[1, 3, 4, 9, 15])
+        return
 
     def stairs_only(cfg):   # only generators that exist in-tree (TER:229-294): stairs up/down
         cfg.terrain.terrain_proportions = [0.0, 0.0, 0.0, 0.0, 0.5, 0.5, 0.0, 0.0, 0.0, 0.0]
