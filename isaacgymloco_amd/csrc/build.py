@@ -73,6 +73,8 @@ def build_variant(out, extra_flags=(), workdir=None):
     hipcc = os.environ.get("HIPCC", "hipcc")
     out = os.path.abspath(out)
     workdir = os.path.abspath(workdir) if workdir else os.path.dirname(out)
+    os.makedirs(workdir, exist_ok=True)
+    os.makedirs(os.path.dirname(out), exist_ok=True)
     objs, procs = [], []
     for src, _, flags in UNITS:
         obj = os.path.join(workdir, os.path.basename(out) + "." + os.path.splitext(src)[0] + ".o")
