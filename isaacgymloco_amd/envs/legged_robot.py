@@ -335,6 +335,15 @@ class LeggedRobot:
             coefs.append((1 - p) * c0 + p * c1)
         self.reward_curriculum_coef = coefs
 
+    def set_camera(self, position, lookat):
+        """LR:1052-1057 points the viewer's camera; this build is headless (viewer = None, BT:81-98 never creates one): accepted and ignored,
+        so that play-style scripts (play.py:117, play.py:143) run unchanged"""
+        return None
+
+    def render(self, sync_frame_time=True):
+        """BT:117-148: viewer events and drawing; nothing to do without a viewer"""
+        return None
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
             torch.cuda.synchronize(self._arena.device)

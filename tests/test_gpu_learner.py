@@ -762,3 +762,58 @@ def test_fused_actor_input_matches_torch():
                 ref = torch.cat((hist[:, :45], vel, latent), dim=-1)
             assert got.shape == ref.shape == (B, 64)
             torch.testing.assert_close(got, ref, rtol=1e-6, atol=1e-6)
+
+
+def test_play_style_loop_runs_on_the_env_surface():
+    """the evaluation loop of the reference's play.py (play.py:70-158) against this env: its config overrides (no termination bodies, no
+    heading command, no command curriculum, one resampling per 10 000 s), commands written by the host every step, the inference policy of a
+    runner, the attributes its logger reads -- and a by-hand reset_idx of a few robots in the middle"""
+    import numpy as np
+    from isaacgymloco_amd.envs import config as C
+    from isaacgymloco_amd.envs.legged_robot import LeggedRobot
+    from isaacgymloco_amd.learn.bench_train import train_cfg_dict
+    from isaacgymloco_amd.learn.runner import HIMOnPolicyRunner
+    cfg = C.TASKS["aliengo"][0]()
+    cfg.env.num_envs = 50                                   # play.py:64
+    cfg.terrain.num_rows, cfg.terrain.num_cols = 5, 5       # play.py:65-66
+    cfg.terrain.curriculum = False
+    cfg.noise.add_noise = False
+    cfg.domain_rand.randomize_friction = False
+    cfg.domain_rand.push_robots = False
+    cfg.domain_rand.disturbance = False
+    cfg.domain_rand.randomize_payload_mass = False
+    cfg.asset.terminate_after_contacts_on = []              # play.py:81
+    cfg.commands.heading_command = False
+    cfg.commands.curriculum = False
+    cfg.commands.resampling_time = 10000.0
+    env = LeggedRobot(cfg, sim_device="cuda:0", seed=1)
+    assert env.viewer is None and len(env.termination_contact_indices) == 0
+    env.commands[:, 0], env.commands[:, 1], env.commands[:, 2] = 1.0, 0.0, 0.5
+    torch.manual_seed(0)
+    runner = HIMOnPolicyRunner(env, train_cfg_dict("aliengo"), log_dir=None, device="cuda:0")
+    policy = runner.get_inference_policy(device=env.device)
+    obs = env.get_observations()
+    env.set_camera(np.array([3.0, 3.0, 3.0]), np.array([10.0, 10.0, 0.0]))
+    x_vel = 2.0 * torch.rand(env.num_envs, device=env.device) - 1.0
+    for i in range(40):
+        actions = policy(obs.detach())
+        env.commands[:, 0] = x_vel
+        env.commands[:, 1] = 0.0
+        env.commands[:, 2] = 0.5
+        obs, _, rews, dones, infos, *_ = env.step(actions.detach())
+        assert obs.shape == (50, 270) and bool(torch.isfinite(obs).all()) and bool(torch.isfinite(rews).all())
+        survivors = ~dones
+        assert torch.equal(env.commands[survivors, 0], x_vel[survivors])       # host-written commands survive the step (no resampling, no heading rule)
+        assert torch.allclose(env.commands[survivors, 2], torch.full_like(x_vel[survivors], 0.5))
+        for v in (env.dof_pos[0, 1], env.dof_vel[0, 1], env.torques[0, 1], env.base_lin_vel[0, 0], env.base_ang_vel[0, 2]):
+            assert np.isfinite(v.item())
+        assert env.contact_forces[0, env.feet_indices, 2].shape == (4,)
+        assert isinstance(infos["episode"], dict)
+        _ = actions[0, 1].item() * env.cfg.control.action_scale + env.default_dof_pos[0, 1].item()
+        if i == 20:
+            ep = env.episode_length_buf.clone()
+            env.reset_idx(torch.tensor([3, 17, 42], device=env.device))
+            assert bool((env.episode_length_buf[[3, 17, 42]] == 0).all())
+            keep = torch.ones(50, dtype=torch.bool, device=env.device); keep[[3, 17, 42]] = False
+            assert torch.equal(env.episode_length_buf[keep], ep[keep])
+    assert not bool(env.reset_buf.all())
