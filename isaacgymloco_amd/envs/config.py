@@ -207,6 +207,30 @@ ALIENGO_AMP_PPO_OVERRIDES = {
 }
 
 
+# ----------------------------------------------------------------------------- Aliengo recovery (aliengo_recover_config.py:38-190): differences only
+# robots start in any orientation (LR:786-794 draws roll / pitch / yaw from +-pi), nothing terminates on contact, the `_up` reward variants
+# (LR:1459-1770: the term times the upright-ness of the base) replace the plain ones.  The reference also switches PhysX self-collisions
+# ON for this task (`self_collisions = 0`); this build has no robot-robot or link-link contact: noted, not modelled.
+_RECOVER_SCALES = dict(
+    termination=-0.0, tracking_lin_vel=2.0, tracking_ang_vel=1.0, lin_vel_z_up=-2.0, ang_vel_xy_up=-0.05, orientation_up=-2.0,
+    base_height_up=-5.0, torques=-0.0002, torque_limits=-0.0, dof_vel=-0.0, dof_acc=-2.5e-7, stand_nice=-0.1, hip_pos_up=-0.3,
+    thigh_pose_up=-0.05, calf_pose_up=-0.05, dof_pos_limits=-0.0, dof_vel_limits=-0.0, joint_power=-2e-5, feet_mirror_up=-0.05,
+    action_rate=-0.02, smoothness=-0.01, hip_action_magnitude=-0.01, collision_up=-0.0, feet_contact_forces=-0.00015,
+    feet_air_time=0.25, has_contact=0.3, feet_stumble_up=-0.0, feet_slide_up=-0.01, foot_clearance_base_up=-0.1,
+    foot_clearance_base_terrain=-0.0, stuck=-0.05, upward=1.0)
+ALIENGO_RECOVER_OVERRIDES = {
+    "commands": dict(max_forward_curriculum=2.0, heading_command=False),
+    "asset": dict(terminate_after_contacts_on=[], self_collisions=0),
+    "terrain": dict(terrain_proportions=[0.5, 0.5]),
+    "domain_rand": dict(_ALIENGO_DOMAIN_RAND, recover_mode=True,
+                        base_init_rot_range=_leaf(roll=[-3.14, 3.14], pitch=[-3.14, 3.14], yaw=[-3.14, 3.14])),
+    "rewards": dict(only_positive_rewards=True, scales=_RECOVER_SCALES),
+}
+ALIENGO_RECOVER_PPO_OVERRIDES = {
+    "runner": dict(max_iterations=2000, experiment_name="recover_aliengo", resume=True),
+}
+
+
 def _build(*layers):
     d = {}
     for layer in layers:
@@ -241,6 +265,15 @@ def aliengo_amp_cfg_ppo():
     return ConfigNode(_build(LEGGED_ROBOT_PPO_DEFAULTS, ALIENGO_PPO_OVERRIDES, ALIENGO_AMP_PPO_OVERRIDES))
 
 
+def aliengo_recover_cfg():
+    """AlienGoRoughRecoverCfg (task "aliengo_recover", envs/__init__.py:55)."""
+    return ConfigNode(_build(LEGGED_ROBOT_DEFAULTS, ALIENGO_OVERRIDES, ALIENGO_RECOVER_OVERRIDES))
+
+
+def aliengo_recover_cfg_ppo():
+    return ConfigNode(_build(LEGGED_ROBOT_PPO_DEFAULTS, ALIENGO_PPO_OVERRIDES, ALIENGO_RECOVER_PPO_OVERRIDES))
+
+
 # ----------------------------------------------------------------------------- Go1 on the Aliengo task (BASELINE config 5's second robot)
 # The reference registers a "go1" task (envs/__init__.py:52) whose config predates its own LeggedRobot (it lacks the
 # dof_init_pos_ratio_range / base_init_*_range / termination keys LR:699-812 read) and does not run.  This task is therefore the
@@ -271,4 +304,5 @@ TASKS = {
     "aliengo": (aliengo_cfg, aliengo_cfg_ppo),
     "aliengo_stairs": (aliengo_stairs_cfg, aliengo_stairs_cfg_ppo),
     "aliengo_amp": (aliengo_amp_cfg, aliengo_amp_cfg_ppo),
+    "aliengo_recover": (aliengo_recover_cfg, aliengo_recover_cfg_ppo),
 }

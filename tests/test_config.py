@@ -7,7 +7,7 @@ import pytest
 from helpers import C, ROOT
 
 
-@pytest.mark.parametrize("task", ["aliengo", "aliengo_stairs", "aliengo_amp"])
+@pytest.mark.parametrize("task", ["aliengo", "aliengo_stairs", "aliengo_amp", "aliengo_recover"])
 def test_config_matches_reference(task):
     ref = json.load(open(os.path.join(ROOT, "tests", "golden", f"ref_cfg_{task}.json")))
     env, ppo = C.TASKS[task]

@@ -46,3 +46,33 @@ def test_emu_matches_reference_step_at_baseline_size(name):
         sim.buf[n][...] = a
     for t, ref in GR.replay(fx, sim, get, put):
         GR.compare_step(t, ref, get, sim.stats_row)
+
+
+def _recover_task_check(make_backend, get, steps=10, N=16):
+    """task "aliengo_recover" (aliengo_recover_config.py): robots reset in ANY orientation (LR:786-794 with +-3.14 ranges), no termination on
+    contact, the `_up` reward variants active -- the trunk and the upper legs carry the robot, which the walking tasks never exercise"""
+    from helpers import C
+    cfg = C.TASKS["aliengo_recover"][0]()
+    orc, lc, model, ter = make_oracle(cfg, N, seed=3)
+    assert model.termination_body_mask == 0 and lc.heading_command == 0 and lc.only_positive_rewards == 1
+    active = {abi.REWARD_NAMES[i] for i in range(abi.NUM_REWARD_TERMS) if lc.reward_scales[i] != 0}
+    assert {"upward", "stand_nice", "orientation_up", "base_height_up", "has_contact"} <= active and "orientation" not in active
+    be = make_backend(cfg, lc, model, ter, N)
+    orc.reset_all(); be.reset_all()
+    rs = np.random.RandomState(0)
+    trunk_load = 0.0
+    for t in range(steps):
+        a = rs.normal(0, 1, (N, 12)).astype(np.float32)
+        orc.step(a); be.step(a)
+        np.testing.assert_array_equal(get(be, "reset"), orc.buf["reset"], err_msg=f"step {t}")
+        np.testing.assert_allclose(get(be, "root_states"), orc.buf["root_states"], atol=2e-3, rtol=1e-3, err_msg=f"step {t}")
+        np.testing.assert_allclose(get(be, "rew"), orc.buf["rew"], atol=1e-4, rtol=1e-3, err_msg=f"step {t}")
+        np.testing.assert_allclose(get(be, "obs"), orc.buf["obs"], atol=5e-3, rtol=1e-3, err_msg=f"step {t}")
+        trunk_load = max(trunk_load, float(orc.buf["contact_forces"][:, 0, 2].max()))
+    assert (orc.buf["projected_gravity"][:, 2] > 0.3).any(), "some robot must be on its back"
+    assert trunk_load > 20.0, "a robot on its back rests on the trunk"
+
+
+def test_emu_recover_task_matches_oracle():
+    import emu_binding
+    _recover_task_check(lambda cfg, lc, model, ter, N: emu_binding.EmuSim(lc, model, ter.heightsamples, ter.env_origins), lambda be, k: be.buf[k])

@@ -376,3 +376,11 @@ def test_hip_leg_kinematics_reproduce_the_reference_mocap_toe_positions():
     got = body[:, feet, 0:3] - be.get("root_states")[:, None, 0:3]
     want = frames[:, 19:31].reshape(N, 4, 3)
     assert float(np.abs(got - want).max()) < 5e-5, float(np.abs(got - want).max())      # fp32 chain of three rotations at |p| ~ 0.4 m + 5 m offset
+
+
+def test_hip_recover_task_matches_oracle():
+    """task "aliengo_recover" on the device: robots on their backs and sides (resets draw roll / pitch / yaw from +-3.14), resting on trunk and
+    upper legs, `_up` reward set -- HIP kernels vs the oracle, the same check as tests/test_emu_golden.py runs on the lane emulator"""
+    from hip_backend import HipBackend
+    from test_emu_golden import _recover_task_check
+    _recover_task_check(lambda cfg, lc, model, ter, N: HipBackend(cfg, N, ter, seed=3), lambda be, k: be.get(k), steps=12)
