@@ -383,4 +383,4 @@ def test_hip_recover_task_matches_oracle():
     upper legs, `_up` reward set -- HIP kernels vs the oracle, the same check as tests/test_emu_golden.py runs on the lane emulator"""
     from hip_backend import HipBackend
     from test_emu_golden import _recover_task_check
-    _recover_task_check(lambda cfg, lc, model, ter, N: HipBackend(cfg, N, ter, seed=3), lambda be, k: be.get(k), steps=12)
+    _recover_task_check(lambda cfg, lc, model, ter, N: HipBackend(cfg, N, ter, seed=3), lambda be, k: be.get(k), lambda be, k, v: be.put(k, v), steps=16)
