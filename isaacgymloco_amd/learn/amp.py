@@ -198,24 +198,27 @@ class _GradPenFn(autograd.Function):
 
     @staticmethod
     def forward(ctx, x, W1, b1, W2, b2, w3, lambda_):
+        # every mask is applied by aten's threshold_backward(grad, pre, 0) = grad where pre > 0 else 0 -- the kernel relu's own backward runs --
+        # on the fp32 activation itself: one pass per mask instead of compare + cast / not + multiply / fill
+        tb = torch.ops.aten.threshold_backward
         a1 = torch._addmm_activation(b1, x, W1.t(), use_gelu=False)      # relu(z1) straight from the GEMM epilogue; z1 > 0  <=>  a1 > 0
-        m1 = a1 > 0
         z2 = torch.addmm(b2, a1, W2.t())
-        u2 = (z2 > 0).to(x.dtype) * w3                      # (B, H2): m2 * w3
-        u1 = (u2 @ W2).masked_fill_(~m1, 0.0)               # (B, H1): m1 * (W2^T u2)
+        u2 = tb(w3.expand_as(z2), z2, 0.0)                  # (B, H2): m2 * w3
+        u1 = tb(u2 @ W2, a1, 0.0)                           # (B, H1): m1 * (W2^T u2)
         g = u1 @ W1                                         # (B, D): dD/dx
-        ctx.save_for_backward(W1, W2, m1, u2, u1, g)
+        ctx.save_for_backward(W1, W2, a1, z2, u2, u1, g)
         ctx.scale = 2.0 * lambda_ / x.shape[0]
         return lambda_ * g.pow(2).sum(dim=1).mean()
 
     @staticmethod
     def backward(ctx, grad_out):
-        W1, W2, m1, u2, u1, g = ctx.saved_tensors
+        tb = torch.ops.aten.threshold_backward
+        W1, W2, a1, z2, u2, u1, g = ctx.saved_tensors
         dg = g * (ctx.scale * grad_out)                     # d penalty / d g
         dW1 = u1.t() @ dg                                   # g = u1 W1
-        du1 = (dg @ W1.t()).masked_fill_(~m1, 0.0)          # through the mask m1 (a constant)
+        du1 = tb(dg @ W1.t(), a1, 0.0)                      # through the mask m1 (a constant)
         dW2 = u2.t() @ du1                                  # u1 = m1 * (u2 W2)
-        dw3 = ((du1 @ W2.t()) * (u2 != 0).to(g.dtype)).sum(dim=0, keepdim=True)   # u2 = m2 * w3; (u2 != 0) is m2 where w3 != 0
+        dw3 = tb(du1 @ W2.t(), z2, 0.0).sum(dim=0, keepdim=True)   # u2 = m2 * w3
         return None, dW1, None, dW2, None, dw3, None
 
 
@@ -233,7 +236,7 @@ class _LinearReluFn(autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, weight, z = ctx.saved_tensors
-        gy = torch.where(z > 0, g, torch.zeros((), dtype=g.dtype, device=g.device))
+        gy = torch.ops.aten.threshold_backward(g, z, 0.0)      # relu's own backward kernel on the saved OUTPUT (z > 0 <=> pre-activation > 0)
         gx = gy @ weight if ctx.needs_input_grad[0] else None
         return gx, gy.t() @ x, gy.sum(dim=0)
 
