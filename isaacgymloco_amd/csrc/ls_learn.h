@@ -568,8 +568,7 @@ extern "C" int lsim_linear_elu_wgrad(const float* x, int64_t ldx, const float* g
 // in ONE pass over act and grad -- the separate column-sum pass over [batch, n] disappears.  A block of 256 threads owns LS_RB_ROWS
 // consecutive rows; a thread owns 4 consecutive columns (16-byte accesses) of every rows_per_pass-th row of the block and keeps their sums
 // in registers; the partial sums of all (block, row lane) pairs are added in a fixed order by a second launch (deterministic).
-#define LS_RB_ROWS 128
-#define LS_RB_UNROLL 4
+#define LS_RB_ROWS 256
 __global__ __launch_bounds__(256) void lsim_k_relu_bwd_bias(const float* __restrict__ act, const float* __restrict__ grad, long batch, int n,
                                                             float* __restrict__ grad_pre, float* __restrict__ partial) {
     typedef float v4 __attribute__((ext_vector_type(4)));
@@ -580,42 +579,22 @@ __global__ __launch_bounds__(256) void lsim_k_relu_bwd_bias(const float* __restr
         const long r0 = (long)blockIdx.x * LS_RB_ROWS;
         long rend = r0 + LS_RB_ROWS;
         if (rend > batch) rend = batch;
-        // LS_RB_UNROLL rows per trip: that many independent 16-byte loads of each input in flight per lane
-        for (long r = r0 + rl; r < rend; r += (long)rpp * LS_RB_UNROLL) {
-            v4 a[LS_RB_UNROLL], g[LS_RB_UNROLL];
-#pragma unroll
-            for (int u = 0; u < LS_RB_UNROLL; ++u) {
-                const long ru = r + (long)u * rpp;
-                const bool ok = ru < rend;
-                a[u] = ok ? ((const v4*)(act + ru * n))[c4] : (v4){0.0f, 0.0f, 0.0f, 0.0f};
-                g[u] = ok ? ((const v4*)(grad + ru * n))[c4] : (v4){0.0f, 0.0f, 0.0f, 0.0f};
-            }
-#pragma unroll
-            for (int u = 0; u < LS_RB_UNROLL; ++u) {
-                const long ru = r + (long)u * rpp;
-                v4 y = {a[u].x > 0.0f ? g[u].x : 0.0f, a[u].y > 0.0f ? g[u].y : 0.0f, a[u].z > 0.0f ? g[u].z : 0.0f, a[u].w > 0.0f ? g[u].w : 0.0f};
-                if (grad_pre && ru < rend) ((v4*)(grad_pre + ru * n))[c4] = y;
-                sum += y;                                   // rows of one lane in ascending order: the same order for every call
-            }
+        for (long r = r0 + rl; r < rend; r += rpp) {
+            const v4 a = ((const v4*)(act + r * n))[c4];
+            const v4 g = ((const v4*)(grad + r * n))[c4];
+            v4 y = {a.x > 0.0f ? g.x : 0.0f, a.y > 0.0f ? g.y : 0.0f, a.z > 0.0f ? g.z : 0.0f, a.w > 0.0f ? g.w : 0.0f};
+            if (grad_pre) ((v4*)(grad_pre + r * n))[c4] = y;
+            sum += y;
         }
         if (partial) ((v4*)(partial + ((long)blockIdx.x * rpp + rl) * n))[c4] = sum;
     }
 }
-// column sums of the partial rows: a block owns 64 columns; 16 groups of 64 lanes walk the partial rows with stride 16, then the 16 group
-// sums are added in group order
-__global__ __launch_bounds__(1024) void lsim_k_colsum_finish(const float* __restrict__ partial, long parts, int n, float* __restrict__ out) {
-    __shared__ float acc[16][64];
-    const int cx = (int)threadIdx.x & 63, gy = (int)threadIdx.x >> 6;
-    const int c = (int)blockIdx.x * 64 + cx;
+__global__ __launch_bounds__(256) void lsim_k_colsum_finish(const float* __restrict__ partial, long parts, int n, float* __restrict__ out) {
+    const int c = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (c >= n) return;
     float s = 0.0f;
-    if (c < n) for (long p = gy; p < parts; p += 16) s += partial[p * n + c];
-    acc[gy][cx] = s;
-    __syncthreads();
-    if (gy == 0 && c < n) {
-        float t = 0.0f;
-        for (int k = 0; k < 16; ++k) t += acc[k][cx];
-        out[c] = t;
-    }
+    for (long p = 0; p < parts; ++p) s += partial[p * n + c];
+    out[c] = s;
 }
 static long ls_rb_parts(long batch, int n) { return ((batch + LS_RB_ROWS - 1) / LS_RB_ROWS) * (256 / (n >> 2)); }
 extern "C" int lsim_relu_backward_bias_workspace(int64_t batch, int n, size_t* bytes) {
@@ -634,7 +613,7 @@ extern "C" int lsim_relu_backward_bias(const float* act_out, const float* grad_o
     const long blocks = (batch + LS_RB_ROWS - 1) / LS_RB_ROWS;
     hipLaunchKernelGGL(lsim_k_relu_bwd_bias, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, act_out, grad_out, (long)batch, n, grad_pre,
                        db ? (float*)workspace : (float*)nullptr);
-    if (db) hipLaunchKernelGGL(lsim_k_colsum_finish, dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, (hipStream_t)stream, (const float*)workspace,
+    if (db) hipLaunchKernelGGL(lsim_k_colsum_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace,
                                ls_rb_parts(batch, n), n, db);
     return hipGetLastError() == hipSuccess ? LSIM_OK : LSIM_E_HIP;
 }
