@@ -550,16 +550,6 @@ int lsim_linear_wgrad(const float* x, int64_t ldx, const float* g, int64_t ldg, 
 int lsim_linear_elu_wgrad(const float* x, int64_t ldx, const float* grad_out, int64_t ldg, const float* elu_out, int64_t ldz, int64_t batch,
                           int k_in, int n_out, float* dw, float* db, float* grad_pre, void* workspace, size_t workspace_bytes, void* stream);
 
-/* Backward of a ReLU that sits between two Linear layers (the AMP discriminator trunk, DISC:27-33), given the gradient of the ReLU's output:
- *   grad_pre[b, c] = act_out[b, c] > 0 ? grad_out[b, c] : 0      (aten's threshold_backward on the saved output)
- *   db[c] = sum_b grad_pre[b, c]                                  (the bias gradient of the Linear layer in front of the ReLU)
- * in one pass over the two [batch, n] inputs (all contiguous fp32, 16-byte aligned).  grad_pre or db may be NULL (only the other is
- * produced).  n a multiple of 4, n <= 1024 (LSIM_E_UNSUPPORTED otherwise: the caller keeps the two torch passes).  workspace:
- * lsim_relu_backward_bias_workspace() bytes; partial sums are added in a fixed order (deterministic). */
-int lsim_relu_backward_bias_workspace(int64_t batch, int n, size_t* bytes);
-int lsim_relu_backward_bias(const float* act_out, const float* grad_out, int64_t batch, int n, float* grad_pre, float* db,
-                            void* workspace, size_t workspace_bytes, void* stream);
-
 /* Clipped-PPO loss of HIMPPO.update (HIMP:136-176), forward AND backward in one pass: per-sample Gaussian log-prob, ratio, clipped
  * surrogate, clipped value loss, entropy bonus, and the KL estimate of the adaptive learning-rate rule (HIMP:144-156).
  *   out5 = { mean surrogate, mean value loss, mean entropy, mean KL, total = surrogate + value_loss_coef * value - entropy_coef * entropy }

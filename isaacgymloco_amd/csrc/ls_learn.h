@@ -563,61 +563,6 @@ extern "C" int lsim_linear_elu_wgrad(const float* x, int64_t ldx, const float* g
     return ls_linear_wgrad_impl(x, ldx, grad_out, ldg, elu_out, ldz, grad_pre, batch, k_in, n_out, dw, db, workspace, workspace_bytes, stream);
 }
 
-// ---- backward of a ReLU in front of a Linear layer's bias / weight gradients (the AMP discriminator's trunk, DISC:27-33):
-//   grad_pre = act > 0 ? grad : 0   (aten's threshold_backward on the saved OUTPUT)   and   db[c] = sum_b grad_pre[b, c]
-// in ONE pass over act and grad -- the separate column-sum pass over [batch, n] disappears.  A block of 256 threads owns LS_RB_ROWS
-// consecutive rows; a thread owns 4 consecutive columns (16-byte accesses) of every rows_per_pass-th row of the block and keeps their sums
-// in registers; the partial sums of all (block, row lane) pairs are added in a fixed order by a second launch (deterministic).
-#define LS_RB_ROWS 256
-__global__ __launch_bounds__(256) void lsim_k_relu_bwd_bias(const float* __restrict__ act, const float* __restrict__ grad, long batch, int n,
-                                                            float* __restrict__ grad_pre, float* __restrict__ partial) {
-    typedef float v4 __attribute__((ext_vector_type(4)));
-    const int tpr = n >> 2, rpp = 256 / tpr;                 // threads per row, rows per pass
-    const int tid = (int)threadIdx.x, rl = tid / tpr, c4 = tid - rl * tpr;
-    v4 sum = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (rl < rpp) {
-        const long r0 = (long)blockIdx.x * LS_RB_ROWS;
-        long rend = r0 + LS_RB_ROWS;
-        if (rend > batch) rend = batch;
-        for (long r = r0 + rl; r < rend; r += rpp) {
-            const v4 a = ((const v4*)(act + r * n))[c4];
-            const v4 g = ((const v4*)(grad + r * n))[c4];
-            v4 y = {a.x > 0.0f ? g.x : 0.0f, a.y > 0.0f ? g.y : 0.0f, a.z > 0.0f ? g.z : 0.0f, a.w > 0.0f ? g.w : 0.0f};
-            if (grad_pre) ((v4*)(grad_pre + r * n))[c4] = y;
-            sum += y;
-        }
-        if (partial) ((v4*)(partial + ((long)blockIdx.x * rpp + rl) * n))[c4] = sum;
-    }
-}
-__global__ __launch_bounds__(256) void lsim_k_colsum_finish(const float* __restrict__ partial, long parts, int n, float* __restrict__ out) {
-    const int c = (int)(blockIdx.x * 256 + threadIdx.x);
-    if (c >= n) return;
-    float s = 0.0f;
-    for (long p = 0; p < parts; ++p) s += partial[p * n + c];
-    out[c] = s;
-}
-static long ls_rb_parts(long batch, int n) { return ((batch + LS_RB_ROWS - 1) / LS_RB_ROWS) * (256 / (n >> 2)); }
-extern "C" int lsim_relu_backward_bias_workspace(int64_t batch, int n, size_t* bytes) {
-    if (!bytes || batch <= 0 || n <= 0 || (n & 3) || n > 1024) return LSIM_E_UNSUPPORTED;
-    *bytes = (size_t)ls_rb_parts(batch, n) * (size_t)n * sizeof(float);
-    return LSIM_OK;
-}
-extern "C" int lsim_relu_backward_bias(const float* act_out, const float* grad_out, int64_t batch, int n, float* grad_pre, float* db,
-                                       void* workspace, size_t workspace_bytes, void* stream) {
-    size_t need = 0;
-    int rc = lsim_relu_backward_bias_workspace(batch, n, &need);
-    if (rc != LSIM_OK) return rc;
-    if (!act_out || !grad_out || (!grad_pre && !db)) return LSIM_E_INVALID;
-    if (db && (!workspace || workspace_bytes < need)) return LSIM_E_INVALID;
-    if ((((uintptr_t)act_out | (uintptr_t)grad_out | (uintptr_t)grad_pre | (uintptr_t)workspace) & 15)) return LSIM_E_INVALID;
-    const long blocks = (batch + LS_RB_ROWS - 1) / LS_RB_ROWS;
-    hipLaunchKernelGGL(lsim_k_relu_bwd_bias, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, act_out, grad_out, (long)batch, n, grad_pre,
-                       db ? (float*)workspace : (float*)nullptr);
-    if (db) hipLaunchKernelGGL(lsim_k_colsum_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace,
-                               ls_rb_parts(batch, n), n, db);
-    return hipGetLastError() == hipSuccess ? LSIM_OK : LSIM_E_HIP;
-}
-
 // ---- Sinkhorn-Knopp assignment of HIMEstimator (HES:119-133): Q = exp(scores / eps)^T, then `iters` x {rows sum to 1/K, columns
 // sum to 1/B}, returned as (Q * B)^T.  Every step of the reference only rescales rows (one factor per prototype) or columns (one
 // factor per sample), so Q[k, b] = E[b, k] * u[k] * v[b] with E = exp(scores / eps) throughout (the initial division by the total

@@ -218,12 +218,7 @@ class _GradPenFn(autograd.Function):
         dW1 = u1.t() @ dg                                   # g = u1 W1
         du1 = tb(dg @ W1.t(), a1, 0.0)                      # through the mask m1 (a constant)
         dW2 = u2.t() @ du1                                  # u1 = m1 * (u2 W2)
-        t = du1 @ W2.t()
-        fused = None
-        if t.is_cuda:
-            from .fused_linear import relu_backward_bias_hip
-            fused = relu_backward_bias_hip(z2, t, want_grad=False)
-        dw3 = fused[1].unsqueeze(0) if fused is not None else tb(t, z2, 0.0).sum(dim=0, keepdim=True)   # u2 = m2 * w3
+        dw3 = tb(du1 @ W2.t(), z2, 0.0).sum(dim=0, keepdim=True)   # u2 = m2 * w3
         return None, dW1, None, dW2, None, dw3, None
 
 
@@ -241,17 +236,9 @@ class _LinearReluFn(autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, weight, z = ctx.saved_tensors
-        fused = None
-        if g.is_cuda and g.dtype == torch.float32:
-            from .fused_linear import relu_backward_bias_hip
-            fused = relu_backward_bias_hip(z, g.contiguous())      # mask and bias gradient in one pass (lsim_relu_backward_bias)
-        if fused is not None:
-            gy, db = fused
-        else:
-            gy = torch.ops.aten.threshold_backward(g, z, 0.0)  # relu's own backward kernel on the saved OUTPUT (z > 0 <=> pre-activation > 0)
-            db = gy.sum(dim=0)
+        gy = torch.ops.aten.threshold_backward(g, z, 0.0)      # relu's own backward kernel on the saved OUTPUT (z > 0 <=> pre-activation > 0)
         gx = gy @ weight if ctx.needs_input_grad[0] else None
-        return gx, gy.t() @ x, db
+        return gx, gy.t() @ x, gy.sum(dim=0)
 
 
 def _trunk_fused(trunk, x):

@@ -149,25 +149,6 @@ class SkinnyLinear(nn.Linear):
         return F.linear(x, self.weight, self.bias)
 
 
-def relu_backward_bias_hip(act_out, grad_out, want_grad=True, want_bias=True):
-    """(grad_pre, db) of a ReLU in front of a Linear layer's bias through lsim_relu_backward_bias (one pass); None when the shape is one the
-    library leaves to torch (the caller then runs threshold_backward + sum)"""
-    from .. import lib
-    L = lib.load()
-    batch, n = act_out.shape
-    need = ctypes.c_size_t()
-    if (not (act_out.is_contiguous() and grad_out.is_contiguous())
-            or L.lsim_relu_backward_bias_workspace(batch, n, ctypes.byref(need)) != 0):
-        return None
-    ws = _workspace("relu_bwd", act_out.device, need.value)
-    gy = torch.empty_like(grad_out) if want_grad else None
-    db = torch.empty(n, device=act_out.device, dtype=torch.float32) if want_bias else None
-    lib.check(L.lsim_relu_backward_bias(act_out.data_ptr(), grad_out.data_ptr(), batch, n, gy.data_ptr() if gy is not None else None,
-                                        db.data_ptr() if db is not None else None, ws.data_ptr(), ws.numel(),
-                                        torch.cuda.current_stream(act_out.device).cuda_stream), what="lsim_relu_backward_bias")
-    return gy, db
-
-
 def sinkhorn_hip(scores, eps, iters):
     """HIMEstimator's Sinkhorn-Knopp assignment through lsim_sinkhorn (same arithmetic as modules.sinkhorn, factored as E * u[k] * v[b])"""
     from .. import lib

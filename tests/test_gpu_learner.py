@@ -817,24 +817,3 @@ def test_play_style_loop_runs_on_the_env_surface():
             keep = torch.ones(50, dtype=torch.bool, device=env.device); keep[[3, 17, 42]] = False
             assert torch.equal(env.episode_length_buf[keep], ep[keep])
     assert not bool(env.reset_buf.all())
-
-
-@pytest.mark.parametrize("batch,n", [(102400, 1024), (102400, 512), (1000, 240), (777, 64), (5, 4)])
-def test_fused_relu_backward_bias_matches_torch(batch, n):
-    """lsim_relu_backward_bias (the AMP discriminator's ReLU backward + bias gradient in one pass) against aten's threshold_backward + sum:
-    the masked gradient bit for bit, the column sums to fp32 summation order; unsupported widths are left to torch"""
-    from isaacgymloco_amd.learn.fused_linear import relu_backward_bias_hip
-    g = torch.Generator(device="cuda:0").manual_seed(batch + n)
-    act = torch.relu(torch.randn(batch, n, device="cuda:0", generator=g))
-    grad = torch.randn(batch, n, device="cuda:0", generator=g)
-    want = torch.ops.aten.threshold_backward(grad, act, 0.0)
-    gy, db = relu_backward_bias_hip(act, grad)
-    assert torch.equal(gy, want)
-    ref = want.double().sum(0)
-    scale = float(want.abs().double().sum(0).max())
-    assert float((db.double() - ref).abs().max()) <= 2e-6 * scale
-    only_db = relu_backward_bias_hip(act, grad, want_grad=False)
-    assert only_db[0] is None and torch.equal(only_db[1], db)          # same partial sums, same order: deterministic
-    assert torch.equal(relu_backward_bias_hip(act, grad)[1], db)
-    assert relu_backward_bias_hip(act[:, :n - 1].contiguous(), grad[:, :n - 1].contiguous()) is None or (n - 1) % 4 == 0
-    assert relu_backward_bias_hip(torch.zeros(8, 2048, device="cuda:0"), torch.zeros(8, 2048, device="cuda:0")) is None
