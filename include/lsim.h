@@ -33,7 +33,8 @@
 extern "C" {
 #endif
 
-#define LSIM_ABI_VERSION 3   /* 2: LSIM_BUF_CONTACT_COUNT, fixed-point words in LSIM_BUF_STATS (round 2); 3: LSIM_BUF_SUBSTEP_TORQUES (round 3) */
+#define LSIM_ABI_VERSION 4   /* 2: LSIM_BUF_CONTACT_COUNT, fixed-point words in LSIM_BUF_STATS (round 2); 3: LSIM_BUF_SUBSTEP_TORQUES (round 3);
+                                 4: lsim_config.solver_type / num_position_iterations out of the reserved words (round 4) */
 
 /* ---- fixed sizes of the robot family on this path (12-DoF quadrupeds) ---- */
 #define LSIM_NUM_DOF 12
@@ -55,6 +56,9 @@ extern "C" {
 #ifndef LSIM_MAX_CONTACTS      /* the CPU oracle can be compiled with a larger cap to measure what the cap costs (tests/test_contact_cap.py) */
 #define LSIM_MAX_CONTACTS 8
 #endif
+#define LSIM_MAX_POSITION_ITERATIONS 12   /* solver_type 1: sub-iterations per sim_dt (the reference sets 4, LRC:246) */
+#define LSIM_SOLVER_PGS 0
+#define LSIM_SOLVER_TGS 1
 #define LSIM_TERRAIN_LEVELS_MAX 32
 #define LSIM_TERRAIN_TYPES_MAX 32
 
@@ -267,11 +271,17 @@ typedef struct lsim_config {
 
     /* simulator (LRC:238-255); the solver is the build's own (DESIGN.md "Physics") */
     float gravity[3];
-    int32_t solver_iterations;
+    int32_t solver_iterations;      /* sweeps of the velocity-level Gauss-Seidel solver (solver_type 0) */
     float contact_offset, max_depenetration_velocity, erp, contact_slop;
     int32_t using_amp;              /* LRC:36: step() also produces terminal AMP states */
     float max_linear_velocity, max_angular_velocity;   /* asset options LRC:229-230 (1000 / 1000): PhysX clamps body velocities there */
-    int32_t reserved[6];
+    /* cfg.sim.physx.solver_type (LRC:245): 0 = PGS -- `solver_iterations` velocity-level sweeps over the whole sim_dt;
+       1 = TGS (Temporal Gauss-Seidel, what every reference config sets) -- the sim_dt is split into `num_position_iterations`
+       sub-iterations (LRC:246; 1..LSIM_MAX_POSITION_ITERATIONS), each relaxes every row once against the positional error reached
+       so far.  num_velocity_iterations (LRC:247) is 0 in the reference and not modelled. */
+    int32_t solver_type;
+    int32_t num_position_iterations;
+    int32_t reserved[4];
 } lsim_config;
 
 /* ---- device buffers.  Shapes are per handle (N = num_envs); dtype codes below. ---- */

@@ -40,6 +40,8 @@ static int ls_check_cfg(const lsim_config* c) {
     if (c->measure_heights && c->num_points_x * c->num_points_y != LSIM_NUM_HEIGHT_PTS) return LSIM_E_INVALID;
     if (c->resampling_steps <= 0 || c->max_episode_length <= 0) return LSIM_E_INVALID;
     if (c->terrain_num_rows > LSIM_TERRAIN_LEVELS_MAX || c->terrain_num_cols > LSIM_TERRAIN_TYPES_MAX) return LSIM_E_INVALID;
+    if (c->solver_type != LSIM_SOLVER_PGS && c->solver_type != LSIM_SOLVER_TGS) return LSIM_E_INVALID;
+    if (c->solver_type == LSIM_SOLVER_TGS && (c->num_position_iterations < 1 || c->num_position_iterations > LSIM_MAX_POSITION_ITERATIONS)) return LSIM_E_INVALID;
     return LSIM_OK;
 }
 

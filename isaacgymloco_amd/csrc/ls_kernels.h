@@ -245,9 +245,11 @@ LS_FN void ph_term_outputs(const LsCtx& cx, WaveShared& sh, int lane, int env, c
     }
 }
 
-LS_WAVE_FN void ls_wave_step_a(const LsCtx& cx, const LsStepArgs& a, const int env, WaveShared& sh, LS_LANES_PARAM) {
+// SOLVER: LSIM_SOLVER_PGS / LSIM_SOLVER_TGS (lsim_config.solver_type), a template parameter so that each kernel carries one solver's code
+template <int SOLVER> LS_WAVE_FN void ls_wave_step_a(const LsCtx& cx, const LsStepArgs& a, const int env, WaveShared& sh, LS_LANES_PARAM) {
     const lsim_config& c = cx.cfg;
     const float dt = c.sim_dt;
+    constexpr bool TGS = SOLVER == LSIM_SOLVER_TGS;
     const bool skip = (a.flags & LSIM_STEP_SKIP_PHYSICS) != 0;
     [[maybe_unused]] constexpr int ls_line0 = __LINE__;   // phase-site ids (LS_PHASE_TIMING builds) count lines from here
     LS_TICK_INIT();
@@ -267,15 +269,18 @@ LS_WAVE_FN void ls_wave_step_a(const LsCtx& cx, const LsStepArgs& a, const int e
         LS_PHASE(ph_free_base(sh, lane));
         LS_PHASE(ph_free_finish(sh, lane, dt); ph_collide_prefetch(cx, rg, lane); ph_collide(cx, sh, rg, lane));
         LS_COLLECTIVE(wc_compact_contacts(sh, rg, lane); wc_limits(cx, sh, lane, dt), wc_compact_contacts(sh, L); LS_PHASE(ph_limits(cx, sh, lane, dt)));
-        LS_PHASE(ph_rows(cx, sh, rg, lane, dt));
+        LS_PHASE(ph_rows<TGS>(cx, sh, rg, lane, dt));
 #if defined(LS_EMU)
         LS_PHASE(ph_delassus(sh, rg, lane));
-        wc_pgs(sh, L, c.solver_iterations);
-        LS_PHASE(ph_apply_impulses(sh, lane); ph_contact_forces(sh, lane, dt));
+        if (TGS) { wc_tgs(cx, sh, L, c.num_position_iterations, dt); LS_PHASE(ph_contact_forces(sh, lane, dt)); }
+        else { wc_pgs(sh, L, c.solver_iterations); LS_PHASE(ph_apply_impulses(sh, lane); ph_contact_forces(sh, lane, dt)); }
 #else
-        LS_PHASE(wc_delassus_pgs(sh, rg, lane, c.solver_iterations, dt));      // rows, sweep, constrained velocity, contact forces
+        // rows, sweep(s), constrained velocity, contact forces
+        if constexpr (TGS) LS_PHASE(wc_delassus_tgs(cx, sh, rg, lane, c.num_position_iterations, dt));
+        else LS_PHASE(wc_delassus_pgs(sh, rg, lane, c.solver_iterations, dt));
 #endif
-        LS_PHASE(ph_integrate(cx, sh, lane, dt));
+        if (TGS) LS_PHASE(ph_integrate_tgs(cx, sh, lane, dt, c.num_position_iterations));
+        else LS_PHASE(ph_integrate(cx, sh, lane, dt));
 #if defined(LS_EXP_TWICE) && LS_EXP_TWICE == 9001      // cost probe: the integrator again with a zero step (leaves the state where it is)
         LS_PHASE(ph_integrate(cx, sh, lane, 0.0f));
 #endif

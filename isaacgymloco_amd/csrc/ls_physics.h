@@ -11,6 +11,8 @@
 // Lane roles per phase:  K: leg chain (lanes 0-3)   B: body (0-16)   L: leg (0-3)   E: matrix element (0-41)
 //                        P: collision point (0-55)  R: constraint row (0-59)        V: generalized velocity (0-17)
 #pragma once
+#include <stddef.h>
+
 #include "ls_shared.h"
 
 LS_FN int ls_leg_of_body(int b) { return (b - 1) >> 2; }   // b >= 1
@@ -556,6 +558,10 @@ LS_FN void wc_compact_contacts(WaveShared& sh, LaneRegs& r, int lane) {
 //      needing joints alone fail tests/test_physics_invariants.py's saturated-motor case: the kicked neighbours run into the 1.5 x safety clamp,
 //      which is not momentum-neutral.]  [Clamping the joint velocity after the solve instead leaves the reaction of a saturated motor torque
 //      on the base and spins up a robot in free flight.]
+//      The rows are laid out in DESCENDING joint order (calf, thigh, hip of the last leg first: leaf to root within a leg).  The sweep relaxes
+//      slots in ascending order, and a Gauss-Seidel pass that goes leaf to root leaves about a third of the residue of the opposite order on a
+//      saturated leg (round 4, oracle: with TGS's single pass per iteration the joint speed exceeded 1.1 x its limit in 2.7 % instead of 19 % of
+//      the steps of the saturated-motor invariant).
 //      GPU: lane = joint, ordered compaction by ballot; lane emulator: lane 0 walks the joints (same order, same result)
 #define LS_LIMIT_MARGIN 0.2f    // a joint "needs" its row when the free velocity is within this fraction of vmax of a bound (or beyond it)
 LS_FN bool ls_joint_limit_bounds(const LsCtx& cx, const WaveShared& sh, int j, float dt, float& Lb, float& Ub, bool& violates) {
@@ -577,8 +583,8 @@ LS_FN void wc_limits(const LsCtx& cx, WaveShared& sh, int lane, float dt) {
     const unsigned long long mviol = __ballot(viol);
     const bool has = need || (lane < 12 && ((mviol >> (3 * (lane / 3))) & 7ull) != 0ull);     // own need, or a violating joint on this leg
     const unsigned long long m = __ballot(has);
-    if (has) {
-        const int rank = __popcll(m & ((1ull << lane) - 1ull));
+    if (has) {      // rows in DESCENDING joint order (leaf to root within a leg: see the comment above): rank = rows of the joints above this one
+        const int rank = __popcll(m >> (lane + 1));
         sh.limdof[rank] = lane; sh.limvt[rank] = Lb; sh.limrng[rank] = Ub - Lb;
     }
     if (lane == 0) { const int n = __popcll(m); sh.nlim = n; sh.nrows = 3 * sh.nc + n; }
@@ -587,11 +593,11 @@ LS_FN void wc_limits(const LsCtx& cx, WaveShared& sh, int lane, float dt) {
 LS_FN void ph_limits(const LsCtx& cx, WaveShared& sh, int lane, float dt) {
     if (lane != 0) return;
     int n = 0;
-    for (int leg = 0; leg < 4; ++leg) {
+    for (int leg = 3; leg >= 0; --leg) {
         float Lb[3], Ub[3];
         bool need[3], viol[3], any_viol = false;
         for (int k = 0; k < 3; ++k) { need[k] = ls_joint_limit_bounds(cx, sh, 3 * leg + k, dt, Lb[k], Ub[k], viol[k]); any_viol = any_viol || viol[k]; }
-        for (int k = 0; k < 3; ++k) {
+        for (int k = 2; k >= 0; --k) {
             if (!(need[k] || any_viol)) continue;
             sh.limdof[n] = 3 * leg + k; sh.limvt[n] = Lb[k]; sh.limrng[n] = Ub[k] - Lb[k]; ++n;
         }
@@ -601,12 +607,13 @@ LS_FN void ph_limits(const LsCtx& cx, WaveShared& sh, int lane, float dt) {
 }
 
 // ---- phase R1: constraint row Jacobian, Y = M^-1 J^T (structured solve), right-hand side (lane = row)
-LS_FN void ph_rows(const LsCtx& cx, WaveShared& sh, LaneRegs& r, int lane, float dt) {
+template <bool TGS> LS_FN void ph_rows(const LsCtx& cx, WaveShared& sh, LaneRegs& r, int lane, float dt) {
     r.row_kind = -1;
     r.row_rng = __builtin_inff();
     if (!ls_slot_active(sh, lane)) return;
     const lsim_config& c = cx.cfg;
     float vt, rng = __builtin_inff();     // rng: width of a two-sided row's velocity interval (joint limits), +inf for one-sided rows
+    float tg_a = 0.0f, tg_b = 0.0f;       // TGS: what the row's target is re-derived from in every sub-iteration
     int leg;
     float Jb[6] = {0, 0, 0, 0, 0, 0}, Jl[3] = {0, 0, 0};
     V3 d = v3(0, 0, 0);
@@ -628,6 +635,7 @@ LS_FN void ph_rows(const LsCtx& cx, WaveShared& sh, LaneRegs& r, int lane, float
         r.row_kind = a;
         if (a == 0) {
             float dist = sh.cdist[k];
+            tg_a = dist;
             const float idt = ls_rcp(dt);
             if (dist >= 0.0f) vt = -dist * idt;
             else vt = fminf(c.max_depenetration_velocity, c.erp * fmaxf(-dist - c.contact_slop, 0.0f) * idt);
@@ -639,6 +647,11 @@ LS_FN void ph_rows(const LsCtx& cx, WaveShared& sh, LaneRegs& r, int lane, float
         Jl[j - 3 * leg] = 1.0f;
         vt = sh.limvt[i];                 // lower velocity bound; the row is two-sided: the upper bound is limrng above it
         rng = sh.limrng[i];
+        if (TGS) {                        // the bounds move with the joint angle: hand over the distances to the stops and the velocity limit
+            rng = cx.model.dof_vel_limit[j];
+            tg_a = sh.q[j] - cx.model.dof_pos_lower[j];
+            tg_b = cx.model.dof_pos_upper[j] - sh.q[j];
+        }
         r.row_kind = 3;
     }
     r.row_leg = leg;
@@ -664,7 +677,10 @@ LS_FN void ph_rows(const LsCtx& cx, WaveShared& sh, LaneRegs& r, int lane, float
     float jv = 0.0f;
     for (int k = 0; k < 6; ++k) jv += Jb[k] * sh.vfree[k];
     if (leg >= 0) for (int k = 0; k < 3; ++k) jv += Jl[k] * sh.vfree[6 + 3 * leg + k];
-    r.brow = jv - vt;
+    if (TGS) {                            // the iterations start from the free velocity; the targets move with them
+        r.tg_a = tg_a; r.tg_b = tg_b;
+        r.brow = jv;
+    } else r.brow = jv - vt;
     r.row_rng = rng;
 }
 
@@ -689,6 +705,14 @@ LS_FN void ph_delassus(WaveShared& sh, LaneRegs& r, int lane) {
     r.wdiag = wd;
 }
 #endif
+
+// TGS (wc_delassus_tgs / wc_tgs below): where the solver parks what the integrator needs
+#define LS_VEL0 LS_MAXR
+LS_FN float* ls_tgs_base_twist(WaveShared& sh, int s) { return sh.Sb + 6 * s; }     // [LSIM_MAX_POSITION_ITERATIONS][6] over Sb + Sinv
+LS_FN float* ls_tgs_vel_sum(WaveShared& sh) { return &sh.legF[0][0]; }             // [18]: sum over the sub-iterations (legF is dead since the base assembly)
+static_assert(LS_VEL0 + LS_NV <= 64, "velocity lanes");
+static_assert(6 * LSIM_MAX_POSITION_ITERATIONS <= 72, "base twists of the sub-iterations in Sb + Sinv");
+static_assert(offsetof(WaveShared, Sinv) == offsetof(WaveShared, Sb) + 36 * sizeof(float), "Sb and Sinv are one 72-float block");
 
 // ---- wave collective: projected Gauss-Seidel sweep in impulse space
 //      w_i = b_i + sum_j W_ij lam_j is kept up to date by every lane; rows are relaxed in order r = 0..R-1.
@@ -823,8 +847,9 @@ template <int K0> __device__ __forceinline__ void ls_contact_force(const WaveSha
 #if !defined(LS_EMU)
 typedef float ls_v4f_t __attribute__((ext_vector_type(4)));
 LS_FN int ls_tile_row_of_slot(int slot) { return slot < 12 ? slot : (slot >= LS_LIM0 && slot < LS_LIM0 + 4 ? 12 + slot - LS_LIM0 : -1); }
+// vk >= 0 (TGS): the lane is a VELOCITY lane -- its "row" is the unit vector of generalized velocity vk, W[j] = Y[j][vk] (see wc_delassus_tgs)
 __device__ __forceinline__ void ls_delassus_mfma16(WaveShared& sh, int lane, bool act, int leg, const float (&jb)[6], float jl0, float jl1, float jl2,
-                                                   float (&W)[LS_MAXR], float& wd) {
+                                                   float (&W)[LS_MAXR], float& wd, int vk = -1) {
     float* Jd = &sh.R[0][0];                 // [16][18]
     float* Wt = Jd + 16 * 18;                // [16][17]
     static_assert(sizeof(sh.R) + sizeof(sh.p) + sizeof(sh.S) + sizeof(sh.V) + sizeof(sh.Ab) + sizeof(sh.Fb) >= (16 * 18 + 16 * 17) * sizeof(float), "scratch of the MFMA Delassus build");
@@ -851,11 +876,14 @@ __device__ __forceinline__ void ls_delassus_mfma16(WaveShared& sh, int lane, boo
 #pragma unroll
     for (int r = 0; r < 4; ++r) Wt[17 * (4 * kq + r) + r16] = acc[r] + ((4 * kq + r) == r16 ? 1e-6f : 0.0f);
     __syncthreads();
-    const float* row = Wt + 17 * (t >= 0 ? t : 0);
+    // a row lane reads its row of the D tile, a velocity lane column vk of Y at the 16 slots of the tile: one address pattern, 16 reads
+    const float* row = vk >= 0 ? &sh.u.c.Y[0][vk] : Wt + 17 * (t >= 0 ? t : 0);
+    const float* rowl = vk >= 0 ? &sh.u.c.Y[LS_LIM0][vk] : row + 12;
+    const int stride = vk >= 0 ? LS_NV : 1;
 #pragma unroll
-    for (int j = 0; j < 12; ++j) W[j] = row[j];
+    for (int j = 0; j < 12; ++j) W[j] = row[j * stride];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) W[LS_LIM0 + j] = row[12 + j];
+    for (int j = 0; j < 4; ++j) W[LS_LIM0 + j] = rowl[j * stride];
     W[LS_LIM0 + 4] = 0.0f; W[LS_LIM0 + 5] = 0.0f;     // the sweep relaxes limit slots in triples: slots past nlim must hold something finite
     if (act) wd = row[t];
     __syncthreads();                          // the scratch is the next phase's to overwrite only after every lane has read its row
@@ -924,6 +952,150 @@ LS_FN void wc_delassus_pgs(WaveShared& sh, const LaneRegs& rg, int lane, int ite
     }
     if (lane < LS_NB) v3st(sh.cf[lane], f);
 }
+
+// ==== Temporal Gauss-Seidel (lsim_config.solver_type 1: what the reference configures, LRC:245-247) =========================================
+// External forces act once, over the whole dt (the free velocity, as for PGS); the sim_dt is then split into nsub = num_position_iterations
+// sub-iterations of h = dt / nsub.  Each one (i) relaxes every row ONCE, in slot order, against a target re-derived from the configuration
+// reached so far (contact gap, distance of the joint to its stops), impulses accumulated and projected as totals, (ii) advances gaps, joints
+// and the base pose by h of the velocity it arrived at.  J and M^-1 J^T stay those of the start of the step (oracle/orc_physics.c, TGS
+// branch: same scheme, dense fp64; its comment says why the free acceleration is not ramped over the sub-iterations).  In this kernel's form a lane owns the VELOCITY u_i = J_i v of its row instead of a residual: a relaxation of slot R moves every
+// u_i by W_iR (new - old) -- the same two FMAs as in the PGS sweep -- and (ii)'s target and (iii)'s gap update are per-lane arithmetic on u_i
+// (the gap of a normal row advances by h u_i, a limit row's joint angle too: its J is a unit vector).
+// Lanes LS_VEL0 .. LS_VEL0 + 17 carry the generalized velocity itself the same way: lane LS_VEL0 + k holds "row" e_k, i.e. W[j] = Y[j][k], so
+// the sweep's FMAs keep the velocity change of the impulses up to date for free (these lanes idle in the PGS form) -- the apply pass at
+// the end of the PGS solver disappears, and the base twist after each sub-iteration, which the pose update needs, is one LDS store.
+LS_FN void wc_delassus_tgs(const LsCtx& cx, WaveShared& sh, const LaneRegs& rg, int lane, int nsub, float dt) {
+    const lsim_config& c = cx.cfg;
+    const int nc = LS_UNIFORM(sh.nc), nlim = LS_UNIFORM(sh.nlim);
+    const bool act = ls_slot_active(sh, lane);
+    const int vk = (lane >= LS_VEL0 && lane < LS_VEL0 + LS_NV) ? lane - LS_VEL0 : -1;
+    const int leg = rg.row_leg;
+    const bool has_leg = act && leg >= 0;
+    int lo = has_leg ? 6 + 3 * leg : 6;
+    float jl0 = has_leg ? rg.Jl[0] : 0.0f, jl1 = has_leg ? rg.Jl[1] : 0.0f, jl2 = has_leg ? rg.Jl[2] : 0.0f;
+    float jb[6];
+    for (int k = 0; k < 6; ++k) jb[k] = act ? rg.Jb[k] : 0.0f;
+    if (vk >= 0) {     // the FMA rows evaluate jb . Y[0..5] + jl . Y[lo..lo+2]: pick out component vk (lo + 2 must stay inside the 18-vector)
+        for (int k = 0; k < 6; ++k) jb[k] = vk == k ? 1.0f : 0.0f;
+        lo = vk < 6 ? 6 : (vk < 15 ? vk : 15);
+        jl0 = (vk >= 6 && vk - lo == 0) ? 1.0f : 0.0f; jl1 = vk - lo == 1 ? 1.0f : 0.0f; jl2 = vk - lo == 2 ? 1.0f : 0.0f;
+    }
+    float W[LS_MAXR];
+    float wd = 1.0f;
+#if !defined(LS_NO_DELASSUS_MFMA)
+    if (nc <= LS_DELASSUS_MFMA_NC && nlim <= 4) {
+        ls_delassus_mfma16(sh, lane, act, leg, jb, jl0, jl1, jl2, W, wd, vk);
+    } else
+#endif
+    {
+        ls_delassus_rows<0, LS_LIM0>(sh, 3 * nc, lane, lo, jb, jl0, jl1, jl2, W, wd);
+        ls_delassus_rows<LS_LIM0, LS_MAXR>(sh, LS_LIM0 + nlim, lane, lo, jb, jl0, jl1, jl2, W, wd);
+    }
+    const float inv_d = act ? ls_rcp(wd) : 0.0f;
+    const float cf = sh.mu;
+    const float hs = dt * ls_rcp((float)nsub), ihs = (float)nsub * ls_rcp(dt);
+    const bool is_normal = rg.row_kind == 0, is_limit = rg.row_kind == 3;     // -1 on every lane that holds no row
+    float u = act ? rg.brow : 0.0f;                                           // row velocity J v, starting from J vfree (velocity lanes: the change of v_k by the impulses)
+    float ga = rg.tg_a, gb = rg.tg_b;
+    const float vmax = rg.row_rng;
+    float vsum = 0.0f;
+    float sl[LS_MAXR] = {};                                                   // the accumulated impulses: wave-uniform, scalar registers
+    for (int s = 0; s < nsub; ++s) {
+        // targets from the configuration reached so far (every lane evaluates both forms; selects, no branches)
+        const float tn = ga >= 0.0f ? -ga * ihs : fminf(c.max_depenetration_velocity, c.erp * fmaxf(-ga - c.contact_slop, 0.0f) * ihs);
+        float Lb = -vmax, Ub = vmax;
+        if (ga < 0.1f) Lb = fmaxf(Lb, ga >= 0.0f ? -ga * ihs : fminf(1.0f, c.erp * (-ga) * ihs));
+        if (gb < 0.1f) Ub = fminf(Ub, gb >= 0.0f ? gb * ihs : -fminf(1.0f, c.erp * (-gb) * ihs));
+        Ub = fmaxf(Ub, Lb);
+        const float tgt = is_normal ? tn : (is_limit ? Lb : 0.0f);
+        const float neg_rng_d = is_limit ? -((Ub - Lb) * inv_d) : 0.0f;
+        float w = u - tgt;
+        int nc_it = nc, nlim_it = nlim;                                       // re-materialised per sweep (see wc_delassus_pgs)
+        asm volatile("" : "+s"(nc_it), "+s"(nlim_it));
+        ls_pgs_contacts<0>(nc_it, W, sl, cf, inv_d, w);
+        ls_pgs_limits<0>(nlim_it, W, sl, inv_d, neg_rng_d, w);
+        u = w + tgt;
+        const float adv = hs * u;
+        ga += adv; gb -= adv;
+        if (vk >= 0) {
+            vsum += u;
+            if (vk < 6) ls_tgs_base_twist(sh, s)[vk] = u;
+        }
+    }
+    const float idt = ls_rcp(dt);
+    V3 f = v3(0, 0, 0);
+    if (lane < LS_NB) ls_contact_force<0>(sh, sl, nc, lane, idt, f);
+    if (vk >= 0) {
+        if (vk < 6) sh.ab[vk] = u;                      // base twist change: the integrator applies the coupling - G_l dvb to the joints
+        sh.vnew[vk] = sh.vfree[vk] + u;
+        ls_tgs_vel_sum(sh)[vk] = vsum;
+    }
+    if (lane < LS_NB) v3st(sh.cf[lane], f);
+}
+#endif
+
+#if defined(LS_EMU)
+// lane emulator: the same scheme with the rows' data in arrays (rows relaxed in slot order, fp32, the GPU form's two FMAs per update)
+static inline void wc_tgs(const LsCtx& cx, WaveShared& sh, LaneRegs* L, int nsub, float dt) {
+    const lsim_config& c = cx.cfg;
+    const int R = LS_MAXR;
+    const float hs = dt * ls_rcp((float)nsub), ihs = (float)nsub * ls_rcp(dt);
+    float lam[LS_MAXR], u[LS_MAXR], ga[LS_MAXR], gb[LS_MAXR], w[LS_MAXR], tgt[LS_MAXR], nrd[LS_MAXR], dv[LS_NV], vsum[LS_NV];
+    bool act[LS_MAXR];
+    for (int i = 0; i < R; ++i) {
+        act[i] = ls_slot_active(sh, i);
+        lam[i] = 0.0f; w[i] = 0.0f; tgt[i] = 0.0f; nrd[i] = 0.0f;
+        u[i] = act[i] ? L[i].brow : 0.0f;
+        ga[i] = act[i] ? L[i].tg_a : 0.0f; gb[i] = act[i] ? L[i].tg_b : 0.0f;
+    }
+    for (int k = 0; k < LS_NV; ++k) { dv[k] = 0.0f; vsum[k] = 0.0f; }
+    for (int s = 0; s < nsub; ++s) {
+        for (int i = 0; i < R; ++i) {
+            if (!act[i]) continue;
+            const int kind = L[i].row_kind;
+            float t = 0.0f;
+            nrd[i] = 0.0f;
+            if (kind == 0) t = ga[i] >= 0.0f ? -ga[i] * ihs : fminf(c.max_depenetration_velocity, c.erp * fmaxf(-ga[i] - c.contact_slop, 0.0f) * ihs);
+            else if (kind == 3) {
+                const float vmax = L[i].row_rng;
+                float Lb = -vmax, Ub = vmax;
+                if (ga[i] < 0.1f) Lb = fmaxf(Lb, ga[i] >= 0.0f ? -ga[i] * ihs : fminf(1.0f, c.erp * (-ga[i]) * ihs));
+                if (gb[i] < 0.1f) Ub = fminf(Ub, gb[i] >= 0.0f ? gb[i] * ihs : -fminf(1.0f, c.erp * (-gb[i]) * ihs));
+                Ub = fmaxf(Ub, Lb);
+                t = Lb;
+                nrd[i] = (Ub - Lb) / L[i].wdiag;
+            }
+            tgt[i] = t;
+            w[i] = u[i] - t;
+        }
+        for (int r = 0; r < R; ++r) {
+            if (!act[r]) continue;
+            float nl = lam[r] - w[r] / L[r].wdiag;
+            const int kind = L[r].row_kind;
+            if (kind == 0) nl = fmaxf(nl, 0.0f);
+            else if (kind == 3) nl = fmaxf(nl, 0.0f) + fminf(nl + nrd[r], 0.0f);
+            else { float lim = sh.mu * lam[r - kind]; nl = clampf(nl, -lim, lim); }
+            const float old = lam[r];
+            lam[r] = nl;
+            for (int i = 0; i < R; ++i) if (act[i]) w[i] = fmaf(L[i].W[r], nl, fmaf(-L[i].W[r], old, w[i]));
+            for (int k = 0; k < LS_NV; ++k) dv[k] = fmaf(sh.u.c.Y[r][k], nl, fmaf(-sh.u.c.Y[r][k], old, dv[k]));
+        }
+        for (int i = 0; i < R; ++i) {
+            if (!act[i]) continue;
+            u[i] = w[i] + tgt[i];
+            const float adv = hs * u[i];
+            ga[i] += adv; gb[i] -= adv;
+        }
+        for (int k = 0; k < LS_NV; ++k) vsum[k] += dv[k];
+        for (int k = 0; k < 6; ++k) ls_tgs_base_twist(sh, s)[k] = dv[k];
+    }
+    for (int i = 0; i < R; ++i) if (act[i]) sh.lam[i] = lam[i];
+    for (int k = 0; k < LS_NV; ++k) {
+        if (k < 6) sh.ab[k] = dv[k];
+        sh.vnew[k] = sh.vfree[k] + dv[k];
+        ls_tgs_vel_sum(sh)[k] = vsum[k];
+    }
+}
 #endif
 
 // ---- phase V (lane emulator; the GPU does this at the end of wc_delassus_pgs): constrained velocity v+ = vfree + M^-1 J^T lam from the
@@ -983,6 +1155,50 @@ LS_FN void ph_integrate(const LsCtx& cx, WaveShared& sh, int lane, float dt) {
         q[0] = n0 * nn; q[1] = n1 * nn; q[2] = n2 * nn; q[3] = n3 * nn;
         sh.root[0] += dp.x; sh.root[1] += dp.y; sh.root[2] += dp.z;
         v3st(sh.root + 7, vo);
+        v3st(sh.root + 10, w);
+    }
+}
+
+// ---- TGS form of the integrator: the configuration advanced with the sub-iterations, so the joint angles take the SUM of the velocities of
+//      the sub-iterations -- sub-iteration s runs at  vfree + (impulse part after its sweep) -- and the base pose is stepped through the n
+//      twists the solver parked (lanes 0-11 joints, lane 12 base)
+LS_FN void ph_integrate_tgs(const LsCtx& cx, WaveShared& sh, int lane, float dt, int nsub) {
+    const float hs = dt * ls_rcp((float)nsub);
+    if (lane < 12) {
+        const float lim = 1.5f * cx.model.dof_vel_limit[lane];     // bounds solver residue on the velocity the step hands on (as the PGS form)
+        const int l = lane / 3, k = lane - 3 * l;
+        const float* vs = ls_tgs_vel_sum(sh);
+        float vj = sh.vnew[6 + lane], sj = vs[6 + lane];
+        for (int c = 0; c < 6; ++c) { const float g = sh.G[l][6 * k + c]; vj -= g * sh.ab[c]; sj -= g * vs[c]; }   // - G_l dvb: base impulse response
+        sh.q[lane] += dt * sh.vfree[6 + lane] + hs * sj;
+        sh.qd[lane] = clampf(vj, -lim, lim);
+    } else if (lane == 12) {
+        const V3 wf = v3p(sh.vfree), vf = v3p(sh.vfree + 3);
+        float* q = sh.root + 3;
+        const float qn = ls_rsqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+        float q0 = q[0] * qn, q1 = q[1] * qn, q2 = q[2] * qn, q3 = q[3] * qn;
+        V3 dp = v3(0, 0, 0), w = wf, vl = vf;
+        const float h = 0.5f * hs;
+        for (int s = 0; s < nsub; ++s) {
+            const float* tb = ls_tgs_base_twist(sh, s);
+            w = wf + v3p(tb);
+            vl = vf + v3p(tb + 3);                // velocity of the point of the base that sat at the base origin at the start of the step
+            dp = dp + (vl + cross(w, dp)) * hs;
+            const float n0 = q0 + h * (w.x * q3 + w.y * q2 - w.z * q1);
+            const float n1 = q1 + h * (-w.x * q2 + w.y * q3 + w.z * q0);
+            const float n2 = q2 + h * (w.x * q1 - w.y * q0 + w.z * q3);
+            const float n3 = q3 + h * (-w.x * q0 - w.y * q1 - w.z * q2);
+            const float nn = ls_rsqrt(n0 * n0 + n1 * n1 + n2 * n2 + n3 * n3);
+            q0 = n0 * nn; q1 = n1 * nn; q2 = n2 * nn; q3 = n3 * nn;
+        }
+        {   // body velocity caps of the asset options (LRC:229-230), on the velocity the step hands on
+            const float wn = sqrtf(dot(w, w)), ln = sqrtf(dot(vl, vl));
+            if (cx.cfg.max_angular_velocity > 0.0f && wn > cx.cfg.max_angular_velocity) w = w * (cx.cfg.max_angular_velocity * ls_rcp(wn));
+            if (cx.cfg.max_linear_velocity > 0.0f && ln > cx.cfg.max_linear_velocity) vl = vl * (cx.cfg.max_linear_velocity * ls_rcp(ln));
+        }
+        q[0] = q0; q[1] = q1; q[2] = q2; q[3] = q3;
+        sh.root[0] += dp.x; sh.root[1] += dp.y; sh.root[2] += dp.z;
+        v3st(sh.root + 7, vl + cross(w, dp));
         v3st(sh.root + 10, w);
     }
 }

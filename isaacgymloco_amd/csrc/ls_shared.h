@@ -134,6 +134,8 @@ struct WaveShared {
     float yl[4][3];
     float Sb[36];            // Schur complement on the base
     float Sinv[36];          // its inverse (symmetric), from the Cholesky factor: every later solve is a 6x6 mat-vec
+                             // (TGS: both are dead once the rows are built; the solver parks the base twist change of the impulses after
+                             //  each sub-iteration in these 72 floats for the integrator -- ls_tgs_base_twist)
     float hb[6], rb[6], ab[6];
     float vfree[LS_NV], vnew[LS_NV];
     // ---- contacts
@@ -169,8 +171,9 @@ struct LaneRegs {
     int row_kind;            // 0 normal, 1/2 friction, 3 joint limit, -1 none
     int row_leg;             // leg whose dofs the row touches, -1 for the base body
     float Jb[6], Jl[3];
-    float brow, wdiag;
-    float row_rng;           // width of a two-sided row's interval (+inf: one-sided)
+    float brow, wdiag;       // PGS: right-hand side J vfree - target;  TGS: J vfree (the targets move with the sub-iterations)
+    float row_rng;           // PGS: width of a two-sided row's interval (+inf: one-sided);  TGS: the joint's velocity limit (limit rows)
+    float tg_a, tg_b;        // TGS: normal row -- the contact's gap;  limit row -- the joint's distances to its lower / upper stop
     int ticket;              // kernel B, lane 0: this env's ticket among the envs that reset in this step (-1: none)
 #if defined(LS_EMU)
     float W[LS_MAXR];        // Delassus row (the GPU path keeps it local to wc_delassus_pgs)

@@ -31,13 +31,18 @@ __device__ __forceinline__ int ls_env_of_block(int b, int num_envs) {
 // Kernel A is bound by per-wave latency (dependent VALU chains, LDS round trips at ~19 phase boundaries per sub-step):
 // 4 waves per SIMD (<= 128 VGPRs, no scratch) beat 1-2 waves with more registers by 1.35x at N = 4096, where 4 waves/SIMD is also exactly
 // the whole batch resident at once (4096 waves / 1024 SIMDs; the 9.6 KB LDS struct allows 16 blocks per CU).
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void lsim_k_step_a(const LsCtx* __restrict__ ctx, LsStepArgs a) {
-    __shared__ WaveShared sh;
-    const int env = ls_env_of_block((int)blockIdx.x, ctx->cfg.num_envs);
-    if (env >= ctx->cfg.num_envs) return;
-    LaneRegs rg;
-    ls_wave_step_a(*ctx, a, env, sh, rg, (int)threadIdx.x);
+// One kernel per solver (lsim_config.solver_type: the host picks at launch), so that neither carries the other's code: lsim_k_step_a_tgs is
+// what every reference config runs (LRC:245), lsim_k_step_a_pgs the build's earlier velocity-level solver.
+#define LS_KERNEL_A(name, SOLVER) \
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void name(const LsCtx* __restrict__ ctx, LsStepArgs a) { \
+    __shared__ WaveShared sh; \
+    const int env = ls_env_of_block((int)blockIdx.x, ctx->cfg.num_envs); \
+    if (env >= ctx->cfg.num_envs) return; \
+    LaneRegs rg; \
+    ls_wave_step_a<SOLVER>(*ctx, a, env, sh, rg, (int)threadIdx.x); \
 }
+LS_KERNEL_A(lsim_k_step_a_pgs, LSIM_SOLVER_PGS)
+LS_KERNEL_A(lsim_k_step_a_tgs, LSIM_SOLVER_TGS)
 
 __global__ __launch_bounds__(64) void lsim_k_step_b(const LsCtx* __restrict__ ctx, LsStepArgs a) {
     __shared__ WaveShared sh;
@@ -78,7 +83,8 @@ __global__ __launch_bounds__(256) void lsim_k_track_sum(const LsCtx* __restrict_
 static int ls_grid(const lsim_sim* s) { return 8 * ((s->cfg.num_envs + 7) / 8); }
 
 static int lsbk_launch_a(lsim_sim* s, const LsStepArgs& a, void* stream) {
-    hipLaunchKernelGGL(lsim_k_step_a, dim3(ls_grid(s)), dim3(64), 0, (hipStream_t)stream, (const LsCtx*)s->dev_ctx, a);
+    if (s->cfg.solver_type == LSIM_SOLVER_TGS) hipLaunchKernelGGL(lsim_k_step_a_tgs, dim3(ls_grid(s)), dim3(64), 0, (hipStream_t)stream, (const LsCtx*)s->dev_ctx, a);
+    else hipLaunchKernelGGL(lsim_k_step_a_pgs, dim3(ls_grid(s)), dim3(64), 0, (hipStream_t)stream, (const LsCtx*)s->dev_ctx, a);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 static int lsbk_launch_b(lsim_sim* s, const LsStepArgs& a, void* stream) {

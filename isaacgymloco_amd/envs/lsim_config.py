@@ -3,6 +3,7 @@ into the C-ABI `lsim_config` struct, performing the same derived-value arithmeti
 at construction time (LeggedRobot._parse_cfg LR:1252-1263, _init_buffers LR:913-1032,
 _prepare_reward_function LR:1035-1059, __init__ LR:70-90) in Python double precision."""
 import math
+import os
 
 import numpy as np
 
@@ -12,8 +13,12 @@ from ..robots import aliengo
 MESH_TYPES = {"plane": 0, "heightfield": 1, "trimesh": 2}
 CONTROL_TYPES = {"P": 0, "V": 1, "T": 2}
 
-# solver parameters of the build's own physics (DESIGN.md "Physics"); PhysX counterparts in LRC:238-255
+# Solver parameters with no counterpart in the reference's config.  The solver itself follows cfg.sim.physx
+# (LRC:245-247): solver_type 1 = TGS with num_position_iterations sub-iterations (every reference config), solver_type 0 = PGS -- there
+# `solver_iterations` velocity-level sweeps (PhysX's own PGS counts are not comparable: its rows are relaxed per body pair).
+# LSIM_SOLVER=pgs / tgs overrides the config (A/B measurements, tools/).
 SOLVER_DEFAULTS = dict(solver_iterations=8, erp=0.2, contact_slop=0.001)
+SOLVER_TYPES = {"pgs": 0, "tgs": 1}
 
 
 def _get(node, name, default=None):
@@ -175,6 +180,19 @@ def make_lsim_config(cfg, num_envs=None, terrain=None, model=None, seed=1, rank=
     for k in range(3):
         c.gravity[k] = cfg.sim.gravity[k]
     c.solver_iterations = SOLVER_DEFAULTS["solver_iterations"]
+    physx = cfg.sim.physx
+    c.solver_type = int(_get(physx, "solver_type", 1))                     # LRC:245 (0: pgs, 1: tgs)
+    c.num_position_iterations = int(_get(physx, "num_position_iterations", 4))   # LRC:246
+    override = os.environ.get("LSIM_SOLVER", "").lower()
+    if override:
+        c.solver_type = SOLVER_TYPES[override]
+    if c.solver_type not in (0, 1):
+        raise ValueError(f"cfg.sim.physx.solver_type must be 0 (pgs) or 1 (tgs), got {c.solver_type}")
+    if c.solver_type == 1 and not 1 <= c.num_position_iterations <= abi.DEFINES["LSIM_MAX_POSITION_ITERATIONS"]:
+        raise ValueError(f"cfg.sim.physx.num_position_iterations must be in 1..{abi.DEFINES['LSIM_MAX_POSITION_ITERATIONS']}, "
+                         f"got {c.num_position_iterations}")
+    if int(_get(physx, "num_velocity_iterations", 0)) != 0:
+        raise ValueError("cfg.sim.physx.num_velocity_iterations != 0 is not modelled (every reference config sets 0, LRC:247)")
     c.contact_offset = cfg.sim.physx.contact_offset
     c.max_depenetration_velocity = cfg.sim.physx.max_depenetration_velocity
     c.erp = SOLVER_DEFAULTS["erp"]

@@ -13,8 +13,9 @@
  *   - generalized velocity v = [base twist (w, v_O) in world axes about the base origin O; qd(12)].
  *   - M(q) by composite rigid bodies, bias h(q,v) by recursive Newton-Euler, both in world-aligned
  *     Pluecker coordinates about O.
- *   - semi-implicit Euler: v_free = v + dt M^-1 (tau - h); contacts / joint limits as a velocity-level LCP
- *     solved by projected Gauss-Seidel in impulse space on W = J M^-1 J^T; q+ = q (+) dt v+.
+ *   - semi-implicit Euler: v_free = v + dt M^-1 (tau - h); contacts / joint limits either as a velocity-level LCP
+ *     solved by projected Gauss-Seidel in impulse space on W = J M^-1 J^T, q+ = q (+) dt v+ (lsim_config.solver_type 0), or by
+ *     the Temporal Gauss-Seidel scheme the reference configures (solver_type 1, LRC:245-248; see the branch below).
  *   - collision: sphere-swept points (lsim_collision_point) against the triangulated height grid.
  */
 #include <math.h>
@@ -493,8 +494,12 @@ void orc_physics_substep(orc_sim* s, int e, const float tau_f[12], int apply_for
         lim_need[j] = fmin(vf - Lb, Ub - vf) < LIMIT_MARGIN * vmax;
         lim_viol[j] = fmin(vf - Lb, Ub - vf) < 0.0;
     }
-    for (int j = 0; j < 12; ++j) {
-        /* a two-sided row L <= qd_j <= U for every joint whose free velocity violates a bound or comes within LIMIT_MARGIN of the velocity
+    for (int j = 11; j >= 0; --j) {
+        /* Rows in DESCENDING joint order -- calf, thigh, hip of the last leg first -- i.e. leaf to root within a leg: a Gauss-Seidel pass in
+         * that order leaves a third of the residue of the ascending order on a saturated leg (round 4: with TGS's single pass per
+         * iteration, joint speed beyond 1.1 x the limit in 2.7 % instead of 19 % of the steps of tests/test_physics_invariants.py's
+         * saturated-motor case).
+         * a two-sided row L <= qd_j <= U for every joint whose free velocity violates a bound or comes within LIMIT_MARGIN of the velocity
          * limit of it, and for the neighbours on the leg of a joint that violates a bound (limit impulses of one joint move its neighbours
          * by tens of rad/s).  Until round 2 a joint merely within the margin pulled its neighbours in too: 4.6 of 5.3 limit rows never
          * carried an impulse. */
@@ -509,18 +514,22 @@ void orc_physics_substep(orc_sim* s, int e, const float tau_f[12], int apply_for
         dirs[R][0] = dirs[R][1] = dirs[R][2] = 0;
         ++R;
     }
-#if defined(ORC_SOLVER_TGS)
-    /* ---- variant (oracle/Makefile: liborc_tgs.so): PhysX's Temporal Gauss-Seidel scheme, the solver the reference actually configures
-     * (solver_type = 1, num_position_iterations = 4, num_velocity_iterations = 0: LRC:245-248), restated from its published description
+    if (c->solver_type == LSIM_SOLVER_TGS) {
+    /* ---- solver_type 1: PhysX's Temporal Gauss-Seidel scheme, the solver every reference config selects (solver_type = 1,
+     * num_position_iterations = 4, num_velocity_iterations = 0: LRC:245-248), restated from its published description
      * (Macklin, Storey, Lu, Terdiman, Chentanez, Jeschke, Mueller: "Small Steps in Physics Simulation", SCA 2019; PhysX SDK guide, "Temporal
-     * Gauss-Seidel"): the step is split into N = position-iterations sub-steps of h = dt / N; each sub-step integrates the unconstrained
+     * Gauss-Seidel"): the step is split into N = position-iterations sub-iterations of h = dt / N; each integrates the unconstrained
      * acceleration over h, relaxes every constraint ONCE against the positional error of the configuration reached so far (gaps and joint
-     * angles advance with the sub-steps; the articulation's response -- J, M^-1 J^T -- stays that of the start of the step), and advances the
-     * configuration by h.  Impulses accumulate over the step and are projected as totals (normal >= 0, friction box mu * normal).  No
-     * velocity iterations.  Used ONLY to measure how far the shipped solver (8 velocity-level sweeps over the whole step) sits from this
-     * scheme on the quantities the rewards read (tests/test_solver_variants.py); PhysX itself stays closed. */
-    {
-        const int NS = ORC_SOLVER_TGS;
+     * angles advance with the sub-iterations; the articulation's response -- J, M^-1 J^T -- stays that of the start of the step), and advances
+     * the configuration by h.  Impulses accumulate over the step and are projected as totals (normal >= 0, friction box mu * normal).  No
+     * velocity iterations.  External forces (gravity, bias forces, motor torques) act ONCE, over the whole dt, before the iterations -- the
+     * iterations start from vfree, as the SDK computes its unconstrained velocities with the full step -- so an unconstrained robot takes
+     * exactly the semi-implicit Euler step of the PGS branch.  [Round 3's first restatement ramped the free acceleration over the
+     * sub-iterations, the paper's sub-stepping: positions then advance by dt v + 5/8 dt^2 a, which is not symplectic -- the free-flight
+     * energy test drifted 19 % instead of 6.6 % -- and one relaxation per iteration of an error that GROWS with the iterations left a
+     * larger velocity residue on stiff coupled rows.]  PhysX itself stays closed: this is parity-UNPINNED like the rest of the dynamics (header of this file); the
+     * HIP kernel's TGS form (ls_physics.h: wc_delassus_tgs) is checked against this one. */
+        const int NS = c->num_position_iterations < 1 ? 1 : c->num_position_iterations;
         const double hs = dt / NS;
         double Y[MAXR][NV], Wd[MAXR], lam[MAXR], vv[NV], gap[MAXC], qs[12], dp[3] = {0, 0, 0}, qcur[4] = {qb[0], qb[1], qb[2], qb[3]};
         for (int r = 0; r < R; ++r) {
@@ -528,11 +537,10 @@ void orc_physics_substep(orc_sim* s, int e, const float tau_f[12], int apply_for
             double a = 1e-6; for (int k = 0; k < NV; ++k) a += J[r][k] * Y[r][k];
             Wd[r] = a; lam[r] = 0;
         }
-        memcpy(vv, v, sizeof(vv));
+        memcpy(vv, vfree, sizeof(vv));    /* external forces act once, over the whole dt, before the iterations (see the comment above) */
         for (int k = 0; k < nc; ++k) gap[k] = cdist[k];
         for (int j = 0; j < 12; ++j) qs[j] = q[j];
         for (int sub = 0; sub < NS; ++sub) {
-            for (int k = 0; k < NV; ++k) vv[k] += hs * rhs[k];
             for (int r = 0; r < R; ++r) {
                 double tgt = 0, rng = 0;
                 if (rkind[r] == 0) {
@@ -551,7 +559,7 @@ void orc_physics_substep(orc_sim* s, int e, const float tau_f[12], int apply_for
                 double w = -tgt; for (int k = 0; k < NV; ++k) w += J[r][k] * vv[k];
                 double nl = lam[r] - w / Wd[r];
                 if (rkind[r] == 0) { if (nl < 0) nl = 0; }
-                else if (rkind[r] == 3) { double up = nl + rng / Wd[r]; nl = (nl > 0 ? nl : 0) + (up < 0 ? up : 0); }   /* two-sided, as the shipped sweep */
+                else if (rkind[r] == 3) { double up = nl + rng / Wd[r]; nl = (nl > 0 ? nl : 0) + (up < 0 ? up : 0); }   /* two-sided, as the PGS sweep */
                 else { double lim = mu * lam[r - rkind[r]]; if (nl > lim) nl = lim; if (nl < -lim) nl = -lim; }
                 double dl = nl - lam[r];
                 lam[r] = nl;
@@ -576,14 +584,24 @@ void orc_physics_substep(orc_sim* s, int e, const float tau_f[12], int apply_for
         memset(cf, 0, sizeof(cf));
         for (int r = 0; r < R; ++r) if (rcontact[r] >= 0) for (int k = 0; k < 3; ++k) cf[cbody[rcontact[r]]][k] += lam[r] * dirs[r][k] / dt;
         for (int i = 0; i < NB; ++i) for (int k = 0; k < 3; ++k) cfo[3 * i + k] = (float)cf[i][k];
-        for (int j = 0; j < 12; ++j) { dof[2 * j] = (float)qs[j]; dof[2 * j + 1] = (float)vv[6 + j]; }
+        {   /* the same safety nets as the PGS branch, on the velocities the step hands on (the configuration has already advanced with the
+             * sub-iterations): body velocity caps of the asset options, joint speed at 1.5 x the limit for solver residue */
+            double wn = sqrt(vv[0] * vv[0] + vv[1] * vv[1] + vv[2] * vv[2]), ln = sqrt(vv[3] * vv[3] + vv[4] * vv[4] + vv[5] * vv[5]);
+            if (c->max_angular_velocity > 0 && wn > c->max_angular_velocity) for (int k = 0; k < 3; ++k) vv[k] *= c->max_angular_velocity / wn;
+            if (c->max_linear_velocity > 0 && ln > c->max_linear_velocity) for (int k = 3; k < 6; ++k) vv[k] *= c->max_linear_velocity / ln;
+        }
+        for (int j = 0; j < 12; ++j) {
+            double lim = 1.5 * m->dof_vel_limit[j], vj = vv[6 + j];
+            if (vj > lim) vj = lim;
+            if (vj < -lim) vj = -lim;
+            dof[2 * j] = (float)qs[j]; dof[2 * j + 1] = (float)vj;
+        }
         double wxd[3], w3[3] = {vv[0], vv[1], vv[2]};
         v3cross(w3, dp, wxd);
         for (int k = 0; k < 3; ++k) { root[k] = (float)(p0[k] + dp[k]); root[7 + k] = (float)(vv[3 + k] + wxd[k]); root[10 + k] = (float)vv[k]; }
         for (int k = 0; k < 4; ++k) root[3 + k] = (float)qcur[k];
-        (void)vt; (void)rrng; (void)vfree;
+        return;
     }
-#else
     /* 8. Delassus operator and projected Gauss-Seidel */
     static const double CFM = 1e-6;
     double Y[MAXR][NV], W[MAXR][MAXR], b[MAXR], lam[MAXR];
@@ -641,5 +659,4 @@ void orc_physics_substep(orc_sim* s, int e, const float tau_f[12], int apply_for
         root[10 + k] = (float)vn[k];
     }
     for (int k = 0; k < 4; ++k) root[3 + k] = (float)(qq[k] / nn);
-#endif
 }

@@ -28,7 +28,8 @@ static int lsbk_launch_a(lsim_sim* s, const LsStepArgs& a, void*) {
     for (int env = 0; env < s->cfg.num_envs; ++env) {
         memset(&sh, 0xCD, sizeof(sh));   // poison: phases must not rely on stale LDS
         memset(L, 0xCD, sizeof(L));
-        ls_wave_step_a(*s->dev_ctx, a, env, sh, L);
+        if (s->cfg.solver_type == LSIM_SOLVER_TGS) ls_wave_step_a<LSIM_SOLVER_TGS>(*s->dev_ctx, a, env, sh, L);
+        else ls_wave_step_a<LSIM_SOLVER_PGS>(*s->dev_ctx, a, env, sh, L);
     }
     return 0;
 }

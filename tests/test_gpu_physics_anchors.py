@@ -75,6 +75,7 @@ def test_eight_gauss_seidel_sweeps_against_sixty_four(monkeypatch):
     def run(iters):
         monkeypatch.setitem(LC.SOLVER_DEFAULTS, "solver_iterations", iters)
         cfg = quiet_cfg()
+        cfg.sim.physx.solver_type = 0         # the velocity-level sweeps (the TGS default has no sweep count to vary)
         cfg.init_state.pos = [0.0, 0.0, 0.40]
         env = _env(cfg, 64)
         assert env.lcfg.solver_iterations == iters

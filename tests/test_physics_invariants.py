@@ -31,6 +31,14 @@ class _HipSim:
 
 
 KINDS = ["oracle", "emu", pytest.param("hip", marks=pytest.mark.gpu)]      # the HIP leg runs with -m gpu on the MI355X
+SOLVERS = {"tgs": 1, "pgs": 0}      # cfg.sim.physx.solver_type (LRC:245): 1 = TGS, 4 position iterations (every reference config); 0 = 8 velocity-level sweeps
+both_solvers = pytest.mark.parametrize("solver", ["tgs", "pgs"])
+
+
+def _quiet(solver, **kw):
+    cfg = quiet_cfg(**kw)
+    cfg.sim.physx.solver_type = SOLVERS[solver]
+    return cfg
 
 
 def _make(kind, cfg, N, seed=1):
@@ -66,8 +74,8 @@ def _total_momentum(sim, model, e=0):
     return P, Lm
 
 
-def _tumble(kind, sim_dt, steps, gz):
-    cfg = quiet_cfg()
+def _tumble(kind, solver, sim_dt, steps, gz):
+    cfg = _quiet(solver)
     cfg.init_state.pos = [0.0, 0.0, 3.0]
     cfg.sim.dt = sim_dt
     cfg.sim.gravity = [0.0, 0.0, gz]
@@ -85,32 +93,35 @@ def _tumble(kind, sim_dt, steps, gz):
     return P0, L0, P1, L1, sum(b.mass for b in model.bodies)
 
 
+@both_solvers
 @pytest.mark.parametrize("kind", KINDS)
-def test_momentum_conserved_without_gravity(kind):
+def test_momentum_conserved_without_gravity(kind, solver):
     """Free flight, g = 0, tumbling robot holding its pose with the PD loop (internal forces only): linear and angular
     momentum are conserved; the residual is the first-order integration error and halves with the time step."""
-    P0, L0, P1, L1, mass = _tumble(kind, 0.005, 10, 0.0)
+    P0, L0, P1, L1, mass = _tumble(kind, solver, 0.005, 10, 0.0)
     assert np.linalg.norm(P1 - P0) < 1.5e-3 * np.linalg.norm(P0)
     assert np.linalg.norm(L1 - L0) < 2e-2 * np.linalg.norm(L0)
-    Ph0, Lh0, Ph1, Lh1, _ = _tumble(kind, 0.0025, 20, 0.0)
+    Ph0, Lh0, Ph1, Lh1, _ = _tumble(kind, solver, 0.0025, 20, 0.0)
     assert np.linalg.norm(Ph1 - Ph0) < 0.65 * np.linalg.norm(P1 - P0)
     assert np.linalg.norm(Lh1 - Lh0) < 0.65 * np.linalg.norm(L1 - L0)
 
 
+@both_solvers
 @pytest.mark.parametrize("kind", KINDS)
-def test_free_fall_under_gravity(kind):
+def test_free_fall_under_gravity(kind, solver):
     """dP_z = -m g t (to the integrator's first order); the horizontal leak of the semi-implicit Euler step is O(dt)."""
-    P0, L0, P1, L1, mass = _tumble(kind, 0.005, 10, -G)
+    P0, L0, P1, L1, mass = _tumble(kind, solver, 0.005, 10, -G)
     t = 10 * 4 * 0.005
     np.testing.assert_allclose(P1[2] - P0[2], -mass * G * t, rtol=2e-3)
-    Ph0, Lh0, Ph1, Lh1, _ = _tumble(kind, 0.0025, 20, -G)
+    Ph0, Lh0, Ph1, Lh1, _ = _tumble(kind, solver, 0.0025, 20, -G)
     assert np.linalg.norm((Ph1 - Ph0)[:2]) < 0.65 * np.linalg.norm((P1 - P0)[:2])
     assert np.linalg.norm((P1 - P0)[:2]) < 0.04 * np.linalg.norm(P0[:2])
 
 
+@both_solvers
 @pytest.mark.parametrize("kind", KINDS)
-def test_static_stance_supports_weight(kind):
-    cfg = quiet_cfg()
+def test_static_stance_supports_weight(kind, solver):
+    cfg = _quiet(solver)
     cfg.init_state.pos = [0.0, 0.0, 0.40]
     sim, model = _make(kind, cfg, 2)
     sim.reset_all()
@@ -129,9 +140,10 @@ def test_static_stance_supports_weight(kind):
     np.testing.assert_allclose(q[1:3], q[4:6], atol=0.02)
 
 
+@both_solvers
 @pytest.mark.parametrize("kind", KINDS)
-def test_limits_respected(kind):
-    cfg = quiet_cfg()
+def test_limits_respected(kind, solver):
+    cfg = _quiet(solver)
     sim, model = _make(kind, cfg, 4)
     sim.reset_all()
     rs = np.random.RandomState(1)
@@ -152,12 +164,13 @@ def test_limits_respected(kind):
     assert within >= 0.95 * total, (within, total)
 
 
+@both_solvers
 @pytest.mark.parametrize("kind", KINDS)
-def test_saturated_motors_do_not_spin_up_a_robot_in_free_flight(kind):
+def test_saturated_motors_do_not_spin_up_a_robot_in_free_flight(kind, solver):
     """Regression for the joint-velocity clamp: with gravity off, far from the ground and every motor saturated against its velocity
     limit or its stops, the robot is a closed system -- its linear momentum must stay (nearly) constant, the joint velocities must hold
     their limits through the constraint rows (not through the 1.5 x safety clamp) and the base must not spin up."""
-    cfg = quiet_cfg()
+    cfg = _quiet(solver)
     cfg.init_state.pos = [0.0, 0.0, 10.0]
     cfg.sim.gravity = [0.0, 0.0, 0.0]
     cfg.termination.fall_down = False
@@ -176,17 +189,47 @@ def test_saturated_motors_do_not_spin_up_a_robot_in_free_flight(kind):
         qdmax = max(qdmax, float(np.abs(sim.buf["dof_state"].reshape(2, 12, 2)[:, :, 1]).max()))
     P1, _ = _total_momentum(sim, model)
     assert wmax < 15.0, wmax                   # the clamp version reached 54 rad/s here and kept accelerating
-    assert qdmax < 22.0, qdmax                 # 20 rad/s limit held by the rows (the safety clamp sits at 30)
+    # the 20 rad/s limit is held by the rows, not by the safety clamp at 30: 8 sweeps converge on it (measured 20.1); TGS relaxes every row
+    # once per position iteration, 4 passes in all, and leaves more on these stiffly coupled rows (measured 25.4; 23.8 with 8 iterations)
+    assert qdmax < (22.0 if solver == "pgs" else 27.0), qdmax
     assert np.abs(P1 - P0).max() < 1.5, (P0, P1)
     assert np.all(np.abs(sim.buf["root_states"][:, 2] - 10.0) < 1.0)
 
 
-def test_emu_stairs_wall_contacts_match_oracle():
+@pytest.mark.parametrize("solver", ["tgs", "pgs"])
+@pytest.mark.parametrize("quiet", [True, False])
+def test_emu_physics_matches_oracle(quiet, solver):
+    """CPU leg of tests/test_gpu_parity.py::test_hip_physics_matches_oracle: the lane-emulated kernel sources (fp32, structured solver, the
+    TGS form with its velocity rows) against the oracle (dense fp64) for both solvers, at the HIP test's tolerances."""
+    import emu_binding
+    N = 16
+    cfg = quiet_cfg("aliengo") if quiet else C.TASKS["aliengo"][0]()
+    cfg.sim.physx.solver_type = SOLVERS[solver]
+    cfg.terrain.terrain_proportions = [1.0, 0.0, 0.0, 0.0]
+    orc, lc, model, ter = make_oracle(cfg, N, seed=5)
+    assert lc.solver_type == SOLVERS[solver]
+    emu = emu_binding.EmuSim(lc, model, ter.heightsamples, ter.env_origins)
+    orc.reset_all(); emu.reset_all()
+    rs = np.random.RandomState(0)
+    for t in range(12):
+        a = rs.normal(0, 1, (N, 12)).astype(np.float32)
+        orc.step(a); emu.step(a)
+        np.testing.assert_array_equal(emu.buf["reset"], orc.buf["reset"], err_msg=f"step {t}")
+        np.testing.assert_allclose(emu.buf["root_states"], orc.buf["root_states"], atol=3e-4, rtol=1e-4, err_msg=f"step {t}")
+        np.testing.assert_allclose(emu.buf["dof_state"], orc.buf["dof_state"], atol=3e-3, rtol=1e-3, err_msg=f"step {t}")
+        np.testing.assert_allclose(emu.buf["contact_forces"], orc.buf["contact_forces"], atol=0.15, rtol=2e-3, err_msg=f"step {t}")
+        np.testing.assert_allclose(emu.buf["rew"], orc.buf["rew"], atol=1e-5, rtol=1e-4, err_msg=f"step {t}")
+        np.testing.assert_allclose(emu.buf["obs"], orc.buf["obs"], atol=3e-4, rtol=1e-4, err_msg=f"step {t}")
+
+
+@pytest.mark.parametrize("solver", ["tgs", "pgs"])
+def test_emu_stairs_wall_contacts_match_oracle(solver):
     """Stairs (slope-corrected mesh with vertical risers, TER:72-75), CPU leg of tests/test_gpu_parity.py's stairs test: the
     lane-emulated kernel sources (fp32) against the oracle (fp64, independent triangle query), states re-synchronised every step."""
     import emu_binding
     N = 16
     cfg = C.TASKS["aliengo_stairs"][0]()
+    cfg.sim.physx.solver_type = SOLVERS[solver]
     cfg.terrain.terrain_proportions = [0, 0, 0, 0, 0.5, 0.5]
     cfg.domain_rand.base_init_pos_range = dict(x=[-3.0, 3.0], y=[-3.0, 3.0], z=[0.0, 0.3])
     orc, lc, model, ter = make_oracle(cfg, N, seed=3)
@@ -254,12 +297,13 @@ def test_go1_table_emu_matches_oracle_and_stands():
     assert np.all(orc.buf["root_states"][:, 2] > 0.2) and np.all(orc.buf["root_states"][:, 2] < 0.45)
 
 
+@both_solvers
 @pytest.mark.parametrize("kind", KINDS)
-def test_foot_contact_forces_stay_in_the_friction_pyramid(kind):
+def test_foot_contact_forces_stay_in_the_friction_pyramid(kind, solver):
     """Flat ground, a robot thrashing under random actions: every foot force pushes (f_z >= 0) and its tangential components stay inside
     the solver's friction pyramid |f_x|, |f_y| <= mu f_z with mu = average(terrain friction, robot friction); feet do not
     sink into the ground by more than the contact offset."""
-    cfg = quiet_cfg()
+    cfg = _quiet(solver)
     cfg.terrain.mesh_type = "plane"
     cfg.init_state.pos = [0.0, 0.0, 0.40]
     sim, model = _make(kind, cfg, 4)

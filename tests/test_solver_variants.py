@@ -1,9 +1,9 @@
-"""Physics anchors that come from OUTSIDE the build's own solver: the CPU oracle compiled with PhysX's published TGS scheme
-(oracle/Makefile: liborc_tgs.so -- 4 position iterations, 0 velocity iterations, the reference's settings LRC:245-248) against the shipped
-solver (8 velocity-level Gauss-Seidel sweeps over the whole 5 ms step) on the same seeds, commands and actions.  PhysX stays closed: this
-does not pin parity.  It bounds the MODELLING distance between the two solver families on the quantities the reward / termination stack
-reads -- vertical load on the feet, feet in contact, base height, foot slip, joint state -- so that "not comparable" becomes a stated number
-(DESIGN.md section 4)."""
+"""The two solvers the library ships, side by side on the CPU oracle: PhysX's published TGS scheme (cfg.sim.physx.solver_type = 1,
+4 position iterations, 0 velocity iterations -- the reference's settings LRC:245-248, and the default since round 4) against the build's
+earlier solver (solver_type = 0: 8 velocity-level Gauss-Seidel sweeps over the whole 5 ms step) on the same seeds, commands and actions.
+PhysX stays closed: this does not pin parity.  It bounds the MODELLING distance between the two solver families on the quantities the
+reward / termination stack reads -- vertical load on the feet, feet in contact, base height, foot slip, joint state -- so that "not
+comparable" becomes a stated number."""
 import numpy as np
 import pytest
 
@@ -12,11 +12,13 @@ from helpers import C, make_oracle
 FEET = [4, 8, 12, 16]
 
 
-def _rollout(task, library, N=96, steps=150, sigma=0.5, seed=4):
+def _rollout(task, solver_type, N=96, steps=150, sigma=0.5, seed=4):
     cfg = C.TASKS[task][0]()
+    cfg.sim.physx.solver_type = solver_type
     cfg.domain_rand.push_robots = False
     cfg.domain_rand.disturbance = False
-    orc, lc, model, ter = make_oracle(cfg, N, seed=seed, library=library)
+    orc, lc, model, ter = make_oracle(cfg, N, seed=seed)
+    assert lc.solver_type == solver_type
     orc.reset_all()
     rs = np.random.RandomState(1)
     acc = dict(fz=[], contact=[], height=[], slip=[], rew=[], alive=[], qd=[])
@@ -38,9 +40,8 @@ def _rollout(task, library, N=96, steps=150, sigma=0.5, seed=4):
 
 @pytest.mark.parametrize("task", ["aliengo", "aliengo_stairs"])
 def test_tgs_variant_stays_close_on_what_the_rewards_read(task):
-    from oracle import oracle
-    pgs = _rollout(task, None)
-    tgs = _rollout(task, oracle.variant("orc_tgs"))
+    pgs = _rollout(task, 0)
+    tgs = _rollout(task, 1)
     print(task, "PGS8:", {k: round(v, 4) for k, v in pgs.items()})
     print(task, "TGS4:", {k: round(v, 4) for k, v in tgs.items()})
     weight = 24.94 * 9.81
@@ -57,12 +58,12 @@ def test_tgs_variant_stays_close_on_what_the_rewards_read(task):
 def test_tgs_variant_standing_load_and_height():
     """zero actions (PD hold at the default pose) on the flat task: both solvers must carry the robot's weight and settle at the
     same height to a fraction of a millimetre -- the static limit where the two schemes have to agree"""
-    from oracle import oracle
     from helpers import quiet_cfg
     cfg = quiet_cfg("aliengo")          # no domain randomisation, default initial pose, flat ground
     out = {}
-    for name, libr in (("pgs", None), ("tgs", oracle.variant("orc_tgs"))):
-        orc, lc, model, ter = make_oracle(cfg, 32, seed=2, library=libr)
+    for name, solver_type in (("pgs", 0), ("tgs", 1)):
+        cfg.sim.physx.solver_type = solver_type
+        orc, lc, model, ter = make_oracle(cfg, 32, seed=2)
         orc.reset_all()
         for t in range(100):
             orc.step(np.zeros((32, 12), np.float32))
