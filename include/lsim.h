@@ -385,6 +385,8 @@ enum lsim_buffer_id {
                                        instead of simulating; still computes torques (E3) for the 4 sub-steps */
 #define LSIM_STEP_NO_RESET 2u       /* test hook: compute reset_buf but do not reset_idx */
 #define LSIM_STEP_RECORD_SUBSTEPS 4u /* test hook: also write LSIM_BUF_SUBSTEP_TORQUES (one 48-byte store per sub-step and robot) */
+#define LSIM_STEP_TWO_KERNELS 8u    /* test / measurement hook: run reset_idx + observations as the separate kernel B on every step (the form the
+                                       command-curriculum steps always take) instead of inside kernel A.  Same results, bit for bit */
 
 typedef struct lsim_sim* lsim_handle;
 

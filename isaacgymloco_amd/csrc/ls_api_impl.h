@@ -3,7 +3,7 @@
 // share the host logic.  The including file must define, before including this header:
 //   LS_API(name)                     symbol name (lsim_##name for the product)
 //   lsbk_malloc / lsbk_free / lsbk_h2d / lsbk_memset       device-memory primitives, return 0 on success
-//   lsbk_launch_a / lsbk_launch_b / lsbk_launch_reduce (lsim_sim*, const LsStepArgs&, void* stream)
+//   lsbk_launch_a / lsbk_launch_b / lsbk_launch_reduce / lsbk_launch_finish (lsim_sim*, const LsStepArgs&, void* stream)
 //   lsbk_set_device(int), lsbk_prof_mark(lsim_sim*, int which, void* stream), lsbk_prof_free(lsim_sim*)
 #pragma once
 #include <stdio.h>
@@ -211,10 +211,15 @@ extern "C" int LS_API(step_ex)(lsim_sim* s, const float* actions_dev, uint32_t f
     a.actions = actions_dev; a.step_counter = s->step_counter; a.flags = flags; a.init_done = s->init_done;
     a.row_in = s->stats_row; a.row_out = s->stats_row ^ 1; a.reset_all = 0;
     s->stats_row = a.row_out;
+    // Kernel B exists for the step's one global dependency; it only bites when the command curriculum evaluates (LR:307: one step in
+    // max_episode_length).  On every other step kernel A runs B's per-env work itself and a few blocks finish the step (ls_kernels.h).
+    const bool curriculum_step = s->cfg.commands_curriculum && (s->step_counter % s->cfg.max_episode_length == 0);
+    a.fuse_tail = (!curriculum_step && !(flags & LSIM_STEP_TWO_KERNELS)) ? 1 : 0;
     lsbk_prof_mark(s, 0, stream);
     if (lsbk_launch_a(s, a, stream) != 0) LS_FAIL(s, LSIM_E_HIP, "kernel A launch failed");
     lsbk_prof_mark(s, 1, stream);
-    if (lsbk_launch_b(s, a, stream) != 0) LS_FAIL(s, LSIM_E_HIP, "kernel B launch failed");
+    if (a.fuse_tail) { if (lsbk_launch_finish(s, a, stream) != 0) LS_FAIL(s, LSIM_E_HIP, "finish kernel launch failed"); }
+    else if (lsbk_launch_b(s, a, stream) != 0) LS_FAIL(s, LSIM_E_HIP, "kernel B launch failed");
     lsbk_prof_mark(s, 2, stream);
     return LSIM_OK;
 }

@@ -245,72 +245,6 @@ LS_FN void ph_term_outputs(const LsCtx& cx, WaveShared& sh, int lane, int env, c
     }
 }
 
-// SOLVER: LSIM_SOLVER_PGS / LSIM_SOLVER_TGS (lsim_config.solver_type), a template parameter so that each kernel carries one solver's code
-template <int SOLVER> LS_WAVE_FN void ls_wave_step_a(const LsCtx& cx, const LsStepArgs& a, const int env, WaveShared& sh, LS_LANES_PARAM) {
-    const lsim_config& c = cx.cfg;
-    const float dt = c.sim_dt;
-    constexpr bool TGS = SOLVER == LSIM_SOLVER_TGS;
-    const bool skip = (a.flags & LSIM_STEP_SKIP_PHYSICS) != 0;
-    [[maybe_unused]] constexpr int ls_line0 = __LINE__;   // phase-site ids (LS_PHASE_TIMING builds) count lines from here
-    LS_TICK_INIT();
-    LS_PHASE(ph_load_a(cx, sh, rg, lane, env, a));
-    for (int sub = 0; sub < c.decimation; ++sub) {
-        if (skip) { LS_PHASE(ph_torques(cx, sh, lane, env, sub, a.flags)); continue; }
-        // phases that do not depend on each other share a barrier: (torques, kinematics), (free velocity, narrow phase),
-        // (contact compaction, joint-limit rows), (apply impulses, contact forces)
-        LS_TORQUES_KINEMATICS();
-        LS_PHASE(ph_body_inertia(cx, sh, lane, sub == 0));
-        LS_PHASE(ph_leg_composite(sh, lane));
-        LS_PHASE(ph_leg_block(sh, lane));
-        LS_PHASE(ph_leg_schur(sh, lane));
-        LS_PHASE(ph_base_assemble(sh, lane));
-        LS_PHASE(ph_base_factor(sh, lane));
-        LS_PHASE(ph_free_leg(sh, lane));
-        LS_PHASE(ph_free_base(sh, lane));
-        LS_PHASE(ph_free_finish(sh, lane, dt); ph_collide_prefetch(cx, rg, lane); ph_collide(cx, sh, rg, lane));
-        LS_COLLECTIVE(wc_compact_contacts(sh, rg, lane); wc_limits(cx, sh, lane, dt), wc_compact_contacts(sh, L); LS_PHASE(ph_limits(cx, sh, lane, dt)));
-        LS_PHASE(ph_rows<TGS>(cx, sh, rg, lane, dt));
-#if defined(LS_EMU)
-        LS_PHASE(ph_delassus(sh, rg, lane));
-        if (TGS) { wc_tgs(cx, sh, L, c.num_position_iterations, dt); LS_PHASE(ph_contact_forces(sh, lane, dt)); }
-        else { wc_pgs(sh, L, c.solver_iterations); LS_PHASE(ph_apply_impulses(sh, lane); ph_contact_forces(sh, lane, dt)); }
-#else
-        // rows, sweep(s), constrained velocity, contact forces
-        if constexpr (TGS) LS_PHASE(wc_delassus_tgs(cx, sh, rg, lane, c.num_position_iterations, dt));
-        else LS_PHASE(wc_delassus_pgs(sh, rg, lane, c.solver_iterations, dt));
-#endif
-        if (TGS) LS_PHASE(ph_integrate_tgs(cx, sh, lane, dt, c.num_position_iterations));
-        else LS_PHASE(ph_integrate(cx, sh, lane, dt));
-#if defined(LS_EXP_TWICE) && LS_EXP_TWICE == 9001      // cost probe: the integrator again with a zero step (leaves the state where it is)
-        LS_PHASE(ph_integrate(cx, sh, lane, 0.0f));
-#endif
-    }
-    if (!skip) {
-        LS_KINEMATICS();
-        LS_PHASE(ph_body_states_all(cx, sh, lane, env));
-        LS_PHASE(ph_store_sim_state(cx, sh, lane, env));
-    } else {
-        LS_PHASE(ph_load_injected(cx, sh, lane, env));
-    }
-    // ---- post_physics_step (LR:178-228)
-    LS_PHASE(ph_store_root_cmd_ranges(cx, sh, lane, env, a));
-    LS_PHASE(ph_post_state(cx, sh, lane, env));
-    LS_PHASE(ph_callback(cx, sh, lane, env, a, sh.ranges));
-#if defined(LS_EXP_TWICE) && LS_EXP_TWICE == 9003      // cost probe: counter-based draws, so a second pass writes the same values
-    LS_PHASE(ph_callback(cx, sh, lane, env, a, sh.ranges));
-#endif
-    LS_PHASE(if (c.measure_heights) ph_heights(cx, sh, lane, env, true); ph_base_height_pts(cx, sh, lane));
-    LS_PHASE(ph_termination(cx, sh, lane, env); ph_reward_parts(cx, sh, lane, env));
-    LS_PHASE(ph_reward_terms(cx, sh, lane, env));
-#if defined(LS_EXP_TWICE) && LS_EXP_TWICE == 9002      // cost probe (adds the step's rewards to the episode sums twice: statistics only)
-    LS_PHASE(ph_reward_terms(cx, sh, lane, env));
-#endif
-    LS_PHASE(ph_reward_total(cx, sh, lane, env));
-    LS_PHASE(if (sh.reset) ph_build_obs(cx, sh, lane, env, (uint32_t)a.step_counter, LSIM_RNG_TERM_NOISE, sh.cur));
-    LS_PHASE(ph_term_outputs(cx, sh, lane, env, a));
-    LS_TICK_FLUSH();
-}
-
 // =============================================================================================== kernel B
 LS_FN void ph_load_b(const LsCtx& cx, WaveShared& sh, int lane, int env, const LsStepArgs& a) {
     const lsim_config& c = cx.cfg;
@@ -515,11 +449,10 @@ LS_FN void ph_b_stats_convert(const LsCtx& cx, WaveShared& sh, int lane, const L
 }
 
 // publish observations (LR:403-404 + clip LR:167-171), AMP features (LR:406-416), last_* roll (LR:235-241)
-LS_FN void ph_b_store(const LsCtx& cx, WaveShared& sh, int lane, int env, const LsStepArgs& a) {
+LS_FN void ph_b_store(const LsCtx& cx, WaveShared& sh, int lane, int env, const LsStepArgs& a, const float* scratch /* the 225 history values */) {
     const lsim_config& c = cx.cfg;
     const float clipv = c.clip_observations;
     LS_GLOBAL float* obs = LSB(cx, LSIM_BUF_OBS, float) + LSIM_NUM_OBS * env;
-    const float* scratch = &sh.u.I6[0][0];
     // rows of 270 / 238 floats start on 8-byte boundaries for every env: two floats per lane and store (half the store instructions)
     static_assert(LSIM_NUM_OBS % 2 == 0 && LSIM_NUM_PRIV_OBS % 2 == 0, "float2 rows");
     LS_STRIDED(m, lane, LSIM_NUM_OBS / 2) {
@@ -563,6 +496,135 @@ LS_FN void ph_b_store_reset_all(const LsCtx& cx, WaveShared& sh, int lane, int e
     if (lane == 41 && sh.any_reset && cx.cfg.send_timeouts) LSB(cx, LSIM_BUF_EXTRAS_TIME_OUTS, uint8_t)[env] = (uint8_t)sh.pre_lc;  // LR:358-359
 }
 
+// =============================================================================================== kernel A
+// ---- the fused tail of kernel A (LsStepArgs::fuse_tail): kernel B's per-env phases run by the same wave, on what it already holds in LDS.
+// Kernel B exists because the step has one global dependency -- whether ANY env reset (the stale extras["time_outs"], LR:358) and the
+// command-curriculum mean over the reset set (LR:307-308, LR:875) -- but the second only matters on the steps where
+// common_step_counter % max_episode_length == 0 (one in a thousand), which the host knows before the launch, and the first only decides
+// whether an N-byte mask is copied.  On every other step the per-env work needs nothing from other envs: this wave does it here, and
+// lsim_k_step_finish (a few blocks) copies the mask if the reset count says so, converts the fixed-point episode sums and swaps the rows.
+// The 225 history values of the observation (LR:403) are the only input the wave does not hold: they are fetched BEFORE the first state store
+// of the kernel (a load behind stores waits for all of them) and parked in the dynamics arrays, which are dead by then.
+LS_FN float* ls_obs_hist(WaveShared& sh) { return &sh.Mbl[0][0]; }
+static_assert(offsetof(WaveShared, Sinv) + sizeof(((WaveShared*)0)->Sinv) - offsetof(WaveShared, Mbl) >= (LSIM_NUM_OBS - LSIM_ONE_STEP_OBS) * sizeof(float),
+              "observation history parked in Mbl .. Sinv");
+static_assert((LSIM_NUM_OBS - LSIM_ONE_STEP_OBS + 63) / 64 <= 4, "LaneRegs::hist");
+LS_FN void ph_hist_load(const LsCtx& cx, LaneRegs& rg, int lane, int env) {
+    for (int it = 0; it < (LSIM_NUM_OBS - LSIM_ONE_STEP_OBS + 63) / 64; ++it) {
+        const int k = lane + 64 * it;
+        rg.hist[it] = LSB(cx, LSIM_BUF_OBS, float)[LSIM_NUM_OBS * env + (k < LSIM_NUM_OBS - LSIM_ONE_STEP_OBS ? k : 0)];
+    }
+}
+LS_FN void ph_hist_stage(WaveShared& sh, const LaneRegs& rg, int lane) {
+    float* hist = ls_obs_hist(sh);
+    for (int it = 0; it < (LSIM_NUM_OBS - LSIM_ONE_STEP_OBS + 63) / 64; ++it) {
+        const int k = lane + 64 * it;
+        if (k < LSIM_NUM_OBS - LSIM_ONE_STEP_OBS) hist[k] = rg.hist[it];
+    }
+}
+// what ph_load_b derives for kernel B, from kernel A's own LDS state
+LS_FN void ph_tail_setup(const LsCtx& cx, WaveShared& sh, int lane, const LsStepArgs& a) {
+    if (lane == 32) {
+        sh.do_reset = sh.reset && !(a.flags & LSIM_STEP_NO_RESET);
+        sh.any_reset = 0;                               // extras["time_outs"] is lsim_k_step_finish's
+        sh.pre_lc = (unsigned int)sh.timeout;
+    }
+    if (lane < 12) { sh.pre_lla[lane] = sh.last_act[lane]; sh.pre_ltau[lane] = sh.tau[lane]; }   // what ph_b_store rolls into last_last_actions / last_torques
+}
+// the episode sums of a resetting env into the fixed-point accumulators (LR:346-350), from LDS; no ticket: lsim_k_step_finish converts
+LS_FN void ph_tail_episode_stats(const LsCtx& cx, WaveShared& sh, int lane, int env, const LsStepArgs& a) {
+    if (!sh.do_reset) return;
+    if (lane == 13) for (int k = 0; k < 4; ++k) sh.cmd[k] = sh.rewv[k];
+    const float den = (float)(sh.eplen < 1 ? 1 : sh.eplen);
+    long long* fix = ls_fix_row(cx, a.row_out);
+    LS_STRIDED(k, lane, LSIM_NUM_REWARD_TERMS) {
+        const float v = sh.pre_es[k];
+        if (v != 0.0f) LS_ATOMIC_ADD_I64(fix + k, ls_to_fix(v / den));
+        LSB(cx, LSIM_BUF_EPISODE_SUMS, float)[env * LSIM_NUM_REWARD_TERMS + k] = 0.0f;
+    }
+}
+
+// SOLVER: LSIM_SOLVER_PGS / LSIM_SOLVER_TGS (lsim_config.solver_type), a template parameter so that each kernel carries one solver's code
+template <int SOLVER> LS_WAVE_FN void ls_wave_step_a(const LsCtx& cx, const LsStepArgs& a, const int env, WaveShared& sh, LS_LANES_PARAM) {
+    const lsim_config& c = cx.cfg;
+    const float dt = c.sim_dt;
+    constexpr bool TGS = SOLVER == LSIM_SOLVER_TGS;
+    const bool skip = (a.flags & LSIM_STEP_SKIP_PHYSICS) != 0;
+    [[maybe_unused]] constexpr int ls_line0 = __LINE__;   // phase-site ids (LS_PHASE_TIMING builds) count lines from here
+    LS_TICK_INIT();
+    LS_PHASE(ph_load_a(cx, sh, rg, lane, env, a));
+    for (int sub = 0; sub < c.decimation; ++sub) {
+        if (skip) { LS_PHASE(ph_torques(cx, sh, lane, env, sub, a.flags)); continue; }
+        // phases that do not depend on each other share a barrier: (torques, kinematics), (free velocity, narrow phase),
+        // (contact compaction, joint-limit rows), (apply impulses, contact forces)
+        LS_TORQUES_KINEMATICS();
+        LS_PHASE(ph_body_inertia(cx, sh, lane, sub == 0));
+        LS_PHASE(ph_leg_composite(sh, lane));
+        LS_PHASE(ph_leg_block(sh, lane));
+        LS_PHASE(ph_leg_schur(sh, lane));
+        LS_PHASE(ph_base_assemble(sh, lane));
+        LS_PHASE(ph_base_factor(sh, lane));
+        LS_PHASE(ph_free_leg(sh, lane));
+        LS_PHASE(ph_free_base(sh, lane));
+        LS_PHASE(ph_free_finish(sh, lane, dt); ph_collide_prefetch(cx, rg, lane); ph_collide(cx, sh, rg, lane));
+        LS_COLLECTIVE(wc_compact_contacts(sh, rg, lane); wc_limits(cx, sh, lane, dt), wc_compact_contacts(sh, L); LS_PHASE(ph_limits(cx, sh, lane, dt)));
+        LS_PHASE(ph_rows<TGS>(cx, sh, rg, lane, dt));
+#if defined(LS_EMU)
+        LS_PHASE(ph_delassus(sh, rg, lane));
+        if (TGS) { wc_tgs(cx, sh, L, c.num_position_iterations, dt); LS_PHASE(ph_contact_forces(sh, lane, dt)); }
+        else { wc_pgs(sh, L, c.solver_iterations); LS_PHASE(ph_apply_impulses(sh, lane); ph_contact_forces(sh, lane, dt)); }
+#else
+        // rows, sweep(s), constrained velocity, contact forces
+        if constexpr (TGS) LS_PHASE(wc_delassus_tgs(cx, sh, rg, lane, c.num_position_iterations, dt));
+        else LS_PHASE(wc_delassus_pgs(sh, rg, lane, c.solver_iterations, dt));
+#endif
+        if (TGS) LS_PHASE(ph_integrate_tgs(cx, sh, lane, dt, c.num_position_iterations));
+        else LS_PHASE(ph_integrate(cx, sh, lane, dt));
+#if defined(LS_EXP_TWICE) && LS_EXP_TWICE == 9001      // cost probe: the integrator again with a zero step (leaves the state where it is)
+        LS_PHASE(ph_integrate(cx, sh, lane, 0.0f));
+#endif
+    }
+    const bool fuse = a.fuse_tail != 0;
+    if (!skip) {
+#if defined(LS_EMU)
+        LS_PHASE(ph_kinematics(sh, lane); if (fuse) ph_hist_load(cx, rg, lane, env));
+#else
+        LS_COLLECTIVE(wc_kinematics(sh, lane); if (fuse) ph_hist_load(cx, rg, lane, env), (void)0);
+#endif
+        LS_PHASE(ph_body_states_all(cx, sh, lane, env));
+        LS_PHASE(ph_store_sim_state(cx, sh, lane, env); if (fuse) ph_hist_stage(sh, rg, lane));     // Mbl .. Sinv, nact are dead from here on
+    } else {
+        LS_PHASE(if (fuse) ph_hist_load(cx, rg, lane, env));
+        LS_PHASE(ph_load_injected(cx, sh, lane, env); if (fuse) ph_hist_stage(sh, rg, lane));
+    }
+    // ---- post_physics_step (LR:178-228)
+    LS_PHASE(ph_store_root_cmd_ranges(cx, sh, lane, env, a));
+    LS_PHASE(ph_post_state(cx, sh, lane, env));
+    LS_PHASE(ph_callback(cx, sh, lane, env, a, sh.ranges));
+#if defined(LS_EXP_TWICE) && LS_EXP_TWICE == 9003      // cost probe: counter-based draws, so a second pass writes the same values
+    LS_PHASE(ph_callback(cx, sh, lane, env, a, sh.ranges));
+#endif
+    LS_PHASE(if (c.measure_heights) ph_heights(cx, sh, lane, env, true); ph_base_height_pts(cx, sh, lane));
+    LS_PHASE(ph_termination(cx, sh, lane, env); ph_reward_parts(cx, sh, lane, env));
+    LS_PHASE(ph_reward_terms(cx, sh, lane, env));
+#if defined(LS_EXP_TWICE) && LS_EXP_TWICE == 9002      // cost probe (adds the step's rewards to the episode sums twice: statistics only)
+    LS_PHASE(ph_reward_terms(cx, sh, lane, env));
+#endif
+    LS_PHASE(ph_reward_total(cx, sh, lane, env));
+    LS_PHASE(if (sh.reset) ph_build_obs(cx, sh, lane, env, (uint32_t)a.step_counter, LSIM_RNG_TERM_NOISE, sh.cur));
+    LS_PHASE(ph_term_outputs(cx, sh, lane, env, a));
+    if (fuse) {     // LR:229-241 + LR:167-171 for this robot (kernel B's phases; its cross-env part is lsim_k_step_finish)
+        LS_PHASE(ph_tail_setup(cx, sh, lane, a));
+        LS_PHASE(ph_b_terrain_curriculum(cx, sh, lane, env, a));
+        LS_PHASE(ph_b_reset(cx, sh, lane, env, a));
+        LS_PHASE(ph_tail_episode_stats(cx, sh, lane, env, a));
+        LS_PHASE(if (sh.do_reset && c.measure_heights) ph_heights(cx, sh, lane, env, true));
+        LS_PHASE(ph_build_obs(cx, sh, lane, env, (uint32_t)a.step_counter, LSIM_RNG_OBS_NOISE, sh.cur));
+        LS_PHASE(ph_b_store(cx, sh, lane, env, a, ls_obs_hist(sh)));
+    }
+    LS_TICK_FLUSH();
+}
+
 LS_WAVE_FN void ls_wave_step_b(const LsCtx& cx, const LsStepArgs& a, const int env, WaveShared& sh, LS_LANES_PARAM) {
     const lsim_config& c = cx.cfg;
     [[maybe_unused]] constexpr int ls_line0 = __LINE__ - 48;   // kernel B's sites land above kernel A's (A uses 0..47)
@@ -578,7 +640,30 @@ LS_WAVE_FN void ls_wave_step_b(const LsCtx& cx, const LsStepArgs& a, const int e
         return;
     }
     LS_PHASE(ph_build_obs(cx, sh, lane, env, (uint32_t)a.step_counter, LSIM_RNG_OBS_NOISE, sh.cur));
-    LS_PHASE(ph_b_store(cx, sh, lane, env, a); ph_b_stats_publish(cx, sh, rg, lane, a));
+    LS_PHASE(ph_b_store(cx, sh, lane, env, a, &sh.u.I6[0][0]); ph_b_stats_publish(cx, sh, rg, lane, a));
     LS_PHASE(ph_b_stats_convert(cx, sh, lane, a));
     LS_TICK_FLUSH();
+}
+
+// =============================================================================================== lsim_k_step_finish
+// The cross-env leftovers of a step whose kernel A ran the fused tail (thread t of a small grid; no LDS):
+//   every env:  extras["time_outs"] = time_out_buf if ANY env reset in this step (LR:358-359: only re-assigned inside reset_idx, quirk 5)
+//   t < ...  :  the live command ranges carried to this step's row, the fixed-point episode sums of the reset set converted to the fp32 row
+//               the host reads (LR:346-350), and the other row cleared for the next step's accumulation (kernel B's housekeeping)
+LS_FN void ls_step_finish_env(const LsCtx& cx, const LsStepArgs& a, int env) {
+    LS_GLOBAL const float* out = LS_G(const float, cx.accum) + a.row_out * LSIM_STATS_SIZE;
+    const bool any = out[LSIM_STATS_RESET_COUNT] > 0.5f && !(a.flags & LSIM_STEP_NO_RESET);
+    if (any && cx.cfg.send_timeouts) LSB(cx, LSIM_BUF_EXTRAS_TIME_OUTS, uint8_t)[env] = LSB(cx, LSIM_BUF_TIME_OUT, uint8_t)[env];
+}
+LS_FN void ls_step_finish_rows(const LsCtx& cx, const LsStepArgs& a, int t) {
+    LS_GLOBAL float* out = LS_G(float, cx.accum) + a.row_out * LSIM_STATS_SIZE;
+    LS_GLOBAL float* nxt = LS_G(float, cx.accum) + a.row_in * LSIM_STATS_SIZE;
+    const bool any = out[LSIM_STATS_RESET_COUNT] > 0.5f;
+    if (t < 8) out[LSIM_STATS_CMD_RANGES + t] = nxt[LSIM_STATS_CMD_RANGES + t];
+    if (t < LSIM_NUM_REWARD_TERMS) {
+        if (any) out[LSIM_STATS_EPISODE_SUMS + t] = ls_from_fix(LS_G(const long long, ls_fix_row(cx, a.row_out))[t]);
+        nxt[LSIM_STATS_EPISODE_SUMS + t] = 0.0f;
+    }
+    if (t < LSIM_STATS_FIX_WORDS) LS_G(long long, ls_fix_row(cx, a.row_in))[t] = 0;
+    if (t == 0) nxt[LSIM_STATS_RESET_COUNT] = 0.0f;
 }

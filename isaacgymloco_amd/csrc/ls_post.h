@@ -433,7 +433,9 @@ LS_FN void ph_reward_total(const LsCtx& cx, WaveShared& sh, int lane, int env) {
     if (c.reward_scales[LSIM_R_TERMINATION] != 0.0f) {
         float v = ((sh.reset && !sh.timeout) ? 1.0f : 0.0f) * c.reward_scales[LSIM_R_TERMINATION];
         rew += v;
-        LSB(cx, LSIM_BUF_EPISODE_SUMS, float)[env * LSIM_NUM_REWARD_TERMS + LSIM_R_TERMINATION] = sh.pre_es[LSIM_R_TERMINATION] + v;
+        const float es = sh.pre_es[LSIM_R_TERMINATION] + v;
+        sh.pre_es[LSIM_R_TERMINATION] = es;            // the fused tail (ls_kernels.h) takes the episode sums of a resetting env from LDS
+        LSB(cx, LSIM_BUF_EPISODE_SUMS, float)[env * LSIM_NUM_REWARD_TERMS + LSIM_R_TERMINATION] = es;
     }
     LSB(cx, LSIM_BUF_REW, float)[env] = rew;
 }

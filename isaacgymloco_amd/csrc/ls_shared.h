@@ -65,6 +65,8 @@ struct LsStepArgs {
     int32_t reset_all;        // kernel B only.  0: the reset tail of a step; 1: a bare reset_idx(all) (BaseTask.reset, BT:113);
                               // 2: a bare reset_idx(env_ids) (LR:290) on the envs flagged in reset_mask
     const uint8_t* reset_mask; // reset_all == 2: u8 [num_envs] on the device, nonzero = reset this env
+    int32_t fuse_tail;        // kernel A only.  1: this wave also runs kernel B's per-env work for its robot (reset_idx, observations, last_* roll)
+                              // and the step's cross-env leftovers go to lsim_k_step_finish; 0: kernel B follows (command-curriculum steps)
 };
 
 // body model entries staged in LDS once per kernel
@@ -175,6 +177,7 @@ struct LaneRegs {
     float row_rng;           // PGS: width of a two-sided row's interval (+inf: one-sided);  TGS: the joint's velocity limit (limit rows)
     float tg_a, tg_b;        // TGS: normal row -- the contact's gap;  limit row -- the joint's distances to its lower / upper stop
     int ticket;              // kernel B, lane 0: this env's ticket among the envs that reset in this step (-1: none)
+    float hist[4];           // kernel A with the fused tail: the 225 observation-history values on their way from global memory to LDS
 #if defined(LS_EMU)
     float W[LS_MAXR];        // Delassus row (the GPU path keeps it local to wc_delassus_pgs)
 #endif

@@ -15,6 +15,7 @@ static int lsbk_memset(void* d, int v, size_t n) { return hipMemset(d, v, n) == 
 static int lsbk_launch_a(lsim_sim* s, const LsStepArgs& a, void* stream);
 static int lsbk_launch_b(lsim_sim* s, const LsStepArgs& a, void* stream);
 static int lsbk_launch_reduce(lsim_sim* s, const LsStepArgs& a, void* stream);
+static int lsbk_launch_finish(lsim_sim* s, const LsStepArgs& a, void* stream);
 static void lsbk_prof_mark(lsim_sim* s, int which, void* stream);
 static void lsbk_prof_free(lsim_sim* s);
 
@@ -50,6 +51,14 @@ __global__ __launch_bounds__(64) void lsim_k_step_b(const LsCtx* __restrict__ ct
     if (env >= ctx->cfg.num_envs) return;
     LaneRegs rg;
     ls_wave_step_b(*ctx, a, env, sh, rg, (int)threadIdx.x);
+}
+
+// after a kernel A with the fused tail: the mask copy that depends on whether any env reset, and the stats rows (ls_kernels.h)
+__global__ __launch_bounds__(256) void lsim_k_step_finish(const LsCtx* __restrict__ ctx, LsStepArgs a) {
+    const LsCtx& cx = *ctx;
+    static_assert(LSIM_STATS_FIX_WORDS <= 256 && LSIM_NUM_REWARD_TERMS <= 256, "one block covers the stats rows");
+    for (int env = (int)(blockIdx.x * blockDim.x + threadIdx.x); env < cx.cfg.num_envs; env += (int)(gridDim.x * blockDim.x)) ls_step_finish_env(cx, a, env);
+    if (blockIdx.x == 0) ls_step_finish_rows(cx, a, (int)threadIdx.x);
 }
 
 // reset_idx outside a step: sum of episode_sums["tracking_lin_vel"] over the resetting envs for the command curriculum (LR:875) and, for a
@@ -89,6 +98,12 @@ static int lsbk_launch_a(lsim_sim* s, const LsStepArgs& a, void* stream) {
 }
 static int lsbk_launch_b(lsim_sim* s, const LsStepArgs& a, void* stream) {
     hipLaunchKernelGGL(lsim_k_step_b, dim3(ls_grid(s)), dim3(64), 0, (hipStream_t)stream, (const LsCtx*)s->dev_ctx, a);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+static int lsbk_launch_finish(lsim_sim* s, const LsStepArgs& a, void* stream) {
+    int blocks = (s->cfg.num_envs + 255) / 256;
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(lsim_k_step_finish, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const LsCtx*)s->dev_ctx, a);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 static int lsbk_launch_reduce(lsim_sim* s, const LsStepArgs& a, void* stream) {

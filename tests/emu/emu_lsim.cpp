@@ -17,6 +17,7 @@ static int lsbk_memset(void* d, int v, size_t n) { memset(d, v, n); return 0; }
 static int lsbk_launch_a(lsim_sim* s, const LsStepArgs& a, void* stream);
 static int lsbk_launch_b(lsim_sim* s, const LsStepArgs& a, void* stream);
 static int lsbk_launch_reduce(lsim_sim* s, const LsStepArgs& a, void* stream);
+static int lsbk_launch_finish(lsim_sim* s, const LsStepArgs& a, void* stream);
 static void lsbk_prof_mark(lsim_sim*, int, void*) {}
 static void lsbk_prof_free(lsim_sim*) {}
 #include "../../isaacgymloco_amd/csrc/ls_api_impl.h"
@@ -41,6 +42,12 @@ static int lsbk_launch_b(lsim_sim* s, const LsStepArgs& a, void*) {
         memset(L, 0xCD, sizeof(L));
         ls_wave_step_b(*s->dev_ctx, a, env, sh, L);
     }
+    return 0;
+}
+static int lsbk_launch_finish(lsim_sim* s, const LsStepArgs& a, void*) {
+    const LsCtx& cx = *s->dev_ctx;
+    for (int env = 0; env < s->cfg.num_envs; ++env) ls_step_finish_env(cx, a, env);
+    for (int t = 0; t < 256; ++t) ls_step_finish_rows(cx, a, t);
     return 0;
 }
 static int lsbk_launch_reduce(lsim_sim* s, const LsStepArgs& a, void*) {   // bare reset_idx: track sum (and count) over the resetting envs (LR:875)

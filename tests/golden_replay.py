@@ -95,8 +95,8 @@ EXACT_CHECKS = [("reset", "reset"), ("time_out", "time_out"), ("extras_time_outs
                 ("episode_length", "episode_length")]
 
 
-def replay(fx, backend, get, put):
-    """get(name) -> numpy copy of a backend buffer; put(name, array) writes one."""
+def replay(fx, backend, get, put, extra_flags=0):
+    """get(name) -> numpy copy of a backend buffer; put(name, array) writes one.  extra_flags: or-ed into the step flags (LSIM_STEP_TWO_KERNELS)."""
     N = int(fx["num_envs"])
     feet = [4, 8, 12, 16]
     big = "big" in fx.files
@@ -129,7 +129,7 @@ def replay(fx, backend, get, put):
             es[:, abi.REWARD_IDS["tracking_lin_vel"]] = fx["in_track_override"][t]
             put("episode_sums", es)
         last_before = get("last_actions")
-        backend.step(inp["actions"], flags=abi.STEP_SKIP_PHYSICS | abi.STEP_RECORD_SUBSTEPS)
+        backend.step(inp["actions"], flags=abi.STEP_SKIP_PHYSICS | abi.STEP_RECORD_SUBSTEPS | extra_flags)
         out = {k[4:]: fx[k][t] for k in fx.files if k.startswith("out_")}
         out["last_actions_before"] = last_before
         if big:

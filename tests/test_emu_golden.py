@@ -19,8 +19,12 @@ def make_emu_from_fixture(name, big=False):
     return fx, emu_binding.EmuSim(lc, model, ter.heightsamples, ter.env_origins)
 
 
+FORMS = {"fused": 0, "two_kernels": abi.STEP_TWO_KERNELS}      # kernel A with the fused tail + the finish kernel (default) / kernels A + B on every step
+
+
+@pytest.mark.parametrize("form", list(FORMS))
 @pytest.mark.parametrize("name", GR.SCENARIOS)
-def test_emu_matches_reference_step(name):
+def test_emu_matches_reference_step(name, form):
     fx, sim = make_emu_from_fixture(name)
 
     def get(n):
@@ -28,7 +32,7 @@ def test_emu_matches_reference_step(name):
 
     def put(n, a):
         sim.buf[n][...] = a
-    for t, ref in GR.replay(fx, sim, get, put):
+    for t, ref in GR.replay(fx, sim, get, put, extra_flags=FORMS[form]):
         GR.compare_step(t, ref, get, sim.stats_row)
     if "fin_ids" in fx.files:     # the reference's by-hand reset_idx(env_ids): kernel B's masked mode (lsim_reset_envs)
         mask = GR.replay_final_reset(fx, sim, get, put)
@@ -88,3 +92,37 @@ def test_emu_recover_task_matches_oracle():
     def put(be, k, v):
         be.buf[k][...] = v
     _recover_task_check(lambda cfg, lc, model, ter, N: emu_binding.EmuSim(lc, model, ter.heightsamples, ter.env_origins), lambda be, k: be.buf[k], put)
+
+
+@pytest.mark.parametrize("task", ["aliengo", "aliengo_stairs"])
+def test_emu_fused_tail_equals_the_two_kernel_form(task):
+    """the per-env work of kernel B run by kernel A's wave (default) against kernels A + B (LSIM_STEP_TWO_KERNELS; the form command-curriculum
+    steps always take): full physics, resets, a command-curriculum step in the window -- EVERY buffer bit for bit after every step"""
+    import emu_binding
+    from helpers import C
+    N = 24
+    sims = []
+    for _ in range(2):
+        cfg = C.TASKS[task][0]()
+        cfg.env.episode_length_s = 0.4          # time-out resets inside the window
+        orc, lc, model, ter = make_oracle(cfg, N, seed=9)
+        orc.close()
+        sims.append(emu_binding.EmuSim(lc, model, ter.heightsamples, ter.env_origins))
+    a_, b_ = sims
+    a_.reset_all(); b_.reset_all()
+    rs = np.random.RandomState(3)
+    resets = 0
+    for t in range(30):
+        if t == 12:      # the next step evaluates the command curriculum (LR:307): the default form falls back to two kernels there
+            a_.step_counter = b_.step_counter = int(lc.max_episode_length) * 2 - 1
+        act = rs.normal(0, 1, (N, 12)).astype(np.float32)
+        a_.step(act); b_.step(act, flags=abi.STEP_TWO_KERNELS)
+        assert a_.stats_row == b_.stats_row
+        for name in abi.BUFFER_IDS:
+            if name == "stats":      # the ticket word is the two-kernel form's own bookkeeping
+                ra, rb = np.array(a_.buf[name]), np.array(b_.buf[name])
+                np.testing.assert_array_equal(ra[:, :abi.STATS["fix"]], rb[:, :abi.STATS["fix"]], err_msg=f"step {t} stats")
+                continue
+            np.testing.assert_array_equal(np.array(a_.buf[name]), np.array(b_.buf[name]), err_msg=f"step {t} buffer {name}")
+        resets += int(np.array(a_.buf["reset"]).sum())
+    assert resets > N // 2

@@ -9,14 +9,18 @@ from helpers import C, T, make_oracle, quiet_cfg, abi
 pytestmark = pytest.mark.gpu
 
 
+FORMS = {"fused": 0, "two_kernels": abi.STEP_TWO_KERNELS}      # kernel A with the fused tail + lsim_k_step_finish (default) / kernels A + B on every step
+
+
+@pytest.mark.parametrize("form", list(FORMS))
 @pytest.mark.parametrize("name", GR.SCENARIOS)
-def test_hip_matches_reference_step(name):
+def test_hip_matches_reference_step(name, form):
     from hip_backend import HipBackend
     fx = GR.load(name)
     cfg = GR.scenario_cfg(name)
     be = HipBackend(cfg, int(fx["num_envs"]), GR.FixtureTerrain(fx), seed=int(fx["seed"]))
     n = 0
-    for t, ref in GR.replay(fx, be, be.get, be.put):
+    for t, ref in GR.replay(fx, be, be.get, be.put, extra_flags=FORMS[form]):
         GR.compare_step(t, ref, be.get, be.stats_row)
         n += 1
     assert n == fx["in_actions"].shape[0]
@@ -402,3 +406,36 @@ def test_hip_recover_task_matches_oracle():
     from hip_backend import HipBackend
     from test_emu_golden import _recover_task_check
     _recover_task_check(lambda cfg, lc, model, ter, N: HipBackend(cfg, N, ter, seed=3), lambda be, k: be.get(k), lambda be, k, v: be.put(k, v), steps=16)
+
+
+@pytest.mark.parametrize("task", ["aliengo", "aliengo_stairs", "aliengo_amp"])
+def test_hip_fused_tail_equals_the_two_kernel_form(task):
+    """kernel A running reset_idx + observations for its own robot (+ lsim_k_step_finish) against kernels A + B on every step
+    (LSIM_STEP_TWO_KERNELS): N = 4096, full physics, time-out and fall resets, a command-curriculum step inside the window -- every
+    buffer of the arena bit for bit after every step (the stats rows up to the two-kernel form's ticket word)"""
+    import torch
+    from isaacgymloco_amd.envs.legged_robot import LeggedRobot
+    envs = []
+    for _ in range(2):
+        cfg = C.TASKS[task][0]()
+        cfg.env.num_envs = 4096
+        cfg.env.episode_length_s = 0.6
+        envs.append(LeggedRobot(cfg, sim_device="cuda:0", seed=11, using_amp=(task == "aliengo_amp")))
+    ea, eb = envs
+    ea.reset(); eb.reset()
+    g = torch.Generator(device="cuda:0").manual_seed(1)
+    resets = 0
+    for t in range(45):
+        if t == 20:
+            for e in envs:
+                e._L.lsim_set_step_counter(e._h, __import__("ctypes").c_int64(int(e.max_episode_length) * 2 - 1))
+        act = torch.randn(4096, 12, device="cuda:0", generator=g)
+        ea.step_device(act); eb.step_device(act, flags=abi.STEP_TWO_KERNELS)
+        torch.cuda.synchronize()
+        for name in abi.BUFFER_IDS:
+            xa, xb = ea.buf[name], eb.buf[name]
+            if name == "stats":
+                xa, xb = xa[:, :abi.STATS["fix"]], xb[:, :abi.STATS["fix"]]
+            assert torch.equal(xa, xb), f"step {t}: buffer {name} differs between the fused and the two-kernel form"
+        resets += int(ea.reset_buf.sum())
+    assert resets > 4096
