@@ -181,7 +181,7 @@ extern "C" int LS_API(create)(const lsim_config* cfg, const lsim_robot_model* mo
     h.accum = (float*)h.buf[LSIM_BUF_STATS];
     h.num_active = 0;
     for (int id = 0; id < LSIM_NUM_REWARD_TERMS; ++id)
-        if (id != LSIM_R_TERMINATION && c.reward_scales[id] != 0.0f) h.active_terms[h.num_active++] = id;
+        if (id != LSIM_R_TERMINATION && c.reward_scales[id] != 0.0f) { h.active_scales[h.num_active] = c.reward_scales[id]; h.active_terms[h.num_active++] = id; }
     for (int ai = 0; ai < h.num_active; ++ai) {       // the (term, part) items of ph_reward_parts, whole terms while the table has room
         const int id = h.active_terms[ai], n = ls_reward_num_parts(id);
         if (n == 0 || h.num_part_items + n > LS_MAX_PART_ITEMS) continue;

@@ -33,14 +33,14 @@ static inline long long ls_emu_fetch_add(long long* p, long long v) { long long 
 __device__ __forceinline__ int ls_opaque_lane(int l) { asm volatile("" : "+v"(l)); return l; }
 #define LS_LANES_PARAM LaneRegs& rg, const int lane0
 #if defined(LS_PHASE_TIMING)   // diagnostics build only (tools/phase_profile.py): shader-clock ticks per phase site, summed over waves
-__device__ unsigned long long g_ls_phase_ticks[64];
-__device__ unsigned long long g_ls_phase_calls[64];
-#define LS_TICK(site) do { if (lane0 == 0) { unsigned long long t_ = clock64(); ls_ticks[(site) & 63] += t_ - ls_t_prev; ls_calls[(site) & 63] += 1; \
+__device__ unsigned long long g_ls_phase_ticks[128];
+__device__ unsigned long long g_ls_phase_calls[128];
+#define LS_TICK(site) do { if (lane0 == 0) { unsigned long long t_ = clock64(); ls_ticks[(site) & 127] += (unsigned int)(t_ - ls_t_prev); ls_calls[(site) & 127] += 1; \
                                              ls_t_prev = t_; } } while (0)
-#define LS_TICK_INIT() __shared__ unsigned long long ls_ticks[64]; __shared__ unsigned int ls_calls[64]; \
-                       ls_ticks[lane0] = 0; ls_calls[lane0] = 0; __syncthreads(); unsigned long long ls_t_prev = clock64()
-#define LS_TICK_FLUSH() do { __syncthreads(); if (ls_calls[lane0]) { atomicAdd(&g_ls_phase_ticks[lane0], ls_ticks[lane0]); \
-                                                                      atomicAdd(&g_ls_phase_calls[lane0], (unsigned long long)ls_calls[lane0]); } } while (0)
+#define LS_TICK_INIT() __shared__ unsigned int ls_ticks[128]; __shared__ unsigned short ls_calls[128]; \
+                       ls_ticks[lane0] = 0; ls_calls[lane0] = 0; ls_ticks[64 + lane0] = 0; ls_calls[64 + lane0] = 0; __syncthreads(); unsigned long long ls_t_prev = clock64()
+#define LS_TICK_FLUSH() do { __syncthreads(); for (int s_ = lane0; s_ < 128; s_ += 64) if (ls_calls[s_]) { atomicAdd(&g_ls_phase_ticks[s_], (unsigned long long)ls_ticks[s_]); \
+                                                                      atomicAdd(&g_ls_phase_calls[s_], (unsigned long long)ls_calls[s_]); } } while (0)
 #else
 #define LS_TICK(site) do { } while (0)
 #define LS_TICK_INIT() do { } while (0)
@@ -112,16 +112,22 @@ LS_FN void ph_load_a(const LsCtx& cx, WaveShared& sh, LaneRegs& rg, int lane, in
     const unsigned int v_lc = LSB(cx, LSIM_BUF_LAST_CONTACTS, unsigned int)[env];
     const int v_level = (int)LSB(cx, LSIM_BUF_TERRAIN_LEVELS, int64_t)[env];
     const float v_es = LSB(cx, LSIM_BUF_EPISODE_SUMS, float)[env * LSIM_NUM_REWARD_TERMS + (lane < LSIM_NUM_REWARD_TERMS ? lane : 0)];
-    uint16_t v_items[LS_MAX_PART_ITEMS / 64];
-    for (int it = 0; it < LS_MAX_PART_ITEMS / 64; ++it) v_items[it] = cx.part_items[lane + 64 * it];
+    const float v_rng = LS_G(const float, cx.accum)[a.row_in * LSIM_STATS_SIZE + LSIM_STATS_CMD_RANGES + (lane & 7)];   // live command ranges (no kernel of this step writes row_in's)
+    float v_jc[7];
+    {
+        const lsim_robot_model& m = cx.model;
+        v_jc[0] = c.default_dof_pos[l12]; v_jc[1] = c.p_gains[l12]; v_jc[2] = c.d_gains[l12]; v_jc[3] = c.torque_limits[l12];
+        v_jc[4] = m.dof_pos_lower[l12]; v_jc[5] = m.dof_pos_upper[l12]; v_jc[6] = m.dof_vel_limit[l12];
+    }
     // ---- LDS writes
     // the tail of the row array Y that no spatial inertia ever overlays (ls_shared.h, union u): the solver reads whole triples of limit slots,
     // i.e. up to two slots that hold no row yet, and multiplies what it finds by a zero impulse -- harmless only if it is finite
     static_assert(sizeof(sh.u.c.Y) - sizeof(sh.u.I6) == 2 * LS_NV * sizeof(float), "rows of Y beyond the inertias");
     if (lane < 2 * LS_NV) (&sh.u.c.Y[LS_MAXR - 2][0])[lane] = 0.0f;
-    for (int it = 0; it < LS_MAX_PART_ITEMS / 64; ++it) sh.items[lane + 64 * it] = v_items[it];
     if (lane < 13) sh.root[lane] = v_root;
     if (lane < 12) {
+        sh.jc_q0[lane] = v_jc[0]; sh.jc_kp[lane] = v_jc[1]; sh.jc_kd[lane] = v_jc[2]; sh.jc_taumax[lane] = v_jc[3];
+        sh.jc_lo[lane] = v_jc[4]; sh.jc_hi[lane] = v_jc[5]; sh.jc_vmax[lane] = v_jc[6];
         sh.q[lane] = v_q;
         sh.qd[lane] = v_qd;
         const float act = clampf(v_act, -c.clip_actions, c.clip_actions);    // LR:129-130
@@ -161,6 +167,7 @@ LS_FN void ph_load_a(const LsCtx& cx, WaveShared& sh, LaneRegs& rg, int lane, in
     else if (lane == 57) sh.pre_lc = v_lc;
     else if (lane == 58) sh.pre_level = v_level;
     if (lane < LSIM_NUM_REWARD_TERMS) sh.pre_es[lane] = v_es;
+    if (lane < 8) sh.ranges[lane] = v_rng;
     rg.cp_active = 0;
     rg.row_kind = -1;
 }
@@ -174,12 +181,12 @@ LS_FN void ph_torques(const LsCtx& cx, WaveShared& sh, int lane, int env, int su
     a = sh.ms[lane] * a;
     float as = a * c.action_scale;
     if (lane % 3 == 0) as *= c.hip_reduction;
-    float target = c.default_dof_pos[lane] + as;
+    float target = sh.jc_q0[lane] + as;
     float q = sh.q[lane], qd = sh.qd[lane], t;
-    if (c.control_type == 0) t = c.p_gains[lane] * sh.kpf * (target - q) - c.d_gains[lane] * sh.kdf * qd;
-    else if (c.control_type == 1) t = c.p_gains[lane] * (as - qd) - c.d_gains[lane] * (qd - sh.pre_ldv[lane]) / c.sim_dt;
+    if (c.control_type == 0) t = sh.jc_kp[lane] * sh.kpf * (target - q) - sh.jc_kd[lane] * sh.kdf * qd;
+    else if (c.control_type == 1) t = sh.jc_kp[lane] * (as - qd) - sh.jc_kd[lane] * (qd - sh.pre_ldv[lane]) / c.sim_dt;
     else t = as;
-    t = clampf(t, -c.torque_limits[lane], c.torque_limits[lane]);
+    t = clampf(t, -sh.jc_taumax[lane], sh.jc_taumax[lane]);
     sh.tau[lane] = t;
     if (flags & LSIM_STEP_RECORD_SUBSTEPS) LSB(cx, LSIM_BUF_SUBSTEP_TORQUES, float)[12 * (c.decimation * env + sub) + lane] = t;   // test hook (wave-uniform branch)
 }
@@ -198,13 +205,12 @@ LS_FN void ph_store_sim_state(const LsCtx& cx, WaveShared& sh, int lane, int env
 }
 LS_FN void ph_body_states_all(const LsCtx& cx, WaveShared& sh, int lane, int env) {
     LS_GLOBAL float* out = LSB(cx, LSIM_BUF_RIGID_BODY_STATES, float) + 13 * LS_NB * env;
-    ph_body_states(sh, lane, out);
-    if (lane < LS_NB)
+    float pv[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    ph_body_states(sh, lane, out, pv);
+    if (lane < LS_NB)       // the feet rows of the tensor for the reward terms, from registers (reading them back from `out` is a store -> load round trip per foot)
         for (int f = 0; f < 4; ++f)
-            if (cx.model.feet_bodies[f] == lane) {
-                LS_GLOBAL const float* o = out + 13 * lane;
-                for (int k = 0; k < 3; ++k) { sh.feet[f][k] = o[k]; sh.feet[f][3 + k] = o[7 + k]; }
-            }
+            if (cx.model.feet_bodies[f] == lane)         // uniform f: scalar loads
+                for (int k = 0; k < 6; ++k) sh.feet[f][k] = pv[k];
 }
 // LSIM_STEP_SKIP_PHYSICS: take the simulator tensors as injected by the caller
 LS_FN void ph_load_injected(const LsCtx& cx, WaveShared& sh, int lane, int env) {
@@ -215,13 +221,9 @@ LS_FN void ph_load_injected(const LsCtx& cx, WaveShared& sh, int lane, int env) 
     if (lane < 3 * LS_NB) sh.cf[lane / 3][lane % 3] = LSB(cx, LSIM_BUF_CONTACT_FORCES, float)[3 * LS_NB * env + lane];
     if (lane < 24) {
         int f = lane / 6, k = lane % 6;
-        LS_GLOBAL const float* bs = LSB(cx, LSIM_BUF_RIGID_BODY_STATES, float) + 13 * (LS_NB * env + cx.model.feet_bodies[f]);
+        LS_GLOBAL const float* bs = LSB(cx, LSIM_BUF_RIGID_BODY_STATES, float) + 13 * (LS_NB * env + ls_foot_body(cx, f));
         sh.feet[f][k] = k < 3 ? bs[k] : bs[7 + k - 3];
     }
-}
-
-LS_FN void ph_store_root_cmd_ranges(const LsCtx& cx, WaveShared& sh, int lane, int env, const LsStepArgs& a) {
-    if (lane < 8) sh.ranges[lane] = LS_G(const float, cx.accum)[a.row_in * LSIM_STATS_SIZE + LSIM_STATS_CMD_RANGES + lane];
 }
 
 // ---- termination observations / terminal AMP states of the pre-reset state + per-step reductions (LR:227-228)
@@ -363,7 +365,7 @@ LS_FN void ph_b_reset(const LsCtx& cx, WaveShared& sh, int lane, int env, const 
     const lsim_config& c = cx.cfg;
     const uint32_t stepw = (uint32_t)a.step_counter;
     if (lane < 12) {  // _reset_dofs (LR:690-716)
-        float pos = c.default_dof_pos[lane];
+        float pos = c.default_dof_pos[lane];      // kernel B has no joint-constant block in LDS (ph_load_a's); resets are rare
         if (c.has_dof_init_pos_ratio)
             pos = pos * rand_range(ls_draw(cx, env, stepw, LSIM_RNG_RESET_DOF, (uint32_t)lane), c.dof_init_pos_ratio_range[0], c.dof_init_pos_ratio_range[1]);
         float vel = 0.0f;
@@ -509,18 +511,33 @@ LS_FN float* ls_obs_hist(WaveShared& sh) { return &sh.Mbl[0][0]; }
 static_assert(offsetof(WaveShared, Sinv) + sizeof(((WaveShared*)0)->Sinv) - offsetof(WaveShared, Mbl) >= (LSIM_NUM_OBS - LSIM_ONE_STEP_OBS) * sizeof(float),
               "observation history parked in Mbl .. Sinv");
 static_assert((LSIM_NUM_OBS - LSIM_ONE_STEP_OBS + 63) / 64 <= 4, "LaneRegs::hist");
-LS_FN void ph_hist_load(const LsCtx& cx, LaneRegs& rg, int lane, int env) {
-    for (int it = 0; it < (LSIM_NUM_OBS - LSIM_ONE_STEP_OBS + 63) / 64; ++it) {
-        const int k = lane + 64 * it;
-        rg.hist[it] = LSB(cx, LSIM_BUF_OBS, float)[LSIM_NUM_OBS * env + (k < LSIM_NUM_OBS - LSIM_ONE_STEP_OBS ? k : 0)];
-    }
+// the reward part items (host-built table, ls_api_impl.h) live behind the history: only the post-physics stack reads them
+LS_FN uint16_t* ls_part_items(WaveShared& sh) { return (uint16_t*)(ls_obs_hist(sh) + (LSIM_NUM_OBS - LSIM_ONE_STEP_OBS + 1)); }
+static_assert(offsetof(WaveShared, nc) - offsetof(WaveShared, Mbl) >= (LSIM_NUM_OBS - LSIM_ONE_STEP_OBS + 1) * sizeof(float) + LS_MAX_PART_ITEMS * sizeof(uint16_t),
+              "reward part items parked behind the observation history (Mbl .. vnew)");
+// everything the post-physics stack needs from global memory that is not per-step state: issued in the last phase before the kernel's
+// first store, written to LDS (dynamics arrays, dead by then) one phase later
+LS_FN void ph_late_load(const LsCtx& cx, LaneRegs& rg, int lane, int env, bool fuse) {
+    if (fuse)
+        for (int it = 0; it < (LSIM_NUM_OBS - LSIM_ONE_STEP_OBS + 63) / 64; ++it) {
+            const int k = lane + 64 * it;
+            rg.hist[it] = LSB(cx, LSIM_BUF_OBS, float)[LSIM_NUM_OBS * env + (k < LSIM_NUM_OBS - LSIM_ONE_STEP_OBS ? k : 0)];
+        }
+    for (int it = 0; it < LS_MAX_PART_ITEMS / 64; ++it) rg.items[it] = cx.part_items[lane + 64 * it];
+    const int ai = lane < LSIM_NUM_REWARD_TERMS ? lane : 0;
+    rg.term_id = cx.active_terms[ai];
+    rg.term_scale = cx.active_scales[ai];          // cfg.reward_scales[active_terms[ai]], tabulated by the host: no dependent load
 }
-LS_FN void ph_hist_stage(WaveShared& sh, const LaneRegs& rg, int lane) {
-    float* hist = ls_obs_hist(sh);
-    for (int it = 0; it < (LSIM_NUM_OBS - LSIM_ONE_STEP_OBS + 63) / 64; ++it) {
-        const int k = lane + 64 * it;
-        if (k < LSIM_NUM_OBS - LSIM_ONE_STEP_OBS) hist[k] = rg.hist[it];
+LS_FN void ph_late_stage(WaveShared& sh, const LaneRegs& rg, int lane, bool fuse) {
+    if (fuse) {
+        float* hist = ls_obs_hist(sh);
+        for (int it = 0; it < (LSIM_NUM_OBS - LSIM_ONE_STEP_OBS + 63) / 64; ++it) {
+            const int k = lane + 64 * it;
+            if (k < LSIM_NUM_OBS - LSIM_ONE_STEP_OBS) hist[k] = rg.hist[it];
+        }
     }
+    uint16_t* items = ls_part_items(sh);
+    for (int it = 0; it < LS_MAX_PART_ITEMS / 64; ++it) items[lane + 64 * it] = rg.items[it];
 }
 // what ph_load_b derives for kernel B, from kernel A's own LDS state
 LS_FN void ph_tail_setup(const LsCtx& cx, WaveShared& sh, int lane, const LsStepArgs& a) {
@@ -587,31 +604,30 @@ template <int SOLVER> LS_WAVE_FN void ls_wave_step_a(const LsCtx& cx, const LsSt
     const bool fuse = a.fuse_tail != 0;
     if (!skip) {
 #if defined(LS_EMU)
-        LS_PHASE(ph_kinematics(sh, lane); if (fuse) ph_hist_load(cx, rg, lane, env));
+        LS_PHASE(ph_kinematics(sh, lane); ph_late_load(cx, rg, lane, env, fuse); ph_heights_issue(cx, sh, rg, lane));
 #else
-        LS_COLLECTIVE(wc_kinematics(sh, lane); if (fuse) ph_hist_load(cx, rg, lane, env), (void)0);
+        LS_COLLECTIVE(wc_kinematics(sh, lane); ph_late_load(cx, rg, lane, env, fuse); ph_heights_issue(cx, sh, rg, lane), (void)0);
 #endif
         LS_PHASE(ph_body_states_all(cx, sh, lane, env));
-        LS_PHASE(ph_store_sim_state(cx, sh, lane, env); if (fuse) ph_hist_stage(sh, rg, lane));     // Mbl .. Sinv, nact are dead from here on
+        LS_PHASE(ph_store_sim_state(cx, sh, lane, env); ph_late_stage(sh, rg, lane, fuse));     // Mbl .. vnew are dead from here on
     } else {
-        LS_PHASE(if (fuse) ph_hist_load(cx, rg, lane, env));
-        LS_PHASE(ph_load_injected(cx, sh, lane, env); if (fuse) ph_hist_stage(sh, rg, lane));
+        LS_PHASE(ph_late_load(cx, rg, lane, env, fuse); ph_heights_issue(cx, sh, rg, lane));
+        LS_PHASE(ph_load_injected(cx, sh, lane, env); ph_late_stage(sh, rg, lane, fuse));
     }
     // ---- post_physics_step (LR:178-228)
-    LS_PHASE(ph_store_root_cmd_ranges(cx, sh, lane, env, a));
     LS_PHASE(ph_post_state(cx, sh, lane, env));
     LS_PHASE(ph_callback(cx, sh, lane, env, a, sh.ranges));
 #if defined(LS_EXP_TWICE) && LS_EXP_TWICE == 9003      // cost probe: counter-based draws, so a second pass writes the same values
     LS_PHASE(ph_callback(cx, sh, lane, env, a, sh.ranges));
 #endif
-    LS_PHASE(if (c.measure_heights) ph_heights(cx, sh, lane, env, true); ph_base_height_pts(cx, sh, lane));
-    LS_PHASE(ph_termination(cx, sh, lane, env); ph_reward_parts(cx, sh, lane, env));
-    LS_PHASE(ph_reward_terms(cx, sh, lane, env));
+    LS_PHASE(ph_heights_finish(cx, sh, rg, lane, env));
+    LS_PHASE(ph_termination(cx, sh, lane, env); ph_reward_parts(cx, sh, ls_part_items(sh), lane, env));
+    LS_PHASE(ph_reward_terms(cx, sh, rg, lane, env));
 #if defined(LS_EXP_TWICE) && LS_EXP_TWICE == 9002      // cost probe (adds the step's rewards to the episode sums twice: statistics only)
-    LS_PHASE(ph_reward_terms(cx, sh, lane, env));
+    LS_PHASE(ph_reward_terms(cx, sh, rg, lane, env));
 #endif
     LS_PHASE(ph_reward_total(cx, sh, lane, env));
-    LS_PHASE(if (sh.reset) ph_build_obs(cx, sh, lane, env, (uint32_t)a.step_counter, LSIM_RNG_TERM_NOISE, sh.cur));
+    LS_PHASE(if (sh.reset) ph_build_obs(cx, sh, lane, env, (uint32_t)a.step_counter, LSIM_RNG_TERM_NOISE, sh.cur, sh.jc_q0));
     LS_PHASE(ph_term_outputs(cx, sh, lane, env, a));
     if (fuse) {     // LR:229-241 + LR:167-171 for this robot (kernel B's phases; its cross-env part is lsim_k_step_finish)
         LS_PHASE(ph_tail_setup(cx, sh, lane, a));
@@ -619,7 +635,7 @@ template <int SOLVER> LS_WAVE_FN void ls_wave_step_a(const LsCtx& cx, const LsSt
         LS_PHASE(ph_b_reset(cx, sh, lane, env, a));
         LS_PHASE(ph_tail_episode_stats(cx, sh, lane, env, a));
         LS_PHASE(if (sh.do_reset && c.measure_heights) ph_heights(cx, sh, lane, env, true));
-        LS_PHASE(ph_build_obs(cx, sh, lane, env, (uint32_t)a.step_counter, LSIM_RNG_OBS_NOISE, sh.cur));
+        LS_PHASE(ph_build_obs(cx, sh, lane, env, (uint32_t)a.step_counter, LSIM_RNG_OBS_NOISE, sh.cur, sh.jc_q0));
         LS_PHASE(ph_b_store(cx, sh, lane, env, a, ls_obs_hist(sh)));
     }
     LS_TICK_FLUSH();
@@ -627,7 +643,7 @@ template <int SOLVER> LS_WAVE_FN void ls_wave_step_a(const LsCtx& cx, const LsSt
 
 LS_WAVE_FN void ls_wave_step_b(const LsCtx& cx, const LsStepArgs& a, const int env, WaveShared& sh, LS_LANES_PARAM) {
     const lsim_config& c = cx.cfg;
-    [[maybe_unused]] constexpr int ls_line0 = __LINE__ - 48;   // kernel B's sites land above kernel A's (A uses 0..47)
+    [[maybe_unused]] constexpr int ls_line0 = __LINE__ - 96;   // kernel B's sites land above kernel A's (A uses 0..95)
     LS_TICK_INIT();
     LS_PHASE(ph_load_b(cx, sh, lane, env, a));
     LS_PHASE(ph_b_housekeeping(cx, sh, lane, env, a); ph_b_terrain_curriculum(cx, sh, lane, env, a));
@@ -639,7 +655,7 @@ LS_WAVE_FN void ls_wave_step_b(const LsCtx& cx, const LsStepArgs& a, const int e
         LS_PHASE(ph_b_stats_convert(cx, sh, lane, a));
         return;
     }
-    LS_PHASE(ph_build_obs(cx, sh, lane, env, (uint32_t)a.step_counter, LSIM_RNG_OBS_NOISE, sh.cur));
+    LS_PHASE(ph_build_obs(cx, sh, lane, env, (uint32_t)a.step_counter, LSIM_RNG_OBS_NOISE, sh.cur, cx.cfg.default_dof_pos));
     LS_PHASE(ph_b_store(cx, sh, lane, env, a, &sh.u.I6[0][0]); ph_b_stats_publish(cx, sh, rg, lane, a));
     LS_PHASE(ph_b_stats_convert(cx, sh, lane, a));
     LS_TICK_FLUSH();

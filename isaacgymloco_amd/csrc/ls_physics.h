@@ -566,8 +566,8 @@ LS_FN void wc_compact_contacts(WaveShared& sh, LaneRegs& r, int lane) {
 #define LS_LIMIT_MARGIN 0.2f    // a joint "needs" its row when the free velocity is within this fraction of vmax of a bound (or beyond it)
 LS_FN bool ls_joint_limit_bounds(const LsCtx& cx, const WaveShared& sh, int j, float dt, float& Lb, float& Ub, bool& violates) {
     const float idt = ls_rcp(dt);
-    const float lo = sh.q[j] - cx.model.dof_pos_lower[j], hi = cx.model.dof_pos_upper[j] - sh.q[j];
-    const float vmax = cx.model.dof_vel_limit[j], vf = sh.vfree[6 + j];
+    const float lo = sh.q[j] - sh.jc_lo[j], hi = sh.jc_hi[j] - sh.q[j];
+    const float vmax = sh.jc_vmax[j], vf = sh.vfree[6 + j];
     Lb = -vmax; Ub = vmax;
     if (lo < 0.1f) Lb = fmaxf(Lb, lo >= 0.0f ? -lo * idt : fminf(1.0f, cx.cfg.erp * (-lo) * idt));
     if (hi < 0.1f) Ub = fminf(Ub, hi >= 0.0f ? hi * idt : -fminf(1.0f, cx.cfg.erp * (-hi) * idt));
@@ -648,9 +648,9 @@ template <bool TGS> LS_FN void ph_rows(const LsCtx& cx, WaveShared& sh, LaneRegs
         vt = sh.limvt[i];                 // lower velocity bound; the row is two-sided: the upper bound is limrng above it
         rng = sh.limrng[i];
         if (TGS) {                        // the bounds move with the joint angle: hand over the distances to the stops and the velocity limit
-            rng = cx.model.dof_vel_limit[j];
-            tg_a = sh.q[j] - cx.model.dof_pos_lower[j];
-            tg_b = cx.model.dof_pos_upper[j] - sh.q[j];
+            rng = sh.jc_vmax[j];
+            tg_a = sh.q[j] - sh.jc_lo[j];
+            tg_b = sh.jc_hi[j] - sh.q[j];
         }
         r.row_kind = 3;
     }
@@ -1127,7 +1127,7 @@ LS_FN void ph_contact_forces(WaveShared& sh, int lane, float dt) {
 // ---- phase: integrate (lanes 0-11 joints, lane 12 base)
 LS_FN void ph_integrate(const LsCtx& cx, WaveShared& sh, int lane, float dt) {
     if (lane < 12) {
-        float lim = 1.5f * cx.model.dof_vel_limit[lane];     // the limit itself is a constraint row; this only bounds solver residue
+        float lim = 1.5f * sh.jc_vmax[lane];     // the limit itself is a constraint row; this only bounds solver residue
         const int l = lane / 3, k = lane - 3 * l;
         float vj = sh.vnew[6 + lane];
         for (int c = 0; c < 6; ++c) vj -= sh.G[l][6 * k + c] * sh.ab[c];      // - G_l dvb: the base impulse response on this joint (ph_apply_impulses)
@@ -1165,7 +1165,7 @@ LS_FN void ph_integrate(const LsCtx& cx, WaveShared& sh, int lane, float dt) {
 LS_FN void ph_integrate_tgs(const LsCtx& cx, WaveShared& sh, int lane, float dt, int nsub) {
     const float hs = dt * ls_rcp((float)nsub);
     if (lane < 12) {
-        const float lim = 1.5f * cx.model.dof_vel_limit[lane];     // bounds solver residue on the velocity the step hands on (as the PGS form)
+        const float lim = 1.5f * sh.jc_vmax[lane];     // bounds solver residue on the velocity the step hands on (as the PGS form)
         const int l = lane / 3, k = lane - 3 * l;
         const float* vs = ls_tgs_vel_sum(sh);
         float vj = sh.vnew[6 + lane], sj = vs[6 + lane];
@@ -1179,8 +1179,8 @@ LS_FN void ph_integrate_tgs(const LsCtx& cx, WaveShared& sh, int lane, float dt,
         float q0 = q[0] * qn, q1 = q[1] * qn, q2 = q[2] * qn, q3 = q[3] * qn;
         V3 dp = v3(0, 0, 0), w = wf, vl = vf;
         const float h = 0.5f * hs;
-        for (int s = 0; s < nsub; ++s) {
-            const float* tb = ls_tgs_base_twist(sh, s);
+        // q <- (I + h Omega(w_s)) q is linear in q: normalising once after the last sub-iteration gives what normalising after each one gives
+        auto sub_iteration = [&](const float* tb) {
             w = wf + v3p(tb);
             vl = vf + v3p(tb + 3);                // velocity of the point of the base that sat at the base origin at the start of the step
             dp = dp + (vl + cross(w, dp)) * hs;
@@ -1188,8 +1188,18 @@ LS_FN void ph_integrate_tgs(const LsCtx& cx, WaveShared& sh, int lane, float dt,
             const float n1 = q1 + h * (-w.x * q2 + w.y * q3 + w.z * q0);
             const float n2 = q2 + h * (w.x * q1 - w.y * q0 + w.z * q3);
             const float n3 = q3 + h * (-w.x * q0 - w.y * q1 - w.z * q2);
-            const float nn = ls_rsqrt(n0 * n0 + n1 * n1 + n2 * n2 + n3 * n3);
-            q0 = n0 * nn; q1 = n1 * nn; q2 = n2 * nn; q3 = n3 * nn;
+            q0 = n0; q1 = n1; q2 = n2; q3 = n3;
+        };
+        if (nsub == 4) {                          // the reference's setting: unrolled, all 24 twist components read before the dependent chain starts
+            float tb[24];
+            for (int k = 0; k < 24; ++k) tb[k] = ls_tgs_base_twist(sh, 0)[k];
+            for (int s = 0; s < 4; ++s) sub_iteration(tb + 6 * s);
+        } else {
+            for (int s = 0; s < nsub; ++s) sub_iteration(ls_tgs_base_twist(sh, s));
+        }
+        {
+            const float nn = ls_rsqrt(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
+            q0 *= nn; q1 *= nn; q2 *= nn; q3 *= nn;
         }
         {   // body velocity caps of the asset options (LRC:229-230), on the velocity the step hands on
             const float wn = sqrtf(dot(w, w)), ln = sqrtf(dot(vl, vl));
@@ -1204,13 +1214,15 @@ LS_FN void ph_integrate_tgs(const LsCtx& cx, WaveShared& sh, int lane, float dt,
 }
 
 // ---- phase B: world state of every body (rigid_body_states, LR:938) from the kinematics phase (lane = body)
-LS_FN void ph_body_states(WaveShared& sh, int lane, LS_GLOBAL float* out /* [17][13] of this env */) {
+LS_FN void ph_body_states(WaveShared& sh, int lane, LS_GLOBAL float* out /* [17][13] of this env */, float* pos_vel /* [6]: the body's world position and linear velocity */) {
     if (lane >= LS_NB) return;
     LS_GLOBAL float* o = out + 13 * lane;
     V3 p = v3p(sh.p[lane]);
     S6 V = s6p(sh.V[lane]);
     V3 vel = V.l + cross(V.a, p);
     o[0] = sh.root[0] + p.x; o[1] = sh.root[1] + p.y; o[2] = sh.root[2] + p.z;
+    pos_vel[0] = sh.root[0] + p.x; pos_vel[1] = sh.root[1] + p.y; pos_vel[2] = sh.root[2] + p.z;
+    v3st(pos_vel + 3, vel);
     float q4[4];
     if (lane == 0) { for (int k = 0; k < 4; ++k) q4[k] = sh.root[3 + k]; }
     else R_to_quat(m3p(sh.R[lane]), q4);

@@ -11,6 +11,13 @@ LS_FN float ls_draw(const LsCtx& cx, int env, uint32_t stepw, uint32_t tag, uint
     return ls_u01(cx.cfg.seed, cx.cfg.rank, (uint32_t)env, stepw, tag, idx);
 }
 
+// body index of foot f for a per-lane f: four uniform (scalar) loads and selects -- indexing the model table in global memory by a lane
+// value is a vector load, and behind the post-physics stack's stores it waits for all of them (vmcnt retires in order)
+LS_FN int ls_foot_body(const LsCtx& cx, int f) {
+    const int b0 = cx.model.feet_bodies[0], b1 = cx.model.feet_bodies[1], b2 = cx.model.feet_bodies[2], b3 = cx.model.feet_bodies[3];
+    return f == 0 ? b0 : (f == 1 ? b1 : (f == 2 ? b2 : b3));
+}
+
 // LR:1342-1355: (x + border) / hscale truncated toward zero, clip, min of 3 samples, * vscale
 LS_FN float ls_sample_height_min3(const LsCtx& cx, float x, float y) {
 #if defined(__clang__)
@@ -53,6 +60,64 @@ LS_FN V3 ls_yaw_point(const float* root, LsYawQuat y, float px, float py) {
     const float ux = 0.0f - y.z * ty, uy = y.z * tx;
     const float wx = px + y.w * tx + ux, wy = py + y.w * ty + uy;
     return v3(wx + root[0], wy + root[1], 0.0f);
+}
+
+// ---- the same two samplers split in two for kernel A, whose post-physics stack begins with the state stores: the grid loads of this lane's
+//      points are ISSUED before the first store (ph_heights_issue, last phase of the physics) and consumed two phases later
+//      (ph_heights_finish), so that neither their latency nor the drain of the stores in front of them sits on the wave's critical path.
+//      Lane l owns height points l, l + 64, l + 128 (187 in all) and base-height point l (63): 4 x 3 int16 samples in LaneRegs::hraw.
+#define LS_HEIGHT_PASSES ((LS_NHP + 63) / 64)
+LS_FN void ls_height_samples3(const LsCtx& cx, float x, float y, int16_t* h3) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+    const lsim_config& c = cx.cfg;
+    float fx = ls_div_exact(x + c.border_size, c.horizontal_scale);
+    float fy = ls_div_exact(y + c.border_size, c.horizontal_scale);
+    int px = (int)fx, py = (int)fy;
+    px = px < 0 ? 0 : (px > c.grid_rows - 2 ? c.grid_rows - 2 : px);
+    py = py < 0 ? 0 : (py > c.grid_cols - 2 ? c.grid_cols - 2 : py);
+    LS_GLOBAL const int16_t* g = LSB(cx, LSIM_BUF_HEIGHT_GRID, const int16_t);
+    h3[0] = g[px * c.grid_cols + py]; h3[1] = g[(px + 1) * c.grid_cols + py]; h3[2] = g[px * c.grid_cols + py + 1];
+}
+LS_FN void ph_heights_issue(const LsCtx& cx, const WaveShared& sh, LaneRegs& rg, int lane) {
+    const lsim_config& c = cx.cfg;
+    if (c.mesh_type == 0) return;
+    const LsYawQuat yq = ls_yaw_quat(sh.root + 3);
+    if (c.measure_heights)
+        for (int it = 0; it < LS_HEIGHT_PASSES; ++it) {
+            const int k = lane + 64 * it, kk = k < LS_NHP ? k : 0;
+            const int ix = kk / c.num_points_y, iy = kk - ix * c.num_points_y;
+            const V3 w = ls_yaw_point(sh.root, yq, c.measured_points_x[ix], c.measured_points_y[iy]);
+            ls_height_samples3(cx, w.x, w.y, rg.hraw + 3 * it);
+        }
+    {
+        const int l = lane < LSIM_NUM_BASE_HEIGHT_PTS ? lane : 0;
+        const int ix = l / 9, iy = l - 9 * ix;
+        const float xs[7] = {-0.15f, -0.1f, -0.05f, 0.f, 0.05f, 0.1f, 0.15f};          // the reference's literal lists (LR:1308-1309)
+        const float ys[9] = {-0.2f, -0.15f, -0.1f, -0.05f, 0.f, 0.05f, 0.1f, 0.15f, 0.2f};
+        const V3 w = ls_yaw_point(sh.root, yq, xs[ix], ys[iy]);
+        ls_height_samples3(cx, w.x, w.y, rg.hraw + 3 * LS_HEIGHT_PASSES);
+    }
+}
+LS_FN float ls_min3_height(const LsCtx& cx, const int16_t* h3) {
+    int16_t h = h3[0] < h3[1] ? h3[0] : h3[1];
+    h = h < h3[2] ? h : h3[2];
+    return (float)h * cx.cfg.vertical_scale;
+}
+LS_FN void ph_heights_finish(const LsCtx& cx, WaveShared& sh, const LaneRegs& rg, int lane, int env) {
+    const lsim_config& c = cx.cfg;
+    if (c.measure_heights) {
+        LS_GLOBAL float* mh = LSB(cx, LSIM_BUF_MEASURED_HEIGHTS, float) + LS_NHP * env;
+        for (int it = 0; it < LS_HEIGHT_PASSES; ++it) {
+            const int k = lane + 64 * it;
+            if (k >= LS_NHP) continue;
+            const float h = c.mesh_type != 0 ? ls_min3_height(cx, rg.hraw + 3 * it) : 0.0f;
+            sh.heights[k] = h;
+            mh[k] = h;
+        }
+    }
+    if (lane < LSIM_NUM_BASE_HEIGHT_PTS) sh.bh[lane] = c.mesh_type == 0 ? sh.root[2] : sh.root[2] - ls_min3_height(cx, rg.hraw + 3 * LS_HEIGHT_PASSES);
 }
 
 // LeggedRobot._get_heights (LR:1318-1355): lanes stride over the 187 points
@@ -119,7 +184,7 @@ LS_FN void ph_post_state(const LsCtx& cx, WaveShared& sh, int lane, int env) {
     } else if (lane < 8) {
         int f = lane - 4;
         const uint8_t lc = (uint8_t)((sh.pre_lc >> (8 * f)) & 0xffu);
-        uint8_t contact = sh.cf[cx.model.feet_bodies[f]][2] > 1.0f;
+        uint8_t contact = sh.cf[ls_foot_body(cx, f)][2] > 1.0f;
         const uint8_t filt = contact | lc;
         sh.filt[f] = filt;
         LSB(cx, LSIM_BUF_CONTACT_FILT, uint8_t)[4 * env + f] = filt;
@@ -260,10 +325,10 @@ LS_FN float ls_reward_part(const LsCtx& cx, WaveShared& sh, const LsRewCtx& x, i
     switch (id) {
         case LSIM_R_DOF_VEL: return x.dof[2 * j + 1] * x.dof[2 * j + 1];
         case LSIM_R_DOF_ACC: { float a = (x.last_dof_vel[j] - x.dof[2 * j + 1]) / dt; return a * a; }
-        case LSIM_R_DOF_VEL_LIMITS: return clampf(fabsf(x.dof[2 * j + 1]) - cx.model.dof_vel_limit[j] * c.soft_dof_vel_limit, 0.0f, 1.0f);
+        case LSIM_R_DOF_VEL_LIMITS: return clampf(fabsf(x.dof[2 * j + 1]) - sh.jc_vmax[j] * c.soft_dof_vel_limit, 0.0f, 1.0f);
         case LSIM_R_DOF_POS_DIF: { float d = x.last_dof_pos[j] - x.dof[2 * j]; return d * d; }
         case LSIM_R_DOF_POS_LIMITS: {
-            float lo = cx.model.dof_pos_lower[j], hi = cx.model.dof_pos_upper[j];
+            float lo = sh.jc_lo[j], hi = sh.jc_hi[j];
             float m = (lo + hi) / 2.0f, r = hi - lo;
             float slo = m - 0.5f * r * c.soft_dof_pos_limit, shi = m + 0.5f * r * c.soft_dof_pos_limit;
             float q = x.dof[2 * j];
@@ -276,12 +341,12 @@ LS_FN float ls_reward_part(const LsCtx& cx, WaveShared& sh, const LsRewCtx& x, i
         case LSIM_R_TORQUES: return x.tau[j] * x.tau[j];
         case LSIM_R_TORQUES_DISTRIBUTION: return fabsf(x.tau[j]);
         case LSIM_R_TORQUES_DIF: { float d = x.tau[j] - x.last_tau[j]; return d * d; }
-        case LSIM_R_TORQUE_LIMITS: return fmaxf(fabsf(x.tau[j]) - c.torque_limits[j] * c.soft_torque_limit, 0.0f);
+        case LSIM_R_TORQUE_LIMITS: return fmaxf(fabsf(x.tau[j]) - sh.jc_taumax[j] * c.soft_torque_limit, 0.0f);
         case LSIM_R_JOINT_POWER: return fabsf(x.dof[2 * j + 1]) * fabsf(x.tau[j]);
         case LSIM_R_POWER: return fabsf(x.tau[j] * x.dof[2 * j + 1]);
         case LSIM_R_POWER_DISTRIBUTION: return fabsf(x.tau[j] * x.dof[2 * j + 1]);
         case LSIM_R_STAND_STILL:
-        case LSIM_R_STAND_NICE: return fabsf(x.dof[2 * j] - c.default_dof_pos[j]);
+        case LSIM_R_STAND_NICE: return fabsf(x.dof[2 * j] - sh.jc_q0[j]);
         case LSIM_R_BASE_HEIGHT:
         case LSIM_R_BASE_HEIGHT_UP: {
             float s = 0.0f;
@@ -289,20 +354,20 @@ LS_FN float ls_reward_part(const LsCtx& cx, WaveShared& sh, const LsRewCtx& x, i
             return s;
         }
         case LSIM_R_HIP_ACTION_MAGNITUDE: { float m = fmaxf(fabsf(x.act[3 * j]) - 1.0f, 0.0f); return m * m; }
-        case LSIM_R_HIP_POS: case LSIM_R_HIP_POS_UP: return fabsf(x.dof[2 * (3 * j)] - c.default_dof_pos[3 * j]);
-        case LSIM_R_THIGH_POSE: case LSIM_R_THIGH_POSE_UP: return fabsf(x.dof[2 * (3 * j + 1)] - c.default_dof_pos[3 * j + 1]);
-        case LSIM_R_CALF_POSE: case LSIM_R_CALF_POSE_UP: return fabsf(x.dof[2 * (3 * j + 2)] - c.default_dof_pos[3 * j + 2]);
+        case LSIM_R_HIP_POS: case LSIM_R_HIP_POS_UP: return fabsf(x.dof[2 * (3 * j)] - sh.jc_q0[3 * j]);
+        case LSIM_R_THIGH_POSE: case LSIM_R_THIGH_POSE_UP: return fabsf(x.dof[2 * (3 * j + 1)] - sh.jc_q0[3 * j + 1]);
+        case LSIM_R_CALF_POSE: case LSIM_R_CALF_POSE_UP: return fabsf(x.dof[2 * (3 * j + 2)] - sh.jc_q0[3 * j + 2]);
         case LSIM_R_FEET_AIR_TIME: {  // LR:1459-1470 (mutates last_contacts and feet_air_time)
             // quirk 2: the reference recomputes contact | last_contacts here AFTER post_physics_step already set last_contacts = contact
             // (LR:207-209), so the filter of this term is the raw contact flag and rewriting last_contacts changes nothing
-            const bool contact = sh.cf[cx.model.feet_bodies[j]][2] > 1.0f;
+            const bool contact = sh.cf[ls_foot_body(cx, j)][2] > 1.0f;
             float a = sh.pre_air[j];
             const float first = (a > 0.0f && contact) ? 1.0f : 0.0f;
             a += dt;
             LSB(cx, LSIM_BUF_FEET_AIR_TIME, float)[4 * env + j] = a * (contact ? 0.0f : 1.0f);
             return (a - 0.5f) * first;
         }
-        case LSIM_R_FEET_CONTACT_FORCES: { V3 F = v3p(sh.cf[cx.model.feet_bodies[j]]); return fmaxf(sqrtf(dot(F, F)) - c.max_contact_force, 0.0f); }
+        case LSIM_R_FEET_CONTACT_FORCES: { V3 F = v3p(sh.cf[ls_foot_body(cx, j)]); return fmaxf(sqrtf(dot(F, F)) - c.max_contact_force, 0.0f); }
         case LSIM_R_FEET_SLIDE: case LSIM_R_FEET_SLIDE_UP: return ls_foot_slide_part(cx, sh, x, false, j);
         case LSIM_R_FOOT_CLEARANCE_BASE: case LSIM_R_FOOT_CLEARANCE_BASE_UP: return ls_foot_slide_part(cx, sh, x, true, j);
         case LSIM_R_FOOT_CLEARANCE_TERRAIN: case LSIM_R_FOOT_CLEARANCE_TERRAIN_UP: return ls_foot_clearance_terrain_part(cx, sh, fct_shifts, j);
@@ -393,21 +458,21 @@ LS_FN int ls_fct_shifts(const LsCtx& cx, int id) {
 }
 // ---- Q5a: the parts of the terms that have them.  Item = (term id << 10) | (term's index in the active list << 4) | part, built by the host
 //      (ls_api_impl.h) and staged in LDS by ph_load_a; same-term items are neighbours, so a pass of 64 lanes runs only a few term bodies.
-LS_FN void ph_reward_parts(const LsCtx& cx, WaveShared& sh, int lane, int env) {
+LS_FN void ph_reward_parts(const LsCtx& cx, WaveShared& sh, const uint16_t* items, int lane, int env) {
     const LsRewCtx x = ls_rew_ctx(sh);
     for (int it = 0; it < (LS_MAX_PART_ITEMS + 63) / 64; ++it) {
         const int k = lane + 64 * it;
         if (64 * it >= cx.num_part_items) break;
         if (k >= cx.num_part_items) continue;
-        const int item = sh.items[k];
+        const int item = items[k];
         const int id = item >> 10, ai = (item >> 4) & 63, j = item & 15;
         sh.u.r.rj[ai][j] = ls_reward_part(cx, sh, x, id, j, env, ls_fct_shifts(cx, id));
     }
 }
 // ---- Q5b: compute_reward (LR:363-380).  Lane i owns active term i; lane 0 then accumulates in the reference's order.
-LS_FN void ph_reward_terms(const LsCtx& cx, WaveShared& sh, int lane, int env) {
+LS_FN void ph_reward_terms(const LsCtx& cx, WaveShared& sh, const LaneRegs& rg, int lane, int env) {
     if (lane >= cx.num_active) return;
-    const int id = cx.active_terms[lane];
+    const int id = rg.term_id;                   // cx.active_terms[lane], fetched by ph_late_load
     const LsRewCtx x = ls_rew_ctx(sh);
     const int n = ls_reward_num_parts(id);
     float v;
@@ -418,7 +483,7 @@ LS_FN void ph_reward_terms(const LsCtx& cx, WaveShared& sh, int lane, int env) {
             for (int j = 0; j < n; ++j) p[j] = ls_reward_part(cx, sh, x, id, j, env, ls_fct_shifts(cx, id));
         v = ls_reward_finish(cx, sh, id, p, n);
     }
-    v *= cx.cfg.reward_scales[id];
+    v *= rg.term_scale;                          // cx.cfg.reward_scales[id]
     sh.rewv[lane] = v;
     const float es = sh.pre_es[id] + v;
     sh.pre_es[id] = es;
@@ -442,13 +507,13 @@ LS_FN void ph_reward_total(const LsCtx& cx, WaveShared& sh, int lane, int env) {
 
 // ---------------------------------------------------------------------------------------------- observations
 // entry e of the 238-vector of compute_observations (LR:382-401) before noise
-LS_FN float ls_obs_entry(const LsCtx& cx, const WaveShared& sh, int e, const float* dof, const float* act, const float* heights) {
+LS_FN float ls_obs_entry(const LsCtx& cx, const WaveShared& sh, int e, const float* dof, const float* act, const float* heights, const float* q0) {
     const lsim_config& c = cx.cfg;
     if (e < 2) return sh.cmd[e] * c.obs_scale_lin_vel;
     if (e == 2) return sh.cmd[2] * c.obs_scale_ang_vel;
     if (e < 6) return sh.bav[e - 3] * c.obs_scale_ang_vel;
     if (e < 9) return sh.grav[e - 6];
-    if (e < 21) return (dof[2 * (e - 9)] - c.default_dof_pos[e - 9]) * c.obs_scale_dof_pos;
+    if (e < 21) return (dof[2 * (e - 9)] - q0[e - 9]) * c.obs_scale_dof_pos;
     if (e < 33) return dof[2 * (e - 21) + 1] * c.obs_scale_dof_vel;
     if (e < 45) return act[e - 33];
     if (e < 48) return sh.blv[e - 45] * c.obs_scale_lin_vel;
@@ -465,13 +530,14 @@ LS_FN float ls_noise_scale(const lsim_config& c, int idx) {  // noise_scale_vec 
     return c.noise_vec_height;
 }
 // lanes 0..57 own one Philox block (4 noisy entries) each, lanes 58..63 the six noise-free entries 45..50
-LS_FN void ph_build_obs(const LsCtx& cx, WaveShared& sh, int lane, int env, uint32_t stepw, uint32_t tag, float* out) {
+// q0: the default joint angles -- kernel A's copy in LDS (sh.jc_q0), or the config's in global memory (kernel B, which stages no joint constants)
+LS_FN void ph_build_obs(const LsCtx& cx, WaveShared& sh, int lane, int env, uint32_t stepw, uint32_t tag, float* out, const float* q0) {
     const lsim_config& c = cx.cfg;
     const float* dof = sh.dofs;
     const float* act = sh.act;
     if (lane >= 58) {
         int e = 45 + (lane - 58);
-        out[e] = ls_obs_entry(cx, sh, e, dof, act, sh.heights);
+        out[e] = ls_obs_entry(cx, sh, e, dof, act, sh.heights, q0);
         return;
     }
     float u[4];
@@ -481,7 +547,7 @@ LS_FN void ph_build_obs(const LsCtx& cx, WaveShared& sh, int lane, int env, uint
         int e = idx < 45 ? idx : idx + 6;
         if (e >= LSIM_NUM_PRIV_OBS) break;
         if (e >= 51 && !c.measure_heights) { out[e] = 0.0f; continue; }
-        float v = ls_obs_entry(cx, sh, e, dof, act, sh.heights);
+        float v = ls_obs_entry(cx, sh, e, dof, act, sh.heights, q0);
         if (idx >= 45 || c.add_noise) v += (2.0f * u[i] - 1.0f) * ls_noise_scale(c, idx);  // LR:400 is not gated by add_noise
         out[e] = v;
     }

@@ -46,6 +46,7 @@ struct LsCtx {
     void* buf[LSIM_NUM_BUFFERS];
     float* accum;                     // [2][LSIM_STATS_SIZE] ping-pong per-step reductions (== buf[LSIM_BUF_STATS])
     int32_t active_terms[LSIM_NUM_REWARD_TERMS];
+    float active_scales[LSIM_NUM_REWARD_TERMS];      // cfg.reward_scales[active_terms[i]]
     int32_t num_active;
     // (term, part) work items of the reward terms that are sums (ls_post.h: ph_reward_parts): (id << 10) | (active index << 4) | part
     uint16_t part_items[LS_MAX_PART_ITEMS];
@@ -95,7 +96,12 @@ struct WaveShared {
     unsigned int pre_lc;                                         // last_contacts: 4 bytes
     float pre_es[LSIM_NUM_REWARD_TERMS];                         // episode_sums row
     unsigned char filt[4];                                       // contact_filt of this step (LR:207-209)
-    uint16_t items[LS_MAX_PART_ITEMS];                           // LsCtx::part_items
+    // ---- per-joint constants of the model / config (ph_load_a): the torque, limit-row, reward and observation code reads them by a per-lane
+    //      joint index, which from the context in global memory is a VECTOR load with its own round trip at every use (and behind the
+    //      kernel's stores once the post-physics stack has begun: vmcnt retires in order) -- round 4: ph_build_obs of the fused tail cost
+    //      22 k of kernel A's 256 k ticks for four such loads
+    float jc_q0[12], jc_kp[12], jc_kd[12], jc_taumax[12];       // default_dof_pos, p_gains, d_gains, torque_limits
+    float jc_lo[12], jc_hi[12], jc_vmax[12];                     // dof_pos_lower / upper, dof_vel_limit
     // ---- kinematics / dynamics of the current sub-step (world axes, positions relative to the base origin), overlaid
     //      with the post-physics scratch that is only used once the last sub-step is over (keeps the block <= 10 KB so
     //      that 16 robots per CU -- all 4096 of a 256-CU launch -- are resident at once)
@@ -178,6 +184,10 @@ struct LaneRegs {
     float tg_a, tg_b;        // TGS: normal row -- the contact's gap;  limit row -- the joint's distances to its lower / upper stop
     int ticket;              // kernel B, lane 0: this env's ticket among the envs that reset in this step (-1: none)
     float hist[4];           // kernel A with the fused tail: the 225 observation-history values on their way from global memory to LDS
+    uint16_t items[LS_MAX_PART_ITEMS / 64];   // kernel A: the reward part items on the same way (ph_late_load -> ph_late_stage)
+    int16_t hraw[3 * ((LSIM_NUM_HEIGHT_PTS + 63) / 64 + 1)];   // kernel A: raw grid samples of this lane's height points (ph_heights_issue -> ph_heights_finish)
+    int term_id;             // kernel A: active reward term owned by this lane in ph_reward_terms and its scale (fetched before the first store)
+    float term_scale;
 #if defined(LS_EMU)
     float W[LS_MAXR];        // Delassus row (the GPU path keeps it local to wc_delassus_pgs)
 #endif

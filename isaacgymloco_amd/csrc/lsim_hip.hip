@@ -203,9 +203,9 @@ extern "C" int lsim_debug_kinematics(lsim_sim* s, const float* in_host, float* o
 // diagnostics build only: read and clear the per-site tick / call accumulators (tools/phase_profile.py)
 extern "C" int lsim_debug_read_phase_ticks(unsigned long long* ticks, unsigned long long* calls) {
     if (hipDeviceSynchronize() != hipSuccess) return 1;
-    if (hipMemcpyFromSymbol(ticks, HIP_SYMBOL(g_ls_phase_ticks), 64 * sizeof(unsigned long long)) != hipSuccess) return 1;
-    if (hipMemcpyFromSymbol(calls, HIP_SYMBOL(g_ls_phase_calls), 64 * sizeof(unsigned long long)) != hipSuccess) return 1;
-    unsigned long long z[64] = {0};
+    if (hipMemcpyFromSymbol(ticks, HIP_SYMBOL(g_ls_phase_ticks), 128 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(calls, HIP_SYMBOL(g_ls_phase_calls), 128 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    unsigned long long z[128] = {0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ls_phase_ticks), z, sizeof(z));
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ls_phase_calls), z, sizeof(z));
     return 0;

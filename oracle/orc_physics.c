@@ -576,10 +576,10 @@ void orc_physics_substep(orc_sim* s, int e, const float tau_f[12], int apply_for
                                  0.5 * hs * (-w3[0] * qcur[2] + w3[1] * qcur[3] + w3[2] * qcur[0]),
                                  0.5 * hs * ( w3[0] * qcur[1] - w3[1] * qcur[0] + w3[2] * qcur[3]),
                                  0.5 * hs * (-w3[0] * qcur[0] - w3[1] * qcur[1] - w3[2] * qcur[2]) };
-                double nn = 0; for (int k = 0; k < 4; ++k) { qcur[k] += dq[k]; nn += qcur[k] * qcur[k]; }
-                nn = sqrt(nn); for (int k = 0; k < 4; ++k) qcur[k] /= nn;
+                for (int k = 0; k < 4; ++k) qcur[k] += dq[k];     /* linear in q: normalised once, after the last sub-iteration */
             }
         }
+        { double nn = 0; for (int k = 0; k < 4; ++k) nn += qcur[k] * qcur[k]; nn = sqrt(nn); for (int k = 0; k < 4; ++k) qcur[k] /= nn; }
         double cf[NB][3];
         memset(cf, 0, sizeof(cf));
         for (int r = 0; r < R; ++r) if (rcontact[r] >= 0) for (int k = 0; k < 3; ++k) cf[cbody[rcontact[r]]][k] += lam[r] * dirs[r][k] / dt;

@@ -29,14 +29,14 @@ def sites():
     out = {}
     for i, l in enumerate(src, 1):
         if "constexpr int ls_line0 = __LINE__" in l:
-            base[len(base)] = i - (48 if "- 48" in l else 0)
+            base[len(base)] = i - (96 if "- 96" in l else 0)
     def base_for(i):
-        cands = [b for k, b in base.items() if (b if k == 0 else b + 48) <= i]
+        cands = [b for k, b in base.items() if (b if k == 0 else b + 96) <= i]
         return cands[-1]
     for i, l in enumerate(src, 1):
         m = re.search(r"LS_(PHASE|COLLECTIVE)\((.*)\);", l) or re.search(r"(LS_)(TORQUES_KINEMATICS|KINEMATICS)\(\);", l)
         if m and not l.lstrip().startswith("#") and base and i > min(base.values()):
-            out[(i - base_for(i)) & 63] = m.group(2)[:70]
+            out[(i - base_for(i)) & 127] = m.group(2)[:70]
     return out
 
 
@@ -78,7 +78,7 @@ if __name__ == "__main__":
     env.episode_length_buf = torch.randint_like(env.episode_length_buf, high=int(env.max_episode_length))
     acts = [torch.randn(N, 12, device="cuda:0") for _ in range(16)]
     L = ctypes.CDLL(OUT)
-    t = (ctypes.c_ulonglong * 64)(); c = (ctypes.c_ulonglong * 64)()
+    t = (ctypes.c_ulonglong * 128)(); c = (ctypes.c_ulonglong * 128)()
     for i in range(50):
         env.step_device(acts[i % 16])
     L.lsim_debug_read_phase_ticks(t, c)
@@ -87,10 +87,10 @@ if __name__ == "__main__":
         env.step_device(acts[i % 16])
     L.lsim_debug_read_phase_ticks(t, c)
     names = sites()
-    tot_a = sum(t[s] for s in range(48)); tot_b = sum(t[s] for s in range(48, 64))
+    tot_a = sum(t[s] for s in range(96)); tot_b = sum(t[s] for s in range(96, 128))
     print(f"task {task} N {N}: mean ticks per wave per step: kernel A {tot_a / (K * N):.0f}, kernel B {tot_b / (K * N):.0f}")
-    for s in range(64):
+    for s in range(128):
         if c[s]:
-            tot = tot_a if s < 48 else tot_b
+            tot = tot_a if s < 96 else tot_b
             nm = names.get(s, "?")
             print(f"site {s:2d} calls/step {c[s] / (K * N):4.1f} ticks/step {t[s] / (K * N):8.0f} {100.0 * t[s] / tot:5.1f}%  busy lanes {nominal_lanes(nm):<28s} {nm}")
