@@ -113,6 +113,8 @@ LS_FN void ph_load_a(const LsCtx& cx, WaveShared& sh, LaneRegs& rg, int lane, in
     const int v_level = (int)LSB(cx, LSIM_BUF_TERRAIN_LEVELS, int64_t)[env];
     const float v_es = LSB(cx, LSIM_BUF_EPISODE_SUMS, float)[env * LSIM_NUM_REWARD_TERMS + (lane < LSIM_NUM_REWARD_TERMS ? lane : 0)];
     const float v_rng = LS_G(const float, cx.accum)[a.row_in * LSIM_STATS_SIZE + LSIM_STATS_CMD_RANGES + (lane & 7)];   // live command ranges (no kernel of this step writes row_in's)
+    const float v_mp = lane < LSIM_MAX_HEIGHT_PTS_X ? c.measured_points_x[lane] : c.measured_points_y[lane - LSIM_MAX_HEIGHT_PTS_X];
+    static_assert(LSIM_MAX_HEIGHT_PTS_X + LSIM_MAX_HEIGHT_PTS_Y == 64, "one lane per measured-point coordinate");
     float v_jc[7];
     {
         const lsim_robot_model& m = cx.model;
@@ -124,6 +126,7 @@ LS_FN void ph_load_a(const LsCtx& cx, WaveShared& sh, LaneRegs& rg, int lane, in
     // i.e. up to two slots that hold no row yet, and multiplies what it finds by a zero impulse -- harmless only if it is finite
     static_assert(sizeof(sh.u.c.Y) - sizeof(sh.u.I6) == 2 * LS_NV * sizeof(float), "rows of Y beyond the inertias");
     if (lane < 2 * LS_NV) (&sh.u.c.Y[LS_MAXR - 2][0])[lane] = 0.0f;
+    if (lane < LSIM_MAX_HEIGHT_PTS_X) sh.mpx[lane] = v_mp; else sh.mpy[lane - LSIM_MAX_HEIGHT_PTS_X] = v_mp;
     if (lane < 13) sh.root[lane] = v_root;
     if (lane < 12) {
         sh.jc_q0[lane] = v_jc[0]; sh.jc_kp[lane] = v_jc[1]; sh.jc_kd[lane] = v_jc[2]; sh.jc_taumax[lane] = v_jc[3];
@@ -537,7 +540,7 @@ LS_FN void ph_late_stage(WaveShared& sh, const LaneRegs& rg, int lane, bool fuse
         }
     }
     uint16_t* items = ls_part_items(sh);
-    for (int it = 0; it < LS_MAX_PART_ITEMS / 64; ++it) items[lane + 64 * it] = rg.items[it];
+    for (int it = 0; it < LS_MAX_PART_ITEMS / 64; ++it) items[lane + 64 * it] = (uint16_t)rg.items[it];
 }
 // what ph_load_b derives for kernel B, from kernel A's own LDS state
 LS_FN void ph_tail_setup(const LsCtx& cx, WaveShared& sh, int lane, const LsStepArgs& a) {

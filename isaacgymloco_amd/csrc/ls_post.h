@@ -65,9 +65,9 @@ LS_FN V3 ls_yaw_point(const float* root, LsYawQuat y, float px, float py) {
 // ---- the same two samplers split in two for kernel A, whose post-physics stack begins with the state stores: the grid loads of this lane's
 //      points are ISSUED before the first store (ph_heights_issue, last phase of the physics) and consumed two phases later
 //      (ph_heights_finish), so that neither their latency nor the drain of the stores in front of them sits on the wave's critical path.
-//      Lane l owns height points l, l + 64, l + 128 (187 in all) and base-height point l (63): 4 x 3 int16 samples in LaneRegs::hraw.
+//      Lane l owns height points l, l + 64, l + 128 (187 in all) and base-height point l (63): 4 x (a 4-byte pair + a 2-byte sample) in LaneRegs::hraw.
 #define LS_HEIGHT_PASSES ((LS_NHP + 63) / 64)
-LS_FN void ls_height_samples3(const LsCtx& cx, float x, float y, int16_t* h3) {
+LS_FN void ls_height_samples3(const LsCtx& cx, float x, float y, int* h2) {
 #if defined(__clang__)
 #pragma clang fp contract(off)
 #endif
@@ -77,8 +77,13 @@ LS_FN void ls_height_samples3(const LsCtx& cx, float x, float y, int16_t* h3) {
     int px = (int)fx, py = (int)fy;
     px = px < 0 ? 0 : (px > c.grid_rows - 2 ? c.grid_rows - 2 : px);
     py = py < 0 ? 0 : (py > c.grid_cols - 2 ? c.grid_cols - 2 : py);
+    // two registers per point and NO arithmetic on them here (anything that looks at a loaded value makes the compiler wait for it in this
+    // phase): the pair (x, y), (x, y + 1) -- neighbours in the row-major grid -- as one 4-byte load, (x + 1, y) as a sign-extended 2-byte load
     LS_GLOBAL const int16_t* g = LSB(cx, LSIM_BUF_HEIGHT_GRID, const int16_t);
-    h3[0] = g[px * c.grid_cols + py]; h3[1] = g[(px + 1) * c.grid_cols + py]; h3[2] = g[px * c.grid_cols + py + 1];
+    LS_GLOBAL const int16_t* p0 = g + px * c.grid_cols + py;
+    struct __attribute__((packed, aligned(2))) Pair { uint32_t w; };          // 2-byte aligned 4-byte load (global memory allows it)
+    h2[0] = (int)((LS_GLOBAL const Pair*)p0)->w;
+    h2[1] = (int)p0[c.grid_cols];
 }
 LS_FN void ph_heights_issue(const LsCtx& cx, const WaveShared& sh, LaneRegs& rg, int lane) {
     const lsim_config& c = cx.cfg;
@@ -88,21 +93,26 @@ LS_FN void ph_heights_issue(const LsCtx& cx, const WaveShared& sh, LaneRegs& rg,
         for (int it = 0; it < LS_HEIGHT_PASSES; ++it) {
             const int k = lane + 64 * it, kk = k < LS_NHP ? k : 0;
             const int ix = kk / c.num_points_y, iy = kk - ix * c.num_points_y;
-            const V3 w = ls_yaw_point(sh.root, yq, c.measured_points_x[ix], c.measured_points_y[iy]);
-            ls_height_samples3(cx, w.x, w.y, rg.hraw + 3 * it);
+            const V3 w = ls_yaw_point(sh.root, yq, sh.mpx[ix], sh.mpy[iy]);
+            ls_height_samples3(cx, w.x, w.y, rg.hraw + 2 * it);
         }
     {
         const int l = lane < LSIM_NUM_BASE_HEIGHT_PTS ? lane : 0;
         const int ix = l / 9, iy = l - 9 * ix;
-        const float xs[7] = {-0.15f, -0.1f, -0.05f, 0.f, 0.05f, 0.1f, 0.15f};          // the reference's literal lists (LR:1308-1309)
-        const float ys[9] = {-0.2f, -0.15f, -0.1f, -0.05f, 0.f, 0.05f, 0.1f, 0.15f, 0.2f};
-        const V3 w = ls_yaw_point(sh.root, yq, xs[ix], ys[iy]);
-        ls_height_samples3(cx, w.x, w.y, rg.hraw + 3 * LS_HEIGHT_PASSES);
+        // the reference's literal lists (LR:1308-1309: x -0.15 .. 0.15, y -0.2 .. 0.2 in steps of 0.05) as selects: a table indexed by a lane
+        // value would be a load from constant memory, and the grid address depends on it
+        const float m5[5] = {0.0f, 0.05f, 0.1f, 0.15f, 0.2f};
+        const int ax = ix < 3 ? 3 - ix : ix - 3, ay = iy < 4 ? 4 - iy : iy - 4;
+        const float mx = ax == 0 ? m5[0] : (ax == 1 ? m5[1] : (ax == 2 ? m5[2] : m5[3]));
+        const float my = ay == 0 ? m5[0] : (ay == 1 ? m5[1] : (ay == 2 ? m5[2] : (ay == 3 ? m5[3] : m5[4])));
+        const V3 w = ls_yaw_point(sh.root, yq, ix < 3 ? -mx : mx, iy < 4 ? -my : my);
+        ls_height_samples3(cx, w.x, w.y, rg.hraw + 2 * LS_HEIGHT_PASSES);
     }
 }
-LS_FN float ls_min3_height(const LsCtx& cx, const int16_t* h3) {
-    int16_t h = h3[0] < h3[1] ? h3[0] : h3[1];
-    h = h < h3[2] ? h : h3[2];
+LS_FN float ls_min3_height(const LsCtx& cx, const int* h2) {
+    const int h1 = (int)(int16_t)(h2[0] & 0xffff), h3 = h2[0] >> 16, hx = h2[1];     // (x, y), (x, y + 1), (x + 1, y)
+    int h = h1 < hx ? h1 : hx;
+    h = h < h3 ? h : h3;
     return (float)h * cx.cfg.vertical_scale;
 }
 LS_FN void ph_heights_finish(const LsCtx& cx, WaveShared& sh, const LaneRegs& rg, int lane, int env) {
@@ -112,12 +122,12 @@ LS_FN void ph_heights_finish(const LsCtx& cx, WaveShared& sh, const LaneRegs& rg
         for (int it = 0; it < LS_HEIGHT_PASSES; ++it) {
             const int k = lane + 64 * it;
             if (k >= LS_NHP) continue;
-            const float h = c.mesh_type != 0 ? ls_min3_height(cx, rg.hraw + 3 * it) : 0.0f;
+            const float h = c.mesh_type != 0 ? ls_min3_height(cx, rg.hraw + 2 * it) : 0.0f;
             sh.heights[k] = h;
             mh[k] = h;
         }
     }
-    if (lane < LSIM_NUM_BASE_HEIGHT_PTS) sh.bh[lane] = c.mesh_type == 0 ? sh.root[2] : sh.root[2] - ls_min3_height(cx, rg.hraw + 3 * LS_HEIGHT_PASSES);
+    if (lane < LSIM_NUM_BASE_HEIGHT_PTS) sh.bh[lane] = c.mesh_type == 0 ? sh.root[2] : sh.root[2] - ls_min3_height(cx, rg.hraw + 2 * LS_HEIGHT_PASSES);
 }
 
 // LeggedRobot._get_heights (LR:1318-1355): lanes stride over the 187 points

@@ -102,6 +102,7 @@ struct WaveShared {
     //      22 k of kernel A's 256 k ticks for four such loads
     float jc_q0[12], jc_kp[12], jc_kd[12], jc_taumax[12];       // default_dof_pos, p_gains, d_gains, torque_limits
     float jc_lo[12], jc_hi[12], jc_vmax[12];                     // dof_pos_lower / upper, dof_vel_limit
+    float mpx[LSIM_MAX_HEIGHT_PTS_X], mpy[LSIM_MAX_HEIGHT_PTS_Y];  // measured_points_x / y (AGC:79-80): the height samplers index them per lane
     // ---- kinematics / dynamics of the current sub-step (world axes, positions relative to the base origin), overlaid
     //      with the post-physics scratch that is only used once the last sub-step is over (keeps the block <= 10 KB so
     //      that 16 robots per CU -- all 4096 of a 256-CU launch -- are resident at once)
@@ -184,8 +185,8 @@ struct LaneRegs {
     float tg_a, tg_b;        // TGS: normal row -- the contact's gap;  limit row -- the joint's distances to its lower / upper stop
     int ticket;              // kernel B, lane 0: this env's ticket among the envs that reset in this step (-1: none)
     float hist[4];           // kernel A with the fused tail: the 225 observation-history values on their way from global memory to LDS
-    uint16_t items[LS_MAX_PART_ITEMS / 64];   // kernel A: the reward part items on the same way (ph_late_load -> ph_late_stage)
-    int16_t hraw[3 * ((LSIM_NUM_HEIGHT_PTS + 63) / 64 + 1)];   // kernel A: raw grid samples of this lane's height points (ph_heights_issue -> ph_heights_finish)
+    uint32_t items[LS_MAX_PART_ITEMS / 64];   // kernel A: the reward part items on the same way (a register each: see hraw) (ph_late_load -> ph_late_stage)
+    int hraw[2 * ((LSIM_NUM_HEIGHT_PTS + 63) / 64 + 1)];   // kernel A (one register per sample: packing two would wait for the loads): raw grid samples of this lane's height points (ph_heights_issue -> ph_heights_finish)
     int term_id;             // kernel A: active reward term owned by this lane in ph_reward_terms and its scale (fetched before the first store)
     float term_scale;
 #if defined(LS_EMU)
