@@ -90,7 +90,7 @@ def parse_args():
     return ap.parse_args()
 
 
-def pmc_for(task, n_envs, mode, actions):
+def pmc_for(task, n_envs, mode, actions, solver="tgs"):
     """HBM traffic / instruction counts per launch of kernel A from separate rocprofv3 --pmc passes of this same command (PMC counters cannot
     be read in-process); tools/pmc_summary.py writes them.  Only valid for the workload they were collected on: task, size, mode and action
     source must all match, otherwise None."""
@@ -99,8 +99,8 @@ def pmc_for(task, n_envs, mode, actions):
         return None
     tj = json.load(open(path))
     for rec in (tj.get("runs") or [tj]):
-        if (rec.get("task"), rec.get("envs_per_gpu"), rec.get("mode"), rec.get("actions")) == (task, n_envs, mode, actions):
-            return rec
+        if (rec.get("task"), rec.get("envs_per_gpu"), rec.get("mode"), rec.get("actions"), rec.get("solver", "pgs")) == (task, n_envs, mode, actions, solver):
+            return rec         # (records from before round 4 carry no solver: they were collected on the PGS kernel)
     return None
 
 
@@ -143,6 +143,13 @@ def main():
         os.environ.setdefault("PYTORCH_TUNABLEOP_TUNING", "1" if os.environ.get("LSIM_TUNE") == "1" else "0")
         os.environ.setdefault("PYTORCH_TUNABLEOP_MAX_TUNING_DURATION_MS", "100")
         os.environ.setdefault("PYTORCH_TUNABLEOP_VERBOSE", "0")
+    # Data-parallel ranks: two hardware queues per process.  The ROCm runtime spreads HIP streams over GPU_MAX_HW_QUEUES (default 4) hardware
+    # queues; with the default, torch's RCCL stream lands on a queue of its own and every hand-off compute stream -> RCCL stream -> compute
+    # stream crosses hardware queues (an inter-queue barrier / signal round trip on each side of every collective).  Measured on one MI355X with
+    # a 1-rank RCCL group and every collective issued (profiles/r04_collective_overhead.json): update 79.1 ms with 4 queues, 77.1 with 8,
+    # 75.7 with 2 -- against 75.4 without collectives.  Must be set before the HIP runtime starts; an explicit setting wins.
+    if world > 1 or (world == 1 and os.environ.get("LSIM_DEBUG_FORCE_COLLECTIVES") == "1"):
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
     import torch
     import torch.distributed as dist
     single_dev = os.environ.get("LSIM_DEBUG_SINGLE_DEVICE") == "1"   # debugging aid: exercise the N > 1 code path on a 1-GPU box (all ranks on
@@ -221,7 +228,7 @@ def main():
     if rank == 0:
         value = world * N * timed_steps / elapsed
         achieved = ALGO_BYTES_PER_ENV_STEP * N / (ka * 1e-3) / 1e9 if ka == ka and ka > 0 else None
-        pmc = pmc_for(args.task, N, mode, actions_src)
+        pmc = pmc_for(args.task, N, mode, actions_src, "tgs" if int(env.lcfg.solver_type) == 1 else "pgs")
         traffic = pmc["traffic_bytes_per_launch"] if pmc else None
         valu_frac = None
         if pmc and pmc.get("valu_wave_insts_per_launch") and achieved:
@@ -242,8 +249,11 @@ def main():
         # dependent-instruction latency, so when wave-instruction counts from a PMC pass of THIS workload are available the line says
         # bound = "valu" with frac = share of the chip's VALU issue slots used; the HBM figures the schema asks for stay beside it.
         hbm = {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None}
-        common = {"traffic": traffic, "kernel": "lsim_k_step_a", "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * N, "kernel_avg_ms": ka,
-                  "hbm": hbm, "valu_issue_frac": valu_frac, "valu_cycles_per_wave_inst": VALU_CYCLES_PER_WAVE_INST,
+        kernel = "lsim_k_step_a_tgs" if int(env.lcfg.solver_type) == 1 else "lsim_k_step_a_pgs"
+        common = {"traffic": traffic, "kernel": kernel, "solver": "tgs" if int(env.lcfg.solver_type) == 1 else "pgs",
+                  "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * N, "kernel_avg_ms": ka,
+                  "hbm": hbm, "hbm_frac": hbm["frac"], "hbm_achieved_gbs": achieved,      # flat copies: parsers that drop nested objects keep these
+                  "valu_issue_frac": valu_frac, "valu_cycles_per_wave_inst": VALU_CYCLES_PER_WAVE_INST,
                   "pmc_source": ({k: pmc.get(k) for k in ("task", "envs_per_gpu", "mode", "actions", "effective_clock_hz", "file")} if pmc else None)}
         if valu_frac is not None:
             clk = pmc.get("effective_clock_hz") or MAX_CLOCK_HZ

@@ -15,6 +15,7 @@ import torch.nn.functional as F
 _MIN_BATCH = 4096
 _workspaces = {}
 _plans = {}
+_adam_tables = {}
 
 
 def _workspace(kind, device, nbytes, floor=0):
@@ -26,6 +27,102 @@ def _workspace(kind, device, nbytes, floor=0):
         ws = torch.empty(max(int(nbytes), int(floor)), dtype=torch.uint8, device=device)
         _workspaces[key] = ws
     return ws
+
+
+class GradArena:
+    """Persistent flat fp32 gradient buffers ("buckets") whose slices ARE the parameters' gradients.
+
+    The weight-gradient kernels of this module write a layer's dW / db straight into the parameter's slice and hand that view to autograd,
+    which adopts it as `.grad` without a copy (a leaf without a gradient takes ownership of the incoming tensor).  Data-parallel training
+    then all-reduces the bucket in place -- no torch.cat of ~40 tensors per bucket and minibatch, no re-viewing afterwards --
+    and the gradient pointers of the fused clip + Adam step stay the same from minibatch to minibatch (its pointer tables are cached).
+    A slice is handed out at most once per cycle (new_cycle(): call it wherever the gradients are reset) and only while the parameter has no
+    gradient: a second contribution within the cycle goes through an ordinary tensor and autograd's accumulation, as without the arena.
+    Gradients that reach a parameter some other way (autograd's own kernels: the action std, the prototypes, layers the kernels leave to
+    BLAS) are copied into their slices by Bucket.adopt()."""
+
+    class Bucket:
+        def __init__(self, params, extra, device):
+            self.params = list(params)
+            self.sizes = [p.numel() for p in self.params]
+            self.extra = int(extra)
+            self.flat = torch.zeros(sum(self.sizes) + self.extra, dtype=torch.float32, device=device)
+            pieces = self.flat.split(self.sizes + ([self.extra] if self.extra else []))
+            self.views = [v.view_as(p) for v, p in zip(pieces, self.params)]
+            self.extra_view = pieces[-1] if self.extra else None
+            self.ptrs = [v.data_ptr() for v in self.views]
+
+        def adopt(self):
+            """make every parameter's .grad its slice of the flat buffer (copying gradients that were produced elsewhere); returns False when a
+            parameter of the bucket has no gradient (the caller rebuilds the bucket: membership follows `p.grad is not None`)"""
+            src, dst = [], []
+            for p, v, ptr in zip(self.params, self.views, self.ptrs):
+                g = p.grad
+                if g is None:
+                    return False
+                if g.data_ptr() != ptr:
+                    src.append(g); dst.append(v)
+                    p.grad = v
+            if src:
+                torch._foreach_copy_(dst, src)
+            return True
+
+    def __init__(self):
+        self.buckets = {}
+        self._slot = {}          # parameter data_ptr -> (parameter, view)
+        self._taken = set()
+
+    def bucket(self, key, params, extra=0):
+        """the bucket registered under `key` for exactly these parameters (created or re-created on demand)"""
+        params = list(params)
+        b = self.buckets.get(key)
+        if b is None or len(b.params) != len(params) or any(x is not y for x, y in zip(b.params, params)) or b.extra != extra:
+            if b is not None:
+                for q in b.params:
+                    self._slot.pop(q.data_ptr(), None)
+            b = GradArena.Bucket(params, extra, params[0].device)
+            self.buckets[key] = b
+            for q, v in zip(b.params, b.views):
+                self._slot[q.data_ptr()] = (q, v)
+        return b
+
+    def take(self, param_ptr, shape):
+        """the gradient slice of the parameter stored at `param_ptr`, or None (unknown parameter, already handed out in this cycle, the
+        parameter already has a gradient, or a shape mismatch)"""
+        ent = self._slot.get(param_ptr)
+        if ent is None or param_ptr in self._taken:
+            return None
+        q, v = ent
+        if q.grad is not None or tuple(v.shape) != tuple(shape):
+            return None
+        self._taken.add(param_ptr)
+        return v.view(v.shape)       # a FRESH alias: autograd adopts an incoming gradient without a copy only if nobody else holds that tensor object
+
+    def new_cycle(self):
+        self._taken.clear()
+
+
+_arena = None
+
+
+def set_grad_arena(arena):
+    global _arena
+    _arena = arena
+
+
+def grad_cycle():
+    """call where gradients are reset (optimizer.zero_grad()): the arena's slices may be handed out again"""
+    if _arena is not None:
+        _arena.new_cycle()
+
+
+def _grad_out(param_ptr, shape, device):
+    """output tensor for a parameter's gradient: its arena slice when there is one to hand out, else a fresh tensor"""
+    if _arena is not None and param_ptr is not None:
+        v = _arena.take(param_ptr, shape)
+        if v is not None:
+            return v
+    return torch.empty(shape, device=device, dtype=torch.float32)
 
 
 def _eligible(batch, k_in, n_out):
@@ -42,8 +139,9 @@ def _eligible(batch, k_in, n_out):
     return ok
 
 
-def linear_wgrad(x, g, want_bias=True):
-    """(g^T x, g.sum(0)) for 2-D fp32 CUDA tensors through lsim_linear_wgrad"""
+def linear_wgrad(x, g, want_bias=True, weight_ptr=None, bias_ptr=None):
+    """(g^T x, g.sum(0)) for 2-D fp32 CUDA tensors through lsim_linear_wgrad; weight_ptr / bias_ptr: data_ptr() of the parameters the results
+    are gradients of (GradArena: they are written into the parameters' gradient slices)"""
     from .. import lib
     L = lib.load()
     if x.stride(1) != 1:
@@ -55,8 +153,8 @@ def linear_wgrad(x, g, want_bias=True):
     need, waves = ctypes.c_size_t(), ctypes.c_int()
     lib.check(L.lsim_linear_wgrad_workspace(batch, k_in, n_out, ctypes.byref(need), ctypes.byref(waves)), what="lsim_linear_wgrad_workspace")
     ws = _workspace("wgrad", x.device, need.value, floor=1 << 20)
-    dw = torch.empty(n_out, k_in, device=x.device, dtype=torch.float32)
-    db = torch.empty(n_out, device=x.device, dtype=torch.float32) if want_bias else None
+    dw = _grad_out(weight_ptr, (n_out, k_in), x.device)
+    db = _grad_out(bias_ptr, (n_out,), x.device) if want_bias else None
     lib.check(L.lsim_linear_wgrad(x.data_ptr(), x.stride(0), g.data_ptr(), g.stride(0), batch, k_in, n_out, dw.data_ptr(),
                                   db.data_ptr() if want_bias else None, ws.data_ptr(), ws.numel(),
                                   torch.cuda.current_stream(x.device).cuda_stream), what="lsim_linear_wgrad")
@@ -68,6 +166,7 @@ class _SkinnyLinearFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        ctx.bias_ptr = bias.data_ptr() if bias is not None else None
         return F.linear(x, weight, bias)
 
     @staticmethod
@@ -76,7 +175,7 @@ class _SkinnyLinearFn(torch.autograd.Function):
         gx = g @ weight if ctx.needs_input_grad[0] else None
         dw = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            dw, db = linear_wgrad(x, g, want_bias=ctx.has_bias)
+            dw, db = linear_wgrad(x, g, want_bias=ctx.has_bias, weight_ptr=weight.data_ptr(), bias_ptr=ctx.bias_ptr)
         return gx, dw, db
 
 
@@ -94,6 +193,7 @@ class _LinearEluFn(torch.autograd.Function):
         z = F.elu(F.linear(x, weight, bias))
         ctx.save_for_backward(x, weight, z)
         ctx.has_bias = bias is not None
+        ctx.bias_ptr = bias.data_ptr() if bias is not None else None
         return z
 
     @staticmethod
@@ -109,8 +209,8 @@ class _LinearEluFn(torch.autograd.Function):
         need, parts = ctypes.c_size_t(), ctypes.c_int()
         lib.check(L.lsim_linear_wgrad_workspace(batch, k_in, n_out, ctypes.byref(need), ctypes.byref(parts)), what="lsim_linear_wgrad_workspace")
         ws = _workspace("wgrad", x.device, need.value, floor=1 << 20)
-        dw = torch.empty(n_out, k_in, device=x.device, dtype=torch.float32)
-        db = torch.empty(n_out, device=x.device, dtype=torch.float32) if ctx.has_bias else None
+        dw = _grad_out(weight.data_ptr(), (n_out, k_in), x.device)
+        db = _grad_out(ctx.bias_ptr, (n_out,), x.device) if ctx.has_bias else None
         # the gradient of the pre-activation is written out only where an input gradient follows (not for a network's first layer: 210 MB per call)
         g_pre = torch.empty(batch, n_out, device=x.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
         lib.check(L.lsim_linear_elu_wgrad(x.data_ptr(), x.stride(0), g.data_ptr(), g.stride(0), z.data_ptr(), z.stride(0), batch, k_in, n_out,
@@ -169,7 +269,7 @@ class _PpoLossFn(torch.autograd.Function):
     """clipped-PPO loss through lsim_ppo_loss: forward and the three input gradients come from the same pass"""
 
     @staticmethod
-    def forward(ctx, mu, sigma, value, actions, old_logp, adv, returns, target_values, old_mu, old_sigma, clip, vcoef, ecoef, clipped):
+    def forward(ctx, mu, sigma, value, actions, old_logp, adv, returns, target_values, old_mu, old_sigma, clip, vcoef, ecoef, clipped, out=None):
         from .. import lib
         L = lib.load()
         c = lambda t: t.detach().contiguous()
@@ -178,7 +278,8 @@ class _PpoLossFn(torch.autograd.Function):
         need = ctypes.c_size_t()
         lib.check(L.lsim_ppo_loss_workspace(B, ctypes.byref(need)), what="lsim_ppo_loss_workspace")
         ws = torch.empty(need.value, dtype=torch.uint8, device=mu.device)
-        out = torch.empty(5, device=mu.device)
+        if out is None:       # [surrogate, value loss, entropy, kl, total]; the data-parallel step passes the tail of its gradient bucket
+            out = torch.empty(5, device=mu.device)
         g_mu, g_sg, g_v = torch.empty_like(mu_), torch.empty_like(sg_), torch.empty_like(v_)
         args = [c(t).reshape(B, -1) if t is not None else None for t in (actions, old_logp, adv, returns, target_values, old_mu, old_sigma)]
         ptr = lambda t: t.data_ptr() if t is not None else None
@@ -195,12 +296,13 @@ class _PpoLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, _g_stats):
         g_mu, g_sg, g_v = ctx.saved_tensors
-        return (g_loss * g_mu, g_loss * g_sg, (g_loss * g_v).reshape(ctx.value_shape)) + (None,) * 11
+        return (g_loss * g_mu, g_loss * g_sg, (g_loss * g_v).reshape(ctx.value_shape)) + (None,) * 12
 
 
-def ppo_loss_hip(mu, sigma, value, actions, old_logp, adv, returns, target_values, old_mu, old_sigma, clip, vcoef, ecoef, clipped):
-    """-> (total loss with autograd to mu / sigma / value, stats = [surrogate, value loss, entropy, kl] means, detached)"""
-    return _PpoLossFn.apply(mu, sigma, value, actions, old_logp, adv, returns, target_values, old_mu, old_sigma, clip, vcoef, ecoef, clipped)
+def ppo_loss_hip(mu, sigma, value, actions, old_logp, adv, returns, target_values, old_mu, old_sigma, clip, vcoef, ecoef, clipped, out=None):
+    """-> (total loss with autograd to mu / sigma / value, stats = [surrogate, value loss, entropy, kl] means, detached).  `out`: optional
+    5-float CUDA tensor the kernel writes [stats, total] into (the tail of a gradient bucket: the KL estimate then travels with the gradients)"""
+    return _PpoLossFn.apply(mu, sigma, value, actions, old_logp, adv, returns, target_values, old_mu, old_sigma, clip, vcoef, ecoef, clipped, out)
 
 
 class _EstimatorLossFn(torch.autograd.Function):
@@ -268,28 +370,36 @@ def adam_clip_step_hip(optimizer, max_grad_norm, clip_params=None):
     if clip_ids is not None:       # the clipped tensors first
         entries = [e for e in entries if id(e[0]) in clip_ids] + [e for e in entries if id(e[0]) not in clip_ids]
     n_clip = len(entries) if clip_ids is None else sum(1 for e in entries if id(e[0]) in clip_ids)
-    tabs = ([], [], [], [], [])
-    for p, _ in entries:
-        st = optimizer.state.get(p)
-        if (not st or not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous()
-                or not torch.is_tensor(st.get("step")) or not st["step"].is_cuda or st["step"].dtype != torch.float32):
-            return False
-        for tab, t in zip(tabs, (p, p.grad, st["exp_avg"], st["exp_avg_sq"], st["step"])):
-            tab.append(t.data_ptr())
     n = len(entries)
     L = lib.load()
     dev = entries[0][0].device
-    need = ctypes.c_size_t()
-    lib.check(L.lsim_adam_clip_step_workspace(n, ctypes.byref(need)), what="lsim_adam_clip_step_workspace")
-    ws = _workspace(("adam", id(optimizer)), dev, need.value)
-    arr = lambda v: (ctypes.c_void_p * n)(*v)
-    numel = (ctypes.c_int64 * n)(*[p.numel() for p, _ in entries])
-    wd = (ctypes.c_float * n)(*[w for _, w in entries])
+    # the C tables of one call are cached by the (parameter, gradient) pointers: with the gradients in a GradArena they repeat every minibatch
+    # and the ~40 state look-ups / 5 x 40 ctypes conversions of a call disappear (the loop is within 1.6 x of launch-bound)
+    key = (id(optimizer), n_clip, tuple(p.data_ptr() for p, _ in entries), tuple(p.grad.data_ptr() for p, _ in entries))
+    cached = _adam_tables.get(id(optimizer))
+    if cached is not None and cached[0] == key:
+        tables = cached[1]
+    else:
+        tabs = ([], [], [], [], [])
+        for p, _ in entries:
+            st = optimizer.state.get(p)
+            if (not st or not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous()
+                    or not torch.is_tensor(st.get("step")) or not st["step"].is_cuda or st["step"].dtype != torch.float32):
+                return False
+            for tab, t in zip(tabs, (p, p.grad, st["exp_avg"], st["exp_avg_sq"], st["step"])):
+                tab.append(t.data_ptr())
+        need = ctypes.c_size_t()
+        lib.check(L.lsim_adam_clip_step_workspace(n, ctypes.byref(need)), what="lsim_adam_clip_step_workspace")
+        arr = lambda v: (ctypes.c_void_p * n)(*v)
+        tables = (arr(tabs[0]), arr(tabs[1]), arr(tabs[2]), arr(tabs[3]), arr(tabs[4]), (ctypes.c_int64 * n)(*[p.numel() for p, _ in entries]),
+                  (ctypes.c_float * n)(*[w for _, w in entries]), need.value)
+        _adam_tables[id(optimizer)] = (key, tables)
+    ws = _workspace(("adam", id(optimizer)), dev, tables[7])
     lr = g0["lr"]
     lr_dev = lr.data_ptr() if torch.is_tensor(lr) and lr.is_cuda else None
     lr_host = 0.0 if lr_dev is not None else float(lr)
     b1, b2 = g0["betas"]
-    lib.check(L.lsim_adam_clip_step_ex(n, numel, arr(tabs[0]), arr(tabs[1]), arr(tabs[2]), arr(tabs[3]), arr(tabs[4]), wd, n_clip, lr_dev, lr_host,
+    lib.check(L.lsim_adam_clip_step_ex(n, tables[5], tables[0], tables[1], tables[2], tables[3], tables[4], tables[6], n_clip, lr_dev, lr_host,
                                        float(b1), float(b2), float(g0["eps"]), float(max_grad_norm), None, ws.data_ptr(), ws.numel(),
                                        torch.cuda.current_stream(dev).cuda_stream), what="lsim_adam_clip_step_ex")
     return True

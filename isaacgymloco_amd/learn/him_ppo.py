@@ -2,15 +2,18 @@
 Same surface and update rule as rsl_rl.algorithms.HIMPPO (HIMP:38-198): act / process_env_step / compute_returns /
 update, value-clip, entropy bonus, KL-adaptive lr x/1.5 (HIMP:144-156), grad-clip, estimator stepped first with the PPO lr.
 
-Data parallel (not in the reference): `dist_ctx` averages gradients over ranks with ONE flattened
-all-reduce per optimiser step (RCCL over xGMI; latency-bound payloads of 0.24 MB and 2.2 MB), so every rank takes identical optimiser
-steps.  Two collectives per minibatch, 41 per PPO iteration (20 minibatches x 2 + the advantage statistics):
-  * the estimator's gradient bucket carries the KL estimate of the adaptive-lr rule in its last element (no separate scalar all-reduce)
-    and is reduced ASYNCHRONOUSLY while the PPO loss back-propagates -- the estimator step does not feed the PPO backward (the actor's
-    input features are detached and were computed before it, HAC:136-141), so moving it behind the PPO backward changes nothing;
-  * the PPO bucket starts right behind its backward and is in flight during the lr rule and the estimator's optimiser step; then it is
-    clipped (HIMP:183: clip AFTER the reduce) and stepped.  Gradients are reduced with ReduceOp.AVG and the parameters' .grad become views of
-    the reduced buffer: one concatenation per bucket, no scaling pass, no copy back.
+Data parallel (not in the reference): `dist_ctx` averages gradients over ranks so that every rank takes identical optimiser
+steps.  ONE collective per minibatch, 21 per PPO iteration (20 minibatches + the advantage statistics; round 3: 41, round 2: 61):
+  * both optimisers' gradients -- the estimator's 0.24 MB and the PPO group's 2.2 MB -- and the KL estimate of the adaptive-lr rule live in ONE
+    persistent flat buffer (fused_linear.GradArena: the weight-gradient kernels write into it, the loss kernel writes its statistics into
+    its tail), which is all-reduced in place (RCCL over xGMI, ReduceOp.AVG: a latency-bound 2.4 MB payload) right behind the PPO backward;
+  * then the lr rule, the estimator's step and the clipped PPO step (HIMP:183: clip AFTER the reduce) follow in the single-rank order.  The
+    estimator's step does not feed the PPO backward (the actor's input features are detached and were computed before it, HAC:136-141),
+    so running it behind that backward changes nothing.
+Round 3 reduced the estimator's bucket separately, in flight under the PPO backward; that hid 0.24 MB of transfer but paid a second
+torch.distributed call and two more stream hand-offs per minibatch in a loop that is within 1.6 x of launch-bound: a one-rank group with
+every collective issued cost 4.5 % (0.0997 vs 0.0954 s per iteration), of which the device shows 40 x ~35 us of idle around the hand-offs and
+the rest is host time (profiles/r04_trace_collectives.txt).  CPU tensors (gloo tests) keep the concatenated form of the same bucket.
 """
 import os
 
@@ -23,44 +26,59 @@ from .storage import HIMRolloutStorage
 _two_stream_memo = {}
 
 
-def _two_streams_allowed(critic, rows, multi_rank=False):
+def _loaded_tunableop_solutions(device):
+    """{shape signature: solution} of the GEMM entries TunableOp ACTUALLY holds in this process.  The table file is read lazily, at the first
+    tunable GEMM, and is rejected as a whole when its Validator lines (torch / HIP / hipBLASLt / rocBLAS versions, GPU architecture) do not
+    match this build -- every GEMM then runs hipBLASLt's default heuristics although the file on disk lists explicit solutions.
+    So: run one small GEMM, then ask TunableOp what it loaded."""
+    tun = torch.cuda.tunable
+    a = torch.zeros(8, 8, device=device)
+    torch.mm(a, a)
+    table = {}
+    for rec in tun.get_results():
+        if len(rec) >= 3 and str(rec[0]).startswith("Gemm"):
+            table[str(rec[1]).split("_ld_")[0]] = str(rec[2])
+    return table
+
+
+def _two_streams_allowed(critic, rows, multi_rank=False, single_device_ranks=False):
     """May the critic chain of the update run on a side stream, concurrently with the actor / estimator chain?  (LSIM_UPDATE_STREAMS = 0 / 1
     forces it off / on.)  Two library GEMMs in flight at once are only safe when neither is a kernel whose workgroups wait for each other
     (hipBLASLt's default heuristics pick such stream-K style kernels for some of these shapes: with TunableOp off, two concurrent GEMM streams
-    hung the device at N = 4096, round 3).  So the automatic answer is yes only when TunableOp is active in look-up mode AND every GEMM shape
-    of the critic chain at this minibatch size has an explicit (non-"Default") solution in the table -- which is the case for the shipped
-    gfx950 table at the BASELINE minibatch of 102 400 rows, the configuration the overlap was measured on (-1.6 % update time)."""
+    hung the device at N = 4096, round 3).  So the automatic answer is yes only when TunableOp is enabled in look-up mode AND it has LOADED an
+    explicit (non-"Default") solution for every BLAS GEMM of the critic chain at this minibatch size: forward (tn_), input gradients (nn_)
+    and the weight gradients (nt_) of the layers the library's own weight-gradient kernel leaves to BLAS.  That holds for the shipped gfx950
+    table on the build it was tuned with, at the BASELINE minibatch of 102 400 rows (the configuration the overlap was measured on:
+    -1.6 % update time); on any other build the table is rejected at load, nothing is found here, and the answer is no.
+    Several ranks: every rank process owns its GPU, so the kernels that share a device are exactly those of the one-rank case plus RCCL's
+    (which wait for the peer GPU, not for a workgroup of another kernel on this one); explicit non-cooperative GEMM solutions cannot form a
+    wait cycle with them, and a 1-rank RCCL group with every collective issued runs both streams (tests/test_bench_cli.py).  What does hang is
+    the DEBUG mode with several rank processes on ONE GPU (LSIM_DEBUG_SINGLE_DEVICE, gloo): four GEMM streams of two processes time-sliced on
+    one device -- `single_device_ranks` keeps the side stream off there."""
     mode = os.environ.get("LSIM_UPDATE_STREAMS", "auto")
     if mode in ("0", "1"):
         return mode == "1"
-    if multi_rank:
-        # Not with more than one rank: two rank processes sharing one GPU (LSIM_DEBUG_SINGLE_DEVICE, gloo) hang when the side stream and the
-        # asynchronous gradient buckets are both in play (two such processes WITHOUT collectives run fine side by side); the combination
-        # could not be run over RCCL between GPUs in the build environment, so it stays off there.  (A 1-rank RCCL group with every
-        # collective issued runs it: tests/test_bench_cli.py.)
+    if multi_rank and (single_device_ranks or os.environ.get("LSIM_DEBUG_SINGLE_DEVICE") == "1"):
         return False
-    if os.environ.get("PYTORCH_TUNABLEOP_ENABLED") != "1" or os.environ.get("PYTORCH_TUNABLEOP_TUNING", "1") != "0":
+    tun = getattr(torch.cuda, "tunable", None)
+    if tun is None or not tun.is_enabled() or tun.tuning_is_enabled():
         return False
     dims = tuple((m.in_features, m.out_features) for m in critic if isinstance(m, nn.Linear))
-    key = (rows, dims, os.environ.get("PYTORCH_TUNABLEOP_FILENAME"))
+    key = (rows, dims, tun.get_filename())
     if key not in _two_stream_memo:
         ok = False
         try:
-            base = os.environ.get("PYTORCH_TUNABLEOP_FILENAME", "")
-            paths = [base] + [base.replace(".csv", f"{d}.csv") for d in range(8)]
-            table = {}
-            for path in paths:
-                if path and os.path.exists(path):
-                    for line in open(path):
-                        f = line.strip().split(",")
-                        if len(f) >= 3 and not f[0].startswith("Validator"):
-                            table[f[1].split("_ld_")[0]] = f[2]
+            from .fused_linear import _eligible
+            table = _loaded_tunableop_solutions(next(critic.parameters()).device)
             need = []
             for i, (k, n) in enumerate(dims):
-                need.append(f"tn_{n}_{rows}_{k}")                      # forward  y = x W^T (+ bias)
+                if n > 1:
+                    need.append(f"tn_{n}_{rows}_{k}")                  # forward  y = x W^T (+ bias); a single output column is a GEMV
                 if i > 0:
                     need.append(f"nn_{k}_{rows}_{n}")                  # input gradient  g W
-            ok = bool(table) and all(table.get(s, "Default") != "Default" for s in need if not s.startswith("tn_1_"))
+                if not _eligible(rows, k, n):
+                    need.append(f"nt_{k}_{n}_{rows}")                  # weight gradient  g^T x through BLAS
+            ok = bool(table) and all(table.get(sig, "Default") != "Default" for sig in need)
         except Exception:
             ok = False
         _two_stream_memo[key] = ok
@@ -81,23 +99,59 @@ class DistCtx:
         self.collectives = 0            # number of collectives issued so far (tests / DESIGN.md section 8 count them per iteration)
 
     def average_grads(self, params):
-        """one flattened all-reduce per optimiser step: cat (1 kernel) -> all_reduce(AVG); the parameters' .grad become views of the reduced
-        buffer (no copy back, no scaling pass)"""
+        """one flattened all-reduce per optimiser step; the parameters' .grad are (or become) views of the reduced buffer"""
         if not self.enabled:
             return
         self.finish_bucket(self.reduce_bucket_async([p for p in params if p.grad is not None]))
 
-    def reduce_bucket_async(self, params, extra=None):
+    def reduce_bucket_async(self, params, extra=None, key=None, n_extra=None, extra_at=0):
         """start the all-reduce of one flattened bucket [gradients of `params`..., extra] WITHOUT waiting for it: RCCL works on its own stream
-        (ordered behind what the compute stream has issued so far), kernels issued after this call overlap with it.  finish_bucket() waits."""
-        parts = [p.grad.reshape(-1) for p in params]
-        if extra is not None:
-            parts.append(extra.detach().reshape(-1).to(parts[0].dtype))
-        flat = torch.cat(parts)
+        (ordered behind what the compute stream has issued so far), kernels issued after this call overlap with it.  finish_bucket() waits.
+        With a gradient arena (fused_linear.GradArena: CUDA parameters) the bucket is a PERSISTENT flat buffer that the gradients already
+        live in -- the weight-gradient kernels wrote them there -- so there is no concatenation and nothing to re-view afterwards; the few
+        gradients that autograd's own kernels produced are copied into their slices by one multi-tensor launch (Bucket.adopt)."""
+        from . import fused_linear as FL
+        if n_extra is None:
+            n_extra = extra.numel() if extra is not None else 0
+            extra_at = 0
+        if FL._arena is not None and params[0].is_cuda:
+            # n_extra / extra_at: size of the bucket's tail and where `extra` goes in it (the PPO loss kernel's 5 statistics: slot 3 is the KL
+            # estimate; when the kernel wrote them there itself, extra is None and nothing is copied)
+            b = FL._arena.bucket(key if key is not None else tuple(id(p) for p in params), params, n_extra)
+            b.adopt()
+            if extra is not None:
+                b.extra_view[extra_at:extra_at + extra.numel()].copy_(extra.detach().reshape(-1))
+            flat = b.flat
+            pieces = None
+        else:
+            parts = [p.grad.reshape(-1) for p in params]
+            n_extra = extra.numel() if extra is not None else 0
+            if extra is not None:
+                parts.append(extra.detach().reshape(-1).to(parts[0].dtype))
+            flat = torch.cat(parts)
+            pieces = params
         self.collectives += 1
         avg = self._avg_op(flat)
-        work = self.dist.all_reduce(flat, op=avg if avg is not None else self.dist.ReduceOp.SUM, async_op=True)
-        return flat, work, params, (extra.numel() if extra is not None else 0), avg is not None
+        work = self._all_reduce_async(flat, avg if avg is not None else self.dist.ReduceOp.SUM)
+        return flat, work, pieces, n_extra, avg is not None
+
+    def _all_reduce_async(self, flat, op):
+        """dist.all_reduce(flat, op, async_op=True) on the default group through the ProcessGroup object itself: the Python wrapper's argument
+        checks and group look-ups are a third of the host time of a call, in a loop whose host time shows"""
+        pg = getattr(self, "_pg", None)
+        if pg is None:
+            try:
+                pg = self._pg = self.dist.distributed_c10d._get_default_group()
+            except Exception:
+                pg = self._pg = False
+        if pg:
+            try:
+                opts = self.dist.AllreduceOptions()
+                opts.reduceOp = op
+                return pg.allreduce([flat], opts)
+            except Exception:
+                self._pg = False
+        return self.dist.all_reduce(flat, op=op, async_op=True)
 
     def _avg_op(self, t):
         """ReduceOp.AVG where the backend has it (RCCL / NCCL: the division happens inside the collective); gloo sums and we scale"""
@@ -109,6 +163,8 @@ class DistCtx:
         work.wait()
         if not averaged:
             flat.div_(self.world)
+        if params is None:                  # arena bucket: the gradients ARE the buffer
+            return flat[flat.numel() - n_extra:] if n_extra else None
         sizes = [p.grad.numel() for p in params]
         pieces = flat.split(sizes + ([n_extra] if n_extra else []))
         for p, v in zip(params, pieces):
@@ -190,6 +246,19 @@ class HIMPPO:
         est.optimizer = rebuild(est.optimizer)
         est.fused_step = True
         return True
+
+    def _grad_arena(self, more_params=()):
+        """persistent gradient buckets on the GPU (fused_linear.GradArena), created at the first update: the estimator's parameters + one slot
+        for the KL estimate, and everything else the PPO optimiser steps (+ `more_params`: HybridPPO's discriminator)"""
+        from . import fused_linear as FL
+        ac = self.actor_critic
+        if getattr(self, "_arena", None) is None:
+            if not next(ac.parameters()).is_cuda or os.environ.get("LSIM_GRAD_ARENA", "1") == "0":
+                return None
+            self._arena = FL.GradArena()
+        if FL._arena is not self._arena:
+            FL.set_grad_arena(self._arena)
+        return self._arena
 
     def _side_stream(self, device):
         if getattr(self, "_side", None) is None:
@@ -286,7 +355,7 @@ class HIMPPO:
         if mu.is_cuda and mu.dtype == torch.float32:
             from .fused_linear import ppo_loss_hip
             loss, st = ppo_loss_hip(mu, sigma, value, actions, old_logp, advantages, returns, target_values, old_mu, old_sigma, self.clip_param,
-                                    self.value_loss_coef, self.entropy_coef, self.use_clipped_value_loss)
+                                    self.value_loss_coef, self.entropy_coef, self.use_clipped_value_loss, out=self._stats_slot())
             return loss, st[0], st[1], st[3]
         logp = ac.get_actions_log_prob(actions)
         entropy = ac.entropy
@@ -300,30 +369,49 @@ class HIMPPO:
             value_loss = (returns - value).pow(2).mean()
         return surrogate_loss + self.value_loss_coef * value_loss - self.entropy_coef * entropy.mean(), surrogate_loss, value_loss, None
 
+    def _stats_slot(self):
+        """the 5-float tail of the gradient bucket, where the loss kernel may write its statistics directly (None until the bucket exists)"""
+        ctx = self.dist_ctx
+        if ctx is None or not ctx.enabled or getattr(self, "_arena", None) is None:
+            return None
+        b = self._arena.buckets.get("all")
+        return b.extra_view if b is not None and b.extra == 5 else None
+
     def _step_minibatch_data_parallel(self, ac, obs, next_critic_obs, loss, mu, sigma, old_mu, old_sigma, kl_mean, adaptive, more_params=()):
-        """the optimiser half of one minibatch on N > 1 ranks: same two optimiser steps as the single-rank order (lr rule -> estimator step -> PPO
-        step, HIMP:144-184), with the estimator's gradient all-reduce -- carrying the KL estimate in its tail -- in flight during the PPO
-        backward.  Returns the estimator's (estimation, swap) losses."""
+        """the optimiser half of one minibatch in the data-parallel order: both backwards, ONE all-reduce of every gradient + the KL estimate,
+        then the same two optimiser steps as the single-rank order (lr rule -> estimator step -> PPO step, HIMP:144-184).  Also the order of
+        the single-rank two-stream path (no collectives).  Returns the estimator's (estimation, swap) losses."""
+        from . import fused_linear as FL
         ctx, est_mod = self.dist_ctx, ac.estimator
         if ctx is not None and not ctx.enabled:
             ctx = None                                               # single rank: same order, no collectives (the two-stream path of update())
         est_params = list(est_mod.parameters())
         self.optimizer.zero_grad()                                   # every parameter of the optimiser, the estimator's included
+        FL.grad_cycle()
         est, swap, total = est_mod.losses(obs, next_critic_obs)
         est_mod._primed = None
         total.backward()
+        loss.backward()                                              # actor / critic / std gradients
         extra = None
         if adaptive:
             extra = kl_mean if kl_mean is not None else self._local_kl(mu, sigma, old_mu, old_sigma)
-        handle = ctx.reduce_bucket_async([p for p in est_params if p.grad is not None], extra=extra) if ctx is not None else None
-        loss.backward()                                              # actor / critic / std gradients: overlaps with the all-reduce above
-        # the PPO bucket starts as soon as its backward is issued and is in flight during the lr rule and the estimator's optimiser step.
         # `more_params`: parameters outside the actor-critic that the same optimiser steps (HybridPPO: the discriminator) -- reduced in the same
         # bucket, not clipped (HYBP:270 clips the actor-critic only)
+        est_live = [p for p in est_params if p.grad is not None]
         est_ids = {id(p) for p in est_params}
         ppo_params = [p for p in ac.parameters() if p.grad is not None and id(p) not in est_ids]
-        handle_ppo = ctx.reduce_bucket_async(ppo_params + [p for p in more_params if p.grad is not None]) if ctx is not None else None
-        kl_global = ctx.finish_bucket(handle) if ctx is not None else extra
+        more = [p for p in more_params if p.grad is not None]
+        kl_global = extra
+        if ctx is not None:
+            slot = self._stats_slot()
+            in_place = slot is not None and extra is not None and extra.data_ptr() == slot[3:4].data_ptr()     # the loss kernel already wrote it there
+            handle = ctx.reduce_bucket_async(est_live + ppo_params + more, extra=None if in_place else extra, key="all",
+                                             n_extra=5 if (extra is not None and extra.is_cuda) else None, extra_at=3)
+            got = ctx.finish_bucket(handle)                          # clip AFTER the all-reduce (HIMP:183)
+            if extra is not None:
+                kl_global = got[3:4] if got.numel() == 5 else got
+        elif self._grad_arena() is not None:                         # single rank: the same bucket, so that the optimisers' pointer tables repeat
+            self._arena.bucket("all", est_live + ppo_params + more, 0).adopt()
         if adaptive:
             self._adapt_lr(mu, sigma, old_mu, old_sigma, kl_global.reshape(()), already_global=True)
         if self._lr_t is None:                                       # host learning rate: the estimator steps with the PPO rate (HIMP:158)
@@ -332,15 +420,12 @@ class HIMPPO:
                 g["lr"] = self.learning_rate
         stepped = False
         if est_mod.fused_step:
-            from .fused_linear import adam_clip_step_hip
-            stepped = adam_clip_step_hip(est_mod.optimizer, est_mod.max_grad_norm)
+            stepped = FL.adam_clip_step_hip(est_mod.optimizer, est_mod.max_grad_norm)
         if not stepped:
             nn.utils.clip_grad_norm_(est_params, est_mod.max_grad_norm)
             est_mod.optimizer.step()
         for p in est_params:                                         # the PPO optimiser also holds these parameters: as in the reference
             p.grad = None                                            # (zero_grad before the PPO backward) it must not step them
-        if ctx is not None:
-            ctx.finish_bucket(handle_ppo)                            # clip AFTER the all-reduce (HIMP:183)
         self._clip_and_step(self.optimizer, ppo_params, self.max_grad_norm)
         return est.detach(), swap.detach()
 
@@ -348,6 +433,7 @@ class HIMPPO:
         ac = self.actor_critic
         sums = torch.zeros(4, device=self.device)
         last_est = last_swap = None
+        self._grad_arena()
         for (obs, critic_obs, actions, next_critic_obs, target_values, advantages, returns, old_logp, old_mu, old_sigma) in \
                 self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs):
             multi_rank = self.dist_ctx is not None and self.dist_ctx.enabled and self.dist_ctx.world > 1
@@ -385,7 +471,11 @@ class HIMPPO:
                     self._adapt_lr(mu, sigma, old_mu, old_sigma, kl_mean)
                 est, swap = ac.estimator.update(obs, next_critic_obs, lr=None if self._lr_t is not None else self.learning_rate)
                 self.optimizer.zero_grad()
+                from . import fused_linear as FL
+                FL.grad_cycle()
                 loss.backward()
+                if FL._arena is not None:
+                    FL._arena.bucket("ppo", [p for p in ac.parameters() if p.grad is not None]).adopt()
                 self._clip_and_step(self.optimizer, ac.parameters(), self.max_grad_norm)
             sums += torch.stack((value_loss.detach(), surrogate_loss.detach(), est, swap))
             last_est, last_swap = est, swap

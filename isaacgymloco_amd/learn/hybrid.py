@@ -51,6 +51,7 @@ class HybridPPO(HIMPPO):
         mb = self.storage.num_envs * self.storage.num_transitions_per_env // self.num_mini_batches
         sums = torch.zeros(6, device=dev)
         est = swap = None
+        self._grad_arena()
         gens = zip(self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs),
                    self.amp_storage.feed_forward_generator(n_updates, mb), self.amp_data.feed_forward_generator(n_updates, mb))
         for sample, (pol_s, pol_ns), (exp_s_raw, exp_ns_raw) in gens:
@@ -88,7 +89,11 @@ class HybridPPO(HIMPPO):
                                                                more_params=list(disc.parameters()))
             else:
                 self.optimizer.zero_grad()
+                from . import fused_linear as FL
+                FL.grad_cycle()
                 loss.backward()
+                if FL._arena is not None:
+                    FL._arena.bucket("ppo", [p for g in self.optimizer.param_groups for p in g["params"] if p.grad is not None]).adopt()
                 self._clip_and_step(self.optimizer, ac.parameters(), self.max_grad_norm)     # HYBP:270-273: clipping over the actor-critic only
             if self.min_std is not None:
                 ac.std.data = ac.std.data.clamp(min=self.min_std)

@@ -127,9 +127,13 @@ class HIMEstimator(nn.Module):
         est, swap, total = self.losses(obs_history, next_critic_obs)
         self._primed = None
         self.optimizer.zero_grad()
+        from . import fused_linear as FL
+        FL.grad_cycle()
         total.backward()
         if self.grad_sync is not None:
             self.grad_sync(list(self.parameters()))
+        elif FL._arena is not None and next(self.parameters()).is_cuda:      # stable gradient pointers for the fused optimiser step
+            FL._arena.bucket("estimator", [p for p in self.parameters() if p.grad is not None]).adopt()
         if self.fused_step:       # set by HIMPPO.enable_device_lr: clip + Adam in one C-ABI call (three launches)
             from .fused_linear import adam_clip_step_hip
             if adam_clip_step_hip(self.optimizer, self.max_grad_norm):

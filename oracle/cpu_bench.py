@@ -65,10 +65,14 @@ if __name__ == "__main__":
     gomp = ctypes.CDLL("libgomp.so.1")
     legs = [leg(a.task, 64, 1, a.seconds * 0.2, gomp), leg(a.task, 64, threads, a.seconds * 0.2, gomp),
             leg(a.task, 4096, threads, a.seconds * 0.6, gomp)]
+    scaling = legs[2]["env_steps_per_s"] / max(legs[0]["env_steps_per_s"], 1e-9)
     print(json.dumps({
         "value": legs[2]["env_steps_per_s"], "unit": "env-steps/s", "cores": threads, "kind": "port",
+        "parallel_speedup_over_one_core": scaling,
         "value_1core": legs[0]["env_steps_per_s"], "value_n64_all_cores": legs[1]["env_steps_per_s"],
         "nproc": os.cpu_count(), "cores_available": avail, "cpu_model": cpu_model(), "legs": legs,
         "sample": f"task {a.task}, N(0,1) actions: {legs[2]['steps']} steps x 4096 envs on {threads} OpenMP threads (value); "
                   f"{legs[1]['steps']} steps x 64 envs on {threads} threads; {legs[0]['steps']} steps x 64 envs on 1 thread (value_1core); "
-                  f"CPU oracle = the build's scalar C restatement, fp64 physics -- not the reference's PhysX CPU path"}))
+                  f"CPU oracle = the build's scalar C restatement, fp64 physics -- not the reference's PhysX CPU path.  A WEAK baseline: {threads} "
+                  f"threads give only {scaling:.1f} x one core (the per-env loops are OpenMP-parallel, reset_idx's cross-env part and the Python "
+                  f"driver are serial; N = 64 on all threads is about one core), so a GPU / CPU ratio from this line says nothing about either"}))

@@ -74,9 +74,9 @@ def test_two_ranks_stay_in_lockstep(tmp_path):
     assert a["lr"] == b["lr"]
     for k in a["sd"]:
         torch.testing.assert_close(a["sd"][k], b["sd"][k], rtol=0, atol=0, msg=k)
-    # two collectives per minibatch (estimator bucket with the KL estimate in its tail, PPO bucket) + the advantage statistics per iteration
-    # (41 per iteration with the reference's 5 epochs x 4 minibatches; here 2 x 2 minibatches, 2 iterations)
-    assert a["collectives"] == b["collectives"] == 2 * (2 * 2 * 2 + 1)
+    # one collective per minibatch (every gradient of both optimisers + the KL estimate in one bucket) + the advantage statistics per iteration
+    # (21 per iteration with the reference's 5 epochs x 4 minibatches; here 2 x 2 minibatches, 2 iterations)
+    assert a["collectives"] == b["collectives"] == 2 * (2 * 2 + 1)
 
 
 def test_data_parallel_order_equals_the_single_rank_order(tmp_path):

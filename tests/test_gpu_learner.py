@@ -817,3 +817,30 @@ def test_play_style_loop_runs_on_the_env_surface():
             keep = torch.ones(50, dtype=torch.bool, device=env.device); keep[[3, 17, 42]] = False
             assert torch.equal(env.episode_length_buf[keep], ep[keep])
     assert not bool(env.reset_buf.all())
+
+
+def test_gradient_arena_changes_nothing_but_where_the_gradients_live(monkeypatch):
+    """fused_linear.GradArena (persistent flat gradient buckets: the weight-gradient kernels write dW / db into the parameters' slices, autograd
+    adopts the slices as .grad) against the same two iterations with LSIM_GRAD_ARENA=0: identical weights and optimiser state bit for bit,
+    and with the arena every gradient of the actor-critic lives inside one of its flat buffers after an update."""
+    from isaacgymloco_amd.learn import fused_linear as FL
+
+    def run(arena):
+        monkeypatch.setenv("LSIM_GRAD_ARENA", "1" if arena else "0")
+        FL.set_grad_arena(None)
+        env, r = _make(seed=5)
+        r.enable_graphs()
+        r.learn(2, init_at_random_ep_len=False)
+        sd = {k: v.clone() for k, v in r.alg.actor_critic.state_dict().items()}
+        return r, sd
+    ra, a = run(True)
+    arena = FL._arena
+    assert arena is not None and {"estimator", "ppo"} <= set(arena.buckets)
+    spans = [(b.flat.data_ptr(), b.flat.data_ptr() + 4 * b.flat.numel()) for b in arena.buckets.values()]
+    grads = [p.grad for p in ra.alg.actor_critic.parameters() if p.grad is not None]
+    assert grads and all(any(lo <= g.data_ptr() < hi for lo, hi in spans) for g in grads)
+    rb, b = run(False)
+    assert FL._arena is None
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    FL.set_grad_arena(None)

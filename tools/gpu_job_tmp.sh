@@ -1,17 +1,17 @@
 export TMPDIR=/tmp
-O=gpurun_out/r04f; mkdir -p $O
-timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_physics_invariants.py tests/test_gpu_physics_anchors.py -m gpu -q -x > $O/gpu_tests.log 2>&1; tail -5 $O/gpu_tests.log
-timeout 600 python tools/phase_profile.py aliengo 4096 > $O/phase_profile_aliengo.txt 2>&1; grep -v "^/opt" $O/phase_profile_aliengo.txt | awk '{ if ($6+0 > 2000 || NR==1) print }'
-for sv in tgs pgs; do
-  LSIM_SOLVER=$sv timeout 600 python bench.py --mode env --steps 500 --warmup 50 --no-cpu-baseline > $O/bench_env_$sv.log 2>&1; tail -1 $O/bench_env_$sv.log > $O/bench_env_$sv.json
-done
-LSIM_SOLVER=tgs timeout 600 python bench.py --mode env --task aliengo_stairs --steps 500 --warmup 50 --no-cpu-baseline > $O/bench_env_stairs_tgs.log 2>&1; tail -1 $O/bench_env_stairs_tgs.log > $O/bench_env_stairs_tgs.json
-timeout 900 python bench.py --no-cpu-baseline > $O/bench_train_tgs.log 2>&1; tail -1 $O/bench_train_tgs.log > $O/bench_train_tgs.json
+O=gpurun_out/r04l; mkdir -p $O
+run() { name=$1; shift; "$@" > $O/$name.log 2>&1; tail -1 $O/$name.log > $O/$name.json; }
+LSIM_DEBUG_FORCE_COLLECTIVES=1 run force_default timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29518 bench.py --gpus 1 --no-cpu-baseline
+GPU_MAX_HW_QUEUES=8 LSIM_DEBUG_FORCE_COLLECTIVES=1 run force_q8 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29519 bench.py --gpus 1 --no-cpu-baseline
+GPU_MAX_HW_QUEUES=2 LSIM_DEBUG_FORCE_COLLECTIVES=1 run force_q2 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29520 bench.py --gpus 1 --no-cpu-baseline
+LSIM_UPDATE_STREAMS=0 LSIM_DEBUG_FORCE_COLLECTIVES=1 run force_onestream timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29521 bench.py --gpus 1 --no-cpu-baseline
+LSIM_UPDATE_STREAMS=0 run plain_onestream timeout 600 python bench.py --no-cpu-baseline
+GPU_MAX_HW_QUEUES=8 run plain_q8 timeout 600 python bench.py --no-cpu-baseline
 python - <<PY
 import json
-for f in ("bench_env_tgs","bench_env_pgs","bench_env_stairs_tgs","bench_train_tgs"):
+for f in ("force_default","force_q8","force_q2","force_onestream","plain_onestream","plain_q8"):
     try:
         j=json.load(open("$O/"+f+".json"))
-        print(f, {k:j.get(k) for k in ("value","ms_per_step","kernel_a_ms","kernel_b_ms","collection_s_per_iteration","learn_s_per_update")})
+        print(f, {k:j.get(k) for k in ("value","collection_s_per_iteration","learn_s_per_update","iteration_wall_s_min_median_max")})
     except Exception as e: print(f, "failed", e)
 PY

@@ -1,7 +1,8 @@
 """Summarise rocprofv3 --pmc passes (one directory per pass, each holding *_counter_collection.csv) into one per-kernel table.
 
-usage: python tools/pmc_summary.py OUT.csv [--traffic OUT.json --kernel lsim_k_step_a --task aliengo --envs 4096 --note "..."]
+usage: python tools/pmc_summary.py OUT.csv [--traffic OUT.json --kernel lsim_k_step_a --task aliengo --envs 4096 --solver tgs --append 1 --note "..."]
                                    [--run MODE:ACTIONS:DIR,DIR,...]...  [PASS_DIR ...]
+--solver: which kernel A the passes ran (tgs / pgs; bench.py matches it).  --append 1: keep the records of OUT.json that describe other workloads.
 
 Plain PASS_DIRs are merged into the table OUT.csv.  Each --run names the workload its passes were collected on (bench.py --mode MODE with
 ACTIONS = policy | normal | zeros) and becomes one record of OUT.json ("runs"), which bench.py matches against its own workload before it
@@ -65,7 +66,7 @@ def table(acc, regs, note):
     return lines
 
 
-def record(acc, dur, kernel, task, envs, mode, actions, note):
+def record(acc, dur, kernel, task, envs, mode, actions, note, solver="tgs"):
     k = next(x for x in sorted(acc) if kernel in x)
     avg = lambda c: (acc[k][c][0] / acc[k][c][1]) if c in acc[k] and acc[k][c][1] else None   # noqa: E731
     fetch_kb, write_kb = avg("FETCH_SIZE"), avg("WRITE_SIZE")
@@ -77,7 +78,7 @@ def record(acc, dur, kernel, task, envs, mode, actions, note):
     lanes = None
     if avg("SQ_THREAD_CYCLES_VALU") and avg("SQ_ACTIVE_INST_VALU"):
         lanes = avg("SQ_THREAD_CYCLES_VALU") / avg("SQ_ACTIVE_INST_VALU")       # both in quad-cycles: mean active lanes of a VALU instruction
-    return {"kernel": kernel, "task": task, "envs_per_gpu": envs, "mode": mode, "actions": actions,
+    return {"kernel": k, "task": task, "envs_per_gpu": envs, "mode": mode, "actions": actions, "solver": solver,
             "valu_wave_insts_per_launch": avg("SQ_INSTS_VALU"), "salu_wave_insts_per_launch": avg("SQ_INSTS_SALU"),
             "lds_wave_insts_per_launch": avg("SQ_INSTS_LDS"), "wave_cycles_quad_per_launch": avg("SQ_WAVE_CYCLES"),
             "wait_any_quad_per_launch": avg("SQ_WAIT_ANY"), "wait_inst_any_quad_per_launch": avg("SQ_WAIT_INST_ANY"),
@@ -92,6 +93,7 @@ def record(acc, dur, kernel, task, envs, mode, actions, note):
 def main(argv):
     out_csv = argv[0]
     traffic_json = kernel = note = task = envs = None
+    solver, append = "tgs", False
     runs = []
     rest = argv[1:]
     while rest and rest[0].startswith("--"):
@@ -100,6 +102,8 @@ def main(argv):
         elif rest[0] == "--note": note = rest[1]
         elif rest[0] == "--task": task = rest[1]
         elif rest[0] == "--envs": envs = int(rest[1])
+        elif rest[0] == "--solver": solver = rest[1]
+        elif rest[0] == "--append": append = rest[1] not in ("0", "")
         elif rest[0] == "--run":
             mode, actions, dirs = rest[1].split(":", 2)
             runs.append((mode, actions, dirs.split(",")))
@@ -114,8 +118,12 @@ def main(argv):
         for mode, actions, dirs in (runs or [("env", "normal", rest)]):
             a, d, _ = collect(dirs)
             if a:
-                recs.append(record(a, d, kernel, task, envs, mode, actions, note))
+                recs.append(record(a, d, kernel, task, envs, mode, actions, note, solver))
                 recs[-1]["file"] = os.path.basename(out_csv)
+        if append and os.path.exists(traffic_json):
+            key = lambda r: (r.get("task"), r.get("envs_per_gpu"), r.get("mode"), r.get("actions"), r.get("solver", "pgs"))   # noqa: E731
+            new = {key(r) for r in recs}
+            recs = [r for r in json.load(open(traffic_json)).get("runs", []) if key(r) not in new] + recs
         json.dump({"runs": recs}, open(traffic_json, "w"), indent=1)
 
 
