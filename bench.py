@@ -86,7 +86,7 @@ def parse_args():
     ap.add_argument("--actions", default="normal", choices=["normal", "zeros"],
                     help="env mode action source (SURVEY.md 8d): N(0,1) = an untrained policy (init_noise_std 1), or zeros = standing robots")
     ap.add_argument("--mixed-robots", action="store_true",
-                    help="BASELINE config 5: the upper half of the ranks simulate Go1 instead of --task's robot (one shared policy; not reference-comparable)")
+                    help="BASELINE config 5: the upper half of the ranks simulate Go2 instead of --task's robot (one shared policy; not reference-comparable)")
     return ap.parse_args()
 
 
@@ -173,7 +173,8 @@ def main():
     mode = args.mode
     base_task = args.task
     if args.mixed_robots and world > 1 and rank >= world // 2:
-        args.task = "go1"           # same observation / action layout, different model table and gains (envs/config.py GO1_OVERRIDES)
+        args.task = "go2"           # same observation / action layout, different model table and gains (envs/config.py GO2_OVERRIDES:
+                                    # kinematics fitted to the reference's Go2 mocap clips, inertial values nominal; rounds 1-3 used Go1 here)
     cfg = C.TASKS[args.task][0]()
     cfg.env.num_envs = args.envs
     env = LeggedRobot(cfg, sim_device=f"cuda:{local_rank}", seed=1, rank=rank, using_amp=(args.task == "aliengo_amp"))

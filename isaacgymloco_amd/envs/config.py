@@ -299,8 +299,32 @@ def go1_cfg_ppo():
     return ConfigNode(_build(LEGGED_ROBOT_PPO_DEFAULTS, ALIENGO_PPO_OVERRIDES, {"runner": dict(experiment_name="flat_go1")}))
 
 
+# ----------------------------------------------------------------------------- Go2 on the Aliengo task (BASELINE config 5 names Go2)
+# The reference has no Go2 asset or task; it does ship Go2 mocap clips (datasets/mocap_motions_go2), to which the kinematics of
+# robots/tables/go2.json are fitted (tools/gen_go2_table.py; inertial values and limits: Unitree's published description, nominal).  Task
+# values: Unitree's own legged_gym settings for the robot (default pose, Kp 20 / Kd 0.5, action scale 0.25).  NOT reference-comparable.
+GO2_OVERRIDES = {
+    "init_state": dict(pos=[0.0, 0.0, 0.42], default_joint_angles=_leaf(
+        FL_hip_joint=0.1, RL_hip_joint=0.1, FR_hip_joint=-0.1, RR_hip_joint=-0.1,
+        FL_thigh_joint=0.8, RL_thigh_joint=1.0, FR_thigh_joint=0.8, RR_thigh_joint=1.0,
+        FL_calf_joint=-1.5, RL_calf_joint=-1.5, FR_calf_joint=-1.5, RR_calf_joint=-1.5)),
+    "control": dict(stiffness=_leaf(joint=20.0), damping=_leaf(joint=0.5), action_scale=0.25),
+    "asset": dict(file="{LEGGED_GYM_ROOT_DIR}/resources/robots/go2/urdf/go2.urdf", name="go2", flip_visual_attachments=False),
+    "rewards": dict(base_height_target=0.3, foot_height_target_base=-0.2),
+}
+
+
+def go2_cfg():
+    return ConfigNode(_build(LEGGED_ROBOT_DEFAULTS, ALIENGO_OVERRIDES, GO2_OVERRIDES))
+
+
+def go2_cfg_ppo():
+    return ConfigNode(_build(LEGGED_ROBOT_PPO_DEFAULTS, ALIENGO_PPO_OVERRIDES, {"runner": dict(experiment_name="flat_go2")}))
+
+
 TASKS = {
     "go1": (go1_cfg, go1_cfg_ppo),
+    "go2": (go2_cfg, go2_cfg_ppo),
     "aliengo": (aliengo_cfg, aliengo_cfg_ppo),
     "aliengo_stairs": (aliengo_stairs_cfg, aliengo_stairs_cfg_ppo),
     "aliengo_amp": (aliengo_amp_cfg, aliengo_amp_cfg_ppo),

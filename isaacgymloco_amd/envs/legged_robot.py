@@ -23,7 +23,7 @@ from ..robots import aliengo
 
 def build_robot_model(asset):
     """lsim_robot_model for cfg.asset (LR:1135-1219): the hand-checked Aliengo table, a URDF file if `asset.file` resolves to one, or a
-    stored table of robots/tables/ (go1, a1) chosen by `asset.name`."""
+    stored table of robots/tables/ (go1, go2, a1) chosen by `asset.name`."""
     import os
     from ..robots import urdf
     pats = dict(penalize_contacts_on=tuple(asset.penalize_contacts_on), terminate_after_contacts_on=tuple(asset.terminate_after_contacts_on),

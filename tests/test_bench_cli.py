@@ -74,7 +74,7 @@ def test_two_ranks_on_the_fused_gpu_path_stay_in_lockstep():
 @pytest.mark.gpu
 def test_mixed_robots_two_ranks_share_one_policy():
     """BASELINE config 5's mapping (`--mixed-robots`: the upper half of the ranks simulate the second robot, one asset per process as in the
-    reference, LR:1135) on the fused GPU path: rank 0 on the Aliengo table, rank 1 REALLY on the Go1 table (total model mass as created),
+    reference, LR:1135) on the fused GPU path: rank 0 on the Aliengo table, rank 1 REALLY on the Go2 table (total model mass as created),
     gradients all-reduced, bit-identical weights on both ranks.  Two ranks on one device, gloo (the 8-GPU RCCL run is the driver's)."""
     r = _run(["--gpus", "2", "--steps", "100", "--warmup", "100", "--envs", "256", "--no-cpu-baseline", "--mixed-robots"],
              env={"LSIM_DEBUG_SINGLE_DEVICE": "1"})
@@ -86,7 +86,7 @@ def test_mixed_robots_two_ranks_share_one_policy():
     m0, m1 = j["robot_mass_kg_by_rank"]
     from isaacgymloco_amd.robots import aliengo, urdf
     want0 = sum(b.mass for b in aliengo.build_model().bodies)
-    want1 = sum(b.mass for b in urdf.build_model_from_table("go1")[0].bodies)
+    want1 = sum(b.mass for b in urdf.build_model_from_table("go2")[0].bodies)
     assert abs(m0 - want0) < 1e-2 and abs(m1 - want1) < 1e-2 and abs(want0 - want1) > 5.0, (m0, m1, want0, want1)
     assert len(j["weights_digest_by_rank"]) == 2 and j["ranks_in_lockstep"] is True
     assert j["ppo_updates_timed"] >= 5

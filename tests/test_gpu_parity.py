@@ -248,11 +248,13 @@ def test_hip_api_rejects_bad_arguments():
     assert torch.isfinite(obs).all()
 
 
-def test_hip_go1_matches_oracle():
-    """second robot (task "go1", model table robots/tables/go1.json): HIP vs oracle with full physics and random actions"""
+@pytest.mark.parametrize("robot", ["go1", "go2"])
+def test_hip_go1_matches_oracle(robot):
+    """second robots (tasks "go1" / "go2", model tables robots/tables/go1.json / go2.json -- BASELINE config 5's Go2, kinematics fitted to the
+    reference's Go2 clips): HIP vs oracle with full physics and random actions"""
     from hip_backend import HipBackend
     N = 16
-    cfg = C.TASKS["go1"][0]()
+    cfg = C.TASKS[robot][0]()
     cfg.terrain.terrain_proportions = [1.0, 0.0, 0.0, 0.0]
     orc, lc, model, ter = make_oracle(cfg, N, seed=5)
     be = HipBackend(cfg, N, ter, seed=5)

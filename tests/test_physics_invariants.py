@@ -276,18 +276,19 @@ def test_emu_plane_ground_ragged_sizes_match_oracle(N):
     assert np.all(emu.buf["measured_heights"] == 0.0)     # LR:1478-1479: zeros on a plane
 
 
-def test_go1_table_emu_matches_oracle_and_stands():
-    """second robot (robots/tables/go1.json, task "go1"): the lane-emulated kernels agree with the oracle, and a zero-action robot dropped
-    from its init height settles on its feet (total foot force ~ m g, no termination)"""
+@pytest.mark.parametrize("robot,total_mass,steps", [("go1", 11.31, 60), ("go2", 15.017, 160)])   # Go2's softer gains (Kp 20, Kd 0.5) settle in ~2.5 s
+def test_go1_table_emu_matches_oracle_and_stands(robot, total_mass, steps):
+    """second robots (robots/tables/go1.json / go2.json, tasks "go1" / "go2"): the lane-emulated kernels agree with the oracle, and a
+    zero-action robot dropped from its init height settles on its feet (total foot force ~ m g, no termination)"""
     import emu_binding
-    cfg = quiet_cfg("go1")
+    cfg = quiet_cfg(robot)
     orc, lc, model, ter = make_oracle(cfg, 4, seed=2)
     mass = sum(model.bodies[i].mass for i in range(17))
-    assert abs(mass - 11.31) < 5e-3
+    assert abs(mass - total_mass) < 5e-3
     emu = emu_binding.EmuSim(lc, model, ter.heightsamples, ter.env_origins)
     orc.reset_all(); emu.reset_all()
     a = np.zeros((4, 12), np.float32)
-    for t in range(60):
+    for t in range(steps):
         orc.step(a); emu.step(a)
         np.testing.assert_array_equal(emu.buf["reset"], orc.buf["reset"], err_msg=f"step {t}")
         np.testing.assert_allclose(emu.buf["root_states"], orc.buf["root_states"], atol=3e-3, rtol=1e-3, err_msg=f"step {t}")
