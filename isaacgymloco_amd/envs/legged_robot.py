@@ -43,9 +43,7 @@ _TORCH_DT = {abi.DT_F32: torch.float32, abi.DT_I64: torch.int64, abi.DT_U8: torc
 class LeggedRobot:
     def __init__(self, cfg, sim_params=None, physics_engine=None, sim_device="cuda:0", headless=True,
                  *, seed=1, rank=0, using_amp=False, terrain=None, terrain_seed=None):
-        if not torch.cuda.is_available():
-            raise lib.LsimError("LeggedRobot needs a ROCm GPU: the simulator is a HIP library with no CPU path")
-        self._L = lib.load()
+        self._L = self._load_library()
         self.cfg = cfg
         self.sim_params = sim_params
         self.physics_engine = physics_engine
@@ -74,7 +72,7 @@ class LeggedRobot:
         self.command_ranges = {k: list(v) for k, v in cfg.commands.ranges.to_dict().items()}
 
         dev = torch.device(sim_device)
-        self._dev_index = dev.index if dev.index is not None else torch.cuda.current_device()
+        self._dev_index = dev.index if dev.index is not None else (torch.cuda.current_device() if dev.type == "cuda" else 0)
         self.terrain = terrain if terrain is not None else Terrain(cfg.terrain, self.num_envs, seed=seed if terrain_seed is None else terrain_seed)
         self.model = build_robot_model(cfg.asset)
         self.lcfg = LC.make_lsim_config(cfg, num_envs=self.num_envs, terrain=self.terrain, model=self.model, seed=seed, rank=rank, using_amp=using_amp)
@@ -88,10 +86,10 @@ class LeggedRobot:
             self._orig = np.ascontiguousarray(self.terrain.env_origins, dtype=np.float32)
             grid_p, orig_p = self._grid.ctypes.data, self._orig.ctypes.data
         self._h = ctypes.c_void_p()
-        torch.cuda.synchronize(dev)
+        self._sync()
         lib.check(self._L.lsim_create(ctypes.byref(self.lcfg), ctypes.byref(self.model), grid_p, orig_p,
                                       self._arena.data_ptr(), self._dev_index, ctypes.byref(self._h)), what="lsim_create")
-        torch.cuda.synchronize(dev)
+        self._sync()
         self._bind_buffers()
         self.extras = {}
         self._disturbance = None
@@ -100,6 +98,17 @@ class LeggedRobot:
             self.extras["time_outs"] = self._extras_time_outs
         self.common_step_counter = 0
         self.init_done = True
+
+    # ------------------------------------------------------------------ the simulator behind this object
+    def _load_library(self):
+        """the HIP library (include/lsim.h).  There is no CPU path: without a GPU this raises.  [tests/emu_env.py overrides this hook, _sync and
+        _stream to put the CPU lane emulator of the kernel sources behind the same Python surface -- a test harness, not a product path]"""
+        if not torch.cuda.is_available():
+            raise lib.LsimError("LeggedRobot needs a ROCm GPU: the simulator is a HIP library with no CPU path")
+        return lib.load()
+
+    def _sync(self):
+        torch.cuda.synchronize(self._arena.device)
 
     # ------------------------------------------------------------------ buffers
     def _bind_buffers(self):
@@ -296,7 +305,7 @@ class LeggedRobot:
         self.env_origins.copy_(d["env_origins"]); self.episode_length_buf.copy_(d["episode_length_buf"])
         S = abi.STATS["cmd_ranges"]
         self.buf["stats"][:, S:S + 8] = d["command_ranges"].to(self.buf["stats"].device)      # both ping-pong rows
-        torch.cuda.synchronize(self.buf["stats"].device)
+        self._sync()
 
     def stats_row(self):
         row = ctypes.c_int()
@@ -346,7 +355,7 @@ class LeggedRobot:
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
-            torch.cuda.synchronize(self._arena.device)
+            self._sync()
             self._L.lsim_destroy(self._h)
             self._h = None
 
