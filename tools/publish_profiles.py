@@ -1,4 +1,4 @@
-"""Copy the judged summaries of one tools/gpu_round3.sh (or gpu_round2.sh) run (gpurun_out/<tag>/) into profiles/ under round-prefixed names.
+"""Copy the judged summaries of one tools/gpu_round4.sh (or gpu_round3.sh / gpu_round2.sh) run (gpurun_out/<tag>/) into profiles/ under round-prefixed names.
 usage: python tools/publish_profiles.py r02a r02"""
 import csv
 import os
@@ -13,7 +13,10 @@ for src, dst in (("bench_default", "bench_default_train"), ("bench_driver_args",
                  ("bench_env_N262144", "bench_env_only_N262144"), ("bench_env_N64", "bench_env_only_N64"),
                  ("bench_env_zero_actions", "bench_env_only_zero_actions"), ("bench_2ranks_debug", "bench_2ranks_one_gpu_debug"),
                  ("bench_2ranks_mixed_debug", "bench_2ranks_mixed_robots_one_gpu_debug"), ("valu_peak", "valu_peak"),
-                 ("bench_rccl_1rank", "bench_rccl_1rank_forced_collectives"), ("delassus_mfma", "delassus_mfma")):
+                 ("bench_rccl_1rank", "bench_rccl_1rank_forced_collectives"), ("delassus_mfma", "delassus_mfma"),
+                 ("bench_env_pgs", "bench_env_only_pgs_solver"), ("bench_default_pgs", "bench_default_train_pgs_solver"), ("bench_go2", "bench_go2"),
+                 ("bench_env_aliengo_stairs", "bench_env_only_aliengo_stairs"), ("bench_env_aliengo_stairs_pgs", "bench_env_only_aliengo_stairs_pgs_solver"),
+                 ("bench_rccl_1rank_4queues", "bench_rccl_1rank_forced_collectives_4_hw_queues"), ("bench_plain_again", "bench_default_train_repeat")):
     f = os.path.join(O, src + ".json")
     if os.path.exists(f) and open(f).read().lstrip().startswith("{"):
         shutil.copy(f, os.path.join(P, f"{rnd}_{dst}.json"))
@@ -34,6 +37,14 @@ for src, dst in (("prof_env/env_kernel_stats.csv", "kernel_stats_env_only"), ("p
         for r in rows:
             r[0] = r[0][:160]     # torch's templated kernel names run to kilobytes
             w.writerow(r)
+for name in ("pmc_stairs_N4096.csv", "phase_profile_aliengo.txt", "phase_profile_aliengo_stairs.txt", "trace_collectives.txt", "trace_idle_rccl.txt"):
+    f = os.path.join(O, name)
+    if os.path.exists(f):
+        shutil.copy(f, os.path.join(P, f"{rnd}_{name}"))
+for src, dst in (("prof_env_stairs/env_stairs_kernel_stats.csv", "kernel_stats_env_only_aliengo_stairs"),):
+    path = os.path.join(O, src)
+    if os.path.exists(path):
+        shutil.copy(path, os.path.join(P, f"{rnd}_{dst}.csv"))
 for name in ("gpu_tests.log",):
     f = os.path.join(O, name)
     if os.path.exists(f):
