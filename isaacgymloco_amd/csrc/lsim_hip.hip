@@ -64,14 +64,16 @@ __global__ __launch_bounds__(256) void lsim_k_step_finish(const LsCtx* __restric
 // reset_idx outside a step: sum of episode_sums["tracking_lin_vel"] over the resetting envs for the command curriculum (LR:875) and, for a
 // subset (reset_all == 2), their number
 __global__ __launch_bounds__(256) void lsim_k_track_sum(const LsCtx* __restrict__ ctx, LsStepArgs a) {
-    __shared__ float part[256];
+    __shared__ long long part[256];
     __shared__ int count[256];
     const LsCtx& cx = *ctx;
-    float acc = 0.0f;
+    long long acc = 0;
     int n = 0;
+    // every env's value goes to fixed point on its own (ls_to_fix clamps ONE addend to +-2^20: converting a block partial instead would clamp
+    // the sum of N / 64 envs silently beyond ~3 M envs); the int64 partials add exactly, in any order
     for (int env = (int)(blockIdx.x * blockDim.x + threadIdx.x); env < cx.cfg.num_envs; env += (int)(gridDim.x * blockDim.x)) {
         if (a.reset_all == 2 && !LS_G(const uint8_t, a.reset_mask)[env]) continue;
-        acc += LSB(cx, LSIM_BUF_EPISODE_SUMS, float)[env * LSIM_NUM_REWARD_TERMS + LSIM_R_TRACKING_LIN_VEL];
+        acc += ls_to_fix(LSB(cx, LSIM_BUF_EPISODE_SUMS, float)[env * LSIM_NUM_REWARD_TERMS + LSIM_R_TRACKING_LIN_VEL]);
         n += 1;
     }
     part[threadIdx.x] = acc;
@@ -81,9 +83,8 @@ __global__ __launch_bounds__(256) void lsim_k_track_sum(const LsCtx* __restrict_
         if ((int)threadIdx.x < s) { part[threadIdx.x] += part[threadIdx.x + s]; count[threadIdx.x] += count[threadIdx.x + s]; }
         __syncthreads();
     }
-    // block partials are formed in a fixed order; their fixed-point sum does not depend on the order the blocks arrive in
     if (threadIdx.x == 0) {
-        LS_ATOMIC_ADD_I64(ls_fix_row(cx, a.row_out) + LSIM_STATS_FIX_TRACK, ls_to_fix(part[0]));
+        LS_ATOMIC_ADD_I64(ls_fix_row(cx, a.row_out) + LSIM_STATS_FIX_TRACK, part[0]);
         if (a.reset_all == 2 && count[0] > 0)     // integer-valued: exact in any order
             LS_ATOMIC_ADD(LS_G(float, cx.accum) + a.row_out * LSIM_STATS_SIZE + LSIM_STATS_RESET_COUNT, (float)count[0]);
     }

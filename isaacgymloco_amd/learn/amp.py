@@ -188,6 +188,14 @@ class ReplayBuffer:
             yield self.states[idx], self.next_states[idx]
 
 
+def _linear_relu(bias, x, weight):
+    """relu(x W^T + b): bias + ReLU in the GEMM epilogue through the PRIVATE torch._addmm_activation where this torch has it, else the two
+    public statements (same values; ADVICE r3: a torch without the private op must keep working)"""
+    if hasattr(torch, "_addmm_activation"):
+        return torch._addmm_activation(bias, x, weight.t(), use_gelu=False)
+    return torch.addmm(bias, x, weight.t()).relu_()
+
+
 class _GradPenFn(autograd.Function):
     """lambda * mean_b || dD/dx (x_b) ||^2 for D = w3 . relu(W2 relu(W1 x + b1) + b2) + b3 (DISC:36-53), forward and backward in closed form.
 
@@ -201,7 +209,7 @@ class _GradPenFn(autograd.Function):
         # every mask is applied by aten's threshold_backward(grad, pre, 0) = grad where pre > 0 else 0 -- the kernel relu's own backward runs --
         # on the fp32 activation itself: one pass per mask instead of compare + cast / not + multiply / fill
         tb = torch.ops.aten.threshold_backward
-        a1 = torch._addmm_activation(b1, x, W1.t(), use_gelu=False)      # relu(z1) straight from the GEMM epilogue; z1 > 0  <=>  a1 > 0
+        a1 = _linear_relu(b1, x, W1)                       # relu(z1) straight from the GEMM epilogue; z1 > 0  <=>  a1 > 0
         z2 = torch.addmm(b2, a1, W2.t())
         u2 = tb(w3.expand_as(z2), z2, 0.0)                  # (B, H2): m2 * w3
         u1 = tb(u2 @ W2, a1, 0.0)                           # (B, H1): m1 * (W2^T u2)
@@ -229,7 +237,7 @@ class _LinearReluFn(autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias):
-        z = torch._addmm_activation(bias, x, weight.t(), use_gelu=False)
+        z = _linear_relu(bias, x, weight)
         ctx.save_for_backward(x, weight, z)
         return z
 
@@ -238,7 +246,9 @@ class _LinearReluFn(autograd.Function):
         x, weight, z = ctx.saved_tensors
         gy = torch.ops.aten.threshold_backward(g, z, 0.0)      # relu's own backward kernel on the saved OUTPUT (z > 0 <=> pre-activation > 0)
         gx = gy @ weight if ctx.needs_input_grad[0] else None
-        return gx, gy.t() @ x, gy.sum(dim=0)
+        gw = gy.t() @ x if ctx.needs_input_grad[1] else None   # a frozen discriminator pays for neither GEMM nor column sum
+        gb = gy.sum(dim=0) if ctx.needs_input_grad[2] else None
+        return gx, gw, gb
 
 
 def _trunk_fused(trunk, x):

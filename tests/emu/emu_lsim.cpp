@@ -52,14 +52,14 @@ static int lsbk_launch_finish(lsim_sim* s, const LsStepArgs& a, void*) {
 }
 static int lsbk_launch_reduce(lsim_sim* s, const LsStepArgs& a, void*) {   // bare reset_idx: track sum (and count) over the resetting envs (LR:875)
     const LsCtx& cx = *s->dev_ctx;
-    float acc = 0.0f;
+    long long acc = 0;
     int n = 0;
     for (int env = 0; env < s->cfg.num_envs; ++env) {
         if (a.reset_all == 2 && !a.reset_mask[env]) continue;
-        acc += LSB(cx, LSIM_BUF_EPISODE_SUMS, float)[env * LSIM_NUM_REWARD_TERMS + LSIM_R_TRACKING_LIN_VEL];
+        acc += ls_to_fix(LSB(cx, LSIM_BUF_EPISODE_SUMS, float)[env * LSIM_NUM_REWARD_TERMS + LSIM_R_TRACKING_LIN_VEL]);
         n += 1;
     }
-    ls_fix_row(cx, a.row_out)[LSIM_STATS_FIX_TRACK] = ls_to_fix(acc);
+    ls_fix_row(cx, a.row_out)[LSIM_STATS_FIX_TRACK] = acc;
     if (a.reset_all == 2) cx.accum[a.row_out * LSIM_STATS_SIZE + LSIM_STATS_RESET_COUNT] = (float)n;
     return 0;
 }

@@ -80,7 +80,7 @@ def test_two_ranks_stay_in_lockstep(tmp_path):
 
 
 def test_data_parallel_order_equals_the_single_rank_order(tmp_path):
-    """the N > 1 path moves the estimator's step behind the PPO backward (its all-reduce is in flight meanwhile); with the SAME data on both
+    """the N > 1 path moves the estimator's step behind the PPO backward (one all-reduce then carries every gradient); with the SAME data on both
     ranks the averaged gradients equal the local ones exactly ((g + g) / 2), so the two ranks must end where a single process running the
     reference's order (lr rule -> estimator step -> PPO backward -> PPO step) ends, bit for bit -- given the same advantage statistics, i.e. the
     single process normalises with the doubled sums the two ranks see (a batch that holds every sample twice)"""
@@ -128,3 +128,77 @@ def test_gradient_average_equals_full_batch(tmp_path):
         d = torch.load(os.path.join(tmp_path, f"g{r}.pt"))
         torch.testing.assert_close(d["g"], lin.weight.grad, rtol=1e-6, atol=1e-7)
         torch.testing.assert_close(d["stats"], torch.stack((x.sum(), (x * x).sum(), torch.tensor(20.0))), rtol=1e-6, atol=1e-6)
+
+
+# ---- HybridPPO (AMP) on the data-parallel path: the discriminator travels in the same bucket as the PPO group (`more_params`), is
+#      averaged, and is NOT clipped (HYBP:270 clips the actor-critic only)
+def _hybrid_alg(dist_ctx):
+    import test_amp_golden as TA
+    from isaacgymloco_amd.learn import amp
+    from isaacgymloco_amd.learn.hybrid import HybridPPO
+    from isaacgymloco_amd.learn.modules import HIMActorCritic
+    fx = np.load(TA.FX)
+    ld = TA._loader()
+    torch.manual_seed(0)
+    ac = HIMActorCritic(270, 238, 45, 12, actor_hidden_dims=[512, 256, 128], critic_hidden_dims=[512, 256, 128], activation="elu", init_noise_std=1.0)
+    disc = amp.AMPDiscriminator(60, 0.5 * 0.02, [1024, 512], "cpu", 0.3)
+    nz = amp.Normalizer(30)
+    alg = HybridPPO(ac, disc, ld, nz, device="cpu", min_std=torch.tensor([0.05, 0.02, 0.05] * 4) * 1.5, dist_ctx=dist_ctx, **TA.ALG)
+    N, T = 8, 6
+    alg.init_storage(N, T, [270], [238], [12])
+    return alg, fx, N, T
+
+
+def _hybrid_run(alg, fx, N, T):
+    obs, crit, ampo = (torch.from_numpy(fx[k]) for k in ("hy_obs", "hy_crit", "hy_amp"))
+    rew, done = torch.from_numpy(fx["hy_rew"]), torch.from_numpy(fx["hy_done"])
+    torch.manual_seed(1)
+    np.random.seed(7)
+    with torch.inference_mode():
+        for t in range(T):
+            alg.act(obs[t], crit[t], ampo[t])
+            r = alg.discriminator.predict_amp_reward(ampo[t], ampo[t + 1], rew[t], normalizer=alg.amp_normalizer)[0]
+            alg.process_env_step(r, done[t], {"time_outs": done[t] & False}, ampo[t + 1], crit[t + 1])
+        alg.compute_returns(crit[T])
+    torch.manual_seed(2)
+    alg.update()
+    return {"ac": {k: v.clone() for k, v in alg.actor_critic.state_dict().items()}, "disc": {k: v.clone() for k, v in alg.discriminator.state_dict().items()},
+            "lr": alg.learning_rate, "nz": (alg.amp_normalizer._mean.clone(), alg.amp_normalizer._var.clone(), alg.amp_normalizer._count.clone())}
+
+
+def _hybrid_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from isaacgymloco_amd.learn.him_ppo import DistCtx
+    ctx = DistCtx()
+    alg, fx, N, T = _hybrid_alg(ctx)
+    c0 = ctx.collectives
+    out = _hybrid_run(alg, fx, N, T)
+    out["collectives"] = ctx.collectives - c0
+    torch.save(out, os.path.join(out_dir, f"hy{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_hybrid_ppo_data_parallel_order_equals_the_single_rank_order(tmp_path):
+    """two gloo ranks fed the SAME AMP fixture data end, bit for bit, where one process running HybridPPO's single-rank order ends (given the
+    doubled advantage / normaliser sums a batch that holds every sample twice has): actor-critic, DISCRIMINATOR, learning rate and the
+    running normaliser.  That pins the `more_params` bucket (the discriminator's gradients are averaged with the PPO group's, and only the
+    actor-critic is clipped) and the normaliser's moment all-reduce."""
+    port = 35500 + (os.getpid() % 2000)
+    mp.spawn(_hybrid_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    alg, fx, N, T = _hybrid_alg(None)
+    alg.storage.advantage_sync = lambda s1, s2, n: (2.0 * s1, 2.0 * s2, 2.0 * n)
+    alg.amp_normalizer.moment_sync = lambda a, b, c: (2.0 * a, 2.0 * b, 2.0 * c)
+    single = _hybrid_run(alg, fx, N, T)
+    for r in range(2):
+        d = torch.load(os.path.join(tmp_path, f"hy{r}.pt"), weights_only=False)
+        assert d["lr"] == single["lr"]
+        # per minibatch one gradient bucket + two normaliser moment reductions; per update the advantage statistics
+        assert d["collectives"] == 2 * 2 * (1 + 2) + 1, d["collectives"]
+        for part in ("ac", "disc"):
+            for k in single[part]:
+                torch.testing.assert_close(d[part][k], single[part][k], rtol=0, atol=0, msg=f"{part}.{k}")
+        for a, b in zip(d["nz"], single["nz"]):
+            torch.testing.assert_close(a, b, rtol=0, atol=0)
