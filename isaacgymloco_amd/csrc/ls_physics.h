@@ -431,6 +431,12 @@ LS_FN void ls_terrain_contact(const LsCtx& cx, V3 cw, float radius, float& dist,
     float fi = clampf(floorf(gx), 0.0f, (float)(c.grid_rows - 2)), fj = clampf(floorf(gy), 0.0f, (float)(c.grid_cols - 2));
     int i = (int)fi, j = (int)fj;
     const int w00 = mesh[i * c.grid_cols + j];
+    {   // nothing within the 4 x 4 vertex block reaches up to the sphere (ls_api_impl.h: bits 24-31 = the block's highest vertex above this
+        // one, rounded up): no contact, whatever the faces look like -- decided after this one load
+        const int dz = (int)((unsigned int)w00 >> 24);
+        const float top = ((float)(int16_t)(w00 & 0xFFFF) + (float)(dz * LSIM_MESH_DZ_UNIT)) * vs;
+        if (dz < 255 && cw.z - top > radius + c.contact_offset) { dist = cw.z - top; n = v3(0, 0, 1); return; }
+    }
 #if defined(LS_NO_WALLS)   // A/B experiments only
     const bool walls = false;
 #else

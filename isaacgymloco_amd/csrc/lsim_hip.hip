@@ -22,11 +22,17 @@ static void lsbk_prof_free(lsim_sim* s);
 #include "ls_api_impl.h"
 #include "ls_kernels.h"
 
-// Each XCD (8 per chip, block b is dispatched to XCD b % 8) works on one contiguous slice of the env range, so a
+// Each XCD (8 per chip, block b is dispatched to XCD b % 8) works on its own slices of the env range, so a
 // robot's state lines stay in one XCD's L2 and neighbouring robots do not false-share lines across XCD L2s.
+// Round 4: the slices are interleaved in GROUPS OF 32 envs (XCD x owns groups x, x + 8, x + 16, ...) instead of one contiguous eighth each.
+// A group of 32 keeps the lines of the per-env 4-byte buffers (128 B = 32 envs) inside one XCD; interleaving spreads the terrain types -- which
+// the reference assigns by env index, LR:1234, ~205 consecutive envs per type -- over all XCDs.  With contiguous eighths one XCD held only
+// staircase robots (whose narrow phase is the slow one) and another only flat-ground robots, and at N = 4096, where every wave is resident at
+// once, the kernel ends with the slowest XCD.
 __device__ __forceinline__ int ls_env_of_block(int b, int num_envs) {
-    const int chunk = (num_envs + 7) >> 3;
-    return (b & 7) * chunk + (b >> 3);
+    const int l = b >> 3;
+    return ((((l >> 5) << 3) + (b & 7)) << 5) + (l & 31);
+    (void)num_envs;
 }
 
 // Kernel A is bound by per-wave latency (dependent VALU chains, LDS round trips at ~19 phase boundaries per sub-step):
@@ -90,7 +96,7 @@ __global__ __launch_bounds__(256) void lsim_k_track_sum(const LsCtx* __restrict_
     }
 }
 
-static int ls_grid(const lsim_sim* s) { return 8 * ((s->cfg.num_envs + 7) / 8); }
+static int ls_grid(const lsim_sim* s) { return 8 * 32 * ((((s->cfg.num_envs + 31) / 32) + 7) / 8); }     // whole groups of 32 envs for each of the 8 XCDs
 
 static int lsbk_launch_a(lsim_sim* s, const LsStepArgs& a, void* stream) {
     if (s->cfg.solver_type == LSIM_SOLVER_TGS) hipLaunchKernelGGL(lsim_k_step_a_tgs, dim3(ls_grid(s)), dim3(64), 0, (hipStream_t)stream, (const LsCtx*)s->dev_ctx, a);

@@ -91,6 +91,7 @@ def test_hip_stairs_wall_contacts_match_oracle(solver):
     be = HipBackend(cfg, N, ter, seed=3)
     mesh = be.get("terrain_mesh")
     np.testing.assert_array_equal((mesh >> 16) & 0xFF, _flags_numpy(ter.heightsamples, cfg))
+    np.testing.assert_array_equal((mesh.view(np.uint32) >> 24).astype(np.int64), _dzmax_numpy(ter.heightsamples))
     np.testing.assert_array_equal((mesh & 0xFFFF).astype(np.uint16).view(np.int16), ter.heightsamples)
     orc.reset_all(); be.reset_all()
     rs = np.random.RandomState(0)
@@ -113,6 +114,20 @@ def test_hip_stairs_wall_contacts_match_oracle(solver):
     print(f"stairs: {ok} of {tot} env-steps within tolerance")
     assert ok >= 0.99 * tot, (ok, tot)
     assert lateral > 5.0, "risers must be able to produce mostly-horizontal foot forces (feet_stumble, LR:1589-1599)"
+
+
+def _dzmax_numpy(hf):
+    """bits 24-31 of the mesh words: highest vertex of the 4 x 4 block (i - 1 .. i + 2) x (j - 1 .. j + 2) above vertex (i, j), in units of 4
+    height steps rounded up, capped at 255 (third restatement of ls_api_impl.h: ls_terrain_mesh_dzmax)"""
+    h = hf.astype(np.int64)
+    R, C = h.shape
+    pad = np.full((R + 3, C + 3), np.iinfo(np.int64).min)
+    pad[1:R + 1, 1:C + 1] = h
+    m = np.full((R, C), np.iinfo(np.int64).min)
+    for a in range(4):
+        for b in range(4):
+            m = np.maximum(m, pad[a:a + R, b:b + C])
+    return np.minimum((m - h + 3) // 4, 255)
 
 
 def _flags_numpy(hf, cfg):

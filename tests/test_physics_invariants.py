@@ -234,6 +234,8 @@ def test_emu_stairs_wall_contacts_match_oracle(solver):
     cfg.domain_rand.base_init_pos_range = dict(x=[-3.0, 3.0], y=[-3.0, 3.0], z=[0.0, 0.3])
     orc, lc, model, ter = make_oracle(cfg, N, seed=3)
     emu = emu_binding.EmuSim(lc, model, ter.heightsamples, ter.env_origins)
+    from test_gpu_parity import _dzmax_numpy           # the packed words' "nothing above this height" byte against a numpy restatement
+    np.testing.assert_array_equal((np.array(emu.buf["terrain_mesh"]).view(np.uint32) >> 24).astype(np.int64), _dzmax_numpy(ter.heightsamples))
     orc.reset_all(); emu.reset_all()
     rs = np.random.RandomState(0)
     ok = tot = walls = 0

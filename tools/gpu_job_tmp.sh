@@ -1,17 +1,19 @@
 export TMPDIR=/tmp
-O=gpurun_out/r04l; mkdir -p $O
+O=gpurun_out/r04p; mkdir -p $O
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_physics_invariants.py tests/test_gpu_physics_anchors.py tests/test_contact_cap.py -m gpu -q -x > $O/gpu_tests.log 2>&1; tail -3 $O/gpu_tests.log
 run() { name=$1; shift; "$@" > $O/$name.log 2>&1; tail -1 $O/$name.log > $O/$name.json; }
-LSIM_DEBUG_FORCE_COLLECTIVES=1 run force_default timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29518 bench.py --gpus 1 --no-cpu-baseline
-GPU_MAX_HW_QUEUES=8 LSIM_DEBUG_FORCE_COLLECTIVES=1 run force_q8 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29519 bench.py --gpus 1 --no-cpu-baseline
-GPU_MAX_HW_QUEUES=2 LSIM_DEBUG_FORCE_COLLECTIVES=1 run force_q2 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29520 bench.py --gpus 1 --no-cpu-baseline
-LSIM_UPDATE_STREAMS=0 LSIM_DEBUG_FORCE_COLLECTIVES=1 run force_onestream timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29521 bench.py --gpus 1 --no-cpu-baseline
-LSIM_UPDATE_STREAMS=0 run plain_onestream timeout 600 python bench.py --no-cpu-baseline
-GPU_MAX_HW_QUEUES=8 run plain_q8 timeout 600 python bench.py --no-cpu-baseline
+for t in aliengo aliengo_stairs; do
+  for n in 4096 65536; do
+    run env_${t}_$n timeout 300 python bench.py --mode env --task $t --envs $n --steps 200 --warmup 50 --no-cpu-baseline
+  done
+done
+run train timeout 600 python bench.py --no-cpu-baseline
+run train_stairs timeout 600 python bench.py --task aliengo_stairs --no-cpu-baseline
 python - <<PY
-import json
-for f in ("force_default","force_q8","force_q2","force_onestream","plain_onestream","plain_q8"):
+import json,glob,os
+for f in sorted(glob.glob("$O/*.json")):
     try:
-        j=json.load(open("$O/"+f+".json"))
-        print(f, {k:j.get(k) for k in ("value","collection_s_per_iteration","learn_s_per_update","iteration_wall_s_min_median_max")})
+        j=json.load(open(f))
+        print(os.path.basename(f), {k:j.get(k) for k in ("value","kernel_a_ms","ms_per_step","collection_s_per_iteration","learn_s_per_update")})
     except Exception as e: print(f, "failed", e)
 PY
