@@ -387,6 +387,8 @@ enum lsim_buffer_id {
 #define LSIM_STEP_RECORD_SUBSTEPS 4u /* test hook: also write LSIM_BUF_SUBSTEP_TORQUES (one 48-byte store per sub-step and robot) */
 #define LSIM_STEP_TWO_KERNELS 8u    /* test / measurement hook: run reset_idx + observations as the separate kernel B on every step (the form the
                                        command-curriculum steps always take) instead of inside kernel A.  Same results, bit for bit */
+#define LSIM_STEP_FLAT_PRIORITY 16u /* measurement hook: every wave of kernel A at the default issue priority (by default a robot's wave is raised with
+                                       its number of contacts, so that the launch's slowest waves are not also waiting for their turn).  Same results */
 
 typedef struct lsim_sim* lsim_handle;
 

@@ -115,6 +115,7 @@ STEP_SKIP_PHYSICS = DEFINES["LSIM_STEP_SKIP_PHYSICS"]
 STEP_NO_RESET = DEFINES["LSIM_STEP_NO_RESET"]
 STEP_RECORD_SUBSTEPS = DEFINES["LSIM_STEP_RECORD_SUBSTEPS"]
 STEP_TWO_KERNELS = DEFINES["LSIM_STEP_TWO_KERNELS"]
+STEP_FLAT_PRIORITY = DEFINES["LSIM_STEP_FLAT_PRIORITY"]
 STATS = {k[len("LSIM_STATS_"):].lower(): v for k, v in DEFINES.items() if k.startswith("LSIM_STATS_")}
 
 

@@ -25,6 +25,8 @@
 #define LS_THREADFENCE() do { } while (0)
 static inline long long ls_emu_fetch_add(long long* p, long long v) { long long o = *p; *p = o + v; return o; }
 #define LS_WAVE_FN static inline
+#define LS_LDS_FENCE() do { } while (0)
+#define LS_SETPRIO(n) do { } while (0)
 #define LS_TICK_INIT() do { } while (0)
 #define LS_TICK_FLUSH() do { } while (0)
 #else
@@ -35,16 +37,23 @@ __device__ __forceinline__ int ls_opaque_lane(int l) { asm volatile("" : "+v"(l)
 #if defined(LS_PHASE_TIMING)   // diagnostics build only (tools/phase_profile.py): shader-clock ticks per phase site, summed over waves
 __device__ unsigned long long g_ls_phase_ticks[128];
 __device__ unsigned long long g_ls_phase_calls[128];
+__device__ unsigned long long g_ls_phase_ticks_by[3][129];    // the same by kind of wave: [0] at most 3 contacts, [1] 6 or more, [2] resetting; [k][128] = waves
 #define LS_TICK(site) do { if (lane0 == 0) { unsigned long long t_ = clock64(); ls_ticks[(site) & 127] += (unsigned int)(t_ - ls_t_prev); ls_calls[(site) & 127] += 1; \
                                              ls_t_prev = t_; } } while (0)
 #define LS_TICK_INIT() __shared__ unsigned int ls_ticks[128]; __shared__ unsigned short ls_calls[128]; \
                        ls_ticks[lane0] = 0; ls_calls[lane0] = 0; ls_ticks[64 + lane0] = 0; ls_calls[64 + lane0] = 0; __syncthreads(); unsigned long long ls_t_prev = clock64()
-#define LS_TICK_FLUSH() do { __syncthreads(); for (int s_ = lane0; s_ < 128; s_ += 64) if (ls_calls[s_]) { atomicAdd(&g_ls_phase_ticks[s_], (unsigned long long)ls_ticks[s_]); \
-                                                                      atomicAdd(&g_ls_phase_calls[s_], (unsigned long long)ls_calls[s_]); } } while (0)
+#define LS_TICK_FLUSH() do { __syncthreads(); const int kind_ = sh.reset ? 2 : (sh.nact_max >= 6 ? 1 : (sh.nact_max <= 3 ? 0 : -1)); \
+                             for (int s_ = lane0; s_ < 128; s_ += 64) if (ls_calls[s_]) { atomicAdd(&g_ls_phase_ticks[s_], (unsigned long long)ls_ticks[s_]); \
+                                                                      atomicAdd(&g_ls_phase_calls[s_], (unsigned long long)ls_calls[s_]); \
+                                                                      if (kind_ >= 0) atomicAdd(&g_ls_phase_ticks_by[kind_][s_], (unsigned long long)ls_ticks[s_]); } \
+                             if (lane0 == 0 && kind_ >= 0) atomicAdd(&g_ls_phase_ticks_by[kind_][128], 1ull); } while (0)
 #else
 #define LS_TICK(site) do { } while (0)
 #define LS_TICK_INIT() do { } while (0)
 #define LS_TICK_FLUSH() do { } while (0)
+#endif
+#if defined(LS_WAVE_TIMES)
+__device__ unsigned long long g_ls_wave_times[4 * 65536];     // per env: start, end (100 MHz wall clock), shader-clock ticks, HW_ID | XCC_ID << 16
 #endif
 #if defined(LS_PHASE_MARKS)    // diagnostics only (tools/phase_static.py): a comment in the assembly behind every phase site
 #define LS_STR2(x) #x
@@ -69,6 +78,8 @@ __device__ unsigned long long g_ls_phase_calls[128];
 #define LS_ATOMIC_READ_I64(ptr) ((long long)atomicAdd((unsigned long long*)(ptr), 0ull))
 #define LS_THREADFENCE() __threadfence()
 #define LS_WAVE_FN __device__ __forceinline__
+#define LS_LDS_FENCE() __syncthreads()       // inside a phase, in wave-uniform control flow only
+#define LS_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
 #endif
 
 // Order-independent reductions over waves (float atomics made extras["episode"] and the command-curriculum decision depend on the
@@ -111,6 +122,8 @@ LS_FN void ph_load_a(const LsCtx& cx, WaveShared& sh, LaneRegs& rg, int lane, in
     const int v_eplen = (int)LSB(cx, LSIM_BUF_EPISODE_LENGTH, int64_t)[env];
     const unsigned int v_lc = LSB(cx, LSIM_BUF_LAST_CONTACTS, unsigned int)[env];
     const int v_level = (int)LSB(cx, LSIM_BUF_TERRAIN_LEVELS, int64_t)[env];
+    const int v_type = (int)LSB(cx, LSIM_BUF_TERRAIN_TYPES, int64_t)[env];
+    const float v_org = LSB(cx, LSIM_BUF_ENV_ORIGINS, float)[3 * env + l3];
     const float v_es = LSB(cx, LSIM_BUF_EPISODE_SUMS, float)[env * LSIM_NUM_REWARD_TERMS + (lane < LSIM_NUM_REWARD_TERMS ? lane : 0)];
     const float v_rng = LS_G(const float, cx.accum)[a.row_in * LSIM_STATS_SIZE + LSIM_STATS_CMD_RANGES + (lane & 7)];   // live command ranges (no kernel of this step writes row_in's)
     const float v_mp = lane < LSIM_MAX_HEIGHT_PTS_X ? c.measured_points_x[lane] : c.measured_points_y[lane - LSIM_MAX_HEIGHT_PTS_X];
@@ -148,6 +161,7 @@ LS_FN void ph_load_a(const LsCtx& cx, WaveShared& sh, LaneRegs& rg, int lane, in
     if (lane < 3) {
         sh.comd[lane] = v_comd;
         sh.pend[lane] = v_pend;
+        sh.pre_org[lane] = v_org;
         if (!(a.flags & LSIM_STEP_SKIP_PHYSICS)) LSB(cx, LSIM_BUF_PENDING_FORCE, float)[3 * env + lane] = 0.0f;   // consumed by the first sub-step
     }
     if (lane == 15) {
@@ -169,6 +183,7 @@ LS_FN void ph_load_a(const LsCtx& cx, WaveShared& sh, LaneRegs& rg, int lane, in
     else if (lane == 56) sh.pre_eplen = v_eplen;
     else if (lane == 57) sh.pre_lc = v_lc;
     else if (lane == 58) sh.pre_level = v_level;
+    else if (lane == 59) sh.pre_type = v_type;
     if (lane < LSIM_NUM_REWARD_TERMS) sh.pre_es[lane] = v_es;
     if (lane < 8) sh.ranges[lane] = v_rng;
     rg.cp_active = 0;
@@ -229,10 +244,16 @@ LS_FN void ph_load_injected(const LsCtx& cx, WaveShared& sh, int lane, int env) 
     }
 }
 
+// the per-step reductions over the resetting envs that the command curriculum and the finish of the step read (lane 0 of a resetting env)
+LS_FN void ls_count_reset(const LsCtx& cx, WaveShared& sh, const LsStepArgs& a) {
+    LS_GLOBAL float* acc = LS_G(float, cx.accum) + a.row_out * LSIM_STATS_SIZE;
+    LS_ATOMIC_ADD(acc + LSIM_STATS_RESET_COUNT, 1.0f);                                   // integer-valued: exact in any order
+    LS_ATOMIC_ADD_I64(ls_fix_row(cx, a.row_out) + LSIM_STATS_FIX_TRACK, ls_to_fix(sh.pre_es[LSIM_R_TRACKING_LIN_VEL]));   // updated by ph_reward_terms
+}
 // ---- termination observations / terminal AMP states of the pre-reset state + per-step reductions (LR:227-228)
 LS_FN void ph_term_outputs(const LsCtx& cx, WaveShared& sh, int lane, int env, const LsStepArgs& a) {
     if (lane < 13) LSB(cx, LSIM_BUF_ROOT_STATES, float)[13 * env + lane] = sh.root[lane];   // push may have changed the velocity
-    if (!sh.reset) return;
+    if (!LS_UNIFORM(sh.reset)) return;
     LS_GLOBAL float* tp = LSB(cx, LSIM_BUF_TERM_PRIV_OBS, float) + LSIM_NUM_PRIV_OBS * env;
     LS_STRIDED(k, lane, LSIM_NUM_PRIV_OBS) tp[k] = sh.cur[k];
     if (lane < LSIM_NUM_AMP_OBS) {
@@ -243,11 +264,10 @@ LS_FN void ph_term_outputs(const LsCtx& cx, WaveShared& sh, int lane, int env, c
         else v = sh.dofs[2 * (lane - 18) + 1];
         LSB(cx, LSIM_BUF_TERM_AMP_OBS, float)[LSIM_NUM_AMP_OBS * env + lane] = v;
     }
-    if (lane == 0 && !(a.flags & LSIM_STEP_NO_RESET)) {
-        LS_GLOBAL float* acc = LS_G(float, cx.accum) + a.row_out * LSIM_STATS_SIZE;
-        LS_ATOMIC_ADD(acc + LSIM_STATS_RESET_COUNT, 1.0f);                                   // integer-valued: exact in any order
-        LS_ATOMIC_ADD_I64(ls_fix_row(cx, a.row_out) + LSIM_STATS_FIX_TRACK, ls_to_fix(sh.pre_es[LSIM_R_TRACKING_LIN_VEL]));   // updated by ph_reward_terms
-    }
+    // with the fused tail the two reductions wait for ph_tail_episode_stats: the resetting waves of a step queue up on these two words, an
+    // atomic is acknowledged when it has been performed, and the loads of the reset path (the terrain under the new pose) would retire behind
+    // them -- 40 k of a resetting wave's 325 k ticks (round 4)
+    if (lane == 0 && !(a.flags & LSIM_STEP_NO_RESET) && !a.fuse_tail) ls_count_reset(cx, sh, a);
 }
 
 // =============================================================================================== kernel B
@@ -284,6 +304,8 @@ LS_FN void ph_load_b(const LsCtx& cx, WaveShared& sh, int lane, int env, const L
     const int v_reset = a.reset_all == 2 ? (LS_G(const uint8_t, a.reset_mask)[env] != 0) : LSB(cx, LSIM_BUF_RESET, uint8_t)[env];
     const int v_tout = LSB(cx, LSIM_BUF_TIME_OUT, uint8_t)[env];
     const int v_eplen = (int)LSB(cx, LSIM_BUF_EPISODE_LENGTH, int64_t)[env];
+    const int v_level = (int)LSB(cx, LSIM_BUF_TERRAIN_LEVELS, int64_t)[env], v_type = (int)LSB(cx, LSIM_BUF_TERRAIN_TYPES, int64_t)[env];
+    const float v_org = LSB(cx, LSIM_BUF_ENV_ORIGINS, float)[3 * env + l3];
     // ---- LDS writes
     if (lane < 13) sh.root[lane] = v_root;
     if (lane < 24) sh.dofs[lane] = v_dof;
@@ -292,6 +314,7 @@ LS_FN void ph_load_b(const LsCtx& cx, WaveShared& sh, int lane, int env, const L
         sh.blv[lane] = v_blv;
         sh.bav[lane] = v_bav;
         sh.grav[lane] = v_grav;
+        sh.pre_org[lane] = v_org;
         const bool disturbed = !a.reset_all && c.disturbance && (a.step_counter % c.disturbance_interval == 0);
         sh.disturbance[lane] = disturbed ? v_pend : 0.0f;
     }
@@ -311,6 +334,7 @@ LS_FN void ph_load_b(const LsCtx& cx, WaveShared& sh, int lane, int env, const L
         sh.reset = v_reset;
         sh.pre_lc = (unsigned int)v_tout;
         sh.eplen = v_eplen;
+        sh.pre_level = v_level; sh.pre_type = v_type;
         float nreset = a.reset_all == 1 ? (float)c.num_envs : v_nreset;     // reset_all == 2: counted by lsim_k_track_sum
         const bool no_reset = (a.flags & LSIM_STEP_NO_RESET) != 0;
         sh.do_reset = a.reset_all == 1 || (v_reset && !no_reset);
@@ -346,29 +370,37 @@ LS_FN void ph_b_housekeeping(const LsCtx& cx, WaveShared& sh, int lane, int env,
 // LeggedRobot._update_terrain_curriculum (LR:846-866), lane 0 of a resetting env
 LS_FN void ph_b_terrain_curriculum(const LsCtx& cx, WaveShared& sh, int lane, int env, const LsStepArgs& a) {
     const lsim_config& c = cx.cfg;
-    if (lane != 0 || !sh.do_reset || !c.terrain_curriculum || c.mesh_type == 0 || !a.init_done) return;
-    LS_GLOBAL float* org = LSB(cx, LSIM_BUF_ENV_ORIGINS, float) + 3 * env;
-    LS_GLOBAL int64_t* lvlp = LSB(cx, LSIM_BUF_TERRAIN_LEVELS, int64_t) + env;
-    int64_t type = LSB(cx, LSIM_BUF_TERRAIN_TYPES, int64_t)[env];
-    float dx = sh.root[0] - org[0], dy = sh.root[1] - org[1];
+    if (!LS_UNIFORM(sh.do_reset) || !c.terrain_curriculum || c.mesh_type == 0 || !a.init_done) return;      // wave-uniform: a scalar branch
+    // Level, type and origin row come from the load phase (sh.pre_*); the new origin is one row of a table no kernel writes, fetched through
+    // the scalar cache (ls_uniform_load: not queued behind the vector stores in flight) and handed to ph_b_reset in sh.pre_org.  Every lane
+    // evaluates the same arithmetic on the same LDS values (a scalar load may only stand in wave-uniform control flow); lane 0 stores.
+    float dx = sh.root[0] - sh.pre_org[0], dy = sh.root[1] - sh.pre_org[1];
     float dist = sqrtf(dx * dx + dy * dy);
     int up = dist > c.terrain_length / 2.0f;
     int down = (dist < sqrtf(sh.cmd[0] * sh.cmd[0] + sh.cmd[1] * sh.cmd[1]) * c.episode_length_s * 0.5f) && !up;
-    int64_t lvl = *lvlp + (int64_t)up - (int64_t)down;
+    int64_t lvl = (int64_t)sh.pre_level + (int64_t)up - (int64_t)down;
     if (lvl >= c.terrain_num_rows) lvl = (int64_t)(ls_draw(cx, env, (uint32_t)a.step_counter, LSIM_RNG_RESET_LEVEL, 0) * (float)c.terrain_num_rows);
     else if (lvl < 0) lvl = 0;
-    *lvlp = lvl;
-    LS_GLOBAL const float* to = LSB(cx, LSIM_BUF_TERRAIN_ORIGINS, float) + (lvl * c.terrain_num_cols + type) * 3;
-    for (int k = 0; k < 3; ++k) org[k] = to[k];
+    LS_GLOBAL const float* to = LSB(cx, LSIM_BUF_TERRAIN_ORIGINS, float) + (lvl * c.terrain_num_cols + (int64_t)sh.pre_type) * 3;
+    float o[3];
+    for (int k = 0; k < 3; ++k) o[k] = ls_uniform_load(to + k);
+    LS_LDS_FENCE();          // every lane has read the old origin before lane 0 replaces it
+    if (lane == 0) {
+        LSB(cx, LSIM_BUF_TERRAIN_LEVELS, int64_t)[env] = lvl;
+        for (int k = 0; k < 3; ++k) { LSB(cx, LSIM_BUF_ENV_ORIGINS, float)[3 * env + k] = o[k]; sh.pre_org[k] = o[k]; }
+    }
 }
 
-// reset_idx body for a resetting env (LR:316-361); lane roles in the comments
-LS_FN void ph_b_reset(const LsCtx& cx, WaveShared& sh, int lane, int env, const LsStepArgs& a) {
-    if (!sh.do_reset) return;
+// reset_idx body for a resetting env (LR:316-361), in two phases: the new state into LDS (ph_b_reset_state), everything that goes to global
+// memory afterwards (ph_b_reset_store).  Kernel A's fused tail samples the terrain under the new pose BETWEEN the two: those loads then
+// queue behind none of reset_idx's stores and atomics (vmcnt retires in order; a resetting wave is the slowest kind of wave of a launch, and a
+// launch of one round of waves lasts as long as its slowest wave).  Lane roles in the comments.
+LS_FN void ph_b_reset_state(const LsCtx& cx, WaveShared& sh, int lane, int env, const LsStepArgs& a, const float* q0 /* default_dof_pos: LDS copy or the config's */) {
+    if (!LS_UNIFORM(sh.do_reset)) return;          // wave-uniform: a scalar branch, nothing of the body is issued for the other waves
     const lsim_config& c = cx.cfg;
     const uint32_t stepw = (uint32_t)a.step_counter;
     if (lane < 12) {  // _reset_dofs (LR:690-716)
-        float pos = c.default_dof_pos[lane];      // kernel B has no joint-constant block in LDS (ph_load_a's); resets are rare
+        float pos = q0[lane];
         if (c.has_dof_init_pos_ratio)
             pos = pos * rand_range(ls_draw(cx, env, stepw, LSIM_RNG_RESET_DOF, (uint32_t)lane), c.dof_init_pos_ratio_range[0], c.dof_init_pos_ratio_range[1]);
         float vel = 0.0f;
@@ -377,15 +409,8 @@ LS_FN void ph_b_reset(const LsCtx& cx, WaveShared& sh, int lane, int env, const 
             vel = ls_draw(cx, env, stepw, LSIM_RNG_RESET_DOF, (uint32_t)(12 + lane)) * fabsf(hi - lo) + fminf(lo, hi);
         }
         sh.dofs[2 * lane] = pos; sh.dofs[2 * lane + 1] = vel;
-        LS_GLOBAL float* dof = LSB(cx, LSIM_BUF_DOF_STATE, float) + 24 * env;
-        dof[2 * lane] = pos; dof[2 * lane + 1] = vel;
-        LSB(cx, LSIM_BUF_LAST_ACTIONS, float)[12 * env + lane] = 0.0f;       // LR:323-327
-        LSB(cx, LSIM_BUF_LAST_LAST_ACTIONS, float)[12 * env + lane] = 0.0f;
-        LSB(cx, LSIM_BUF_LAST_DOF_POS, float)[12 * env + lane] = 0.0f;
-        LSB(cx, LSIM_BUF_LAST_DOF_VEL, float)[12 * env + lane] = 0.0f;
-        LSB(cx, LSIM_BUF_LAST_TORQUES, float)[12 * env + lane] = 0.0f;
     } else if (lane == 12) {  // _reset_root_states (LR:718-820)
-        LS_GLOBAL const float* org = LSB(cx, LSIM_BUF_ENV_ORIGINS, float) + 3 * env;
+        const float* org = sh.pre_org;          // this env's origin row, as ph_b_terrain_curriculum left it
         float u[12];
         for (int b = 0; b < 3; ++b) ls_u01x4(c.seed, c.rank, (uint32_t)env, stepw, LSIM_RNG_RESET_ROOT, (uint32_t)b, u + 4 * b);
         float r[13];
@@ -401,14 +426,28 @@ LS_FN void ph_b_reset(const LsCtx& cx, WaveShared& sh, int lane, int env, const 
             quat_from_euler_xyz(rpy[0], rpy[1], rpy[2], r + 3);
         }
         for (int k = 0; k < 6; ++k) r[7 + k] = rand_range(u[6 + k], c.base_init_vel_range[k][0], c.base_init_vel_range[k][1]);
-        for (int k = 0; k < 13; ++k) { sh.root[k] = r[k]; LSB(cx, LSIM_BUF_ROOT_STATES, float)[13 * env + k] = r[k]; }
+        for (int k = 0; k < 13; ++k) sh.root[k] = r[k];
     } else if (lane == 13) {  // _resample_commands (LR:320)
-        LS_GLOBAL float* cmd = LSB(cx, LSIM_BUF_COMMANDS, float) + 4 * env;
         float cm[4] = {sh.cmd[0], sh.cmd[1], sh.cmd[2], sh.cmd[3]};
         ls_resample_commands(cx, env, stepw, LSIM_RNG_RESET_CMD, sh.ranges, cm);
-        for (int k = 0; k < 4; ++k) { cmd[k] = cm[k]; }
-        // sh.cmd is refreshed in the next phase (lane 13 owns it here, other lanes may still read the old value)
+        // sh.cmd is refreshed by the episode-statistics phase (lane 13 owns it here, other lanes may still read the old value)
         sh.rewv[0] = cm[0]; sh.rewv[1] = cm[1]; sh.rewv[2] = cm[2]; sh.rewv[3] = cm[3];
+    }
+}
+LS_FN void ph_b_reset_store(const LsCtx& cx, WaveShared& sh, int lane, int env, const LsStepArgs& a) {
+    if (!LS_UNIFORM(sh.do_reset)) return;          // wave-uniform: a scalar branch, nothing of the body is issued for the other waves
+    const lsim_config& c = cx.cfg;
+    const uint32_t stepw = (uint32_t)a.step_counter;
+    if (lane < 12) {
+        LS_GLOBAL float* dof = LSB(cx, LSIM_BUF_DOF_STATE, float) + 24 * env;
+        dof[2 * lane] = sh.dofs[2 * lane]; dof[2 * lane + 1] = sh.dofs[2 * lane + 1];
+        LSB(cx, LSIM_BUF_LAST_ACTIONS, float)[12 * env + lane] = 0.0f;       // LR:323-327
+        LSB(cx, LSIM_BUF_LAST_LAST_ACTIONS, float)[12 * env + lane] = 0.0f;
+        LSB(cx, LSIM_BUF_LAST_DOF_POS, float)[12 * env + lane] = 0.0f;
+        LSB(cx, LSIM_BUF_LAST_DOF_VEL, float)[12 * env + lane] = 0.0f;
+        LSB(cx, LSIM_BUF_LAST_TORQUES, float)[12 * env + lane] = 0.0f;
+    } else if (lane == 12) {
+        for (int k = 0; k < 4; ++k) LSB(cx, LSIM_BUF_COMMANDS, float)[4 * env + k] = sh.rewv[k];
     } else if (lane == 14) {  // domain-randomisation redraw (LR:336-343, LR:533-537)
         float u[8];
         ls_u01x4(c.seed, c.rank, (uint32_t)env, stepw, LSIM_RNG_RESET_DR, 0, u);
@@ -421,6 +460,8 @@ LS_FN void ph_b_reset(const LsCtx& cx, WaveShared& sh, int lane, int env, const 
     } else if (lane == 15) {
         for (int f = 0; f < 4; ++f) LSB(cx, LSIM_BUF_FEET_AIR_TIME, float)[4 * env + f] = 0.0f;   // LR:328
         LSB(cx, LSIM_BUF_RESET, uint8_t)[env] = 1;                                                 // LR:329
+    } else if (lane >= 16 && lane < 29) {
+        LSB(cx, LSIM_BUF_ROOT_STATES, float)[13 * env + lane - 16] = sh.root[lane - 16];
     }
 }
 // extras["episode"] sums (LR:346-350); lane = reward term.  Three steps so that the result is the same whatever order the waves run in:
@@ -553,8 +594,9 @@ LS_FN void ph_tail_setup(const LsCtx& cx, WaveShared& sh, int lane, const LsStep
 }
 // the episode sums of a resetting env into the fixed-point accumulators (LR:346-350), from LDS; no ticket: lsim_k_step_finish converts
 LS_FN void ph_tail_episode_stats(const LsCtx& cx, WaveShared& sh, int lane, int env, const LsStepArgs& a) {
-    if (!sh.do_reset) return;
+    if (!LS_UNIFORM(sh.do_reset)) return;
     if (lane == 13) for (int k = 0; k < 4; ++k) sh.cmd[k] = sh.rewv[k];
+    if (lane == 63) ls_count_reset(cx, sh, a);           // (ph_term_outputs left them to this phase)
     const float den = (float)(sh.eplen < 1 ? 1 : sh.eplen);
     long long* fix = ls_fix_row(cx, a.row_out);
     LS_STRIDED(k, lane, LSIM_NUM_REWARD_TERMS) {
@@ -572,6 +614,9 @@ template <int SOLVER> LS_WAVE_FN void ls_wave_step_a(const LsCtx& cx, const LsSt
     const bool skip = (a.flags & LSIM_STEP_SKIP_PHYSICS) != 0;
     [[maybe_unused]] constexpr int ls_line0 = __LINE__;   // phase-site ids (LS_PHASE_TIMING builds) count lines from here
     LS_TICK_INIT();
+#if defined(LS_WAVE_TIMES)    // diagnostics build only (tools/wave_times.py): when each wave of the latest step started and ended
+    const unsigned long long ls_wt0 = wall_clock64(), ls_wc0 = clock64();
+#endif
     LS_PHASE(ph_load_a(cx, sh, rg, lane, env, a));
     for (int sub = 0; sub < c.decimation; ++sub) {
         if (skip) { LS_PHASE(ph_torques(cx, sh, lane, env, sub, a.flags)); continue; }
@@ -588,6 +633,14 @@ template <int SOLVER> LS_WAVE_FN void ls_wave_step_a(const LsCtx& cx, const LsSt
         LS_PHASE(ph_free_base(sh, lane));
         LS_PHASE(ph_free_finish(sh, lane, dt); ph_collide_prefetch(cx, rg, lane); ph_collide(cx, sh, rg, lane));
         LS_COLLECTIVE(wc_compact_contacts(sh, rg, lane); wc_limits(cx, sh, lane, dt), wc_compact_contacts(sh, L); LS_PHASE(ph_limits(cx, sh, lane, dt)));
+        // A launch of <= 4096 robots is ONE round of waves, over when its slowest wave is: the median wave needs 83 us, one with 8 contacts 97
+        // (2.3 us per contact: rows, Delassus entries, relaxations), the kernel 117 (tools/wave_times.py).  The more contacts a robot has in
+        // this sub-step, the higher its wave's issue priority over the three it shares a SIMD with, which have the slack: kernel A 0.1176 ->
+        // 0.1104 ms on the flat task, 0.1405 -> 0.1298 on stairs (LSIM_STEP_FLAT_PRIORITY switches it off).  Results do not change.
+        if (!(a.flags & LSIM_STEP_FLAT_PRIORITY)) {
+            const int ncu = LS_UNIFORM(sh.nc);
+            if (ncu >= 5) LS_SETPRIO(3); else if (ncu >= 3) LS_SETPRIO(2); else if (ncu >= 1) LS_SETPRIO(1); else LS_SETPRIO(0);
+        }
         LS_PHASE(ph_rows<TGS>(cx, sh, rg, lane, dt));
 #if defined(LS_EMU)
         LS_PHASE(ph_delassus(sh, rg, lane));
@@ -630,18 +683,24 @@ template <int SOLVER> LS_WAVE_FN void ls_wave_step_a(const LsCtx& cx, const LsSt
     LS_PHASE(ph_reward_terms(cx, sh, rg, lane, env));
 #endif
     LS_PHASE(ph_reward_total(cx, sh, lane, env));
-    LS_PHASE(if (sh.reset) ph_build_obs(cx, sh, lane, env, (uint32_t)a.step_counter, LSIM_RNG_TERM_NOISE, sh.cur, sh.jc_q0));
+    LS_PHASE(if (LS_UNIFORM(sh.reset)) ph_build_obs(cx, sh, lane, env, (uint32_t)a.step_counter, LSIM_RNG_TERM_NOISE, sh.cur, sh.jc_q0));
     LS_PHASE(ph_term_outputs(cx, sh, lane, env, a));
     if (fuse) {     // LR:229-241 + LR:167-171 for this robot (kernel B's phases; its cross-env part is lsim_k_step_finish)
         LS_PHASE(ph_tail_setup(cx, sh, lane, a));
         LS_PHASE(ph_b_terrain_curriculum(cx, sh, lane, env, a));
-        LS_PHASE(ph_b_reset(cx, sh, lane, env, a));
-        LS_PHASE(ph_tail_episode_stats(cx, sh, lane, env, a));
-        LS_PHASE(if (sh.do_reset && c.measure_heights) ph_heights(cx, sh, lane, env, true));
+        LS_PHASE(ph_b_reset_state(cx, sh, lane, env, a, sh.jc_q0));
+        LS_PHASE(if (LS_UNIFORM(sh.do_reset) && c.measure_heights) ph_heights(cx, sh, lane, env, true, sh.mpx, sh.mpy));     // loads: ahead of reset_idx's stores and atomics
+        LS_PHASE(ph_b_reset_store(cx, sh, lane, env, a); ph_tail_episode_stats(cx, sh, lane, env, a));
         LS_PHASE(ph_build_obs(cx, sh, lane, env, (uint32_t)a.step_counter, LSIM_RNG_OBS_NOISE, sh.cur, sh.jc_q0));
         LS_PHASE(ph_b_store(cx, sh, lane, env, a, ls_obs_hist(sh)));
     }
     LS_TICK_FLUSH();
+#if defined(LS_WAVE_TIMES)
+    if (lane0 == 0 && env < 65536) {
+        g_ls_wave_times[4 * env + 0] = ls_wt0; g_ls_wave_times[4 * env + 1] = wall_clock64();
+        g_ls_wave_times[4 * env + 2] = clock64() - ls_wc0; g_ls_wave_times[4 * env + 3] = __builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 16);
+    }
+#endif
 }
 
 LS_WAVE_FN void ls_wave_step_b(const LsCtx& cx, const LsStepArgs& a, const int env, WaveShared& sh, LS_LANES_PARAM) {
@@ -650,9 +709,10 @@ LS_WAVE_FN void ls_wave_step_b(const LsCtx& cx, const LsStepArgs& a, const int e
     LS_TICK_INIT();
     LS_PHASE(ph_load_b(cx, sh, lane, env, a));
     LS_PHASE(ph_b_housekeeping(cx, sh, lane, env, a); ph_b_terrain_curriculum(cx, sh, lane, env, a));
-    LS_PHASE(ph_b_reset(cx, sh, lane, env, a));
+    LS_PHASE(ph_b_reset_state(cx, sh, lane, env, a, cx.cfg.default_dof_pos));
+    LS_PHASE(ph_b_reset_store(cx, sh, lane, env, a));
     LS_PHASE(ph_b_episode_stats(cx, sh, rg, lane, env, a));
-    LS_PHASE(if (sh.do_reset && c.measure_heights) ph_heights(cx, sh, lane, env, true));
+    LS_PHASE(if (LS_UNIFORM(sh.do_reset) && c.measure_heights) ph_heights(cx, sh, lane, env, true, c.measured_points_x, c.measured_points_y));
     if (a.reset_all) {   // reset_idx only: the observation roll belongs to the step that follows (BT:114)
         LS_PHASE(ph_b_store_reset_all(cx, sh, lane, env, a); ph_b_stats_publish(cx, sh, rg, lane, a));
         LS_PHASE(ph_b_stats_convert(cx, sh, lane, a));

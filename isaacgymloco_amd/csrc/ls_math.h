@@ -37,6 +37,23 @@
 #define LS_UNIFORM(x) (x)
 #endif
 
+// One float of a table that no kernel writes, at an address that is the same for every active lane, through the SCALAR data cache: the
+// request counts in lgkmcnt, not vmcnt, so it does not queue behind the vector stores the wave has in flight (vmcnt retires in order: a
+// vector load late in a kernel waits for every store before it).  Not for data a kernel of the step writes: the scalar cache is not
+// coherent with vector stores.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ float ls_uniform_load(LS_GLOBAL const float* p) {
+    const unsigned long long a = (unsigned long long)p;
+    // (readfirstlane returns a SIGNED int: widen through unsigned, or the low word's bit 31 floods the high word)
+    const unsigned long long u = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) | (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)a);
+    float v;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(u) : "memory");
+    return v;
+}
+#else
+static inline float ls_uniform_load(const float* p) { return *p; }
+#endif
+
 struct alignas(8) LsF2 { float x, y; };   // one 8-byte global store
 
 struct V3 {

@@ -130,18 +130,28 @@ LS_FN void ph_heights_finish(const LsCtx& cx, WaveShared& sh, const LaneRegs& rg
     if (lane < LSIM_NUM_BASE_HEIGHT_PTS) sh.bh[lane] = c.mesh_type == 0 ? sh.root[2] : sh.root[2] - ls_min3_height(cx, rg.hraw + 2 * LS_HEIGHT_PASSES);
 }
 
-// LeggedRobot._get_heights (LR:1318-1355): lanes stride over the 187 points
-LS_FN void ph_heights(const LsCtx& cx, WaveShared& sh, int lane, int env, bool store_global) {
+// LeggedRobot._get_heights (LR:1318-1355) in one phase (reset_idx: the terrain under the new pose): lane l owns points l, l + 64, l + 128.
+// Every sample of every pass is requested before the first result is stored -- a pass that stored its heights before the next pass's
+// loads went out made those wait for the stores (vmcnt retires in order), and the point tables were read per lane from the context, one
+// more dependent round trip per pass: 64 k of a resetting wave's 346 k ticks (round 4).  mpx / mpy: measured_points_x / y (kernel A: its
+// LDS copies).
+LS_FN void ph_heights(const LsCtx& cx, WaveShared& sh, int lane, int env, bool store_global, const float* mpx, const float* mpy) {
     const lsim_config& c = cx.cfg;
     LS_GLOBAL float* mh = LSB(cx, LSIM_BUF_MEASURED_HEIGHTS, float) + LS_NHP * env;
-    const LsYawQuat yq = ls_yaw_quat(sh.root + 3);
-    LS_STRIDED(k, lane, LS_NHP) {
-        float h = 0.0f;
-        if (c.mesh_type != 0) {
-            int ix = k / c.num_points_y, iy = k - ix * c.num_points_y;
-            V3 w = ls_yaw_point(sh.root, yq, c.measured_points_x[ix], c.measured_points_y[iy]);
-            h = ls_sample_height_min3(cx, w.x, w.y);
+    int raw[2 * LS_HEIGHT_PASSES];
+    if (c.mesh_type != 0) {
+        const LsYawQuat yq = ls_yaw_quat(sh.root + 3);
+        for (int it = 0; it < LS_HEIGHT_PASSES; ++it) {
+            const int k = lane + 64 * it, kk = k < LS_NHP ? k : 0;
+            const int ix = kk / c.num_points_y, iy = kk - ix * c.num_points_y;
+            const V3 w = ls_yaw_point(sh.root, yq, mpx[ix], mpy[iy]);
+            ls_height_samples3(cx, w.x, w.y, raw + 2 * it);
         }
+    }
+    for (int it = 0; it < LS_HEIGHT_PASSES; ++it) {
+        const int k = lane + 64 * it;
+        if (k >= LS_NHP) continue;
+        const float h = c.mesh_type != 0 ? ls_min3_height(cx, raw + 2 * it) : 0.0f;
         sh.heights[k] = h;
         if (store_global) mh[k] = h;
     }

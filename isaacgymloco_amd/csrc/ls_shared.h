@@ -93,6 +93,10 @@ struct WaveShared {
     };
     float pre_cmd[4], pre_air[4];                                // commands, feet_air_time
     int pre_eplen, pre_level;                                    // episode_length_buf, terrain_levels (low words)
+    int pre_type;                                                // terrain_types (low word)
+    float pre_org[3];                                            // env_origins row: reset_idx's inputs (LR:846-866, LR:718-731) fetched with everything
+                                                                 // else, because a load issued once the kernel's stores are in flight waits for all of
+                                                                 // them (a resetting wave spent 54 k of its 331 k ticks in two such waits, round 4)
     unsigned int pre_lc;                                         // last_contacts: 4 bytes
     float pre_es[LSIM_NUM_REWARD_TERMS];                         // episode_sums row
     unsigned char filt[4];                                       // contact_filt of this step (LR:207-209)
@@ -149,7 +153,7 @@ struct WaveShared {
     float vfree[LS_NV], vnew[LS_NV];
     // ---- contacts
     int nc, nrows;
-    int nact, nact_max;      // collision points in contact before the cap (diagnostic, LSIM_BUF_CONTACT_COUNT)
+    short nact, nact_max;    // collision points in contact before the cap (diagnostic, LSIM_BUF_CONTACT_COUNT)
     int cbody[LS_MAXC];
     float cpos[LS_MAXC][3], cn[LS_MAXC][3], cdist[LS_MAXC];
     int limdof[12];

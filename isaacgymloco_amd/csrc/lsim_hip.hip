@@ -218,3 +218,22 @@ extern "C" int lsim_debug_read_phase_ticks(unsigned long long* ticks, unsigned l
     return 0;
 }
 #endif
+
+#if defined(LS_PHASE_TIMING)
+// the per-site ticks again by kind of wave ([3][129]: few contacts / many contacts / resetting; last column = waves), read and cleared
+extern "C" int lsim_debug_read_phase_ticks_by(unsigned long long* out) {
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ls_phase_ticks_by), 3 * 129 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    static unsigned long long z[3 * 129];
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ls_phase_ticks_by), z, sizeof(z));
+    return 0;
+}
+#endif
+
+#if defined(LS_WAVE_TIMES)
+// diagnostics build only: per-env (start, end, ticks, hardware id) of the latest kernel A (tools/wave_times.py)
+extern "C" int lsim_debug_read_wave_times(unsigned long long* out, int n) {
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ls_wave_times), (size_t)4 * n * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
+#endif

@@ -13,6 +13,7 @@ by the HIP kernels behind include/lsim.h (isaacgymloco_amd/csrc); this file only
 the current torch stream and assembles the reference's return tuple.  There is no CPU fallback.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -39,6 +40,9 @@ from .terrain import Terrain
 
 _TORCH_DT = {abi.DT_F32: torch.float32, abi.DT_I64: torch.int64, abi.DT_U8: torch.uint8, abi.DT_I32: torch.int32, abi.DT_I16: torch.int16}
 
+
+# measurement hook: LSIM_STEP_* bits or-ed into every step (e.g. LSIM_STEP_FLAGS=16: the separate finish kernel; 8: kernels A + B on every step)
+_EXTRA_STEP_FLAGS = int(os.environ.get("LSIM_STEP_FLAGS", "0"), 0)
 
 class LeggedRobot:
     def __init__(self, cfg, sim_params=None, physics_engine=None, sim_device="cuda:0", headless=True,
@@ -267,7 +271,7 @@ class LeggedRobot:
         if actions.dtype != torch.float32 or not actions.is_contiguous() or actions.device != self._arena.device:
             actions = actions.to(device=self._arena.device, dtype=torch.float32).contiguous()
         with lib.roctx_range("lsim_step"):
-            lib.check(self._L.lsim_step_ex(self._h, actions.data_ptr(), ctypes.c_uint32(flags), self._stream()), self._h, "lsim_step")
+            lib.check(self._L.lsim_step_ex(self._h, actions.data_ptr(), ctypes.c_uint32(flags | _EXTRA_STEP_FLAGS), self._stream()), self._h, "lsim_step")
         self.common_step_counter += 1
         self._last_actions_ref = actions   # keep alive until the kernels ran
         return self.obs_buf, self.privileged_obs_buf, self.rew_buf, self.reset_buf

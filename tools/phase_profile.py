@@ -49,7 +49,7 @@ NOMINAL_LANES = [("KINEMATICS", "48 (12 matrix elements x 4 legs)"), ("ph_torque
                  ("ph_body_states_all", "17"), ("ph_store_sim_state", "51"), ("ph_load_a", "64"), ("ph_post_state", "8"), ("ph_callback", "3"),
                  ("ph_heights", "64 (187 + 63 points)"), ("ph_termination", "1"), ("ph_reward_terms", "one per active term (21)"),
                  ("ph_reward_total", "1"), ("ph_build_obs", "64"), ("ph_term_outputs", "64"), ("ph_load_b", "64"), ("ph_b_store", "64"),
-                 ("ph_b_reset", "16"), ("ph_b_episode_stats", "51"), ("ph_b_housekeeping", "53 (env 0 only)")]
+                 ("ph_b_reset_state", "14"), ("ph_b_reset_store", "29"), ("ph_b_episode_stats", "51"), ("ph_b_housekeeping", "53 (env 0 only)")]
 
 
 def nominal_lanes(text):
@@ -78,14 +78,16 @@ if __name__ == "__main__":
     env.episode_length_buf = torch.randint_like(env.episode_length_buf, high=int(env.max_episode_length))
     acts = [torch.randn(N, 12, device="cuda:0") for _ in range(16)]
     L = ctypes.CDLL(OUT)
-    t = (ctypes.c_ulonglong * 128)(); c = (ctypes.c_ulonglong * 128)()
+    t = (ctypes.c_ulonglong * 128)(); c = (ctypes.c_ulonglong * 128)(); by = (ctypes.c_ulonglong * (3 * 129))()
     for i in range(50):
         env.step_device(acts[i % 16])
     L.lsim_debug_read_phase_ticks(t, c)
+    L.lsim_debug_read_phase_ticks_by(by)
     K = 200
     for i in range(K):
         env.step_device(acts[i % 16])
     L.lsim_debug_read_phase_ticks(t, c)
+    L.lsim_debug_read_phase_ticks_by(by)
     names = sites()
     tot_a = sum(t[s] for s in range(96)); tot_b = sum(t[s] for s in range(96, 128))
     print(f"task {task} N {N}: mean ticks per wave per step: kernel A {tot_a / (K * N):.0f}, kernel B {tot_b / (K * N):.0f}")
@@ -93,4 +95,8 @@ if __name__ == "__main__":
         if c[s]:
             tot = tot_a if s < 96 else tot_b
             nm = names.get(s, "?")
-            print(f"site {s:2d} calls/step {c[s] / (K * N):4.1f} ticks/step {t[s] / (K * N):8.0f} {100.0 * t[s] / tot:5.1f}%  busy lanes {nominal_lanes(nm):<28s} {nm}")
+            kinds = " ".join(f"{by[k * 129 + s] / max(by[k * 129 + 128], 1):7.0f}" for k in range(3)) if s < 96 else ""
+            print(f"site {s:2d} calls/step {c[s] / (K * N):4.1f} ticks/step {t[s] / (K * N):8.0f} {100.0 * t[s] / tot:5.1f}%  [<=3 contacts / >=6 / resetting: {kinds}]  busy lanes {nominal_lanes(nm):<28s} {nm}")
+    tot_by = [sum(by[k * 129 + s] for s in range(96)) / max(by[k * 129 + 128], 1) for k in range(3)]
+    print(f"kernel A by kind of wave: at most 3 contacts {tot_by[0]:.0f} ticks ({by[128] / K:.0f} waves per step), 6 or more {tot_by[1]:.0f} ({by[129 + 128] / K:.0f}), "
+          f"resetting {tot_by[2]:.0f} ({by[2 * 129 + 128] / K:.0f})")

@@ -1,0 +1,79 @@
+"""Per-wave start / end times of kernel A (diagnostics; not part of the product build).
+
+Builds isaacgymloco_amd/csrc/variants/liblsim_wavetimes.so with -DLS_WAVE_TIMES (lane 0 of every wave records the 100 MHz wall clock at
+its first and last instruction, its shader-clock ticks and its hardware id), runs the env-only loop and prints, for a few steps, how
+the waves' durations and end times are distributed -- is the launch as long as its mean wave or as its slowest one -- and which
+property of a robot (contacts, reset, terrain type) or of its place on the chip (XCD, CU, SIMD) the slow ones share.
+Run on the GPU box:  python tools/wave_times.py [task] [N]"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+OUT = os.path.join(ROOT, "isaacgymloco_amd", "csrc", "variants", "liblsim_wavetimes.so")
+
+
+def build():
+    from isaacgymloco_amd.csrc import build as B
+    return B.build_variant(OUT, ["-DLS_WAVE_TIMES"])
+
+
+def main():
+    task = sys.argv[1] if len(sys.argv) > 1 else "aliengo"
+    N = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+    if not os.path.exists(OUT):
+        build()
+    os.environ["LSIM_LIB"] = OUT
+    import torch
+    from isaacgymloco_amd import lib
+    from isaacgymloco_amd.envs import config as C
+    from isaacgymloco_amd.envs.legged_robot import LeggedRobot
+    cfg = C.TASKS[task][0]()
+    cfg.env.num_envs = N
+    env = LeggedRobot(cfg, sim_device="cuda:0", seed=1)
+    env.reset()
+    L = lib.load()
+    g = torch.Generator(device="cuda:0").manual_seed(0)
+    buf = (ctypes.c_ulonglong * (4 * N))()
+    print(f"task {task} N {N}: times in us relative to the first wave's start")
+    for t in range(260):
+        env.step_device(torch.randn(N, 12, device="cuda:0", generator=g))
+        if t < 200 or t % 20:
+            continue
+        assert L.lsim_debug_read_wave_times(buf, N) == 0
+        a = np.frombuffer(buf, dtype=np.uint64).reshape(N, 4).astype(np.int64)
+        t0 = a[:, 0].min()
+        start, end = (a[:, 0] - t0) / 100.0, (a[:, 1] - t0) / 100.0
+        dur = end - start
+        hw = a[:, 3]
+        simd, cu, se, xcc = (hw >> 4) & 3, (hw >> 8) & 15, (hw >> 13) & 7, (hw >> 16) & 15
+        nc = env.buf["contact_count"][:, 0].cpu().numpy()
+        rst = env.reset_buf.cpu().numpy().astype(bool)
+        q = lambda x: " ".join(f"{v:6.1f}" for v in np.percentile(x, [0, 10, 50, 90, 99, 100]))
+        print(f"step {t}: launch {end.max():6.1f} | start p0/10/50/90/99/100 {q(start)} | end {q(end)} | duration {q(dur)} | clock {np.median(a[:, 2] / dur / 1e3):.2f} GHz")
+        slow = dur >= np.percentile(dur, 95)
+        print(f"          slowest 5 %: contacts {nc[slow].mean():.1f} (all {nc.mean():.1f}), resetting {rst[slow].mean():.2f} (all {rst.mean():.2f}); "
+              f"duration vs contacts r = {np.corrcoef(dur, nc)[0, 1]:.2f}")
+        # a SIMD's four waves: how different are they, and how different are the SIMDs
+        key = ((xcc * 8 + se) * 16 + cu) * 4 + simd
+        order = np.argsort(key, kind="stable")
+        ks, ds, es = key[order], dur[order], end[order]
+        uniq, idx, cnt = np.unique(ks, return_index=True, return_counts=True)
+        per = np.array([es[i:i + c].max() for i, c in zip(idx, cnt)])
+        mean_in = np.array([ds[i:i + c].mean() for i, c in zip(idx, cnt)])
+        print(f"          {len(uniq)} SIMDs seen, waves per SIMD {cnt.min()}..{cnt.max()}; last end per SIMD {q(per)}; mean duration per SIMD {q(mean_in)}")
+        rows = " ".join(f"{k}:{dur[(nc == k) & ~rst].mean():.1f}({int(((nc == k) & ~rst).sum())})" for k in range(0, 13) if ((nc == k) & ~rst).sum() > 4)
+        print(f"          mean duration by contacts (not resetting): {rows}; resetting: {dur[rst].mean() if rst.any() else 0:.1f} ({int(rst.sum())})")
+        worst = np.argsort(-dur)[:12]
+        print("          slowest 12: " + " ".join(f"{dur[i]:.0f}us/c{nc[i]}{'R' if rst[i] else ''}/x{xcc[i]}" for i in worst))
+        mates = np.array([ds[i:i + c].sum() for i, c in zip(idx, cnt)])
+        print(f"          sum of the four durations per SIMD {q(mates)}; r(last end per SIMD, that sum) = {np.corrcoef(per, mates)[0, 1]:.2f}")
+        byx = [f"{end[xcc == x].max():.1f}" for x in np.unique(xcc)]
+        print(f"          last end per XCD: {' '.join(byx)}")
+
+
+if __name__ == "__main__":
+    main()
