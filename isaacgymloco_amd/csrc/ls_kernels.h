@@ -29,6 +29,7 @@ static inline long long ls_emu_fetch_add(long long* p, long long v) { long long 
 #define LS_SETPRIO(n) do { } while (0)
 #define LS_TICK_INIT() do { } while (0)
 #define LS_TICK_FLUSH() do { } while (0)
+#define LS_CP(i) do { } while (0)
 #else
 // Every phase re-derives its lane id from an opaque copy: the compiler then cannot hoist the dozens of per-phase lane
 // predicates and LDS addresses out of the sub-step loop (it did, and spilled ~50 VGPRs + 128 SGPRs to keep them alive).
@@ -54,6 +55,10 @@ __device__ unsigned long long g_ls_phase_ticks_by[3][129];    // the same by kin
 #endif
 #if defined(LS_WAVE_TIMES)
 __device__ unsigned long long g_ls_wave_times[4 * 65536];     // per env: start, end (100 MHz wall clock), shader-clock ticks, HW_ID | XCC_ID << 16
+__device__ unsigned int g_ls_wave_cp[16 * 65536];              // per env: shader-clock ticks since the wave's start at up to 16 checkpoints (LS_CP)
+#define LS_CP(i) do { ls_cp[i] = (unsigned int)(clock64() - ls_wc0); } while (0)
+#else
+#define LS_CP(i) do { } while (0)
 #endif
 #if defined(LS_PHASE_MARKS)    // diagnostics only (tools/phase_static.py): a comment in the assembly behind every phase site
 #define LS_STR2(x) #x
@@ -221,14 +226,21 @@ LS_FN void ph_store_sim_state(const LsCtx& cx, WaveShared& sh, int lane, int env
     if (lane < 3 * LS_NB) LSB(cx, LSIM_BUF_CONTACT_FORCES, float)[3 * LS_NB * env + lane] = sh.cf[lane / 3][lane % 3];
     if (lane == 52) { LSB(cx, LSIM_BUF_CONTACT_COUNT, int32_t)[2 * env] = sh.nact_max; LSB(cx, LSIM_BUF_CONTACT_COUNT, int32_t)[2 * env + 1] = sh.nact; }
 }
-LS_FN void ph_body_states_all(const LsCtx& cx, WaveShared& sh, int lane, int env) {
-    LS_GLOBAL float* out = LSB(cx, LSIM_BUF_RIGID_BODY_STATES, float) + 13 * LS_NB * env;
-    float pv[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    ph_body_states(sh, lane, out, pv);
-    if (lane < LS_NB)       // the feet rows of the tensor for the reward terms, from registers (reading them back from `out` is a store -> load round trip per foot)
+// the rigid-body state rows into registers (LaneRegs::bs) while the kinematics arrays are still alive -- the height samples overlay them --
+// and stored by ph_store_body_states once everything the wave had requested from memory has been consumed: a load whose result is read
+// while stores are in flight waits for the stores too (vmcnt retires in order), and at 4096 robots in lockstep a store burst takes ~5 us
+LS_FN void ph_body_states_all(const LsCtx& cx, WaveShared& sh, LaneRegs& rg, int lane) {
+    ph_body_states(sh, lane, rg.bs);
+    if (lane < LS_NB)       // the feet rows of the tensor for the reward terms, from registers
         for (int f = 0; f < 4; ++f)
-            if (cx.model.feet_bodies[f] == lane)         // uniform f: scalar loads
-                for (int k = 0; k < 6; ++k) sh.feet[f][k] = pv[k];
+            if (cx.model.feet_bodies[f] == lane) {         // uniform f: scalar loads
+                for (int k = 0; k < 3; ++k) { sh.feet[f][k] = rg.bs[k]; sh.feet[f][3 + k] = rg.bs[7 + k]; }
+            }
+}
+LS_FN void ph_store_body_states(const LsCtx& cx, const LaneRegs& rg, int lane, int env) {
+    if (lane >= LS_NB) return;
+    LS_GLOBAL float* o = LSB(cx, LSIM_BUF_RIGID_BODY_STATES, float) + 13 * (LS_NB * env + lane);
+    for (int k = 0; k < 13; ++k) o[k] = rg.bs[k];
 }
 // LSIM_STEP_SKIP_PHYSICS: take the simulator tensors as injected by the caller
 LS_FN void ph_load_injected(const LsCtx& cx, WaveShared& sh, int lane, int env) {
@@ -616,8 +628,10 @@ template <int SOLVER> LS_WAVE_FN void ls_wave_step_a(const LsCtx& cx, const LsSt
     LS_TICK_INIT();
 #if defined(LS_WAVE_TIMES)    // diagnostics build only (tools/wave_times.py): when each wave of the latest step started and ended
     const unsigned long long ls_wt0 = wall_clock64(), ls_wc0 = clock64();
+    unsigned int ls_cp[16] = {};
 #endif
     LS_PHASE(ph_load_a(cx, sh, rg, lane, env, a));
+    LS_CP(0);
     for (int sub = 0; sub < c.decimation; ++sub) {
         if (skip) { LS_PHASE(ph_torques(cx, sh, lane, env, sub, a.flags)); continue; }
         // phases that do not depend on each other share a barrier: (torques, kinematics), (free velocity, narrow phase),
@@ -653,6 +667,7 @@ template <int SOLVER> LS_WAVE_FN void ls_wave_step_a(const LsCtx& cx, const LsSt
 #endif
         if (TGS) LS_PHASE(ph_integrate_tgs(cx, sh, lane, dt, c.num_position_iterations));
         else LS_PHASE(ph_integrate(cx, sh, lane, dt));
+        if (sub < 4) LS_CP(1 + sub);
 #if defined(LS_EXP_TWICE) && LS_EXP_TWICE == 9001      // cost probe: the integrator again with a zero step (leaves the state where it is)
         LS_PHASE(ph_integrate(cx, sh, lane, 0.0f));
 #endif
@@ -664,25 +679,31 @@ template <int SOLVER> LS_WAVE_FN void ls_wave_step_a(const LsCtx& cx, const LsSt
 #else
         LS_COLLECTIVE(wc_kinematics(sh, lane); ph_late_load(cx, rg, lane, env, fuse); ph_heights_issue(cx, sh, rg, lane), (void)0);
 #endif
-        LS_PHASE(ph_body_states_all(cx, sh, lane, env));
-        LS_PHASE(ph_store_sim_state(cx, sh, lane, env); ph_late_stage(sh, rg, lane, fuse));     // Mbl .. vnew are dead from here on
+        LS_CP(5);
+        LS_PHASE(ph_body_states_all(cx, sh, rg, lane));
+        LS_PHASE(ph_heights_finish(cx, sh, rg, lane, env); ph_late_stage(sh, rg, lane, fuse));   // the loads' results, before the first store; Mbl .. vnew are dead from here on
+        LS_CP(6);
+        LS_PHASE(ph_store_body_states(cx, rg, lane, env); ph_store_sim_state(cx, sh, lane, env));
+        LS_CP(7);
     } else {
         LS_PHASE(ph_late_load(cx, rg, lane, env, fuse); ph_heights_issue(cx, sh, rg, lane));
-        LS_PHASE(ph_load_injected(cx, sh, lane, env); ph_late_stage(sh, rg, lane, fuse));
+        LS_PHASE(ph_heights_finish(cx, sh, rg, lane, env); ph_late_stage(sh, rg, lane, fuse));
+        LS_PHASE(ph_load_injected(cx, sh, lane, env));
     }
     // ---- post_physics_step (LR:178-228)
     LS_PHASE(ph_post_state(cx, sh, lane, env));
     LS_PHASE(ph_callback(cx, sh, lane, env, a, sh.ranges));
+    LS_CP(8);
 #if defined(LS_EXP_TWICE) && LS_EXP_TWICE == 9003      // cost probe: counter-based draws, so a second pass writes the same values
     LS_PHASE(ph_callback(cx, sh, lane, env, a, sh.ranges));
 #endif
-    LS_PHASE(ph_heights_finish(cx, sh, rg, lane, env));
     LS_PHASE(ph_termination(cx, sh, lane, env); ph_reward_parts(cx, sh, ls_part_items(sh), lane, env));
     LS_PHASE(ph_reward_terms(cx, sh, rg, lane, env));
 #if defined(LS_EXP_TWICE) && LS_EXP_TWICE == 9002      // cost probe (adds the step's rewards to the episode sums twice: statistics only)
     LS_PHASE(ph_reward_terms(cx, sh, rg, lane, env));
 #endif
     LS_PHASE(ph_reward_total(cx, sh, lane, env));
+    LS_CP(9);
     LS_PHASE(if (LS_UNIFORM(sh.reset)) ph_build_obs(cx, sh, lane, env, (uint32_t)a.step_counter, LSIM_RNG_TERM_NOISE, sh.cur, sh.jc_q0));
     LS_PHASE(ph_term_outputs(cx, sh, lane, env, a));
     if (fuse) {     // LR:229-241 + LR:167-171 for this robot (kernel B's phases; its cross-env part is lsim_k_step_finish)
@@ -691,13 +712,17 @@ template <int SOLVER> LS_WAVE_FN void ls_wave_step_a(const LsCtx& cx, const LsSt
         LS_PHASE(ph_b_reset_state(cx, sh, lane, env, a, sh.jc_q0));
         LS_PHASE(if (LS_UNIFORM(sh.do_reset) && c.measure_heights) ph_heights(cx, sh, lane, env, true, sh.mpx, sh.mpy));     // loads: ahead of reset_idx's stores and atomics
         LS_PHASE(ph_b_reset_store(cx, sh, lane, env, a); ph_tail_episode_stats(cx, sh, lane, env, a));
+        LS_CP(10);
         LS_PHASE(ph_build_obs(cx, sh, lane, env, (uint32_t)a.step_counter, LSIM_RNG_OBS_NOISE, sh.cur, sh.jc_q0));
+        LS_CP(11);
         LS_PHASE(ph_b_store(cx, sh, lane, env, a, ls_obs_hist(sh)));
+        LS_CP(12);
     }
     LS_TICK_FLUSH();
 #if defined(LS_WAVE_TIMES)
     if (lane0 == 0 && env < 65536) {
         g_ls_wave_times[4 * env + 0] = ls_wt0; g_ls_wave_times[4 * env + 1] = wall_clock64();
+        for (int i = 0; i < 16; ++i) g_ls_wave_cp[16 * env + i] = ls_cp[i];
         g_ls_wave_times[4 * env + 2] = clock64() - ls_wc0; g_ls_wave_times[4 * env + 3] = __builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 16);
     }
 #endif

@@ -421,71 +421,82 @@ LS_FN V3 ls_mesh_vertex(const lsim_config& c, int word, int a, int b) {
 //   wall path: closest point over the triangles of the 3x3 cells around the point in the displaced mesh (TER:72-75).  Only
 //   features within reach = radius + contact_offset can make a contact, so cells whose bounding box (grown by reach in x/y,
 //   and in +z) excludes the centre are skipped, as are triangles whose plane lies more than reach below the centre.
-LS_FN void ls_terrain_contact(const LsCtx& cx, V3 cw, float radius, float& dist, V3& n) {
+// In pieces, because the GPU spreads the wall path's 18 (cell, triangle) candidates of a point over the lanes of the wave (wc_wall_contacts
+// below) while the lane emulator and the single-point form walk them in order: the same arithmetic per candidate, the same winner.
+//
+// ls_terrain_fast: everything up to the decision.  true: (dist, n) are final; false: the point needs the wall path around cell (gi, gj).
+LS_FN bool ls_terrain_fast(const LsCtx& cx, V3 cw, float radius, float& dist, V3& n, int& gi, int& gj) {
     const lsim_config& c = cx.cfg;
-    if (c.mesh_type == 0) { dist = cw.z; n = v3(0, 0, 1); return; }
+    gi = 0; gj = 0;
+    if (c.mesh_type == 0) { dist = cw.z; n = v3(0, 0, 1); return true; }
     LS_GLOBAL const int* mesh = LS_G(const int, cx.buf[LSIM_BUF_TERRAIN_MESH]);
     const float hs = c.horizontal_scale, vs = c.vertical_scale;
     const float ihs = ls_rcp(hs);
     float gx = (cw.x + c.border_size) * ihs, gy = (cw.y + c.border_size) * ihs;
     float fi = clampf(floorf(gx), 0.0f, (float)(c.grid_rows - 2)), fj = clampf(floorf(gy), 0.0f, (float)(c.grid_cols - 2));
     int i = (int)fi, j = (int)fj;
+    gi = i; gj = j;
     const int w00 = mesh[i * c.grid_cols + j];
     {   // nothing within the 4 x 4 vertex block reaches up to the sphere (ls_api_impl.h: bits 24-31 = the block's highest vertex above this
         // one, rounded up): no contact, whatever the faces look like -- decided after this one load
         const int dz = (int)((unsigned int)w00 >> 24);
         const float top = ((float)(int16_t)(w00 & 0xFFFF) + (float)(dz * LSIM_MESH_DZ_UNIT)) * vs;
-        if (dz < 255 && cw.z - top > radius + c.contact_offset) { dist = cw.z - top; n = v3(0, 0, 1); return; }
+        if (dz < 255 && cw.z - top > radius + c.contact_offset) { dist = cw.z - top; n = v3(0, 0, 1); return true; }
     }
 #if defined(LS_NO_WALLS)   // A/B experiments only
     const bool walls = false;
 #else
     const bool walls = (w00 & (1 << 20)) != 0;
 #endif
-    if (!walls) {
-        float h00 = (float)(int16_t)(w00 & 0xFFFF) * vs, h10 = (float)(int16_t)(mesh[(i + 1) * c.grid_cols + j] & 0xFFFF) * vs;
-        float h01 = (float)(int16_t)(mesh[i * c.grid_cols + j + 1] & 0xFFFF) * vs;
-        float h11 = (float)(int16_t)(mesh[(i + 1) * c.grid_cols + j + 1] & 0xFFFF) * vs;
-        float u = clampf(gx - fi, 0.0f, 1.0f), v = clampf(gy - fj, 0.0f, 1.0f);
-        float dhx, dhy, h;
-        if (u >= v) { dhx = h10 - h00; dhy = h11 - h10; h = h00 + u * dhx + v * dhy; }
-        else { dhx = h11 - h01; dhy = h01 - h00; h = h00 + v * dhy + u * dhx; }
-        float nx = -dhx * ihs, ny = -dhy * ihs, inv = ls_rsqrt(nx * nx + ny * ny + 1.0f);
-        n = v3(nx * inv, ny * inv, inv);
-        dist = (cw.z - h) * inv;
-        return;
-    }
-    const float reach = radius + c.contact_offset;
+    if (walls) return false;
+    float h00 = (float)(int16_t)(w00 & 0xFFFF) * vs, h10 = (float)(int16_t)(mesh[(i + 1) * c.grid_cols + j] & 0xFFFF) * vs;
+    float h01 = (float)(int16_t)(mesh[i * c.grid_cols + j + 1] & 0xFFFF) * vs;
+    float h11 = (float)(int16_t)(mesh[(i + 1) * c.grid_cols + j + 1] & 0xFFFF) * vs;
+    float u = clampf(gx - fi, 0.0f, 1.0f), v = clampf(gy - fj, 0.0f, 1.0f);
+    float dhx, dhy, h;
+    if (u >= v) { dhx = h10 - h00; dhy = h11 - h10; h = h00 + u * dhx + v * dhy; }
+    else { dhx = h11 - h01; dhy = h01 - h00; h = h00 + v * dhy + u * dhx; }
+    float nx = -dhx * ihs, ny = -dhy * ihs, inv = ls_rsqrt(nx * nx + ny * ny + 1.0f);
+    n = v3(nx * inv, ny * inv, inv);
+    dist = (cw.z - h) * inv;
+    return true;
+}
+// one candidate cell of the wall path: cell number `cell` (0..8, row-major) of the 3 x 3 block around (gi, gj), its two triangles
+// (ind0, ind3, ind1) then (ind0, ind2, ind3).  Returns the smaller squared distance of cw to them (the first on a tie) -- 1e30 when the cell
+// lies outside the grid or out of reach, or both triangles are collapsed or have their plane out of reach below the centre -- with the
+// closest point q and the unit face normal fn.
+LS_FN float ls_wall_cell(const LsCtx& cx, V3 cw, float reach, int gi, int gj, int cell, V3& q, V3& fn) {
+    const lsim_config& c = cx.cfg;
+    LS_GLOBAL const int* mesh = LS_G(const int, cx.buf[LSIM_BUF_TERRAIN_MESH]);
+    q = v3(0, 0, 0); fn = v3(0, 0, 1);
     float best = 1e30f;
-    V3 bq = v3(0, 0, 0), bn = v3(0, 0, 1);
-    // rolled on purpose: 18 inlined copies of the triangle query cost 24 KB of code and 160 VGPRs
+    const int ci = gi - 1 + cell / 3, cj = gj - 1 + cell % 3;
+    if (ci < 0 || cj < 0 || ci > c.grid_rows - 2 || cj > c.grid_cols - 2) return best;
+    LS_GLOBAL const int* row = mesh + ci * c.grid_cols + cj;
+    V3 p00 = ls_mesh_vertex(c, row[0], ci, cj), p10 = ls_mesh_vertex(c, row[c.grid_cols], ci + 1, cj);
+    V3 p01 = ls_mesh_vertex(c, row[1], ci, cj + 1), p11 = ls_mesh_vertex(c, row[c.grid_cols + 1], ci + 1, cj + 1);
+    float xlo = fminf(fminf(p00.x, p10.x), fminf(p01.x, p11.x)), xhi = fmaxf(fmaxf(p00.x, p10.x), fmaxf(p01.x, p11.x));
+    float ylo = fminf(fminf(p00.y, p10.y), fminf(p01.y, p11.y)), yhi = fmaxf(fmaxf(p00.y, p10.y), fmaxf(p01.y, p11.y));
+    float zhi = fmaxf(fmaxf(p00.z, p10.z), fmaxf(p01.z, p11.z));
+    if (cw.x < xlo - reach || cw.x > xhi + reach || cw.y < ylo - reach || cw.y > yhi + reach || cw.z > zhi + reach) return best;
+    // rolled on purpose: two inlined copies of the triangle query per cell cost code and registers
 #pragma unroll 1
-    for (int cell = 0; cell < 9; ++cell) {
-        {
-            const int ci = i - 1 + cell / 3, cj = j - 1 + cell % 3;
-            if (ci < 0 || cj < 0 || ci > c.grid_rows - 2 || cj > c.grid_cols - 2) continue;
-            LS_GLOBAL const int* row = mesh + ci * c.grid_cols + cj;
-            V3 p00 = ls_mesh_vertex(c, row[0], ci, cj), p10 = ls_mesh_vertex(c, row[c.grid_cols], ci + 1, cj);
-            V3 p01 = ls_mesh_vertex(c, row[1], ci, cj + 1), p11 = ls_mesh_vertex(c, row[c.grid_cols + 1], ci + 1, cj + 1);
-            float xlo = fminf(fminf(p00.x, p10.x), fminf(p01.x, p11.x)), xhi = fmaxf(fmaxf(p00.x, p10.x), fmaxf(p01.x, p11.x));
-            float ylo = fminf(fminf(p00.y, p10.y), fminf(p01.y, p11.y)), yhi = fmaxf(fmaxf(p00.y, p10.y), fmaxf(p01.y, p11.y));
-            float zhi = fmaxf(fmaxf(p00.z, p10.z), fmaxf(p01.z, p11.z));
-            if (cw.x < xlo - reach || cw.x > xhi + reach || cw.y < ylo - reach || cw.y > yhi + reach || cw.z > zhi + reach) continue;
-#pragma unroll 1
-            for (int t = 0; t < 2; ++t) {
-                V3 a = p00, b = t == 0 ? p11 : p10, cc = t == 0 ? p01 : p11;   // (ind0,ind3,ind1) and (ind0,ind2,ind3)
-                V3 nt = cross(b - a, cc - a);
-                float nl2 = dot(nt, nt);
-                if (nl2 < 1e-16f) continue;                                   // collapsed triangle
-                float nl = sqrtf(nl2);
-                if (dot(nt, cw - a) > reach * nl) continue;                   // plane out of reach below the centre
-                V3 q = ls_closest_on_triangle(cw, a, b, cc);
-                V3 dq = cw - q;
-                float d2 = dot(dq, dq);
-                if (d2 < best) { best = d2; bq = q; bn = nt * ls_rcp(nl); }
-            }
-        }
+    for (int t = 0; t < 2; ++t) {
+        V3 a = p00, b = t == 0 ? p11 : p10, cc = t == 0 ? p01 : p11;
+        V3 nt = cross(b - a, cc - a);
+        float nl2 = dot(nt, nt);
+        if (nl2 < 1e-16f) continue;                                   // collapsed triangle
+        float nl = sqrtf(nl2);
+        if (dot(nt, cw - a) > reach * nl) continue;                   // plane out of reach below the centre
+        V3 qt = ls_closest_on_triangle(cw, a, b, cc);
+        V3 dq = cw - qt;
+        float d2 = dot(dq, dq);
+        if (d2 < best) { best = d2; q = qt; fn = nt * ls_rcp(nl); }
     }
+    return best;
+}
+// from the winning candidate (best = its squared distance; > 1e29: none) to (dist, n)
+LS_FN void ls_wall_finish(V3 cw, float radius, float best, V3 bq, V3 bn, float& dist, V3& n) {
     if (best > 1e29f) { dist = 1.0f + radius; n = v3(0, 0, 1); return; }
     float d = sqrtf(best);
     V3 dq = cw - bq;
@@ -493,6 +504,24 @@ LS_FN void ls_terrain_contact(const LsCtx& cx, V3 cw, float radius, float& dist,
     if (side < -1e-6f) { dist = -d; n = bn; }                  // centre behind the face: inside the ground
     else if (d > 1e-6f) { dist = d; n = dq * ls_rcp(d); }
     else { dist = 0.0f; n = bn; }
+}
+// the wall path of one point, cells in order (the first strict minimum wins)
+LS_FN void ls_wall_serial(const LsCtx& cx, V3 cw, float radius, int gi, int gj, float& dist, V3& n) {
+    const float reach = radius + cx.cfg.contact_offset;
+    float best = 1e30f;
+    V3 bq = v3(0, 0, 0), bn = v3(0, 0, 1);
+    // rolled on purpose: nine inlined copies of the cell query cost 24 KB of code and 160 VGPRs
+#pragma unroll 1
+    for (int cell = 0; cell < 9; ++cell) {
+        V3 q, fn;
+        const float d2 = ls_wall_cell(cx, cw, reach, gi, gj, cell, q, fn);
+        if (d2 < best) { best = d2; bq = q; bn = fn; }
+    }
+    ls_wall_finish(cw, radius, best, bq, bn, dist, n);
+}
+LS_FN void ls_terrain_contact(const LsCtx& cx, V3 cw, float radius, float& dist, V3& n) {
+    int gi, gj;
+    if (!ls_terrain_fast(cx, cw, radius, dist, n, gi, gj)) ls_wall_serial(cx, cw, radius, gi, gj, dist, n);
 }
 
 // ---- the collision point's constants (lane = point): re-read from the cache-resident model every sub-step rather than held in registers through
@@ -504,15 +533,74 @@ LS_FN void ph_collide_prefetch(const LsCtx& cx, LaneRegs& r, int lane) {
     for (int k = 0; k < 3; ++k) r.cp_pos[k] = cp.pos[k];
 }
 // ---- phase P: narrow phase, one collision point per lane
+#if !defined(LS_EMU) && defined(__HIP_DEVICE_COMPILE__)
+// Wall path of the points in `mask` (lane = point; `mine`: this lane is one of them), all lanes of the wave at work: a point's nine cells
+// walked by its own lane while the lanes without a wall wait was the slowest thing a wave could meet (stairs: the 1-2 % of the waves with
+// feet at a riser ended 40 us after the median wave; 0.131 ms per launch against 0.110 on the flat task).  Seven points per round: their
+// owners post (centre, reach, cell), lane 9 o + k evaluates cell k of owner o, the owners pick the first strict minimum of their nine
+// results -- the order and the arithmetic of ls_wall_serial.  Scratch: the spatial-inertia array, dead between the composite pass and the
+// row build.  With most of the wave in the wall path (a robot lying on a staircase) the rounds stop paying: every lane walks its own cells.
+#define LS_WALL_OWNERS 7
+__device__ __forceinline__ void wc_wall_contacts(const LsCtx& cx, WaveShared& sh, int lane, bool mine, unsigned long long mask, V3 cw, float radius, int gi, int gj,
+                                                 float& dist, V3& n) {
+    float* own = &sh.u.I6[0][0];                  // [7][8]: cw.x, cw.y, cw.z, reach, gi, gj
+    float* res = own + 8 * LS_WALL_OWNERS;        // [63][8]: d2, q.xyz, fn.xyz
+    static_assert(sizeof(sh.u.I6) >= (8 * LS_WALL_OWNERS + 9 * LS_WALL_OWNERS * 8) * sizeof(float), "scratch of the wall path");
+    const int m = __popcll(mask);
+    if (m > 5 * LS_WALL_OWNERS) {                 // wave-uniform
+        if (mine) ls_wall_serial(cx, cw, radius, gi, gj, dist, n);
+        return;
+    }
+    const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+    const float reach = radius + cx.cfg.contact_offset;
+    for (int c0 = 0; c0 < m; c0 += LS_WALL_OWNERS) {
+        const bool posting = mine && rank >= c0 && rank < c0 + LS_WALL_OWNERS;
+        if (posting) {
+            float* o = own + 8 * (rank - c0);
+            o[0] = cw.x; o[1] = cw.y; o[2] = cw.z; o[3] = reach; o[4] = __int_as_float(gi); o[5] = __int_as_float(gj);
+        }
+        __syncthreads();
+        {
+            const int o = lane / 9, k = lane - 9 * o;
+            if (lane < 9 * LS_WALL_OWNERS && c0 + o < m) {
+                const float* od = own + 8 * o;
+                V3 q, fn;
+                const float d2 = ls_wall_cell(cx, v3(od[0], od[1], od[2]), od[3], __float_as_int(od[4]), __float_as_int(od[5]), k, q, fn);
+                float* r = res + 8 * lane;
+                r[0] = d2; r[1] = q.x; r[2] = q.y; r[3] = q.z; r[4] = fn.x; r[5] = fn.y; r[6] = fn.z;
+            }
+        }
+        __syncthreads();
+        if (posting) {
+            const float* r = res + 8 * 9 * (rank - c0);
+            float best = 1e30f;
+            int win = 0;
+            for (int k = 0; k < 9; ++k) { const float d2 = r[8 * k]; if (d2 < best) { best = d2; win = k; } }
+            const float* w = r + 8 * win;
+            ls_wall_finish(cw, radius, best, v3(w[1], w[2], w[3]), v3(w[4], w[5], w[6]), dist, n);
+        }
+        __syncthreads();
+    }
+}
+#endif
 LS_FN void ph_collide(const LsCtx& cx, WaveShared& sh, LaneRegs& r, int lane) {
     r.cp_active = 0;
-    if (lane >= cx.model.num_collision_points) return;
+    const bool has = lane < cx.model.num_collision_points;
     const int b = r.cp_body;
     const float cp_r = r.cp_r;
     V3 pw = mul(m3p(sh.R[b]), v3(r.cp_pos[0], r.cp_pos[1], r.cp_pos[2])) + v3p(sh.p[b]);
-    float d;
-    V3 n;
-    ls_terrain_contact(cx, v3(sh.root[0] + pw.x, sh.root[1] + pw.y, sh.root[2] + pw.z), cp_r, d, n);
+    const V3 cw = v3(sh.root[0] + pw.x, sh.root[1] + pw.y, sh.root[2] + pw.z);
+    float d = 1.0f;
+    V3 n = v3(0, 0, 1);
+    int gi = 0, gj = 0;
+    const bool walls = has && !ls_terrain_fast(cx, cw, cp_r, d, n, gi, gj);
+#if !defined(LS_EMU) && defined(__HIP_DEVICE_COMPILE__) && !defined(LS_SERIAL_WALLS)
+    const unsigned long long mask = __ballot(walls);
+    if (mask != 0ull) wc_wall_contacts(cx, sh, lane, walls, mask, cw, cp_r, gi, gj, d, n);      // wave-uniform branch
+#else
+    if (walls) ls_wall_serial(cx, cw, cp_r, gi, gj, d, n);
+#endif
+    if (!has) return;
     float dist = d - cp_r;
     if (dist < cx.cfg.contact_offset) {
         r.cp_active = 1;
@@ -1220,15 +1308,12 @@ LS_FN void ph_integrate_tgs(const LsCtx& cx, WaveShared& sh, int lane, float dt,
 }
 
 // ---- phase B: world state of every body (rigid_body_states, LR:938) from the kinematics phase (lane = body)
-LS_FN void ph_body_states(WaveShared& sh, int lane, LS_GLOBAL float* out /* [17][13] of this env */, float* pos_vel /* [6]: the body's world position and linear velocity */) {
+LS_FN void ph_body_states(WaveShared& sh, int lane, float* o /* [13]: this body's row of the rigid-body state tensor (position, quaternion, linear, angular velocity) */) {
     if (lane >= LS_NB) return;
-    LS_GLOBAL float* o = out + 13 * lane;
     V3 p = v3p(sh.p[lane]);
     S6 V = s6p(sh.V[lane]);
     V3 vel = V.l + cross(V.a, p);
     o[0] = sh.root[0] + p.x; o[1] = sh.root[1] + p.y; o[2] = sh.root[2] + p.z;
-    pos_vel[0] = sh.root[0] + p.x; pos_vel[1] = sh.root[1] + p.y; pos_vel[2] = sh.root[2] + p.z;
-    v3st(pos_vel + 3, vel);
     float q4[4];
     if (lane == 0) { for (int k = 0; k < 4; ++k) q4[k] = sh.root[3 + k]; }
     else R_to_quat(m3p(sh.R[lane]), q4);

@@ -191,6 +191,7 @@ struct LaneRegs {
     float hist[4];           // kernel A with the fused tail: the 225 observation-history values on their way from global memory to LDS
     uint32_t items[LS_MAX_PART_ITEMS / 64];   // kernel A: the reward part items on the same way (a register each: see hraw) (ph_late_load -> ph_late_stage)
     int hraw[2 * ((LSIM_NUM_HEIGHT_PTS + 63) / 64 + 1)];   // kernel A (one register per sample: packing two would wait for the loads): raw grid samples of this lane's height points (ph_heights_issue -> ph_heights_finish)
+    float bs[13];            // kernel A, lane = body: its row of the rigid-body state tensor between ph_body_states_all and ph_store_body_states
     int term_id;             // kernel A: active reward term owned by this lane in ph_reward_terms and its scale (fetched before the first store)
     float term_scale;
 #if defined(LS_EMU)

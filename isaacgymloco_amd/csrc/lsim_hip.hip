@@ -236,4 +236,8 @@ extern "C" int lsim_debug_read_wave_times(unsigned long long* out, int n) {
     if (hipDeviceSynchronize() != hipSuccess) return 1;
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ls_wave_times), (size_t)4 * n * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
 }
+extern "C" int lsim_debug_read_wave_checkpoints(unsigned int* out, int n) {
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ls_wave_cp), (size_t)16 * n * sizeof(unsigned int)) == hipSuccess ? 0 : 1;
+}
 #endif

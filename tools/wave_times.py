@@ -71,6 +71,15 @@ def main():
         print("          slowest 12: " + " ".join(f"{dur[i]:.0f}us/c{nc[i]}{'R' if rst[i] else ''}/x{xcc[i]}" for i in worst))
         mates = np.array([ds[i:i + c].sum() for i, c in zip(idx, cnt)])
         print(f"          sum of the four durations per SIMD {q(mates)}; r(last end per SIMD, that sum) = {np.corrcoef(per, mates)[0, 1]:.2f}")
+        cpb = (ctypes.c_uint * (16 * N))()
+        if L.lsim_debug_read_wave_checkpoints(cpb, N) == 0:
+            cp = np.frombuffer(cpb, dtype=np.uint32).reshape(N, 16).astype(np.float64)
+            ghz = np.median(a[:, 2] / dur / 1e3)
+            names = ["load", "sub-step 0", "sub-step 1", "sub-step 2", "sub-step 3", "final kinematics + load issue", "body states + loads consumed", "state stores",
+                     "derived state + callback", "termination + rewards", "term. obs + reset path", "observation build", "observation / last_* stores"]
+            seg = np.diff(np.concatenate([np.zeros((N, 1)), cp[:, :13]], axis=1), axis=1) / (ghz * 1e3)
+            ok = ~rst
+            print("          segments, mean us (not resetting | resetting): " + "; ".join(f"{nm} {seg[ok, i].mean():.1f}|{seg[rst, i].mean() if rst.any() else 0:.1f}" for i, nm in enumerate(names)))
         byx = [f"{end[xcc == x].max():.1f}" for x in np.unique(xcc)]
         print(f"          last end per XCD: {' '.join(byx)}")
 
