@@ -645,14 +645,15 @@ template <int SOLVER> LS_WAVE_FN void ls_wave_step_a(const LsCtx& cx, const LsSt
         LS_PHASE(ph_base_factor(sh, lane));
         LS_PHASE(ph_free_leg(sh, lane));
         LS_PHASE(ph_free_base(sh, lane));
-        LS_PHASE(ph_free_finish(sh, lane, dt); ph_collide_prefetch(cx, rg, lane); ph_collide(cx, sh, rg, lane));
+        bool walls = false;       // a point of this robot is in the wall path of the narrow phase (stair risers)
+        LS_PHASE(ph_free_finish(sh, lane, dt); ph_collide_prefetch(cx, rg, lane); walls |= ph_collide(cx, sh, rg, lane));
         LS_COLLECTIVE(wc_compact_contacts(sh, rg, lane); wc_limits(cx, sh, lane, dt), wc_compact_contacts(sh, L); LS_PHASE(ph_limits(cx, sh, lane, dt)));
         // A launch of <= 4096 robots is ONE round of waves, over when its slowest wave is: the median wave needs 83 us, one with 8 contacts 97
         // (2.3 us per contact: rows, Delassus entries, relaxations), the kernel 117 (tools/wave_times.py).  The more contacts a robot has in
         // this sub-step, the higher its wave's issue priority over the three it shares a SIMD with, which have the slack: kernel A 0.1176 ->
         // 0.1104 ms on the flat task, 0.1405 -> 0.1298 on stairs (LSIM_STEP_FLAT_PRIORITY switches it off).  Results do not change.
         if (!(a.flags & LSIM_STEP_FLAT_PRIORITY)) {
-            const int ncu = LS_UNIFORM(sh.nc);
+            const int ncu = LS_UNIFORM(sh.nc) + (walls ? 2 : 0);      // a point in the wall path of the narrow phase counts like two contacts (stairs: -1.2 %)
             if (ncu >= 5) LS_SETPRIO(3); else if (ncu >= 3) LS_SETPRIO(2); else if (ncu >= 1) LS_SETPRIO(1); else LS_SETPRIO(0);
         }
         LS_PHASE(ph_rows<TGS>(cx, sh, rg, lane, dt));

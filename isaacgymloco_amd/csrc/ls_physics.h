@@ -583,7 +583,8 @@ __device__ __forceinline__ void wc_wall_contacts(const LsCtx& cx, WaveShared& sh
     }
 }
 #endif
-LS_FN void ph_collide(const LsCtx& cx, WaveShared& sh, LaneRegs& r, int lane) {
+// returns whether any point of the wave took the wall path (GPU: wave-uniform; lane emulator: this lane's point)
+LS_FN bool ph_collide(const LsCtx& cx, WaveShared& sh, LaneRegs& r, int lane) {
     r.cp_active = 0;
     const bool has = lane < cx.model.num_collision_points;
     const int b = r.cp_body;
@@ -597,10 +598,12 @@ LS_FN void ph_collide(const LsCtx& cx, WaveShared& sh, LaneRegs& r, int lane) {
 #if !defined(LS_EMU) && defined(__HIP_DEVICE_COMPILE__) && !defined(LS_SERIAL_WALLS)
     const unsigned long long mask = __ballot(walls);
     if (mask != 0ull) wc_wall_contacts(cx, sh, lane, walls, mask, cw, cp_r, gi, gj, d, n);      // wave-uniform branch
+    const bool any_walls = mask != 0ull;
 #else
     if (walls) ls_wall_serial(cx, cw, cp_r, gi, gj, d, n);
+    const bool any_walls = walls;
 #endif
-    if (!has) return;
+    if (!has) return any_walls;
     float dist = d - cp_r;
     if (dist < cx.cfg.contact_offset) {
         r.cp_active = 1;
@@ -608,6 +611,7 @@ LS_FN void ph_collide(const LsCtx& cx, WaveShared& sh, LaneRegs& r, int lane) {
         v3st(r.cp_n, n);
         v3st(r.cp_x, pw - n * cp_r);
     }
+    return any_walls;
 }
 
 // ---- wave collective: ordered compaction of the active points into at most LS_MAXC contacts

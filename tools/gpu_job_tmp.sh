@@ -1,8 +1,10 @@
 #!/bin/bash
 export TMPDIR=/tmp
 ulimit -c 0
-O=gpurun_out/r04w; mkdir -p $O
-timeout 1500 python -m pytest tests -m gpu -q -x > $O/gpu_tests.log 2>&1; tail -3 $O/gpu_tests.log
-timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
-for t in 1 2; do timeout 600 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('train', round(d['value']), d.get('collection_s_per_iteration'), d.get('learn_s_per_update'))"; done
-timeout 600 python bench.py --task aliengo_stairs --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('train stairs', round(d['value']), d.get('collection_s_per_iteration'), d.get('learn_s_per_update'))"
+line() { timeout 300 python bench.py --mode env "$@" --steps 1000 --warmup 100 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value']), 'A', round(d['kernel_a_ms'],4), 'B', round(d['kernel_b_ms'],4))" 2>/dev/null || echo failed; }
+for rep in 1 2 3; do
+for fl in 0 256 512 768; do
+  echo "flags $fl flat:   $(LSIM_STEP_FLAGS=$fl line)"
+  echo "flags $fl stairs: $(LSIM_STEP_FLAGS=$fl line --task aliengo_stairs)"
+done
+done

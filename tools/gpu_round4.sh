@@ -15,6 +15,8 @@ b bench_driver_args timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 -
 b bench_env timeout 600 python bench.py --mode env --steps 500 --warmup 50 --no-cpu-baseline
 LSIM_SOLVER=pgs b bench_env_pgs timeout 600 python bench.py --mode env --steps 500 --warmup 50 --no-cpu-baseline
 LSIM_SOLVER=pgs b bench_default_pgs timeout 600 python bench.py --no-cpu-baseline
+LSIM_STEP_FLAGS=16 b bench_env_flat_priority timeout 600 python bench.py --mode env --steps 500 --warmup 50 --no-cpu-baseline
+LSIM_STEP_FLAGS=16 b bench_env_aliengo_stairs_flat_priority timeout 300 python bench.py --mode env --task aliengo_stairs --steps 500 --warmup 50 --no-cpu-baseline
 b bench_env_N262144 timeout 300 python bench.py --mode env --envs 262144 --steps 50 --warmup 10 --no-cpu-baseline
 b bench_env_zero_actions timeout 300 python bench.py --mode env --actions zeros --steps 500 --warmup 50 --no-cpu-baseline
 b bench_env_N64 timeout 300 python bench.py --mode env --envs 64 --steps 500 --warmup 50 --no-cpu-baseline
@@ -30,6 +32,9 @@ b bench_plain_again timeout 600 python bench.py --no-cpu-baseline
 timeout 120 tools/micro/valu_peak > $O/valu_peak.json 2>/dev/null
 timeout 300 python tools/phase_profile.py aliengo 4096 > $O/phase_profile_aliengo.txt 2>&1
 timeout 300 python tools/phase_profile.py aliengo_stairs 4096 > $O/phase_profile_aliengo_stairs.txt 2>&1
+timeout 300 python tools/wave_times.py aliengo 4096 > $O/wave_times_aliengo.txt 2>&1
+timeout 300 python tools/wave_times.py aliengo_stairs 4096 > $O/wave_times_aliengo_stairs.txt 2>&1
+timeout 300 python tools/wave_times.py aliengo 256 > $O/wave_times_aliengo_N256.txt 2>&1
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_env -o env -- python3 $R/bench.py --mode env --steps 100 --warmup 20 --no-cpu-baseline > $R/$O/prof_env.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_env_stairs -o env_stairs -- python3 $R/bench.py --mode env --task aliengo_stairs --steps 100 --warmup 20 --no-cpu-baseline > $R/$O/prof_env_stairs.log 2>&1
