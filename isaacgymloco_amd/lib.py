@@ -16,12 +16,17 @@ class LsimError(RuntimeError):
 
 def load():
     global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise LsimError(f"{LIB_PATH} not found: build the HIP extension first (python -m isaacgymloco_amd.csrc.build); "
+    if _lib is None:
+        _lib = load_path(LIB_PATH)
+    return _lib
+
+
+def load_path(path):
+    """a build of the HIP library at `path`, prototypes set (load() = the product build, cached; tests load diagnostics variants beside it)"""
+    if not os.path.exists(path):
+        raise LsimError(f"{path} not found: build the HIP extension first (python -m isaacgymloco_amd.csrc.build); "
                         "there is no CPU fallback for the simulator")
-    L = ctypes.CDLL(LIB_PATH)
+    L = ctypes.CDLL(path)
     abi.check_abi(L, prefix="lsim")
     L.lsim_abi_version.restype = ctypes.c_int
     if L.lsim_abi_version() != abi.ABI_VERSION:
@@ -69,7 +74,6 @@ def load():
     L.lsim_linear_elu_wgrad.argtypes = [vp, i64, vp, i64, vp, i64, i64, i32, i32, vp, vp, vp, vp, ctypes.c_size_t, vp]
     L.lsim_destroy.argtypes = [vp]
     L.lsim_destroy.restype = None
-    _lib = L
     return L
 
 
