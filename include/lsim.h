@@ -421,8 +421,9 @@ int lsim_reset_all(lsim_handle h, void* hip_stream);
  * clears, extras["episode"] sums into the stats row, episode_length_buf = 0.  reset_mask_dev: device uint8 [N], nonzero = reset this env
  * (the boolean form of env_ids; it is read by the kernels of this call only).  An all-zero mask is the reference's early return
  * (LR:298): only the stats rows swap, with a reset count of 0.  As after lsim_reset_all, observations are not recomputed (the reference
- * does not either): they are those of the next lsim_step.  Random draws are keyed by (env, common_step_counter), like the reset tail of
- * a step: resetting the same env twice between two steps redraws the same state.  Asynchronous on hip_stream. */
+ * does not either): they are those of the next lsim_step.  Random draws are keyed by (env, common_step_counter, number of lsim_reset_envs
+ * calls on this handle so far): every call draws fresh values, as every reset_idx of the reference does -- resetting an env that already
+ * reset in the adjacent step, or the same env twice between two steps, gives it a new state each time.  Asynchronous on hip_stream. */
 int lsim_reset_envs(lsim_handle h, const uint8_t* reset_mask_dev, void* hip_stream);
 
 /* LeggedRobot.step(actions) (LR:122-176): replaces set_dof_actuation_force_tensor/simulate/fetch_results/

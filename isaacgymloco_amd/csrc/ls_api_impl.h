@@ -25,6 +25,7 @@ struct lsim_sim {
     size_t offsets[LSIM_NUM_BUFFERS];
     int device_id;
     int64_t step_counter;
+    uint32_t reset_calls;   // lsim_reset_envs calls so far (salt of their random draws)
     int init_done;
     int stats_row;
     void* prof;        // backend-owned profiling state (HIP events), may be null
@@ -276,6 +277,7 @@ extern "C" int LS_API(reset_envs)(lsim_sim* s, const uint8_t* mask_dev, void* st
     memset(&a, 0, sizeof(a));
     a.actions = nullptr; a.step_counter = s->step_counter; a.flags = 0; a.init_done = s->init_done;
     a.row_in = s->stats_row; a.row_out = s->stats_row ^ 1; a.reset_all = 2; a.reset_mask = mask_dev;
+    a.rng_salt = (++s->reset_calls) * 0x9E3779B9u;
     s->stats_row = a.row_out;
     if (lsbk_launch_reduce(s, a, stream) != 0) LS_FAIL(s, LSIM_E_HIP, "reduction kernel launch failed");
     if (lsbk_launch_b(s, a, stream) != 0) LS_FAIL(s, LSIM_E_HIP, "reset kernel launch failed");

@@ -391,7 +391,7 @@ LS_FN void ph_b_terrain_curriculum(const LsCtx& cx, WaveShared& sh, int lane, in
     int up = dist > c.terrain_length / 2.0f;
     int down = (dist < sqrtf(sh.cmd[0] * sh.cmd[0] + sh.cmd[1] * sh.cmd[1]) * c.episode_length_s * 0.5f) && !up;
     int64_t lvl = (int64_t)sh.pre_level + (int64_t)up - (int64_t)down;
-    if (lvl >= c.terrain_num_rows) lvl = (int64_t)(ls_draw(cx, env, (uint32_t)a.step_counter, LSIM_RNG_RESET_LEVEL, 0) * (float)c.terrain_num_rows);
+    if (lvl >= c.terrain_num_rows) lvl = (int64_t)(ls_draw(cx, env, (uint32_t)a.step_counter ^ a.rng_salt, LSIM_RNG_RESET_LEVEL, 0) * (float)c.terrain_num_rows);
     else if (lvl < 0) lvl = 0;
     LS_GLOBAL const float* to = LSB(cx, LSIM_BUF_TERRAIN_ORIGINS, float) + (lvl * c.terrain_num_cols + (int64_t)sh.pre_type) * 3;
     float o[3];
@@ -410,7 +410,7 @@ LS_FN void ph_b_terrain_curriculum(const LsCtx& cx, WaveShared& sh, int lane, in
 LS_FN void ph_b_reset_state(const LsCtx& cx, WaveShared& sh, int lane, int env, const LsStepArgs& a, const float* q0 /* default_dof_pos: LDS copy or the config's */) {
     if (!LS_UNIFORM(sh.do_reset)) return;          // wave-uniform: a scalar branch, nothing of the body is issued for the other waves
     const lsim_config& c = cx.cfg;
-    const uint32_t stepw = (uint32_t)a.step_counter;
+    const uint32_t stepw = (uint32_t)a.step_counter ^ a.rng_salt;
     if (lane < 12) {  // _reset_dofs (LR:690-716)
         float pos = q0[lane];
         if (c.has_dof_init_pos_ratio)
@@ -449,7 +449,7 @@ LS_FN void ph_b_reset_state(const LsCtx& cx, WaveShared& sh, int lane, int env, 
 LS_FN void ph_b_reset_store(const LsCtx& cx, WaveShared& sh, int lane, int env, const LsStepArgs& a) {
     if (!LS_UNIFORM(sh.do_reset)) return;          // wave-uniform: a scalar branch, nothing of the body is issued for the other waves
     const lsim_config& c = cx.cfg;
-    const uint32_t stepw = (uint32_t)a.step_counter;
+    const uint32_t stepw = (uint32_t)a.step_counter ^ a.rng_salt;
     if (lane < 12) {
         LS_GLOBAL float* dof = LSB(cx, LSIM_BUF_DOF_STATE, float) + 24 * env;
         dof[2 * lane] = sh.dofs[2 * lane]; dof[2 * lane + 1] = sh.dofs[2 * lane + 1];

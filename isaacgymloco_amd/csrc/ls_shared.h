@@ -66,6 +66,8 @@ struct LsStepArgs {
     int32_t reset_all;        // kernel B only.  0: the reset tail of a step; 1: a bare reset_idx(all) (BaseTask.reset, BT:113);
                               // 2: a bare reset_idx(env_ids) (LR:290) on the envs flagged in reset_mask
     const uint8_t* reset_mask; // reset_all == 2: u8 [num_envs] on the device, nonzero = reset this env
+    uint32_t rng_salt;        // xor-ed into the step word of reset_idx's draws: 0 inside a step and for lsim_reset_all; a multiple of the golden ratio
+                              // per lsim_reset_envs call, so that by-hand resets never repeat the adjacent step's draws or each other's
     int32_t fuse_tail;        // kernel A only.  1: this wave also runs kernel B's per-env work for its robot (reset_idx, observations, last_* roll)
                               // and the step's cross-env leftovers go to lsim_k_step_finish; 0: kernel B follows (command-curriculum steps)
 };

@@ -840,7 +840,7 @@ int orc_reset_envs(orc_sim* s, const uint8_t* mask) { /* LR:290: reset_idx(env_i
     st[LSIM_STATS_RESET_COUNT] = 0.0f;
     for (int k = 0; k < LSIM_NUM_REWARD_TERMS; ++k) st[LSIM_STATS_EPISODE_SUMS + k] = 0.0f;
     refresh_stats_ranges(s);
-    reset_idx(s, mask, n, (uint32_t)s->step_counter);
+    reset_idx(s, mask, n, (uint32_t)s->step_counter ^ ((++s->reset_calls) * 0x9E3779B9u));
     return LSIM_OK;
 }
 

@@ -10,6 +10,7 @@ typedef struct orc_sim {
     lsim_robot_model model;
     void* buf[LSIM_NUM_BUFFERS];
     int64_t step_counter;       /* common_step_counter, LR:948 */
+    uint32_t reset_calls;       /* orc_reset_envs calls so far: salt of their random draws (include/lsim.h: lsim_reset_envs) */
     int init_done;              /* LR:97, LR:116 */
     int stats_row;              /* row of LSIM_BUF_STATS filled by the latest call */
     double command_ranges[4][2];/* python floats in the reference (LR:1256) */

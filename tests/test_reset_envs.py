@@ -112,7 +112,19 @@ def _check(orc, be, get, put, stats_row, set_counter, exact=True):
     _compare(orc, get, stats_row, mask, before, "empty", exact)
     for k in SYNC:
         np.testing.assert_array_equal(get(k), before[k], err_msg=f"empty: {k}")
-    # 5: every env through the mask form equals reset_idx(all)
+    # 4b: every by-hand call draws fresh values (include/lsim.h: the draws are salted with the handle's call count): the same robots
+    #     reset twice between two steps get two different states
+    mask = np.zeros(N, np.uint8); mask[[1, 2, 7]] = 1
+    before = snapshot()
+    orc.reset_envs(mask); be.reset_envs(mask)
+    _compare(orc, get, stats_row, mask, before, "by hand, first", exact)
+    first = {k: orc.buf[k][mask == 1].copy() for k in ("dof_state", "root_states", "commands", "kp_factors")}
+    before = snapshot()
+    orc.reset_envs(mask); be.reset_envs(mask)
+    _compare(orc, get, stats_row, mask, before, "by hand, again", exact)
+    for k, v in first.items():
+        assert not np.array_equal(orc.buf[k][mask == 1], v), f"{k}: the second by-hand reset repeated the first"
+    # 5: every env through the mask form equals reset_idx(all) in everything that is not drawn (the by-hand call salts its draws)
     orc.step_counter = c.max_episode_length + 1; set_counter(c.max_episode_length + 1)
     mask = np.ones(N, np.uint8)
     before = snapshot()
@@ -122,8 +134,10 @@ def _check(orc, be, get, put, stats_row, set_counter, exact=True):
     for k in SYNC:
         orc.buf[k][...] = before[k]; put(k, before[k])
     orc.reset_all(); be.reset_all()
-    for k in EXACT:
+    for k in ("last_actions", "last_last_actions", "last_dof_pos", "last_dof_vel", "last_torques", "episode_length", "feet_air_time", "episode_sums",
+              "reset", "extras_time_outs", "obs"):
         np.testing.assert_array_equal(get(k), snap[k], err_msg=f"reset_all vs mask of ones: {k}")
+    assert not np.array_equal(get("dof_state"), snap["dof_state"])
 
 
 def test_emu_reset_envs_matches_oracle():

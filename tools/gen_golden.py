@@ -490,7 +490,10 @@ def run_scenario(name, task, ref_cfg_cls, N, segments, seed=1, tweak=None, using
         pack["fin_counter"] = np.int64(env.common_step_counter)
         pack["fin_ranges_before"] = np.array([env.command_ranges[k] for k in ("lin_vel_x", "lin_vel_y", "ang_vel_yaw", "heading")], dtype=np.float64)
         before = capture(env, tensors, N)
-        env.reset_idx(torch.from_numpy(ids))          # draws keyed by the step word of the last step (CTX.stepw), as lsim_reset_envs keys them
+        # draws keyed as lsim_reset_envs keys them: the step word of the last step, salted with the handle's by-hand-reset count
+        # (the first such call here: 1 x 0x9E3779B9 -- include/lsim.h)
+        CTX.stepw = (int(CTX.stepw) ^ 0x9E3779B9) & 0xFFFFFFFF
+        env.reset_idx(torch.from_numpy(ids))
         after = capture(env, tensors, N)
         for k in ("commands", "root_states", "dof_state", "terrain_levels", "env_origins", "episode_length", "kp_factors", "kd_factors", "friction",
                   "last_actions", "last_last_actions", "last_dof_vel", "feet_air_time", "reset", "extras_time_outs", "time_out", "episode_sums",
