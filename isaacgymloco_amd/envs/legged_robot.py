@@ -41,7 +41,7 @@ from .terrain import Terrain
 _TORCH_DT = {abi.DT_F32: torch.float32, abi.DT_I64: torch.int64, abi.DT_U8: torch.uint8, abi.DT_I32: torch.int32, abi.DT_I16: torch.int16}
 
 
-# measurement hook: LSIM_STEP_* bits or-ed into every step (e.g. LSIM_STEP_FLAGS=16: the separate finish kernel; 8: kernels A + B on every step)
+# measurement hook: LSIM_STEP_* bits or-ed into every step (LSIM_STEP_FLAGS=16: kernel A without the contact-count wave priorities; 8: kernels A + B on every step)
 _EXTRA_STEP_FLAGS = int(os.environ.get("LSIM_STEP_FLAGS", "0"), 0)
 
 class LeggedRobot:
