@@ -707,11 +707,14 @@ template <int SOLVER> LS_WAVE_FN void ls_wave_step_a(const LsCtx& cx, const LsSt
     LS_CP(9);
     LS_PHASE(if (LS_UNIFORM(sh.reset)) ph_build_obs(cx, sh, lane, env, (uint32_t)a.step_counter, LSIM_RNG_TERM_NOISE, sh.cur, sh.jc_q0));
     LS_PHASE(ph_term_outputs(cx, sh, lane, env, a));
+    LS_CP(13);
     if (fuse) {     // LR:229-241 + LR:167-171 for this robot (kernel B's phases; its cross-env part is lsim_k_step_finish)
         LS_PHASE(ph_tail_setup(cx, sh, lane, a));
         LS_PHASE(ph_b_terrain_curriculum(cx, sh, lane, env, a));
         LS_PHASE(ph_b_reset_state(cx, sh, lane, env, a, sh.jc_q0));
+        LS_CP(14);
         LS_PHASE(if (LS_UNIFORM(sh.do_reset) && c.measure_heights) ph_heights(cx, sh, lane, env, true, sh.mpx, sh.mpy));     // loads: ahead of reset_idx's stores and atomics
+        LS_CP(15);
         LS_PHASE(ph_b_reset_store(cx, sh, lane, env, a); ph_tail_episode_stats(cx, sh, lane, env, a));
         LS_CP(10);
         LS_PHASE(ph_build_obs(cx, sh, lane, env, (uint32_t)a.step_counter, LSIM_RNG_OBS_NOISE, sh.cur, sh.jc_q0));

@@ -78,6 +78,10 @@ def main():
             names = ["load", "sub-step 0", "sub-step 1", "sub-step 2", "sub-step 3", "final kinematics + load issue", "body states + loads consumed", "state stores",
                      "derived state + callback", "termination + rewards", "term. obs + reset path", "observation build", "observation / last_* stores"]
             seg = np.diff(np.concatenate([np.zeros((N, 1)), cp[:, :13]], axis=1), axis=1) / (ghz * 1e3)
+            if rst.any():       # inside the reset path (checkpoints 13-15 sit between 9 and 10)
+                r = cp[rst] / (ghz * 1e3)
+                print(f"          resetting waves, mean us: termination obs build + rows {np.mean(r[:, 13] - r[:, 9]):.1f}; tail set-up + curriculum + new state "
+                      f"{np.mean(r[:, 14] - r[:, 13]):.1f}; terrain under the new pose {np.mean(r[:, 15] - r[:, 14]):.1f}; stores + episode sums {np.mean(r[:, 10] - r[:, 15]):.1f}")
             ok = ~rst
             print("          segments, mean us (not resetting | resetting): " + "; ".join(f"{nm} {seg[ok, i].mean():.1f}|{seg[rst, i].mean() if rst.any() else 0:.1f}" for i, nm in enumerate(names)))
         byx = [f"{end[xcc == x].max():.1f}" for x in np.unique(xcc)]
