@@ -395,7 +395,7 @@ LS_FN void ph_b_terrain_curriculum(const LsCtx& cx, WaveShared& sh, int lane, in
     else if (lvl < 0) lvl = 0;
     LS_GLOBAL const float* to = LSB(cx, LSIM_BUF_TERRAIN_ORIGINS, float) + (lvl * c.terrain_num_cols + (int64_t)sh.pre_type) * 3;
     float o[3];
-    for (int k = 0; k < 3; ++k) o[k] = ls_uniform_load(to + k);
+    ls_uniform_load3(to, o);
     LS_LDS_FENCE();          // every lane has read the old origin before lane 0 replaces it
     if (lane == 0) {
         LSB(cx, LSIM_BUF_TERRAIN_LEVELS, int64_t)[env] = lvl;
@@ -407,24 +407,44 @@ LS_FN void ph_b_terrain_curriculum(const LsCtx& cx, WaveShared& sh, int lane, in
 // memory afterwards (ph_b_reset_store).  Kernel A's fused tail samples the terrain under the new pose BETWEEN the two: those loads then
 // queue behind none of reset_idx's stores and atomics (vmcnt retires in order; a resetting wave is the slowest kind of wave of a launch, and a
 // launch of one round of waves lasts as long as its slowest wave).  Lane roles in the comments.
-LS_FN void ph_b_reset_state(const LsCtx& cx, WaveShared& sh, int lane, int env, const LsStepArgs& a, const float* q0 /* default_dof_pos: LDS copy or the config's */) {
-    if (!LS_UNIFORM(sh.do_reset)) return;          // wave-uniform: a scalar branch, nothing of the body is issued for the other waves
+// Every uniform reset_idx consumes for this env, one Philox block per lane and all of them at once: lanes 0-5 the six blocks of the joint
+// stream (24 draws), 6-8 the three of the root state, 9 the commands', 10-11 the domain randomisation's -- the values and keys of the
+// draws the roles used to make one after the other inside their divergent branches (nine blocks in a row on a resetting wave, which is
+// the slowest kind of wave of a launch).  `dr`: 48 floats of dead LDS -- kernel A: the reward-part array (dead since ph_reward_terms; its
+// observation history sits in Mbl .. Sinv); kernel B: Mbl .. (it has no dynamics, and ITS history is parked where the reward parts are).
+LS_FN float* ls_reset_draws_a(WaveShared& sh) { return &sh.u.r.rj[0][0]; }
+LS_FN float* ls_reset_draws_b(WaveShared& sh) { return &sh.Mbl[0][0]; }
+static_assert(sizeof(((WaveShared*)0)->u.r.rj) >= 48 * sizeof(float) && sizeof(((WaveShared*)0)->Mbl) >= 48 * sizeof(float), "reset draws parked in dead arrays");
+LS_FN void ph_b_reset_draws(const LsCtx& cx, WaveShared& sh, int lane, int env, const LsStepArgs& a, float* dr) {
+    if (!LS_UNIFORM(sh.do_reset)) return;
+    if (lane >= 12) return;
     const lsim_config& c = cx.cfg;
     const uint32_t stepw = (uint32_t)a.step_counter ^ a.rng_salt;
+    const uint32_t tag = lane < 6 ? LSIM_RNG_RESET_DOF : (lane < 9 ? LSIM_RNG_RESET_ROOT : (lane < 10 ? LSIM_RNG_RESET_CMD : LSIM_RNG_RESET_DR));
+    const uint32_t block = (uint32_t)(lane < 6 ? lane : (lane < 9 ? lane - 6 : (lane < 10 ? 0 : lane - 10)));
+    float u[4];
+    ls_u01x4(c.seed, c.rank, (uint32_t)env, stepw, tag, block, u);
+    for (int k = 0; k < 4; ++k) dr[4 * lane + k] = u[k];
+}
+LS_FN void ph_b_reset_state(const LsCtx& cx, WaveShared& sh, int lane, int env, const LsStepArgs& a, const float* q0 /* default_dof_pos: LDS copy or the config's */,
+                            const float* dr /* ph_b_reset_draws */) {
+    if (!LS_UNIFORM(sh.do_reset)) return;          // wave-uniform: a scalar branch, nothing of the body is issued for the other waves
+    const lsim_config& c = cx.cfg;
+    // dr: [0..23] joints (stream index = position), [24..35] root, [36..39] commands, [40..47] domain randomisation
     if (lane < 12) {  // _reset_dofs (LR:690-716)
         float pos = q0[lane];
         if (c.has_dof_init_pos_ratio)
-            pos = pos * rand_range(ls_draw(cx, env, stepw, LSIM_RNG_RESET_DOF, (uint32_t)lane), c.dof_init_pos_ratio_range[0], c.dof_init_pos_ratio_range[1]);
+            pos = pos * rand_range(dr[lane], c.dof_init_pos_ratio_range[0], c.dof_init_pos_ratio_range[1]);
         float vel = 0.0f;
         if (c.randomize_dof_vel) {
             float lo = c.dof_init_vel_range[0], hi = c.dof_init_vel_range[1];
-            vel = ls_draw(cx, env, stepw, LSIM_RNG_RESET_DOF, (uint32_t)(12 + lane)) * fabsf(hi - lo) + fminf(lo, hi);
+            vel = dr[12 + lane] * fabsf(hi - lo) + fminf(lo, hi);
         }
         sh.dofs[2 * lane] = pos; sh.dofs[2 * lane + 1] = vel;
     } else if (lane == 12) {  // _reset_root_states (LR:718-820)
         const float* org = sh.pre_org;          // this env's origin row, as ph_b_terrain_curriculum left it
         float u[12];
-        for (int b = 0; b < 3; ++b) ls_u01x4(c.seed, c.rank, (uint32_t)env, stepw, LSIM_RNG_RESET_ROOT, (uint32_t)b, u + 4 * b);
+        for (int k = 0; k < 12; ++k) u[k] = dr[24 + k];
         float r[13];
         for (int k = 0; k < 13; ++k) r[k] = c.base_init_state[k];
         for (int k = 0; k < 3; ++k) r[k] += org[k];
@@ -441,15 +461,14 @@ LS_FN void ph_b_reset_state(const LsCtx& cx, WaveShared& sh, int lane, int env, 
         for (int k = 0; k < 13; ++k) sh.root[k] = r[k];
     } else if (lane == 13) {  // _resample_commands (LR:320)
         float cm[4] = {sh.cmd[0], sh.cmd[1], sh.cmd[2], sh.cmd[3]};
-        ls_resample_commands(cx, env, stepw, LSIM_RNG_RESET_CMD, sh.ranges, cm);
+        ls_resample_commands_u(cx, env, dr + 36, sh.ranges, cm);
         // sh.cmd is refreshed by the episode-statistics phase (lane 13 owns it here, other lanes may still read the old value)
         sh.rewv[0] = cm[0]; sh.rewv[1] = cm[1]; sh.rewv[2] = cm[2]; sh.rewv[3] = cm[3];
     }
 }
-LS_FN void ph_b_reset_store(const LsCtx& cx, WaveShared& sh, int lane, int env, const LsStepArgs& a) {
+LS_FN void ph_b_reset_store(const LsCtx& cx, WaveShared& sh, int lane, int env, const LsStepArgs& a, const float* dr) {
     if (!LS_UNIFORM(sh.do_reset)) return;          // wave-uniform: a scalar branch, nothing of the body is issued for the other waves
     const lsim_config& c = cx.cfg;
-    const uint32_t stepw = (uint32_t)a.step_counter ^ a.rng_salt;
     if (lane < 12) {
         LS_GLOBAL float* dof = LSB(cx, LSIM_BUF_DOF_STATE, float) + 24 * env;
         dof[2 * lane] = sh.dofs[2 * lane]; dof[2 * lane + 1] = sh.dofs[2 * lane + 1];
@@ -461,9 +480,7 @@ LS_FN void ph_b_reset_store(const LsCtx& cx, WaveShared& sh, int lane, int env, 
     } else if (lane == 12) {
         for (int k = 0; k < 4; ++k) LSB(cx, LSIM_BUF_COMMANDS, float)[4 * env + k] = sh.rewv[k];
     } else if (lane == 14) {  // domain-randomisation redraw (LR:336-343, LR:533-537)
-        float u[8];
-        ls_u01x4(c.seed, c.rank, (uint32_t)env, stepw, LSIM_RNG_RESET_DR, 0, u);
-        ls_u01x4(c.seed, c.rank, (uint32_t)env, stepw, LSIM_RNG_RESET_DR, 1, u + 4);
+        const float* u = dr + 40;
         if (c.randomize_kp) LSB(cx, LSIM_BUF_KP_FACTORS, float)[env] = rand_range(u[0], c.kp_range[0], c.kp_range[1]);
         if (c.randomize_kd) LSB(cx, LSIM_BUF_KD_FACTORS, float)[env] = rand_range(u[1], c.kd_range[0], c.kd_range[1]);
         if (c.randomize_motor_strength) LSB(cx, LSIM_BUF_MOTOR_STRENGTH_FACTORS, float)[env] = rand_range(u[2], c.motor_strength_range[0], c.motor_strength_range[1]);
@@ -710,12 +727,12 @@ template <int SOLVER> LS_WAVE_FN void ls_wave_step_a(const LsCtx& cx, const LsSt
     LS_CP(13);
     if (fuse) {     // LR:229-241 + LR:167-171 for this robot (kernel B's phases; its cross-env part is lsim_k_step_finish)
         LS_PHASE(ph_tail_setup(cx, sh, lane, a));
-        LS_PHASE(ph_b_terrain_curriculum(cx, sh, lane, env, a));
-        LS_PHASE(ph_b_reset_state(cx, sh, lane, env, a, sh.jc_q0));
+        LS_PHASE(ph_b_terrain_curriculum(cx, sh, lane, env, a); ph_b_reset_draws(cx, sh, lane, env, a, ls_reset_draws_a(sh)));
+        LS_PHASE(ph_b_reset_state(cx, sh, lane, env, a, sh.jc_q0, ls_reset_draws_a(sh)));
         LS_CP(14);
         LS_PHASE(if (LS_UNIFORM(sh.do_reset) && c.measure_heights) ph_heights(cx, sh, lane, env, true, sh.mpx, sh.mpy));     // loads: ahead of reset_idx's stores and atomics
         LS_CP(15);
-        LS_PHASE(ph_b_reset_store(cx, sh, lane, env, a); ph_tail_episode_stats(cx, sh, lane, env, a));
+        LS_PHASE(ph_b_reset_store(cx, sh, lane, env, a, ls_reset_draws_a(sh)); ph_tail_episode_stats(cx, sh, lane, env, a));
         LS_CP(10);
         LS_PHASE(ph_build_obs(cx, sh, lane, env, (uint32_t)a.step_counter, LSIM_RNG_OBS_NOISE, sh.cur, sh.jc_q0));
         LS_CP(11);
@@ -737,9 +754,9 @@ LS_WAVE_FN void ls_wave_step_b(const LsCtx& cx, const LsStepArgs& a, const int e
     [[maybe_unused]] constexpr int ls_line0 = __LINE__ - 96;   // kernel B's sites land above kernel A's (A uses 0..95)
     LS_TICK_INIT();
     LS_PHASE(ph_load_b(cx, sh, lane, env, a));
-    LS_PHASE(ph_b_housekeeping(cx, sh, lane, env, a); ph_b_terrain_curriculum(cx, sh, lane, env, a));
-    LS_PHASE(ph_b_reset_state(cx, sh, lane, env, a, cx.cfg.default_dof_pos));
-    LS_PHASE(ph_b_reset_store(cx, sh, lane, env, a));
+    LS_PHASE(ph_b_housekeeping(cx, sh, lane, env, a); ph_b_terrain_curriculum(cx, sh, lane, env, a); ph_b_reset_draws(cx, sh, lane, env, a, ls_reset_draws_b(sh)));
+    LS_PHASE(ph_b_reset_state(cx, sh, lane, env, a, cx.cfg.default_dof_pos, ls_reset_draws_b(sh)));
+    LS_PHASE(ph_b_reset_store(cx, sh, lane, env, a, ls_reset_draws_b(sh)));
     LS_PHASE(ph_b_episode_stats(cx, sh, rg, lane, env, a));
     LS_PHASE(if (LS_UNIFORM(sh.do_reset) && c.measure_heights) ph_heights(cx, sh, lane, env, true, c.measured_points_x, c.measured_points_y));
     if (a.reset_all) {   // reset_idx only: the observation roll belongs to the step that follows (BT:114)

@@ -50,8 +50,17 @@ __device__ __forceinline__ float ls_uniform_load(LS_GLOBAL const float* p) {
     asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(u) : "memory");
     return v;
 }
+// three consecutive floats the same way, one wait
+__device__ __forceinline__ void ls_uniform_load3(LS_GLOBAL const float* p, float out[3]) {
+    const unsigned long long a = (unsigned long long)p;
+    const unsigned long long u = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) | (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)a);
+    float v0, v1, v2;
+    asm volatile("s_load_dword %0, %3, 0x0\n\ts_load_dword %1, %3, 0x4\n\ts_load_dword %2, %3, 0x8\n\ts_waitcnt lgkmcnt(0)" : "=&s"(v0), "=&s"(v1), "=&s"(v2) : "s"(u) : "memory");
+    out[0] = v0; out[1] = v1; out[2] = v2;
+}
 #else
 static inline float ls_uniform_load(const float* p) { return *p; }
+static inline void ls_uniform_load3(const float* p, float out[3]) { out[0] = p[0]; out[1] = p[1]; out[2] = p[2]; }
 #endif
 
 struct alignas(8) LsF2 { float x, y; };   // one 8-byte global store

@@ -171,9 +171,14 @@ LS_FN void ph_base_height_pts(const LsCtx& cx, WaveShared& sh, int lane) {
 }
 
 // LeggedRobot._resample_commands (LR:634-656) for this env; `ranges` = live command ranges [4][2]
+// ... from the four uniforms of block 0 of its stream (drawn by the caller)
+LS_FN void ls_resample_commands_u(const LsCtx& cx, int env, const float* u, const float* ranges, float* cmd);
 LS_FN void ls_resample_commands(const LsCtx& cx, int env, uint32_t stepw, uint32_t tag, const float* ranges, float* cmd) {
     float u[4];
     ls_u01x4(cx.cfg.seed, cx.cfg.rank, (uint32_t)env, stepw, tag, 0, u);
+    ls_resample_commands_u(cx, env, u, ranges, cmd);
+}
+LS_FN void ls_resample_commands_u(const LsCtx& cx, int env, const float* u, const float* ranges, float* cmd) {
     cmd[0] = rand_range(u[0], -1.0f, 1.0f);
     cmd[1] = rand_range(u[1], ranges[2], ranges[3]);
     if (cx.cfg.heading_command) cmd[3] = rand_range(u[2], ranges[6], ranges[7]);
