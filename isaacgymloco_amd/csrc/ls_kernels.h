@@ -56,9 +56,16 @@ __device__ unsigned long long g_ls_phase_ticks_by[3][129];    // the same by kin
 #if defined(LS_WAVE_TIMES)
 __device__ unsigned long long g_ls_wave_times[4 * 65536];     // per env: start, end (100 MHz wall clock), shader-clock ticks, HW_ID | XCC_ID << 16
 __device__ unsigned int g_ls_wave_cp[16 * 65536];              // per env: shader-clock ticks since the wave's start at up to 16 checkpoints (LS_CP)
+#if LS_WAVE_TIMES == 2      // the 16 checkpoints behind the phases of sub-step 1 instead (tools/wave_times.py --phases)
+#define LS_CP(i) do { } while (0)
+#define LS_SUBCP() do { if (ls_sub == 1 && ls_k < 16) ls_cp[ls_k++] = (unsigned int)(clock64() - ls_wc0); } while (0)
+#else
 #define LS_CP(i) do { ls_cp[i] = (unsigned int)(clock64() - ls_wc0); } while (0)
+#define LS_SUBCP() do { } while (0)
+#endif
 #else
 #define LS_CP(i) do { } while (0)
+#define LS_SUBCP() do { } while (0)
 #endif
 #if defined(LS_PHASE_MARKS)    // diagnostics only (tools/phase_static.py): a comment in the assembly behind every phase site
 #define LS_STR2(x) #x
@@ -72,8 +79,8 @@ __device__ unsigned int g_ls_wave_cp[16 * 65536];              // per env: shade
 #else
 #define LS_AGAIN(call) do { } while (0)
 #endif
-#define LS_PHASE(call) do { { const int lane = ls_opaque_lane(lane0); call; } __syncthreads(); LS_AGAIN(call); LS_MARK(); LS_TICK(__LINE__ - ls_line0); } while (0)
-#define LS_COLLECTIVE(gpu_call, emu_call) do { { const int lane = ls_opaque_lane(lane0); gpu_call; } __syncthreads(); LS_AGAIN(gpu_call); LS_MARK(); LS_TICK(__LINE__ - ls_line0); } while (0)
+#define LS_PHASE(call) do { { const int lane = ls_opaque_lane(lane0); call; } __syncthreads(); LS_AGAIN(call); LS_MARK(); LS_TICK(__LINE__ - ls_line0); LS_SUBCP(); } while (0)
+#define LS_COLLECTIVE(gpu_call, emu_call) do { { const int lane = ls_opaque_lane(lane0); gpu_call; } __syncthreads(); LS_AGAIN(gpu_call); LS_MARK(); LS_TICK(__LINE__ - ls_line0); LS_SUBCP(); } while (0)
 #define LS_KINEMATICS() LS_COLLECTIVE(wc_kinematics(sh, lane), (void)0)
 #define LS_TORQUES_KINEMATICS() LS_COLLECTIVE(ph_torques(cx, sh, lane, env, sub, a.flags); wc_kinematics(sh, lane), (void)0)
 #define LS_ATOMIC_ADD(ptr, v) atomicAdd((ptr), (v))
@@ -646,10 +653,15 @@ template <int SOLVER> LS_WAVE_FN void ls_wave_step_a(const LsCtx& cx, const LsSt
 #if defined(LS_WAVE_TIMES)    // diagnostics build only (tools/wave_times.py): when each wave of the latest step started and ended
     const unsigned long long ls_wt0 = wall_clock64(), ls_wc0 = clock64();
     unsigned int ls_cp[16] = {};
+    [[maybe_unused]] int ls_sub = -1, ls_k = 0;
 #endif
     LS_PHASE(ph_load_a(cx, sh, rg, lane, env, a));
     LS_CP(0);
     for (int sub = 0; sub < c.decimation; ++sub) {
+#if defined(LS_WAVE_TIMES)
+        ls_sub = sub;
+        if (sub == 1) { ls_cp[0] = (unsigned int)(clock64() - ls_wc0) * (LS_WAVE_TIMES == 2); ls_k = 1; }
+#endif
         if (skip) { LS_PHASE(ph_torques(cx, sh, lane, env, sub, a.flags)); continue; }
         // phases that do not depend on each other share a barrier: (torques, kinematics), (free velocity, narrow phase),
         // (contact compaction, joint-limit rows), (apply impulses, contact forces)
@@ -686,6 +698,9 @@ template <int SOLVER> LS_WAVE_FN void ls_wave_step_a(const LsCtx& cx, const LsSt
         if (TGS) LS_PHASE(ph_integrate_tgs(cx, sh, lane, dt, c.num_position_iterations));
         else LS_PHASE(ph_integrate(cx, sh, lane, dt));
         if (sub < 4) LS_CP(1 + sub);
+#if defined(LS_WAVE_TIMES)
+        ls_sub = -1;
+#endif
 #if defined(LS_EXP_TWICE) && LS_EXP_TWICE == 9001      // cost probe: the integrator again with a zero step (leaves the state where it is)
         LS_PHASE(ph_integrate(cx, sh, lane, 0.0f));
 #endif
@@ -752,6 +767,9 @@ template <int SOLVER> LS_WAVE_FN void ls_wave_step_a(const LsCtx& cx, const LsSt
 LS_WAVE_FN void ls_wave_step_b(const LsCtx& cx, const LsStepArgs& a, const int env, WaveShared& sh, LS_LANES_PARAM) {
     const lsim_config& c = cx.cfg;
     [[maybe_unused]] constexpr int ls_line0 = __LINE__ - 96;   // kernel B's sites land above kernel A's (A uses 0..95)
+#if defined(LS_WAVE_TIMES)
+    [[maybe_unused]] int ls_sub = -1, ls_k = 0; [[maybe_unused]] unsigned int ls_cp[16]; [[maybe_unused]] const unsigned long long ls_wc0 = 0;   // (LS_PHASE's checkpoint hook: kernel A only)
+#endif
     LS_TICK_INIT();
     LS_PHASE(ph_load_b(cx, sh, lane, env, a));
     LS_PHASE(ph_b_housekeeping(cx, sh, lane, env, a); ph_b_terrain_curriculum(cx, sh, lane, env, a); ph_b_reset_draws(cx, sh, lane, env, a, ls_reset_draws_b(sh)));

@@ -35,6 +35,8 @@ timeout 300 python tools/phase_profile.py aliengo_stairs 4096 > $O/phase_profile
 timeout 300 python tools/wave_times.py aliengo 4096 > $O/wave_times_aliengo.txt 2>&1
 timeout 300 python tools/wave_times.py aliengo_stairs 4096 > $O/wave_times_aliengo_stairs.txt 2>&1
 timeout 300 python tools/wave_times.py aliengo 256 > $O/wave_times_aliengo_N256.txt 2>&1
+timeout 300 python tools/wave_times.py aliengo 4096 --phases > $O/wave_phases_aliengo.txt 2>&1
+timeout 300 python tools/wave_times.py aliengo 256 --phases > $O/wave_phases_aliengo_N256.txt 2>&1
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_env -o env -- python3 $R/bench.py --mode env --steps 100 --warmup 20 --no-cpu-baseline > $R/$O/prof_env.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_env_stairs -o env_stairs -- python3 $R/bench.py --mode env --task aliengo_stairs --steps 100 --warmup 20 --no-cpu-baseline > $R/$O/prof_env_stairs.log 2>&1

@@ -39,7 +39,7 @@ for src, dst in (("prof_env/env_kernel_stats.csv", "kernel_stats_env_only"), ("p
             r[0] = r[0][:160]     # torch's templated kernel names run to kilobytes
             w.writerow(r)
 for name in ("pmc_stairs_N4096.csv", "phase_profile_aliengo.txt", "phase_profile_aliengo_stairs.txt", "trace_collectives.txt", "trace_idle_rccl.txt",
-             "wave_times_aliengo.txt", "wave_times_aliengo_stairs.txt", "wave_times_aliengo_N256.txt"):
+             "wave_times_aliengo.txt", "wave_times_aliengo_stairs.txt", "wave_times_aliengo_N256.txt", "wave_phases_aliengo.txt", "wave_phases_aliengo_N256.txt"):
     f = os.path.join(O, name)
     if os.path.exists(f):
         shutil.copy(f, os.path.join(P, f"{rnd}_{name}"))

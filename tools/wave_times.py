@@ -21,9 +21,53 @@ def build():
     return B.build_variant(OUT, ["-DLS_WAVE_TIMES"])
 
 
+PHASES = ["torques + kinematics", "body inertias + bias forces", "leg composites", "leg block", "leg Schur", "base assemble", "base factor", "free leg",
+          "free base", "free finish + narrow phase", "contact compaction + limit rows", "constraint rows", "Delassus + TGS sub-iterations + contact forces",
+          "integrator"]
+
+
+def phases(task, N):
+    """--phases: the 14 phases of sub-step 1, product code path (a -DLS_WAVE_TIMES=2 build: the 16 checkpoints sit behind those phases)"""
+    out = OUT.replace("wavetimes", "wavephases")
+    if not os.path.exists(out):
+        from isaacgymloco_amd.csrc import build as B
+        B.build_variant(out, ["-DLS_WAVE_TIMES=2"])
+    os.environ["LSIM_LIB"] = out
+    import torch
+    from isaacgymloco_amd import lib
+    from isaacgymloco_amd.envs import config as C
+    from isaacgymloco_amd.envs.legged_robot import LeggedRobot
+    cfg = C.TASKS[task][0]()
+    cfg.env.num_envs = N
+    env = LeggedRobot(cfg, sim_device="cuda:0", seed=1)
+    env.reset()
+    L = lib.load()
+    g = torch.Generator(device="cuda:0").manual_seed(0)
+    acc = np.zeros(14)
+    n = 0
+    tb = (ctypes.c_ulonglong * (4 * N))(); cpb = (ctypes.c_uint * (16 * N))()
+    for t in range(260):
+        env.step_device(torch.randn(N, 12, device="cuda:0", generator=g))
+        if t < 200 or t % 10:
+            continue
+        assert L.lsim_debug_read_wave_times(tb, N) == 0 and L.lsim_debug_read_wave_checkpoints(cpb, N) == 0
+        a = np.frombuffer(tb, dtype=np.uint64).reshape(N, 4).astype(np.float64)
+        ghz = np.median(a[:, 2] / ((a[:, 1] - a[:, 0]) / 100.0) / 1e3)
+        cp = np.frombuffer(cpb, dtype=np.uint32).reshape(N, 16).astype(np.float64)
+        acc += np.diff(cp[:, :15], axis=1).mean(0) / (ghz * 1e3)
+        n += 1
+    acc /= n
+    print(f"task {task} N {N}: phases of sub-step 1, mean us per wave (sum {acc.sum():.2f})")
+    for nm, v in zip(PHASES, acc):
+        print(f"  {v:6.2f}  {nm}")
+
+
 def main():
-    task = sys.argv[1] if len(sys.argv) > 1 else "aliengo"
-    N = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+    args = [x for x in sys.argv[1:] if not x.startswith("--")]
+    task = args[0] if len(args) > 0 else "aliengo"
+    N = int(args[1]) if len(args) > 1 else 4096
+    if "--phases" in sys.argv:
+        return phases(task, N)
     if not os.path.exists(OUT):
         build()
     os.environ["LSIM_LIB"] = OUT
