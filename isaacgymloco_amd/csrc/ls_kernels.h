@@ -658,9 +658,9 @@ template <int SOLVER> LS_WAVE_FN void ls_wave_step_a(const LsCtx& cx, const LsSt
     LS_PHASE(ph_load_a(cx, sh, rg, lane, env, a));
     LS_CP(0);
     for (int sub = 0; sub < c.decimation; ++sub) {
-#if defined(LS_WAVE_TIMES)
+#if defined(LS_WAVE_TIMES) && LS_WAVE_TIMES == 2
         ls_sub = sub;
-        if (sub == 1) { ls_cp[0] = (unsigned int)(clock64() - ls_wc0) * (LS_WAVE_TIMES == 2); ls_k = 1; }
+        if (sub == 1) { ls_cp[0] = (unsigned int)(clock64() - ls_wc0); ls_k = 1; }
 #endif
         if (skip) { LS_PHASE(ph_torques(cx, sh, lane, env, sub, a.flags)); continue; }
         // phases that do not depend on each other share a barrier: (torques, kinematics), (free velocity, narrow phase),
