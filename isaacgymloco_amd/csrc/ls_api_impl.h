@@ -26,6 +26,7 @@ struct lsim_sim {
     int device_id;
     int64_t step_counter;
     uint32_t reset_calls;   // lsim_reset_envs calls so far (salt of their random draws)
+    int priority_max_envs;  // contact-count wave priorities up to this many robots (LSIM_PRIORITY_MAX_ENVS overrides: a measurement hook)
     int init_done;
     int stats_row;
     void* prof;        // backend-owned profiling state (HIP events), may be null
@@ -223,6 +224,8 @@ extern "C" int LS_API(create)(const lsim_config* cfg, const lsim_robot_model* mo
     else bad |= lsbk_h2d(s->dev_ctx, &h, sizeof(LsCtx));
     if (bad) { if (s->owns_arena) lsbk_free(s->arena); if (s->dev_ctx) lsbk_free(s->dev_ctx); free(s); return LSIM_E_HIP; }
     s->step_counter = 0;
+    s->priority_max_envs = 32768;
+    if (const char* e = getenv("LSIM_PRIORITY_MAX_ENVS")) s->priority_max_envs = atoi(e);
     s->init_done = 1;   // construction completes before the runner's first reset (LR:116, HIMR:84)
     *out = s;
     return LSIM_OK;
@@ -246,9 +249,10 @@ extern "C" int LS_API(step_ex)(lsim_sim* s, const float* actions_dev, uint32_t f
     // max_episode_length).  On every other step kernel A runs B's per-env work itself and a few blocks finish the step (ls_kernels.h).
     const bool curriculum_step = s->cfg.commands_curriculum && (s->step_counter % s->cfg.max_episode_length == 0);
     a.fuse_tail = (!curriculum_step && !(flags & LSIM_STEP_TWO_KERNELS)) ? 1 : 0;
-    // contact-count wave priorities pay where a launch is one or two rounds of waves (4096 resident at a time); with many rounds in flight the
-    // slowest wave of a round hides behind the next round and the priorities only perturb the arbiter (-0.4 % at N = 65 536 / 262 144)
-    if (s->cfg.num_envs > 8192) a.flags |= LSIM_STEP_FLAT_PRIORITY;
+    // contact-count wave priorities pay while a launch is a few rounds of waves (4096 resident at a time): +6.5 % at N = 4096, +3.7 % at 8192,
+    // +2.1 % at 12 288, +1.2 % at 16 384, nothing at 32 768; with many rounds in flight the slowest wave of a round hides behind the next
+    // and the priorities only perturb the arbiter (-0.4 % at N = 65 536 / 262 144)
+    if (s->cfg.num_envs > s->priority_max_envs) a.flags |= LSIM_STEP_FLAT_PRIORITY;
     lsbk_prof_mark(s, 0, stream);
     if (lsbk_launch_a(s, a, stream) != 0) LS_FAIL(s, LSIM_E_HIP, "kernel A launch failed");
     lsbk_prof_mark(s, 1, stream);
