@@ -565,6 +565,22 @@ int lsim_linear_wgrad(const float* x, int64_t ldx, const float* g, int64_t ldg, 
 int lsim_linear_elu_wgrad(const float* x, int64_t ldx, const float* grad_out, int64_t ldg, const float* elu_out, int64_t ldz, int64_t batch,
                           int k_in, int n_out, float* dw, float* db, float* grad_pre, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same two calls with the final, fixed-order sum of the partial results left to the caller: `pending` receives what that sum needs, the
+ * workspace must stay untouched until lsim_wgrad_reduce_batch has run for it, and dw / db hold nothing until then.  A backward pass
+ * collects the records of all its layers and sums them in ONE launch behind the last weight-gradient kernel (15 launches of a few
+ * microseconds per minibatch become one); same arithmetic, same results bit for bit.  items: host array; any n (the call splits it). */
+typedef struct lsim_wgrad_pending {
+    const float* part; const float* part2;      /* partial results of dw [num_partials, count] and of db [num_partials, count2] (NULL: no bias) */
+    float* out; float* out2;                    /* dw, db */
+    int32_t num_partials, count, count2, reserved;
+} lsim_wgrad_pending;
+int lsim_linear_wgrad_deferred(const float* x, int64_t ldx, const float* g, int64_t ldg, int64_t batch, int k_in, int n_out,
+                               float* dw, float* db, void* workspace, size_t workspace_bytes, void* stream, lsim_wgrad_pending* pending);
+int lsim_linear_elu_wgrad_deferred(const float* x, int64_t ldx, const float* grad_out, int64_t ldg, const float* elu_out, int64_t ldz, int64_t batch,
+                                   int k_in, int n_out, float* dw, float* db, float* grad_pre, void* workspace, size_t workspace_bytes, void* stream,
+                                   lsim_wgrad_pending* pending);
+int lsim_wgrad_reduce_batch(const lsim_wgrad_pending* items, int n, void* stream);
+
 /* Clipped-PPO loss of HIMPPO.update (HIMP:136-176), forward AND backward in one pass: per-sample Gaussian log-prob, ratio, clipped
  * surrogate, clipped value loss, entropy bonus, and the KL estimate of the adaptive learning-rate rule (HIMP:144-156).
  *   out5 = { mean surrogate, mean value loss, mean entropy, mean KL, total = surrogate + value_loss_coef * value - entropy_coef * entropy }

@@ -106,15 +106,15 @@ __global__ __launch_bounds__(64 * LS_WGRAD_WAVES_PER_BLOCK) void lsim_k_linear_w
 
 // out[o] = sum over waves of part[w][o] in a fixed order.  Block = 16 outputs x 16 wave-slices: thread (o, s) adds the partials
 // w = s, s + 16, ... with four independent accumulators (64-byte coalesced rows), then the 16 slices meet in LDS.
-__global__ __launch_bounds__(256) void lsim_k_wgrad_reduce(const float* __restrict__ part, int num_waves, int count, float* __restrict__ out,
-                                                           const float* __restrict__ part2, int count2, float* __restrict__ out2) {
+__device__ __forceinline__ void ls_wgrad_reduce_body(const float* __restrict__ part, int num_waves, int count, float* __restrict__ out,
+                                                     const float* __restrict__ part2, int count2, float* __restrict__ out2, int block) {
     // one launch serves the weight-gradient partials (count outputs) and, in the blocks after them, the bias-gradient partials (count2)
     __shared__ float red[16][17];
     const int ol = threadIdx.x & 15, sl = threadIdx.x >> 4;
     const int nb1 = (count + 15) >> 4;
-    const bool second = (int)blockIdx.x >= nb1;
+    const bool second = block >= nb1;
     if (second) { part = part2; out = out2; count = count2; }
-    const int o = ((int)blockIdx.x - (second ? nb1 : 0)) * 16 + ol;
+    const int o = (block - (second ? nb1 : 0)) * 16 + ol;
     float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
     if (o < count) {
         int w = sl;
@@ -132,6 +132,23 @@ __global__ __launch_bounds__(256) void lsim_k_wgrad_reduce(const float* __restri
         for (int k = 0; k < 16; ++k) t += red[k][ol];
         out[o] = t;
     }
+}
+__global__ __launch_bounds__(256) void lsim_k_wgrad_reduce(const float* __restrict__ part, int num_waves, int count, float* __restrict__ out,
+                                                           const float* __restrict__ part2, int count2, float* __restrict__ out2) {
+    ls_wgrad_reduce_body(part, num_waves, count, out, part2, count2, out2, (int)blockIdx.x);
+}
+// the same for up to LS_REDUCE_BATCH layers in one launch (lsim_wgrad_reduce_batch): block -> (layer, block of that layer) by the table
+#define LS_REDUCE_BATCH 24
+struct LsReduceBatch {
+    lsim_wgrad_pending it[LS_REDUCE_BATCH];
+    int first[LS_REDUCE_BATCH + 1];
+    int n;
+};
+__global__ __launch_bounds__(256) void lsim_k_wgrad_reduce_batch(LsReduceBatch b) {
+    int e = 0;
+    while (e + 1 < b.n && (int)blockIdx.x >= b.first[e + 1]) ++e;           // wave-uniform
+    const lsim_wgrad_pending& p = b.it[e];
+    ls_wgrad_reduce_body(p.part, p.num_partials, p.count, p.out, p.part2, p.count2, p.out2, (int)blockIdx.x - b.first[e]);
 }
 
 // VEC: 2 = 16-byte vector load (rows 16-byte aligned), 1 = two 8-byte loads (rows 8-byte aligned, e.g. ld = 238 or 270), 0 = scalars
@@ -506,7 +523,8 @@ extern "C" int lsim_linear_wgrad_workspace(long batch, int k_in, int n_out, size
 }
 
 static int ls_linear_wgrad_impl(const float* x, int64_t ldx, const float* g, int64_t ldg, const float* z, int64_t ldz, float* gy, int64_t batch,
-                                int k_in, int n_out, float* dw, float* db, void* workspace, size_t workspace_bytes, void* stream) {
+                                int k_in, int n_out, float* dw, float* db, void* workspace, size_t workspace_bytes, void* stream,
+                                lsim_wgrad_pending* pending = nullptr) {
     if (!x || !g || !dw || !workspace) return LSIM_E_INVALID;
     LsWgradPlan p;
     int rc = ls_wgrad_plan(batch, k_in, n_out, &p);
@@ -547,8 +565,43 @@ static int ls_linear_wgrad_impl(const float* x, int64_t ldx, const float* g, int
 #undef LS_T
     }
     const int count = n_out * k_in;
+    if (pending) {       // the caller sums the partial results later (lsim_wgrad_reduce_batch)
+        pending->part = pdw; pending->part2 = pdb; pending->out = dw; pending->out2 = db;
+        pending->num_partials = p.partials; pending->count = count; pending->count2 = db ? n_out : 0; pending->reserved = 0;
+        return hipGetLastError() == hipSuccess ? LSIM_OK : LSIM_E_HIP;
+    }
     hipLaunchKernelGGL(lsim_k_wgrad_reduce, dim3((count + 15) / 16 + (db ? (n_out + 15) / 16 : 0)), dim3(256), 0, s, (const float*)pdw, p.partials, count, dw,
                        (const float*)pdb, n_out, db);
+    return hipGetLastError() == hipSuccess ? LSIM_OK : LSIM_E_HIP;
+}
+
+extern "C" int lsim_linear_wgrad_deferred(const float* x, int64_t ldx, const float* g, int64_t ldg, int64_t batch, int k_in, int n_out,
+                                          float* dw, float* db, void* workspace, size_t workspace_bytes, void* stream, lsim_wgrad_pending* pending) {
+    if (!pending) return LSIM_E_INVALID;
+    return ls_linear_wgrad_impl(x, ldx, g, ldg, nullptr, 0, nullptr, batch, k_in, n_out, dw, db, workspace, workspace_bytes, stream, pending);
+}
+extern "C" int lsim_linear_elu_wgrad_deferred(const float* x, int64_t ldx, const float* grad_out, int64_t ldg, const float* elu_out, int64_t ldz, int64_t batch,
+                                              int k_in, int n_out, float* dw, float* db, float* grad_pre, void* workspace, size_t workspace_bytes, void* stream,
+                                              lsim_wgrad_pending* pending) {
+    if (!elu_out || !pending) return LSIM_E_INVALID;
+    return ls_linear_wgrad_impl(x, ldx, grad_out, ldg, elu_out, ldz, grad_pre, batch, k_in, n_out, dw, db, workspace, workspace_bytes, stream, pending);
+}
+extern "C" int lsim_wgrad_reduce_batch(const lsim_wgrad_pending* items, int n, void* stream) {
+    if (n < 0 || (n > 0 && !items)) return LSIM_E_INVALID;
+    for (int i0 = 0; i0 < n; i0 += LS_REDUCE_BATCH) {
+        LsReduceBatch b;
+        b.n = n - i0 < LS_REDUCE_BATCH ? n - i0 : LS_REDUCE_BATCH;
+        int blocks = 0;
+        for (int i = 0; i < b.n; ++i) {
+            const lsim_wgrad_pending& p = items[i0 + i];
+            if (!p.part || !p.out || p.num_partials <= 0 || p.count <= 0 || (p.count2 > 0 && (!p.part2 || !p.out2))) return LSIM_E_INVALID;
+            b.it[i] = p;
+            b.first[i] = blocks;
+            blocks += (p.count + 15) / 16 + (p.count2 > 0 ? (p.count2 + 15) / 16 : 0);
+        }
+        b.first[b.n] = blocks;
+        hipLaunchKernelGGL(lsim_k_wgrad_reduce_batch, dim3(blocks), dim3(256), 0, (hipStream_t)stream, b);
+    }
     return hipGetLastError() == hipSuccess ? LSIM_OK : LSIM_E_HIP;
 }
 

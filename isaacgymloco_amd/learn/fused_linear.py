@@ -7,6 +7,7 @@ needs 260 us for 19 columns); the MFMA kernels in csrc/ls_learn.h read x and g o
 same state_dict keys, same initialisation as nn.Linear (it IS an nn.Linear); results differ from BLAS by fp32 summation order.
 """
 import ctypes
+import os
 
 import torch
 import torch.nn as nn
@@ -116,13 +117,80 @@ def grad_cycle():
         _arena.new_cycle()
 
 
-def _grad_out(param_ptr, shape, device):
-    """output tensor for a parameter's gradient: its arena slice when there is one to hand out, else a fresh tensor"""
+def _grad_out(param_ptr, shape, device, hit=None):
+    """output tensor for a parameter's gradient: its arena slice when there is one to hand out (then hit[0] stays as it is), else a fresh
+    tensor (hit[0] = False)"""
     if _arena is not None and param_ptr is not None:
         v = _arena.take(param_ptr, shape)
         if v is not None:
             return v
+    if hit is not None:
+        hit[0] = False
     return torch.empty(shape, device=device, dtype=torch.float32)
+
+
+# ---- deferred sums of the weight-gradient partial results: inside `with deferred_wgrad_reduce():` the backward functions below run their
+# MFMA kernels as usual but leave the final fixed-order sum of the partial results to ONE launch at the end of the block (15 launches of a few
+# microseconds per minibatch become one; same arithmetic, same bits).  Each layer then needs its own partial-result buffer until that launch.
+_defer_without_arena = False   # tests only: defer for plain output tensors too (no autograd behind the call)
+_pending = None          # None: sums are launched at once; else [record, ...] with the tensors they refer to kept alive
+_pending_keep = []
+_pending_params = set()
+
+
+class deferred_wgrad_reduce:
+    """LSIM_DEFER_WGRAD_REDUCE=0 makes it a no-op (A/B: every layer sums its partial results at once)"""
+
+    def __enter__(self):
+        global _pending
+        self._outer = _pending is not None or os.environ.get("LSIM_DEFER_WGRAD_REDUCE", "1") == "0"
+        if not self._outer:
+            _pending = []
+        return self
+
+    def __exit__(self, *exc):
+        global _pending
+        if not self._outer:
+            try:
+                flush_wgrad_reduces()
+            finally:
+                _pending = None
+        return False
+
+
+def flush_wgrad_reduces():
+    """sum every pending set of partial results (on the current stream: call it where the backward passes that produced them have
+    returned -- autograd has then ordered this stream behind the streams their kernels ran on)"""
+    if not _pending:
+        return
+    from .. import abi, lib
+    arr = (abi.LsimWgradPending * len(_pending))(*_pending)
+    dev = _pending_keep[0][0].device
+    lib.check(lib.load().lsim_wgrad_reduce_batch(arr, len(_pending), torch.cuda.current_stream(dev).cuda_stream), what="lsim_wgrad_reduce_batch")
+    if _arena is not None:       # the sums went to the arena slices: they are the gradients only if autograd adopted those slices
+        for wptr in _pending_params:
+            ent = _arena._slot.get(wptr)
+            if ent is not None and ent[0].grad is not None and ent[0].grad.data_ptr() != ent[1].data_ptr():
+                raise RuntimeError("deferred weight-gradient sum: autograd copied a gradient instead of adopting the arena slice")
+    _pending.clear(); _pending_keep.clear(); _pending_params.clear()
+
+
+def _wgrad_call(L, fn_now, fn_deferred, args, weight_ptr, ws, keep, in_arena):
+    """run one weight-gradient call, deferring its final sum when a deferred block is open AND the results go to gradient-arena slices: the
+    sum is written after autograd has taken the returned tensor as `.grad`, which is only the same memory if autograd adopted it without a copy
+    -- the arena hands out a fresh alias for exactly that, and flush_wgrad_reduces() checks it.  (`keep` must not hold dW / db: a second
+    owner makes autograd clone the gradient, and the clone would be of memory that holds nothing yet.)  A second contribution to the same
+    parameter inside one block first flushes."""
+    if _pending is None or not in_arena:
+        return getattr(L, fn_now)(*args)
+    if weight_ptr in _pending_params:
+        flush_wgrad_reduces()
+    from .. import abi
+    rec = abi.LsimWgradPending()
+    rc = getattr(L, fn_deferred)(*args, ctypes.byref(rec))
+    if rc == 0:
+        _pending.append(rec); _pending_keep.append((ws,) + tuple(keep)); _pending_params.add(weight_ptr)
+    return rc
 
 
 def _eligible(batch, k_in, n_out):
@@ -152,12 +220,15 @@ def linear_wgrad(x, g, want_bias=True, weight_ptr=None, bias_ptr=None):
     n_out = g.shape[1]
     need, waves = ctypes.c_size_t(), ctypes.c_int()
     lib.check(L.lsim_linear_wgrad_workspace(batch, k_in, n_out, ctypes.byref(need), ctypes.byref(waves)), what="lsim_linear_wgrad_workspace")
-    ws = _workspace("wgrad", x.device, need.value, floor=1 << 20)
-    dw = _grad_out(weight_ptr, (n_out, k_in), x.device)
-    db = _grad_out(bias_ptr, (n_out,), x.device) if want_bias else None
-    lib.check(L.lsim_linear_wgrad(x.data_ptr(), x.stride(0), g.data_ptr(), g.stride(0), batch, k_in, n_out, dw.data_ptr(),
-                                  db.data_ptr() if want_bias else None, ws.data_ptr(), ws.numel(),
-                                  torch.cuda.current_stream(x.device).cuda_stream), what="lsim_linear_wgrad")
+    # inside a deferred block every layer keeps its partial results until the block's one summing launch: a buffer per parameter
+    ws = _workspace("wgrad" if _pending is None else ("wgrad", weight_ptr), x.device, need.value, floor=1 << 20 if _pending is None else 0)
+    hit = [True]
+    dw = _grad_out(weight_ptr, (n_out, k_in), x.device, hit)
+    db = _grad_out(bias_ptr, (n_out,), x.device, hit) if want_bias else None
+    lib.check(_wgrad_call(L, "lsim_linear_wgrad", "lsim_linear_wgrad_deferred",
+                          (x.data_ptr(), x.stride(0), g.data_ptr(), g.stride(0), batch, k_in, n_out, dw.data_ptr(),
+                           db.data_ptr() if want_bias else None, ws.data_ptr(), ws.numel(), torch.cuda.current_stream(x.device).cuda_stream),
+                          weight_ptr, ws, (x, g), hit[0] or _defer_without_arena), what="lsim_linear_wgrad")
     return dw, db
 
 
@@ -208,14 +279,18 @@ class _LinearEluFn(torch.autograd.Function):
         n_out = weight.shape[0]
         need, parts = ctypes.c_size_t(), ctypes.c_int()
         lib.check(L.lsim_linear_wgrad_workspace(batch, k_in, n_out, ctypes.byref(need), ctypes.byref(parts)), what="lsim_linear_wgrad_workspace")
-        ws = _workspace("wgrad", x.device, need.value, floor=1 << 20)
-        dw = _grad_out(weight.data_ptr(), (n_out, k_in), x.device)
-        db = _grad_out(ctx.bias_ptr, (n_out,), x.device) if ctx.has_bias else None
+        wptr = weight.data_ptr()
+        ws = _workspace("wgrad" if _pending is None else ("wgrad", wptr), x.device, need.value, floor=1 << 20 if _pending is None else 0)
+        hit = [True]
+        dw = _grad_out(wptr, (n_out, k_in), x.device, hit)
+        db = _grad_out(ctx.bias_ptr, (n_out,), x.device, hit) if ctx.has_bias else None
         # the gradient of the pre-activation is written out only where an input gradient follows (not for a network's first layer: 210 MB per call)
         g_pre = torch.empty(batch, n_out, device=x.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
-        lib.check(L.lsim_linear_elu_wgrad(x.data_ptr(), x.stride(0), g.data_ptr(), g.stride(0), z.data_ptr(), z.stride(0), batch, k_in, n_out,
-                                          dw.data_ptr(), db.data_ptr() if db is not None else None, g_pre.data_ptr() if g_pre is not None else None,
-                                          ws.data_ptr(), ws.numel(), torch.cuda.current_stream(x.device).cuda_stream), what="lsim_linear_elu_wgrad")
+        lib.check(_wgrad_call(L, "lsim_linear_elu_wgrad", "lsim_linear_elu_wgrad_deferred",
+                              (x.data_ptr(), x.stride(0), g.data_ptr(), g.stride(0), z.data_ptr(), z.stride(0), batch, k_in, n_out,
+                               dw.data_ptr(), db.data_ptr() if db is not None else None, g_pre.data_ptr() if g_pre is not None else None,
+                               ws.data_ptr(), ws.numel(), torch.cuda.current_stream(x.device).cuda_stream),
+                              wptr, ws, (x, g, z), hit[0]), what="lsim_linear_elu_wgrad")
         gx = g_pre @ weight if g_pre is not None else None
         return gx, dw, db
 

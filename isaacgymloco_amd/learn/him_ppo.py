@@ -390,8 +390,9 @@ class HIMPPO:
         FL.grad_cycle()
         est, swap, total = est_mod.losses(obs, next_critic_obs)
         est_mod._primed = None
-        total.backward()
-        loss.backward()                                              # actor / critic / std gradients
+        with FL.deferred_wgrad_reduce():                             # one summing launch for the partial results of all ~15 layers
+            total.backward()
+            loss.backward()                                          # actor / critic / std gradients
         extra = None
         if adaptive:
             extra = kl_mean if kl_mean is not None else self._local_kl(mu, sigma, old_mu, old_sigma)
@@ -473,7 +474,8 @@ class HIMPPO:
                 self.optimizer.zero_grad()
                 from . import fused_linear as FL
                 FL.grad_cycle()
-                loss.backward()
+                with FL.deferred_wgrad_reduce():
+                    loss.backward()
                 if FL._arena is not None:
                     FL._arena.bucket("ppo", [p for p in ac.parameters() if p.grad is not None]).adopt()
                 self._clip_and_step(self.optimizer, ac.parameters(), self.max_grad_norm)

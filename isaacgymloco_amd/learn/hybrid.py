@@ -91,7 +91,8 @@ class HybridPPO(HIMPPO):
                 self.optimizer.zero_grad()
                 from . import fused_linear as FL
                 FL.grad_cycle()
-                loss.backward()
+                with FL.deferred_wgrad_reduce():
+                    loss.backward()
                 if FL._arena is not None:
                     FL._arena.bucket("ppo", [p for g in self.optimizer.param_groups for p in g["params"] if p.grad is not None]).adopt()
                 self._clip_and_step(self.optimizer, ac.parameters(), self.max_grad_norm)     # HYBP:270-273: clipping over the actor-critic only

@@ -129,7 +129,8 @@ class HIMEstimator(nn.Module):
         self.optimizer.zero_grad()
         from . import fused_linear as FL
         FL.grad_cycle()
-        total.backward()
+        with FL.deferred_wgrad_reduce():
+            total.backward()
         if self.grad_sync is not None:
             self.grad_sync(list(self.parameters()))
         elif FL._arena is not None and next(self.parameters()).is_cuda:      # stable gradient pointers for the fused optimiser step

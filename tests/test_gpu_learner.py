@@ -844,3 +844,38 @@ def test_gradient_arena_changes_nothing_but_where_the_gradients_live(monkeypatch
     for k in a:
         assert torch.equal(a[k], b[k]), k
     FL.set_grad_arena(None)
+
+
+def test_deferred_weight_gradient_sums_change_nothing(monkeypatch):
+    """fused_linear.deferred_wgrad_reduce (the partial results of all layers of a backward pass summed by ONE launch,
+    lsim_wgrad_reduce_batch) against the same two iterations with every layer summing at once (LSIM_DEFER_WGRAD_REDUCE=0): identical weights
+    bit for bit; and on one layer directly: both forms of the call, with and without the ELU backward, the same dW / db."""
+    import ctypes
+    from isaacgymloco_amd import abi, lib
+    from isaacgymloco_amd.learn import fused_linear as FL
+
+    def run(defer):
+        monkeypatch.setenv("LSIM_DEFER_WGRAD_REDUCE", "1" if defer else "0")
+        FL.set_grad_arena(None)
+        env, r = _make(seed=7)
+        r.enable_graphs()
+        r.learn(2, init_at_random_ep_len=False)
+        return {k: v.clone() for k, v in r.alg.actor_critic.state_dict().items()}
+    a, b = run(True), run(False)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    FL.set_grad_arena(None)
+    monkeypatch.setenv("LSIM_DEFER_WGRAD_REDUCE", "1")
+    monkeypatch.setattr(FL, "_defer_without_arena", True)         # plain output tensors, no autograd behind these calls
+    g = torch.Generator(device="cuda:0").manual_seed(3)
+    for k_in, n_out in ((64, 512), (512, 256), (270, 128), (128, 12)):
+        x = torch.randn(8192, k_in, device="cuda:0", generator=g)
+        go = torch.randn(8192, n_out, device="cuda:0", generator=g)
+        dw0, db0 = FL.linear_wgrad(x, go)
+        with FL.deferred_wgrad_reduce():
+            dw1, db1 = FL.linear_wgrad(x, go, weight_ptr=1234)
+            dw2, db2 = FL.linear_wgrad(x, 2.0 * go, weight_ptr=5678)       # a second layer in the same block: its own partial-result buffer
+        torch.cuda.synchronize()
+        assert torch.equal(dw0, dw1) and torch.equal(db0, db1), (k_in, n_out)
+        assert torch.equal(2.0 * dw0, dw2) and torch.equal(2.0 * db0, db2), (k_in, n_out)
+
