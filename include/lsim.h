@@ -581,6 +581,11 @@ int lsim_linear_elu_wgrad_deferred(const float* x, int64_t ldx, const float* gra
                                    lsim_wgrad_pending* pending);
 int lsim_wgrad_reduce_batch(const lsim_wgrad_pending* items, int n, void* stream);
 
+/* w[r, :] /= max(||w[r, :]||_2, eps) in place for a small matrix (rows * cols <= 4096): torch.nn.functional.normalize(w, dim=-1, p=2, eps) written
+ * back, as HIMEstimator.update does with its prototypes before every loss evaluation (HES:80-81) -- one launch instead of clone, norm, clamp,
+ * divide and copy.  Sums in column order: may differ from torch's reduction in the last bit. */
+int lsim_normalize_rows(float* w, int rows, int cols, float eps, void* stream);
+
 /* Clipped-PPO loss of HIMPPO.update (HIMP:136-176), forward AND backward in one pass: per-sample Gaussian log-prob, ratio, clipped
  * surrogate, clipped value loss, entropy bonus, and the KL estimate of the adaptive learning-rate rule (HIMP:144-156).
  *   out5 = { mean surrogate, mean value loss, mean entropy, mean KL, total = surrogate + value_loss_coef * value - entropy_coef * entropy }

@@ -1098,6 +1098,22 @@ extern "C" int lsim_estimator_loss(const float* enc_out, int64_t ld_enc, const f
     return hipGetLastError() == hipSuccess ? LSIM_OK : LSIM_E_HIP;
 }
 
+// ---- F.normalize(w, dim=-1) in place for a small matrix: one thread per row
+__global__ __launch_bounds__(256) void lsim_k_normalize_rows(float* __restrict__ w, int rows, int cols, float eps) {
+    const int r = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (r >= rows) return;
+    float* p = w + (size_t)r * cols;
+    float ss = 0.0f;
+    for (int c = 0; c < cols; ++c) ss += p[c] * p[c];
+    const float d = fmaxf(sqrtf(ss), eps);
+    for (int c = 0; c < cols; ++c) p[c] = p[c] / d;
+}
+extern "C" int lsim_normalize_rows(float* w, int rows, int cols, float eps, void* stream) {
+    if (!w || rows <= 0 || cols <= 0 || (long)rows * cols > 4096 || !(eps > 0.0f)) return LSIM_E_INVALID;
+    hipLaunchKernelGGL(lsim_k_normalize_rows, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, rows, cols, eps);
+    return hipGetLastError() == hipSuccess ? LSIM_OK : LSIM_E_HIP;
+}
+
 // ---- clipped-PPO loss of HIMPPO.update (HIMP:136-176), forward and backward in one pass over the minibatch.
 //   logp_b   = sum_j -(a - mu)^2 / (2 sigma^2) - log sigma - log sqrt(2 pi)            ratio_b = exp(logp_b - old_logp_b)
 //   surrogate = mean_b max(-A_b ratio_b, -A_b clamp(ratio_b, 1 - eps, 1 + eps))

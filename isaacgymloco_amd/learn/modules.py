@@ -99,8 +99,14 @@ class HIMEstimator(nn.Module):
         next_obs = next_critic_obs.detach()[:, 3:n + 3]
         out = self._encoder_out(obs_history, want_grad=True)
         tgt = self.target(next_obs)
-        with torch.no_grad():
-            self.proto.weight.copy_(F.normalize(self.proto.weight.data.clone(), dim=-1, p=2))
+        w = self.proto.weight
+        if w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and w.numel() <= 4096:
+            from .. import lib      # the same statement in one launch instead of five (include/lsim.h: lsim_normalize_rows)
+            lib.check(lib.load().lsim_normalize_rows(w.data_ptr(), w.shape[0], w.shape[1], 1e-12, torch.cuda.current_stream(w.device).cuda_stream),
+                      what="lsim_normalize_rows")
+        else:
+            with torch.no_grad():
+                w.copy_(F.normalize(w.data.clone(), dim=-1, p=2))
         if out.is_cuda and out.dim() == 2:
             from .fused_linear import estimator_loss_hip, estimator_loss_supported
             if estimator_loss_supported(tgt.shape[1], self.proto.weight.shape[0]):
