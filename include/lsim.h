@@ -597,6 +597,16 @@ int lsim_ppo_loss(const float* mu, const float* sigma, const float* value, const
                   const float* returns, const float* target_values, const float* old_mu, const float* old_sigma, int64_t batch, int num_actions,
                   float clip_param, float value_loss_coef, float entropy_coef, int use_clipped_value_loss,
                   float* out5, float* grad_mu, float* grad_sigma, float* grad_value, void* workspace, size_t workspace_bytes, void* stream);
+/* The same with the state-independent standard deviation of HIMActorCritic (HAC:93: `std`, one value per action) passed as what it is: `std`
+ * [A] instead of its broadcast sigma [B, A] (the reference forms mean * 0 + std, HAC:147), and grad_std [A] = the column sums of what
+ * grad_sigma would hold, added up in a fixed order -- the broadcast, its backward and the column sum (five launches and 10 MB per minibatch)
+ * disappear.  workspace: lsim_ppo_loss_std_workspace() bytes.  num_actions <= 60. */
+int lsim_ppo_loss_std_workspace(long batch, int num_actions, size_t* bytes);
+int lsim_ppo_loss_std(const float* mu, const float* std, const float* value, const float* actions, const float* old_logp, const float* advantages,
+                      const float* returns, const float* target_values, const float* old_mu, const float* old_sigma, int64_t batch, int num_actions,
+                      float clip_param, float value_loss_coef, float entropy_coef, int use_clipped_value_loss,
+                      float* out5, float* grad_mu, float* grad_std, float* grad_value, void* workspace, size_t workspace_bytes, void* stream);
+
 
 /* Adaptive learning rate of HIMPPO (HIMP:144-156) evaluated on the device: *lr_dev /= factor when *kl_mean_dev > 2 desired_kl,
  * *= factor when 0 < *kl_mean_dev < desired_kl / 2, clamped to [lr_min, lr_max].  Both scalars live in device memory (the optimisers read

@@ -1132,16 +1132,20 @@ struct LsPpoLossArgs {
     float* partial;                                                          // [blocks][4]: surrogate, value, entropy, kl sums
     long batch; int A;
     float clip, value_coef, entropy_coef; int clipped_value;
+    int std_mode;                                                            // 1: sigma is std [A] (row stride 0), g_sigma = per-block column sums [blocks][A] behind the 4 statistics
 };
 
+#define LS_PPO_MAX_A 60
 __global__ __launch_bounds__(256) void lsim_k_ppo_loss(LsPpoLossArgs a) {
     __shared__ float red[4][4];
+    __shared__ float red_gs[4][LS_PPO_MAX_A];
     const long b = (long)blockIdx.x * 256 + threadIdx.x;
     float s_sur = 0.0f, s_val = 0.0f, s_ent = 0.0f, s_kl = 0.0f;
+    float dS_keep = 0.0f;      // std mode: d surrogate / d logp of this sample for the column sums below (0 past the batch)
     if (b < a.batch) {
         const int A = a.A;
         const float invB = 1.0f / (float)a.batch;
-        const float* mu = a.mu + b * A; const float* sg = a.sigma + b * A; const float* ac = a.actions + b * A;
+        const float* mu = a.mu + b * A; const float* sg = a.std_mode ? a.sigma : a.sigma + b * A; const float* ac = a.actions + b * A;
         const float* omu = a.old_mu + b * A; const float* osg = a.old_sigma + b * A;
         float logp = 0.0f, ent = 0.0f, kl = 0.0f;
         for (int j = 0; j < A; ++j) {
@@ -1180,9 +1184,24 @@ __global__ __launch_bounds__(256) void lsim_k_ppo_loss(LsPpoLossArgs a) {
         for (int j = 0; j < A; ++j) {
             const float s = sg[j], d = ac[j] - mu[j];
             a.g_mu[b * A + j] = dS_dlogp * d / (s * s);
-            a.g_sigma[b * A + j] = dS_dlogp * (d * d / (s * s * s) - 1.0f / s) - a.entropy_coef * invB / s;
+            if (!a.std_mode) a.g_sigma[b * A + j] = dS_dlogp * (d * d / (s * s * s) - 1.0f / s) - a.entropy_coef * invB / s;
         }
         s_ent = ent; s_kl = kl;
+        dS_keep = dS_dlogp;
+    }
+    if (a.std_mode) {      // block-uniform: column sums of d total / d sigma over the block's samples, the same fixed order as the statistics
+        const int A = a.A;
+        const float invB = 1.0f / (float)a.batch;
+        const bool live = b < a.batch;
+        for (int j = 0; j < A; ++j) {
+            float x = 0.0f;
+            if (live) {
+                const float s = a.sigma[j], d = a.actions[b * A + j] - a.mu[b * A + j];
+                x = dS_keep * (d * d / (s * s * s) - 1.0f / s) - a.entropy_coef * invB / s;
+            }
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+            if ((threadIdx.x & 63) == 0) red_gs[threadIdx.x >> 6][j] = x;
+        }
     }
     // block sums in a fixed order: wave shuffle tree, then the four waves
     float v4[4] = {s_sur, s_val, s_ent, s_kl};
@@ -1193,7 +1212,34 @@ __global__ __launch_bounds__(256) void lsim_k_ppo_loss(LsPpoLossArgs a) {
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = x;
     }
     __syncthreads();
-    if (threadIdx.x < 4) a.partial[(size_t)blockIdx.x * 4 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    const int stride = a.std_mode ? 4 + a.A : 4;
+    if (threadIdx.x < 4) a.partial[(size_t)blockIdx.x * stride + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (a.std_mode && (int)threadIdx.x < a.A)
+        a.partial[(size_t)blockIdx.x * stride + 4 + threadIdx.x] = (red_gs[0][threadIdx.x] + red_gs[1][threadIdx.x]) + (red_gs[2][threadIdx.x] + red_gs[3][threadIdx.x]);
+}
+// std mode: wave 0 forms out[0..4] exactly as lsim_k_ppo_loss_finish does (same order of additions: the statistics do not depend on the mode);
+// waves 1-3: g_std[j] = sum over the blocks of their column sums, thread = (column j, one of 3 interleaved parts)
+__global__ __launch_bounds__(256) void lsim_k_ppo_loss_finish_std(const float* __restrict__ partial, int blocks, long batch, int A, float value_coef, float entropy_coef,
+                                                                 float* __restrict__ out, float* __restrict__ g_std) {
+    const int nq = 4 + A;
+    __shared__ float m[4];
+    __shared__ float acc[3][64];
+    if (threadIdx.x < 64) {
+        const int k = threadIdx.x & 3, part = threadIdx.x >> 2;      // 16 interleaved partial sums per quantity
+        float s = 0.0f;
+        for (int i = part; i < blocks; i += 16) s += partial[(size_t)i * nq + k];
+        for (int off = 32; off >= 4; off >>= 1) s += __shfl_down(s, off, 64);
+        if (threadIdx.x < 4) m[k] = s / (float)batch;
+    } else {
+        const int j = threadIdx.x & 63, part = (threadIdx.x >> 6) - 1;
+        float s = 0.0f;
+        if (j < A) for (int i = part; i < blocks; i += 3) s += partial[(size_t)i * nq + 4 + j];
+        acc[part][j] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) out[threadIdx.x] = m[threadIdx.x];
+    if (threadIdx.x == 0) out[4] = m[0] + value_coef * m[1] - entropy_coef * m[2];
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + A) g_std[threadIdx.x - 64] = (acc[0][threadIdx.x - 64] + acc[1][threadIdx.x - 64]) + acc[2][threadIdx.x - 64];
 }
 
 // out[0..3] = means of surrogate, value, entropy, kl; out[4] = total loss
@@ -1228,11 +1274,36 @@ extern "C" int lsim_ppo_loss(const float* mu, const float* sigma, const float* v
     a.mu = mu; a.sigma = sigma; a.value = value; a.actions = actions; a.old_logp = old_logp; a.adv = advantages; a.returns = returns;
     a.target_values = target_values; a.old_mu = old_mu; a.old_sigma = old_sigma; a.g_mu = grad_mu; a.g_sigma = grad_sigma; a.g_value = grad_value;
     a.partial = (float*)workspace; a.batch = batch; a.A = num_actions; a.clip = clip_param; a.value_coef = value_loss_coef;
-    a.entropy_coef = entropy_coef; a.clipped_value = use_clipped_value_loss;
+    a.entropy_coef = entropy_coef; a.clipped_value = use_clipped_value_loss; a.std_mode = 0;
     const int blocks = (int)((batch + 255) / 256);
     hipLaunchKernelGGL(lsim_k_ppo_loss, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     hipLaunchKernelGGL(lsim_k_ppo_loss_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)workspace, blocks, (long)batch, value_loss_coef,
                        entropy_coef, out5);
+    return hipGetLastError() == hipSuccess ? LSIM_OK : LSIM_E_HIP;
+}
+
+extern "C" int lsim_ppo_loss_std_workspace(long batch, int num_actions, size_t* bytes) {
+    if (!bytes || batch <= 0 || num_actions <= 0 || num_actions > LS_PPO_MAX_A) return LSIM_E_INVALID;
+    *bytes = (size_t)((batch + 255) / 256) * (4 + num_actions) * sizeof(float);
+    return LSIM_OK;
+}
+extern "C" int lsim_ppo_loss_std(const float* mu, const float* std, const float* value, const float* actions, const float* old_logp, const float* advantages,
+                                 const float* returns, const float* target_values, const float* old_mu, const float* old_sigma, int64_t batch, int num_actions,
+                                 float clip_param, float value_loss_coef, float entropy_coef, int use_clipped_value_loss,
+                                 float* out5, float* grad_mu, float* grad_std, float* grad_value, void* workspace, size_t workspace_bytes, void* stream) {
+    size_t need;
+    if (lsim_ppo_loss_std_workspace(batch, num_actions, &need) != LSIM_OK) return LSIM_E_INVALID;
+    if (!mu || !std || !value || !actions || !old_logp || !advantages || !returns || !old_mu || !old_sigma || !out5 || !grad_mu || !grad_std ||
+        !grad_value || !workspace || workspace_bytes < need || (use_clipped_value_loss && !target_values)) return LSIM_E_INVALID;
+    LsPpoLossArgs a;
+    a.mu = mu; a.sigma = std; a.value = value; a.actions = actions; a.old_logp = old_logp; a.adv = advantages; a.returns = returns;
+    a.target_values = target_values; a.old_mu = old_mu; a.old_sigma = old_sigma; a.g_mu = grad_mu; a.g_sigma = nullptr; a.g_value = grad_value;
+    a.partial = (float*)workspace; a.batch = batch; a.A = num_actions; a.clip = clip_param; a.value_coef = value_loss_coef;
+    a.entropy_coef = entropy_coef; a.clipped_value = use_clipped_value_loss; a.std_mode = 1;
+    const int blocks = (int)((batch + 255) / 256);
+    hipLaunchKernelGGL(lsim_k_ppo_loss, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(lsim_k_ppo_loss_finish_std, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, blocks, (long)batch, num_actions,
+                       value_loss_coef, entropy_coef, out5, grad_std);
     return hipGetLastError() == hipSuccess ? LSIM_OK : LSIM_E_HIP;
 }
 

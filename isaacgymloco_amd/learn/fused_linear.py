@@ -341,7 +341,9 @@ def sinkhorn_hip(scores, eps, iters):
 
 
 class _PpoLossFn(torch.autograd.Function):
-    """clipped-PPO loss through lsim_ppo_loss: forward and the three input gradients come from the same pass"""
+    """clipped-PPO loss through lsim_ppo_loss: forward and the three input gradients come from the same pass.  `sigma` is either the
+    per-sample [B, A] tensor or the policy's state-independent std [A] itself (lsim_ppo_loss_std: the broadcast mean * 0 + std of HAC:147, its
+    backward and the column sum of its gradient are then never formed)"""
 
     @staticmethod
     def forward(ctx, mu, sigma, value, actions, old_logp, adv, returns, target_values, old_mu, old_sigma, clip, vcoef, ecoef, clipped, out=None):
@@ -350,18 +352,23 @@ class _PpoLossFn(torch.autograd.Function):
         c = lambda t: t.detach().contiguous()
         mu_, sg_, v_ = c(mu), c(sigma), c(value).reshape(-1)
         B, A = mu_.shape
+        std_mode = sg_.dim() == 1
         need = ctypes.c_size_t()
-        lib.check(L.lsim_ppo_loss_workspace(B, ctypes.byref(need)), what="lsim_ppo_loss_workspace")
+        if std_mode:
+            lib.check(L.lsim_ppo_loss_std_workspace(B, A, ctypes.byref(need)), what="lsim_ppo_loss_std_workspace")
+        else:
+            lib.check(L.lsim_ppo_loss_workspace(B, ctypes.byref(need)), what="lsim_ppo_loss_workspace")
         ws = torch.empty(need.value, dtype=torch.uint8, device=mu.device)
         if out is None:       # [surrogate, value loss, entropy, kl, total]; the data-parallel step passes the tail of its gradient bucket
             out = torch.empty(5, device=mu.device)
         g_mu, g_sg, g_v = torch.empty_like(mu_), torch.empty_like(sg_), torch.empty_like(v_)
         args = [c(t).reshape(B, -1) if t is not None else None for t in (actions, old_logp, adv, returns, target_values, old_mu, old_sigma)]
         ptr = lambda t: t.data_ptr() if t is not None else None
-        lib.check(L.lsim_ppo_loss(mu_.data_ptr(), sg_.data_ptr(), v_.data_ptr(), ptr(args[0]), ptr(args[1]), ptr(args[2]), ptr(args[3]), ptr(args[4]),
-                                  ptr(args[5]), ptr(args[6]), B, A, float(clip), float(vcoef), float(ecoef), int(bool(clipped)), out.data_ptr(),
-                                  g_mu.data_ptr(), g_sg.data_ptr(), g_v.data_ptr(), ws.data_ptr(), ws.numel(),
-                                  torch.cuda.current_stream(mu.device).cuda_stream), what="lsim_ppo_loss")
+        fn = L.lsim_ppo_loss_std if std_mode else L.lsim_ppo_loss
+        lib.check(fn(mu_.data_ptr(), sg_.data_ptr(), v_.data_ptr(), ptr(args[0]), ptr(args[1]), ptr(args[2]), ptr(args[3]), ptr(args[4]),
+                     ptr(args[5]), ptr(args[6]), B, A, float(clip), float(vcoef), float(ecoef), int(bool(clipped)), out.data_ptr(),
+                     g_mu.data_ptr(), g_sg.data_ptr(), g_v.data_ptr(), ws.data_ptr(), ws.numel(),
+                     torch.cuda.current_stream(mu.device).cuda_stream), what="lsim_ppo_loss")
         ctx.save_for_backward(g_mu, g_sg, g_v)
         ctx.value_shape = value.shape
         stats = out[:4]

@@ -452,7 +452,13 @@ class HIMPPO:
             ac.estimator.prime(obs)        # one encoder forward serves the policy features and the estimator loss below
             # the reference calls act() here (HIMP:141) and throws the sample away; torch.normal(mean, std) validates std >= 0 with a
             # host read-back, i.e. one pipeline drain per minibatch on the GPU: only the distribution is needed
-            if obs.is_cuda:
+            std_direct = obs.is_cuda and obs.dtype == torch.float32 and ac.std.dim() == 1 and ac.std.numel() <= 60 and \
+                os.environ.get("LSIM_PPO_STD_DIRECT", "1") != "0"
+            if std_direct:
+                # the policy's std is one value per action (HAC:93): the loss kernel takes it as it is (lsim_ppo_loss_std) instead of the
+                # broadcast mean * 0 + std the distribution object forms (HAC:147) -- no [B, A] sigma, no backward of the broadcast, no column sum
+                mu_direct = ac.actor(ac._actor_input(obs))
+            elif obs.is_cuda:
                 ac.update_distribution(obs)
             else:
                 ac.act(obs)
@@ -461,7 +467,7 @@ class HIMPPO:
                 value.record_stream(cur)
             else:
                 value = ac.evaluate(critic_obs)
-            mu, sigma = ac.action_mean, ac.action_std
+            mu, sigma = (mu_direct, ac.std) if std_direct else (ac.action_mean, ac.action_std)
             loss, surrogate_loss, value_loss, kl_mean = self._ppo_loss(ac, mu, sigma, value, actions, old_logp, advantages, returns, target_values,
                                                                        old_mu, old_sigma)
             adaptive = self.desired_kl is not None and self.schedule == "adaptive"

@@ -70,6 +70,8 @@ def load_path(path):
     L.lsim_actor_input.argtypes = [vp, i64, i32, vp, i64, i32, i64, vp, vp]
     L.lsim_ppo_loss_workspace.argtypes = [ctypes.c_long, ctypes.POINTER(ctypes.c_size_t)]
     L.lsim_ppo_loss.argtypes = [vp] * 10 + [i64, i32, f32, f32, f32, i32, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
+    L.lsim_ppo_loss_std_workspace.argtypes = [ctypes.c_long, i32, ctypes.POINTER(ctypes.c_size_t)]
+    L.lsim_ppo_loss_std.argtypes = [vp] * 10 + [i64, i32, f32, f32, f32, i32, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
     L.lsim_adaptive_lr.argtypes = [vp, f32, f32, f32, f32, vp, vp]
     L.lsim_linear_elu_wgrad.argtypes = [vp, i64, vp, i64, vp, i64, i64, i32, i32, vp, vp, vp, vp, ctypes.c_size_t, vp]
     pend = ctypes.POINTER(abi.LsimWgradPending)

@@ -879,3 +879,28 @@ def test_deferred_weight_gradient_sums_change_nothing(monkeypatch):
         assert torch.equal(dw0, dw1) and torch.equal(db0, db1), (k_in, n_out)
         assert torch.equal(2.0 * dw0, dw2) and torch.equal(2.0 * db0, db2), (k_in, n_out)
 
+
+def test_ppo_loss_with_the_std_vector_equals_the_broadcast_form():
+    """lsim_ppo_loss_std (the policy's std [A] as it is) against lsim_ppo_loss on its broadcast [B, A]: the five statistics, grad_mu and
+    grad_value bit for bit (the same arithmetic in the same order), grad_std = the column sums of grad_sigma to summation order"""
+    from isaacgymloco_amd.learn.fused_linear import ppo_loss_hip
+    g = torch.Generator(device="cuda:0").manual_seed(11)
+    B, A = 102400, 12
+    r = lambda *s: torch.randn(*s, device="cuda:0", generator=g)
+    mu, value = r(B, A).requires_grad_(True), r(B, 1).requires_grad_(True)
+    std = (0.5 + torch.rand(A, device="cuda:0", generator=g)).requires_grad_(True)
+    actions, old_mu, old_sigma = r(B, A), r(B, A), 0.5 + torch.rand(B, A, device="cuda:0", generator=g)
+    old_logp, adv, returns, tv = r(B, 1), r(B, 1), r(B, 1), r(B, 1)
+    res = []
+    for form in ("std", "broadcast"):
+        for t in (mu, value, std):
+            t.grad = None
+        sigma = std if form == "std" else mu.detach() * 0.0 + std
+        loss, st = ppo_loss_hip(mu, sigma, value, actions, old_logp, adv, returns, tv, old_mu, old_sigma, 0.2, 1.0, 0.01, True)
+        loss.backward()
+        res.append((loss.detach().clone(), st.clone(), mu.grad.clone(), value.grad.clone(), std.grad.clone()))
+    (l0, s0, gm0, gv0, gs0), (l1, s1, gm1, gv1, gs1) = res
+    assert torch.equal(l0, l1) and torch.equal(s0, s1) and torch.equal(gm0, gm1) and torch.equal(gv0, gv1)
+    torch.testing.assert_close(gs0, gs1, rtol=2e-5, atol=1e-7)
+    assert float(gs1.abs().max()) > 0
+
