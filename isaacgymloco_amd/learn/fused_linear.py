@@ -371,6 +371,7 @@ class _PpoLossFn(torch.autograd.Function):
                      torch.cuda.current_stream(mu.device).cuda_stream), what="lsim_ppo_loss")
         ctx.save_for_backward(g_mu, g_sg, g_v)
         ctx.value_shape = value.shape
+        _PpoLossFn.last_grads = (g_mu, g_sg, g_v.reshape(value.shape))
         stats = out[:4]
         ctx.mark_non_differentiable(stats)
         return out[4], stats
@@ -384,7 +385,10 @@ class _PpoLossFn(torch.autograd.Function):
 def ppo_loss_hip(mu, sigma, value, actions, old_logp, adv, returns, target_values, old_mu, old_sigma, clip, vcoef, ecoef, clipped, out=None):
     """-> (total loss with autograd to mu / sigma / value, stats = [surrogate, value loss, entropy, kl] means, detached).  `out`: optional
     5-float CUDA tensor the kernel writes [stats, total] into (the tail of a gradient bucket: the KL estimate then travels with the gradients)"""
-    return _PpoLossFn.apply(mu, sigma, value, actions, old_logp, adv, returns, target_values, old_mu, old_sigma, clip, vcoef, ecoef, clipped, out)
+    loss, stats = _PpoLossFn.apply(mu, sigma, value, actions, old_logp, adv, returns, target_values, old_mu, old_sigma, clip, vcoef, ecoef, clipped, out)
+    loss._lsim_direct = ((mu, sigma, value), _PpoLossFn.last_grads)          # see backward_losses()
+    _PpoLossFn.last_grads = None
+    return loss, stats
 
 
 class _EstimatorLossFn(torch.autograd.Function):
@@ -408,6 +412,7 @@ class _EstimatorLossFn(torch.autograd.Function):
                                         g_tgt.data_ptr(), g_proto.data_ptr(), ws.data_ptr(), ws.numel(),
                                         torch.cuda.current_stream(enc_.device).cuda_stream), what="lsim_estimator_loss")
         ctx.save_for_backward(g_enc, g_tgt, g_proto)
+        _EstimatorLossFn.last_grads = (g_enc, g_tgt, g_proto)
         parts = out[:2]
         ctx.mark_non_differentiable(parts)
         return out[2], parts
@@ -421,7 +426,30 @@ class _EstimatorLossFn(torch.autograd.Function):
 
 def estimator_loss_hip(enc_out, tgt_out, proto, vel, temperature, eps=0.05, iters=3):
     """-> (est + swap with autograd to enc_out / tgt_out / proto, [est, swap] detached); see include/lsim.h lsim_estimator_loss"""
-    return _EstimatorLossFn.apply(enc_out, tgt_out, proto, vel, temperature, eps, iters)
+    total, parts = _EstimatorLossFn.apply(enc_out, tgt_out, proto, vel, temperature, eps, iters)
+    total._lsim_direct = ((enc_out, tgt_out, proto), _EstimatorLossFn.last_grads)      # see backward_losses()
+    _EstimatorLossFn.last_grads = None
+    return total, parts
+
+
+def backward_losses(*losses):
+    """loss.backward() for each of `losses`, except that a loss that came out of one of the fused loss kernels above is back-propagated from
+    the gradients that kernel already produced: torch.autograd.backward(inputs, d loss / d inputs) instead of a root gradient of ones times
+    those gradients -- the ones_like fill and the three multiplications by 1.0 per loss disappear (14 MB per minibatch for the estimator's);
+    multiplying by one changes no bit.  All such losses go through ONE engine run.  Losses without the recipe (torch statements, sums of
+    losses) take the ordinary path."""
+    tensors, grads, rest = [], [], []
+    direct = os.environ.get("LSIM_DIRECT_LOSS_BACKWARD", "1") != "0"        # A/B hook
+    for l in losses:
+        d = getattr(l, "_lsim_direct", None) if direct else None
+        if d is None or not all(t.requires_grad for t in d[0]):
+            rest.append(l)
+        else:
+            tensors += list(d[0]); grads += list(d[1])
+    if tensors:
+        torch.autograd.backward(tensors, grads)
+    for l in rest:
+        l.backward()
 
 
 def estimator_loss_supported(latent, K):

@@ -391,8 +391,7 @@ class HIMPPO:
         est, swap, total = est_mod.losses(obs, next_critic_obs)
         est_mod._primed = None
         with FL.deferred_wgrad_reduce():                             # one summing launch for the partial results of all ~15 layers
-            total.backward()
-            loss.backward()                                          # actor / critic / std gradients
+            FL.backward_losses(total, loss)                          # estimator; actor / critic / std gradients
         extra = None
         if adaptive:
             extra = kl_mean if kl_mean is not None else self._local_kl(mu, sigma, old_mu, old_sigma)
@@ -481,7 +480,7 @@ class HIMPPO:
                 from . import fused_linear as FL
                 FL.grad_cycle()
                 with FL.deferred_wgrad_reduce():
-                    loss.backward()
+                    FL.backward_losses(loss)
                 if FL._arena is not None:
                     FL._arena.bucket("ppo", [p for p in ac.parameters() if p.grad is not None]).adopt()
                 self._clip_and_step(self.optimizer, ac.parameters(), self.max_grad_norm)

@@ -136,7 +136,7 @@ class HIMEstimator(nn.Module):
         from . import fused_linear as FL
         FL.grad_cycle()
         with FL.deferred_wgrad_reduce():
-            total.backward()
+            FL.backward_losses(total)
         if self.grad_sync is not None:
             self.grad_sync(list(self.parameters()))
         elif FL._arena is not None and next(self.parameters()).is_cuda:      # stable gradient pointers for the fused optimiser step

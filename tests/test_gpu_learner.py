@@ -904,3 +904,21 @@ def test_ppo_loss_with_the_std_vector_equals_the_broadcast_form():
     torch.testing.assert_close(gs0, gs1, rtol=2e-5, atol=1e-7)
     assert float(gs1.abs().max()) > 0
 
+
+def test_backward_from_the_loss_kernels_gradients_changes_nothing(monkeypatch):
+    """fused_linear.backward_losses (torch.autograd.backward(inputs, the gradients the fused loss kernels already produced)) against the ordinary
+    loss.backward() (a root gradient of ones times the same gradients): two iterations, identical weights bit for bit"""
+    from isaacgymloco_amd.learn import fused_linear as FL
+
+    def run(direct):
+        monkeypatch.setenv("LSIM_DIRECT_LOSS_BACKWARD", "1" if direct else "0")
+        FL.set_grad_arena(None)
+        env, r = _make(seed=9)
+        r.enable_graphs()
+        r.learn(2, init_at_random_ep_len=False)
+        return {k: v.clone() for k, v in r.alg.actor_critic.state_dict().items()}
+    a, b = run(True), run(False)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    FL.set_grad_arena(None)
+
