@@ -581,6 +581,11 @@ int lsim_linear_elu_wgrad_deferred(const float* x, int64_t ldx, const float* gra
                                    lsim_wgrad_pending* pending);
 int lsim_wgrad_reduce_batch(const lsim_wgrad_pending* items, int n, void* stream);
 
+/* dst[r, :] = src[index[r], :] for 4-byte elements (rows of `cols` elements, both contiguous; index: int64 [n] on the device): the once-per-update
+ * shuffle of the rollout storage through the minibatch permutation (HST:140-164) at copy bandwidth -- torch's advanced indexing computes an
+ * offset per element (2.6 TB/s on these row widths). */
+int lsim_gather_rows(const void* src, int64_t cols, const int64_t* index, int64_t n, void* dst, void* stream);
+
 /* w[r, :] /= max(||w[r, :]||_2, eps) in place for a small matrix (rows * cols <= 4096): torch.nn.functional.normalize(w, dim=-1, p=2, eps) written
  * back, as HIMEstimator.update does with its prototypes before every loss evaluation (HES:80-81) -- one launch instead of clone, norm, clamp,
  * divide and copy.  Sums in column order: may differ from torch's reduction in the last bit. */

@@ -1098,6 +1098,27 @@ extern "C" int lsim_estimator_loss(const float* enc_out, int64_t ld_enc, const f
     return hipGetLastError() == hipSuccess ? LSIM_OK : LSIM_E_HIP;
 }
 
+// ---- row gather: block = 256 / CPT rows x CPT column lanes (CPT = the row width rounded up to a power of two, at most 256)
+__global__ __launch_bounds__(256) void lsim_k_gather_rows(const uint32_t* __restrict__ src, long cols, const long long* __restrict__ index, long n,
+                                                          uint32_t* __restrict__ dst, int cpt_log2) {
+    const int cpt = 1 << cpt_log2, rpb = 256 >> cpt_log2;
+    const long r = (long)blockIdx.x * rpb + (threadIdx.x >> cpt_log2);
+    if (r >= n) return;
+    const uint32_t* s = src + (size_t)index[r] * cols;
+    uint32_t* d = dst + (size_t)r * cols;
+    for (long c = threadIdx.x & (cpt - 1); c < cols; c += cpt) d[c] = s[c];
+}
+extern "C" int lsim_gather_rows(const void* src, int64_t cols, const int64_t* index, int64_t n, void* dst, void* stream) {
+    if (!src || !index || !dst || cols <= 0 || n < 0) return LSIM_E_INVALID;
+    if (n == 0) return LSIM_OK;
+    int lg = 0;
+    while ((1 << lg) < cols && lg < 8) ++lg;
+    const long rpb = 256 >> lg;
+    hipLaunchKernelGGL(lsim_k_gather_rows, dim3((unsigned)((n + rpb - 1) / rpb)), dim3(256), 0, (hipStream_t)stream, (const uint32_t*)src, (long)cols,
+                       (const long long*)index, (long)n, (uint32_t*)dst, lg);
+    return hipGetLastError() == hipSuccess ? LSIM_OK : LSIM_E_HIP;
+}
+
 // ---- F.normalize(w, dim=-1) in place for a small matrix: one thread per row
 __global__ __launch_bounds__(256) void lsim_k_normalize_rows(float* __restrict__ w, int rows, int cols, float eps) {
     const int r = (int)(blockIdx.x * blockDim.x + threadIdx.x);

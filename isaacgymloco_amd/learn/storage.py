@@ -136,7 +136,20 @@ class HIMRolloutStorage:
         # The reference draws ONE permutation and reuses it for every epoch (HST:140, HST:159-164), so minibatch i holds the same
         # rows in all epochs: gather the whole batch through the permutation once and hand out contiguous slices, instead of
         # re-gathering ~800 floats per sample for each of the epochs x minibatches (same values, 1/num_epochs of the gather traffic).
-        shuffled = tuple(f[perm] for f in fields)
+        shuffled = tuple(_gather_rows(f, perm) for f in fields)
         for _ in range(num_epochs):
             for i in range(num_mini_batches):
                 yield tuple(f[i * mb:(i + 1) * mb] for f in shuffled)
+
+
+def _gather_rows(f, perm):
+    """f[perm] for a contiguous tensor of 4-byte elements on the GPU through lsim_gather_rows (rows at copy bandwidth); anything else: f[perm]"""
+    if not (f.is_cuda and f.is_contiguous() and f.element_size() == 4 and f.dim() >= 1 and perm.dtype == torch.int64 and perm.is_contiguous()):
+        return f[perm]
+    from .. import lib
+    cols = f[0].numel() if f.dim() > 1 else 1
+    out = torch.empty((perm.numel(),) + tuple(f.shape[1:]), dtype=f.dtype, device=f.device)
+    lib.check(lib.load().lsim_gather_rows(f.data_ptr(), cols, perm.data_ptr(), perm.numel(), out.data_ptr(), torch.cuda.current_stream(f.device).cuda_stream),
+              what="lsim_gather_rows")
+    return out
+

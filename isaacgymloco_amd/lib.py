@@ -79,6 +79,7 @@ def load_path(path):
     L.lsim_linear_elu_wgrad_deferred.argtypes = [vp, i64, vp, i64, vp, i64, i64, i32, i32, vp, vp, vp, vp, ctypes.c_size_t, vp, pend]
     L.lsim_wgrad_reduce_batch.argtypes = [pend, i32, vp]
     L.lsim_normalize_rows.argtypes = [vp, i32, i32, f32, vp]
+    L.lsim_gather_rows.argtypes = [vp, i64, vp, i64, vp, vp]
     L.lsim_destroy.argtypes = [vp]
     L.lsim_destroy.restype = None
     return L

@@ -922,3 +922,15 @@ def test_backward_from_the_loss_kernels_gradients_changes_nothing(monkeypatch):
         assert torch.equal(a[k], b[k]), k
     FL.set_grad_arena(None)
 
+
+def test_gather_rows_equals_advanced_indexing():
+    from isaacgymloco_amd.learn.storage import _gather_rows
+    g = torch.Generator(device="cuda:0").manual_seed(1)
+    for shape in ((4096, 270), (5000, 238), (4096, 12), (4097, 1), (3000,), (1000, 3, 5)):
+        f = torch.randn(*shape, device="cuda:0", generator=g)
+        perm = torch.randperm(shape[0] - 7, device="cuda:0")
+        assert torch.equal(_gather_rows(f, perm), f[perm]), shape
+    b = torch.randint(0, 2, (500, 1), device="cuda:0", dtype=torch.uint8)          # not 4-byte elements: the torch statement
+    perm = torch.randperm(500, device="cuda:0")
+    assert torch.equal(_gather_rows(b, perm), b[perm])
+
