@@ -377,7 +377,8 @@ class HIMPPO:
         b = self._arena.buckets.get("all")
         return b.extra_view if b is not None and b.extra == 5 else None
 
-    def _step_minibatch_data_parallel(self, ac, obs, next_critic_obs, loss, mu, sigma, old_mu, old_sigma, kl_mean, adaptive, more_params=()):
+    def _step_minibatch_data_parallel(self, ac, obs, next_critic_obs, loss, mu, sigma, old_mu, old_sigma, kl_mean, adaptive, more_params=(),
+                                      est_losses=None):
         """the optimiser half of one minibatch in the data-parallel order: both backwards, ONE all-reduce of every gradient + the KL estimate,
         then the same two optimiser steps as the single-rank order (lr rule -> estimator step -> PPO step, HIMP:144-184).  Also the order of
         the single-rank two-stream path (no collectives).  Returns the estimator's (estimation, swap) losses."""
@@ -388,7 +389,8 @@ class HIMPPO:
         est_params = list(est_mod.parameters())
         self.optimizer.zero_grad()                                   # every parameter of the optimiser, the estimator's included
         FL.grad_cycle()
-        est, swap, total = est_mod.losses(obs, next_critic_obs)
+        # est_losses: the estimator's losses when update() already formed them (before the critic's stream was joined)
+        est, swap, total = est_losses if est_losses is not None else est_mod.losses(obs, next_critic_obs)
         est_mod._primed = None
         with FL.deferred_wgrad_reduce():                             # one summing launch for the partial results of all ~15 layers
             FL.backward_losses(total, loss)                          # estimator; actor / critic / std gradients
@@ -449,6 +451,12 @@ class HIMPPO:
                 with torch.cuda.stream(side):
                     value = ac.evaluate(critic_obs)
             ac.estimator.prime(obs)        # one encoder forward serves the policy features and the estimator loss below
+            early_est = None
+            if two_streams and os.environ.get("LSIM_EARLY_EST_LOSS", "1") != "0":
+                # The estimator's loss head -- target encoder, prototype scores, three Sinkhorn rounds, log-softmax, losses and their gradients:
+                # ~15 launches that each leave most of the device idle -- depends on the encoder output alone.  Formed HERE, while the critic's
+                # GEMMs run on the side stream, it fills what they leave; behind the join it ran by itself (0.27 ms per minibatch).  Same values.
+                early_est = ac.estimator.losses(obs, next_critic_obs)
             # the reference calls act() here (HIMP:141) and throws the sample away; torch.normal(mean, std) validates std >= 0 with a
             # host read-back, i.e. one pipeline drain per minibatch on the GPU: only the distribution is needed
             std_direct = obs.is_cuda and obs.dtype == torch.float32 and ac.std.dim() == 1 and ac.std.numel() <= 60 and \
@@ -471,7 +479,8 @@ class HIMPPO:
                                                                        old_mu, old_sigma)
             adaptive = self.desired_kl is not None and self.schedule == "adaptive"
             if (self.dist_ctx is not None and self.dist_ctx.enabled) or two_streams:
-                est, swap = self._step_minibatch_data_parallel(ac, obs, next_critic_obs, loss, mu, sigma, old_mu, old_sigma, kl_mean, adaptive)
+                est, swap = self._step_minibatch_data_parallel(ac, obs, next_critic_obs, loss, mu, sigma, old_mu, old_sigma, kl_mean, adaptive,
+                                                               est_losses=early_est)
             else:
                 if adaptive:
                     self._adapt_lr(mu, sigma, old_mu, old_sigma, kl_mean)
