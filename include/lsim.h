@@ -641,7 +641,7 @@ int lsim_estimator_loss(const float* enc_out, int64_t ld_enc, const float* tgt_o
                         float* losses3, float* grad_enc, float* grad_tgt, float* grad_proto, void* workspace, size_t workspace_bytes,
                         void* stream);
 
-/* Gradient clipping + Adam of one optimiser step in three launches (HIMP:183-184, HES:113-114: clip_grad_norm_(params, max_grad_norm) then
+/* Gradient clipping + Adam of one optimiser step in two launches (HIMP:183-184, HES:113-114: clip_grad_norm_(params, max_grad_norm) then
  * torch.optim.Adam.step(), no amsgrad / weight decay / maximize), on the caller's tensors: `count` <= 48 parameters with numel[i] elements
  * each, their gradients (rescaled in place by min(max_grad_norm / (||g|| + 1e-6), 1), as clip_grad_norm_ does; max_grad_norm <= 0: no
  * clipping), first / second moment estimates and per-parameter step counters (float scalars, incremented).  The pointer tables are HOST

@@ -1345,11 +1345,11 @@ extern "C" int lsim_adaptive_lr(const float* kl_mean_dev, float desired_kl, floa
     return hipGetLastError() == hipSuccess ? LSIM_OK : LSIM_E_HIP;
 }
 
-// ---- gradient clipping + Adam in three launches (HIMP:183-184, HES:113-114: clip_grad_norm_ then optimizer.step(); torch's foreach
+// ---- gradient clipping + Adam in two launches (HIMP:183-184, HES:113-114: clip_grad_norm_ then optimizer.step(); torch's foreach
 // clipping and fused Adam need ~12 launches per optimiser step, 24 per minibatch):
-//   sumsq : per-tensor-slice partial sums of g^2                      (grid: LS_ADAM_SLICES x tensors)
-//   finish: total norm (fixed summation order), clip coefficient min(max_norm / (norm + 1e-6), 1), step counters += 1
-//   apply : g <- coef * g (written back, as clip_grad_norm_ does);  m <- lerp(m, g, 1 - b1);  v <- b2 v + (1 - b2) g^2;
+//   sumsq : per-tensor-slice partial sums of g^2; step counters += 1  (grid: LS_ADAM_SLICES x tensors)
+//   apply : total norm (fixed summation order, every block for itself), clip coefficient min(max_norm / (norm + 1e-6), 1);
+//           g <- coef * g (written back, as clip_grad_norm_ does);  m <- lerp(m, g, 1 - b1);  v <- b2 v + (1 - b2) g^2;
 //           p <- p - (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)           (torch.optim.Adam, no amsgrad / weight decay)
 // The tensors are the caller's (torch's parameter, .grad and optimizer-state tensors: checkpoints stay torch's); pointers travel by
 // value in the kernel arguments, so nothing is staged on the device.
@@ -1379,40 +1379,41 @@ __global__ __launch_bounds__(256) void lsim_k_adam_sumsq(LsAdamTable t, float* _
         if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
         __syncthreads();
     }
-    if (threadIdx.x == 0) part[ti * LS_ADAM_SLICES + blockIdx.x] = red[0];
+    if (threadIdx.x == 0) {
+        part[ti * LS_ADAM_SLICES + blockIdx.x] = red[0];
+        if (blockIdx.x == 0) *t.step[ti] += 1.0f;        // this launch reads no step counter; lsim_k_adam_apply reads the incremented ones
+    }
 }
 
-// scal[0] = clip coefficient, [1] = total gradient norm, [2] = step count after the increment
-__global__ __launch_bounds__(64) void lsim_k_adam_finish(LsAdamTable t, const float* __restrict__ part, float max_norm, float* __restrict__ scal) {
+// The clip coefficient is formed by every block for itself, from the partial sums, in the order lsim_k_adam_finish used (that launch -- 5.7 us
+// behind a dependent launch, twice per minibatch -- is gone): thread i adds tensor i's LS_ADAM_SLICES partials, thread 0 the tensors of the
+// clipped group.  Block (0, 0) leaves {coefficient, norm, step count} in scal for the caller.
+__global__ __launch_bounds__(256) void lsim_k_adam_apply(LsAdamTable t, const float* __restrict__ part, float max_norm, float* __restrict__ scal,
+                                                         const float* __restrict__ lr_dev, float lr_host, float b1, float b2, float eps) {
     __shared__ float tot[LS_ADAM_MAX_TENSORS];
-    const int i = threadIdx.x;
-    if (i < t.count) {
+    __shared__ float coef_s;
+    if ((int)threadIdx.x < t.count) {
         float s = 0.0f;
-        for (int k = 0; k < LS_ADAM_SLICES; ++k) s += part[i * LS_ADAM_SLICES + k];
-        tot[i] = s;
-        *t.step[i] += 1.0f;
+        for (int k = 0; k < LS_ADAM_SLICES; ++k) s += part[threadIdx.x * LS_ADAM_SLICES + k];
+        tot[threadIdx.x] = s;
     }
     __syncthreads();
-    if (i == 0) {
+    if (threadIdx.x == 0) {
         float s = 0.0f;
         for (int k = 0; k < t.clip_count; ++k) s += tot[k];
         const float norm = sqrtf(s);
-        scal[0] = max_norm > 0.0f ? fminf(max_norm / (norm + 1e-6f), 1.0f) : 1.0f;
-        scal[1] = norm;
-        scal[2] = *t.step[0];
+        coef_s = max_norm > 0.0f ? fminf(max_norm / (norm + 1e-6f), 1.0f) : 1.0f;
+        if (blockIdx.x == 0 && blockIdx.y == 0) { scal[0] = coef_s; scal[1] = norm; scal[2] = *t.step[0]; }
     }
-}
-
-__global__ __launch_bounds__(256) void lsim_k_adam_apply(LsAdamTable t, const float* __restrict__ scal, const float* __restrict__ lr_dev, float lr_host,
-                                                         float b1, float b2, float eps) {
+    __syncthreads();
     const int ti = blockIdx.y, n = t.n[ti];
     float* __restrict__ p = t.p[ti];
     float* __restrict__ g = t.g[ti];
     float* __restrict__ m = t.m[ti];
     float* __restrict__ v = t.v[ti];
-    // the bias correction uses THIS tensor's step count (already incremented by lsim_k_adam_finish), as torch's Adam does: a parameter that
+    // the bias correction uses THIS tensor's step count (already incremented by lsim_k_adam_sumsq), as torch's Adam does: a parameter that
     // received gradients on fewer steps (frozen layer, partially restored state) must not borrow tensor 0's counter
-    const float coef = ti < t.clip_count ? scal[0] : 1.0f, step = *t.step[ti], lr = lr_dev ? *lr_dev : lr_host, wd = t.wd[ti];
+    const float coef = ti < t.clip_count ? coef_s : 1.0f, step = *t.step[ti], lr = lr_dev ? *lr_dev : lr_host, wd = t.wd[ti];
     const float bc1 = 1.0f - powf(b1, step), bc2s = sqrtf(1.0f - powf(b2, step));
     const float step_size = lr / bc1;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += LS_ADAM_SLICES * 256) {
@@ -1466,8 +1467,8 @@ extern "C" int lsim_adam_clip_step_ex(int count, const int64_t* numel, float* co
     float* scal = part + (size_t)count * LS_ADAM_SLICES;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(lsim_k_adam_sumsq, dim3(LS_ADAM_SLICES, count), dim3(256), 0, s, t, part);
-    hipLaunchKernelGGL(lsim_k_adam_finish, dim3(1), dim3(64), 0, s, t, (const float*)part, max_grad_norm, scal);
-    hipLaunchKernelGGL(lsim_k_adam_apply, dim3(LS_ADAM_SLICES, count), dim3(256), 0, s, t, (const float*)scal, lr_dev, lr_host, beta1, beta2, eps);
+    hipLaunchKernelGGL(lsim_k_adam_apply, dim3(LS_ADAM_SLICES, count), dim3(256), 0, s, t, (const float*)part, max_grad_norm, scal, lr_dev, lr_host, beta1,
+                       beta2, eps);
     if (grad_norm_out && hipMemcpyAsync(grad_norm_out, scal + 1, sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return LSIM_E_HIP;
     return hipGetLastError() == hipSuccess ? LSIM_OK : LSIM_E_HIP;
 }

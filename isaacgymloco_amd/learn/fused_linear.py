@@ -458,7 +458,7 @@ def estimator_loss_supported(latent, K):
 
 def adam_clip_step_hip(optimizer, max_grad_norm, clip_params=None):
     """clip_grad_norm_(clip_params or all params, max_grad_norm) + optimizer.step() for a plain torch.optim.Adam through lsim_adam_clip_step_ex
-    (3 launches instead of ~12): works on the optimizer's own parameter / state tensors, so state_dict() and checkpoints stay torch's.
+    (2 launches instead of ~12): works on the optimizer's own parameter / state tensors, so state_dict() and checkpoints stay torch's.
     Several parameter groups are fine as long as they share lr / betas / eps (HybridPPO: three groups that differ in weight decay only);
     `clip_params` restricts the clipped norm to a subset (HybridPPO clips the actor-critic only, HYBP:270).  Returns False when the
     optimizer is not eligible (the caller then runs the torch statements): amsgrad / maximize, non-fp32 or non-CUDA parameters, more than

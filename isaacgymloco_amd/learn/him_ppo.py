@@ -266,7 +266,7 @@ class HIMPPO:
         return self._side
 
     def _clip_and_step(self, optimizer, params, max_grad_norm):
-        """clip_grad_norm_ + optimizer.step() (HIMP:183-184); on the device-lr fast path one C-ABI call of three launches"""
+        """clip_grad_norm_ + optimizer.step() (HIMP:183-184); on the device-lr fast path one C-ABI call of two launches"""
         params = list(params)
         if self._lr_t is not None:
             from .fused_linear import adam_clip_step_hip

@@ -141,7 +141,7 @@ class HIMEstimator(nn.Module):
             self.grad_sync(list(self.parameters()))
         elif FL._arena is not None and next(self.parameters()).is_cuda:      # stable gradient pointers for the fused optimiser step
             FL._arena.bucket("estimator", [p for p in self.parameters() if p.grad is not None]).adopt()
-        if self.fused_step:       # set by HIMPPO.enable_device_lr: clip + Adam in one C-ABI call (three launches)
+        if self.fused_step:       # set by HIMPPO.enable_device_lr: clip + Adam in one C-ABI call (two launches)
             from .fused_linear import adam_clip_step_hip
             if adam_clip_step_hip(self.optimizer, self.max_grad_norm):
                 return est.detach(), swap.detach()
