@@ -565,6 +565,15 @@ int lsim_linear_wgrad(const float* x, int64_t ldx, const float* g, int64_t ldg, 
 int lsim_linear_elu_wgrad(const float* x, int64_t ldx, const float* grad_out, int64_t ldg, const float* elu_out, int64_t ldz, int64_t batch,
                           int k_in, int n_out, float* dw, float* db, float* grad_pre, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Opt-in form of the two calls above for layers whose k_in and n_out are multiples of 128 (and whose operands are 16-byte aligned): the same fp32
+ * sums on the bf16 matrix pipe.  Every fp32 operand is split exactly into three bf16 terms (3 x 8 significand bits) and the six products of
+ * order <= 2 are accumulated in fp32: products exact, truncation 2^-24 |a||b| per product -- fp32's own rounding (measured against fp64 sums:
+ * at or below the fp32 pipe's error, tools/micro/split_bf16.hip, tests/test_gpu_learner.py).  fp32 in, fp32 out, fp32 accumulate; a different
+ * instruction stream than the default, hence a switch: on = 1 / 0 sets it, anything else only queries; returns the previous setting.
+ * Initial value: environment variable LSIM_WGRAD_SPLIT_BF16=1, else off.  Changes what lsim_linear_wgrad_workspace() reports: set it before
+ * sizing workspaces. */
+int lsim_wgrad_split_bf16(int on);
+
 /* The same two calls with the final, fixed-order sum of the partial results left to the caller: `pending` receives what that sum needs, the
  * workspace must stay untouched until lsim_wgrad_reduce_batch has run for it, and dw / db hold nothing until then.  A backward pass
  * collects the records of all its layers and sums them in ONE launch behind the last weight-gradient kernel (15 launches of a few

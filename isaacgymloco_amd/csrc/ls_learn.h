@@ -486,6 +486,148 @@ void lsim_k_linear_wgrad_tiled(const float* __restrict__ x, long ldx, const floa
     }
 }
 
+// ---- weight gradient of the 128-multiple layers on the bf16 matrix pipe, fp32 in and out (LSIM_WGRAD_SPLIT_BF16=1; tools/micro/split_bf16.hip has
+// the arithmetic and its measured accuracy): an fp32 value is EXACTLY the sum of three bf16 terms a0 + a1 + a2 (3 x 8 significand bits); the six
+// products a_i b_j with i + j <= 2 are exact in the pipe's fp32 accumulator and leave a truncation of 2^-24 |a||b| per product -- fp32's own
+// rounding -- while v_mfma_f32_16x16x32_bf16 moves 16 x the multiply-adds per cycle of v_mfma_f32_16x16x4_f32: six of them per K chunk are
+// 2.67 x the fp32 pipe's rate.  One block per (128 x 128 output tile, batch slice); per step of 32 rows:
+//   load  : thread (half, c4, rg) fetches rows 8 rg .. + 7 of column quad c4 of g (half 0; with z: times elu'(z), g_y stored, db summed) or x (half 1)
+//   split : its 32 values into three bf16 planes, 8 consecutive rows of one column = one 16-byte LDS write (layout [plane][column][32 k + 8 pad]:
+//           the pad makes both the writes of 16 consecutive lanes and the fragment reads of a quarter wave conflict-free)
+//   mfma  : wave (wn, wk) owns the 64 x 64 quarter: 4 + 4 fragments x 3 planes by ds_read_b128, 16 tiles x 6 products, smallest terms first
+// The next step's global loads are issued before the MFMAs; two blocks per CU (61 KB of LDS each) overlap one's load / split with the other's MFMAs.
+typedef __bf16 ls_bf8 __attribute__((ext_vector_type(8)));
+#define LS_SP_STRIDE 40
+#ifndef LS_SP_KNOCKOUT
+#define LS_SP_KNOCKOUT 0      // diagnostic builds (tools/wgrad_split_probe.py): 1 no MFMA phase, 2 no global loads in the loop, 3 no split / LDS writes
+#endif
+template <bool FZ>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void lsim_k_linear_wgrad_split(const float* __restrict__ x, long ldx, const float* __restrict__ g, long ldg, const float* __restrict__ z, long ldz,
+                               float* __restrict__ gy, long batch, int k_in, int n_out,
+                               int k_blocks, int tiles, int slices, long rows_per_slice, float* __restrict__ part_dw, float* __restrict__ part_db) {
+    __shared__ __attribute__((aligned(16))) __bf16 planes[2][3][128 * LS_SP_STRIDE];
+    const int total = (int)gridDim.x, xcd = (int)blockIdx.x & 7;          // XCD-aware order, as lsim_k_linear_wgrad_tiled
+    const long v = (long)xcd * (total >> 3) + (xcd < (total & 7) ? xcd : (total & 7)) + ((long)blockIdx.x >> 3);
+    const long slice = v / tiles;
+    const int tile = (int)(v - slice * tiles);
+    const int nb = tile / k_blocks, kb = tile - nb * k_blocks;
+    const int n_base = nb * 128, k_base = kb * 128;
+    const int t = threadIdx.x, lane = t & 63;
+    const int half = __builtin_amdgcn_readfirstlane(t >> 7);                // waves 0, 1: g; waves 2, 3: x
+    const int pch = t & 127, rg = pch & 3, c4 = pch >> 2;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6), wn = wv & 1, wk = wv >> 1;
+    const int col16 = lane & 15, kg = lane >> 4;
+    const long s0 = slice * rows_per_slice;
+    long s1 = s0 + rows_per_slice;
+    if (s1 > batch) s1 = batch;
+    const float* src = half ? x + k_base + 4 * c4 : g + n_base + 4 * c4;
+    const long ld = half ? ldx : ldg;
+    const bool is_g = half == 0, wgy = FZ && is_g && kb == 0 && gy != nullptr;
+    float4 cur[8], zc[8];
+    float dbacc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    ls_v4f acc[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[j][q] = (ls_v4f){0.0f, 0.0f, 0.0f, 0.0f};
+#define LS_SP_LOAD(RB) do {                                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                                       \
+            const long row_ = (RB) + 8 * rg + i;                                                                              \
+            const bool in_ = row_ < s1;                                                                                       \
+            const long rr_ = in_ ? row_ : s0;                                                                                 \
+            const float4 v_ = *(const float4*)(src + rr_ * ld);                                                               \
+            cur[i] = in_ ? v_ : make_float4(0.0f, 0.0f, 0.0f, 0.0f);                                                          \
+            if (FZ && is_g) zc[i] = *(const float4*)(z + rr_ * ldz + n_base + 4 * c4);                                         \
+        } } while (0)
+    if (s0 < s1) LS_SP_LOAD(s0);
+    for (long rb = s0; rb < s1; rb += 32) {
+        if (FZ && is_g) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                cur[i].x *= zc[i].x > 0.0f ? 1.0f : zc[i].x + 1.0f; cur[i].y *= zc[i].y > 0.0f ? 1.0f : zc[i].y + 1.0f;
+                cur[i].z *= zc[i].z > 0.0f ? 1.0f : zc[i].z + 1.0f; cur[i].w *= zc[i].w > 0.0f ? 1.0f : zc[i].w + 1.0f;
+                const long row = rb + 8 * rg + i;
+                if (wgy && row < s1) *(float4*)(gy + row * (long)n_out + n_base + 4 * c4) = cur[i];
+            }
+        }
+        if (is_g) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { dbacc[0] += cur[i].x; dbacc[1] += cur[i].y; dbacc[2] += cur[i].z; dbacc[3] += cur[i].w; }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (LS_SP_KNOCKOUT == 3 && rb > s0) break;
+            ls_bf8 p0, p1, p2;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float val = j == 0 ? cur[i].x : j == 1 ? cur[i].y : j == 2 ? cur[i].z : cur[i].w;
+                const __bf16 h = (__bf16)val;
+                const float r1 = val - (float)h;           // exact
+                const __bf16 m = (__bf16)r1;
+                const float r2 = r1 - (float)m;            // exact
+                p0[i] = h; p1[i] = m; p2[i] = (__bf16)r2;
+            }
+            const int o = (4 * c4 + j) * LS_SP_STRIDE + 8 * rg;
+            *(ls_bf8*)&planes[half][0][o] = p0; *(ls_bf8*)&planes[half][1][o] = p1; *(ls_bf8*)&planes[half][2][o] = p2;
+        }
+        __syncthreads();
+        if (LS_SP_KNOCKOUT != 2 && rb + 32 < s1) LS_SP_LOAD(rb + 32);
+        if (LS_SP_KNOCKOUT == 1) { __syncthreads(); continue; }
+        ls_bf8 fa[4][3];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) fa[j][pl] = *(const ls_bf8*)&planes[0][pl][(64 * wn + 16 * j + col16) * LS_SP_STRIDE + 8 * kg];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            ls_bf8 fb[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) fb[pl] = *(const ls_bf8*)&planes[1][pl][(64 * wk + 16 * q + col16) * LS_SP_STRIDE + 8 * kg];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[j][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[j][2], fb[0], acc[j][q], 0, 0, 0);
+                acc[j][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[j][1], fb[1], acc[j][q], 0, 0, 0);
+                acc[j][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[j][0], fb[2], acc[j][q], 0, 0, 0);
+                acc[j][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[j][1], fb[0], acc[j][q], 0, 0, 0);
+                acc[j][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[j][0], fb[1], acc[j][q], 0, 0, 0);
+                acc[j][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[j][0], fb[0], acc[j][q], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+#undef LS_SP_LOAD
+    // accumulator (j, q)[r] of lane (kg, col16): n = n_base + 64 wn + 16 j + 4 kg + r (the A operand's row), k = k_base + 64 wk + 16 q + col16
+    float* pw = part_dw + (size_t)slice * n_out * k_in;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n_base + 64 * wn + 16 * j + 4 * kg + r;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pw[(size_t)n * k_in + k_base + 64 * wk + 16 * q + col16] = acc[j][q][r];
+        }
+    if (part_db && kb == 0 && is_g) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float d = dbacc[j];
+            d += __shfl_xor(d, 1, 64);
+            d += __shfl_xor(d, 2, 64);
+            if (rg == 0) part_db[(size_t)slice * n_out + n_base + 4 * c4 + j] = d;
+        }
+    }
+}
+static int g_ls_wgrad_split = -1;        // -1: not decided yet (LSIM_WGRAD_SPLIT_BF16 at the first use), 0 / 1
+static bool ls_wgrad_split_enabled() {
+    if (g_ls_wgrad_split < 0) { const char* e = getenv("LSIM_WGRAD_SPLIT_BF16"); g_ls_wgrad_split = (e && e[0] == '1') ? 1 : 0; }
+    return g_ls_wgrad_split == 1;
+}
+extern "C" int lsim_wgrad_split_bf16(int on) {
+    const int was = ls_wgrad_split_enabled() ? 1 : 0;
+    if (on == 0 || on == 1) g_ls_wgrad_split = on;
+    return was;
+}
+
 #define LS_WGRAD_MAX_TILES 32
 
 template <int NT, int KT> static void ls_wgrad_launch(const float* x, long ldx, const float* g, long ldg, long batch, int k_in, int n_out,
@@ -510,6 +652,7 @@ struct LsWgradPlan {
     int partials;         // number of partial results per output element
     long rows;            // batch rows per partial
     int n_blocks, k_blocks;
+    int split;            // 1: 128 x 128 tiles on the bf16 pipe (lsim_k_linear_wgrad_split) when the operands turn out 16-byte aligned
 };
 static int ls_wgrad_plan(long batch, int k_in, int n_out, LsWgradPlan* p) {
     // measured against TunableOp-selected hipBLASLt (tools/wgrad_sweep.sh): the block-cooperative tiled kernel wins up to 512 -> 256
@@ -520,6 +663,7 @@ static int ls_wgrad_plan(long batch, int k_in, int n_out, LsWgradPlan* p) {
     const int nt = (n_out + 15) / 16, kt = (k_in + 15) / 16;
     if (nt <= 8 && kt <= 8 && nt * kt <= LS_WGRAD_MAX_TILES && (long)n_out * k_in <= 4096) {
         p->small = 1;
+        p->split = 0;
         long rpw = ((batch + 1023) / 1024 + 3) & ~3L;      // one wave per SIMD of the 256-CU part; 4 rows per MFMA
         if (rpw < 16) rpw = 16;
         p->rows = rpw;
@@ -528,6 +672,7 @@ static int ls_wgrad_plan(long batch, int k_in, int n_out, LsWgradPlan* p) {
         return LSIM_OK;
     }
     p->small = 0;
+    p->split = 0;
     p->n_blocks = (n_out + 63) / 64;
     p->k_blocks = k_in <= 64 ? 1 : (k_in + 127) / 128;     // 64-wide k tile for the narrow inputs, 128-wide otherwise
     const int tiles = p->n_blocks * p->k_blocks;
@@ -537,6 +682,14 @@ static int ls_wgrad_plan(long batch, int k_in, int n_out, LsWgradPlan* p) {
     if (slices < 1) slices = 1;
     long rps = ((batch + slices - 1) / slices + 15) & ~15L;  // each of the block's four waves takes a quarter, in steps of 4 rows
     if (rps < 64) rps = 64;
+    if (ls_wgrad_split_enabled() && n_out % 128 == 0 && k_in % 128 == 0) {
+        p->split = 1;
+        const int tiles128 = (n_out / 128) * (k_in / 128);
+        slices = 512 / tiles128;                             // two blocks per CU
+        if (slices > cap) slices = cap;
+        if (slices < 1) slices = 1;
+        rps = ((batch + slices - 1) / slices + 31) & ~31L;   // whole steps of 32 rows
+    }
     p->rows = rps;
     p->partials = (int)((batch + rps - 1) / rps);
     return LSIM_OK;
@@ -584,6 +737,13 @@ static int ls_linear_wgrad_impl(const float* x, int64_t ldx, const float* g, int
         int vg = ((ldg % 4 == 0) && (((uintptr_t)g & 15) == 0)) ? 2 : 0;
         if (fz && !((ldz % 4 == 0) && (((uintptr_t)z & 15) == 0))) vg = 0;
         const int kg = k_in <= 64 ? 1 : 2;
+        if (p.split && vx == 2 && vg == 2 && (!gy || (((uintptr_t)gy & 15) == 0))) {
+            const int kb128 = k_in / 128, tiles128 = (n_out / 128) * kb128;
+            if (fz) hipLaunchKernelGGL((lsim_k_linear_wgrad_split<true>), dim3(tiles128 * p.partials), dim3(256), 0, s, x, (long)ldx, g, (long)ldg, z, (long)ldz,
+                                       gy, (long)batch, k_in, n_out, kb128, tiles128, p.partials, p.rows, pdw, pdb);
+            else hipLaunchKernelGGL((lsim_k_linear_wgrad_split<false>), dim3(tiles128 * p.partials), dim3(256), 0, s, x, (long)ldx, g, (long)ldg, z, (long)ldz,
+                                    gy, (long)batch, k_in, n_out, kb128, tiles128, p.partials, p.rows, pdw, pdb);
+        } else {
 #define LS_T(VX, VG, KG, FZ) hipLaunchKernelGGL((lsim_k_linear_wgrad_tiled<VX, VG, KG, FZ>), dim3(blocks), dim3(256), 0, s, x, (long)ldx, g, (long)ldg, z, (long)ldz, \
                                                 gy, (long)batch, k_in, n_out, p.k_blocks, tiles, p.partials, p.rows, pdw, pdb)
 #define LS_TZ(VX, VG, KG) do { if (fz) LS_T(VX, VG, KG, true); else LS_T(VX, VG, KG, false); } while (0)
@@ -593,6 +753,7 @@ static int ls_linear_wgrad_impl(const float* x, int64_t ldx, const float* g, int
 #undef LS_TK
 #undef LS_TZ
 #undef LS_T
+        }
     }
     const int count = n_out * k_in;
     if (pending) {       // the caller sums the partial results later (lsim_wgrad_reduce_batch)

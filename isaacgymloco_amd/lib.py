@@ -57,6 +57,7 @@ def load_path(path):
     L.lsim_rollout_gae.argtypes = [ctypes.POINTER(abi.LsimRolloutStorage), vp, f32, f32, vp, vp, vp]
     L.lsim_linear_wgrad_workspace.argtypes = [ctypes.c_long, i32, i32, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(i32)]
     L.lsim_linear_wgrad.argtypes = [vp, i64, vp, i64, i64, i32, i32, vp, vp, vp, ctypes.c_size_t, vp]
+    L.lsim_wgrad_split_bf16.argtypes = [i32]
     L.lsim_sinkhorn_workspace.argtypes = [ctypes.c_long, i32, ctypes.POINTER(ctypes.c_size_t)]
     L.lsim_sinkhorn.argtypes = [vp, i64, i64, i32, f32, i32, vp, vp, ctypes.c_size_t, vp]
     L.lsim_policy_forward.argtypes = [ctypes.POINTER(abi.LsimHimPolicy), vp, vp, i64, vp, vp, vp]

@@ -934,3 +934,49 @@ def test_gather_rows_equals_advanced_indexing():
     perm = torch.randperm(500, device="cuda:0")
     assert torch.equal(_gather_rows(b, perm), b[perm])
 
+
+
+@pytest.mark.parametrize("k_in,n_out,B", [(512, 256, 102400), (256, 128, 102400), (128, 128, 20480 + 12), (512, 256, 4099)])
+def test_weight_gradient_on_the_bf16_pipe_is_an_fp32_result(k_in, n_out, B):
+    """lsim_wgrad_split_bf16(1): the weight / bias gradient and the ELU backward of the 128-multiple layers with every fp32 operand split
+    exactly into three bf16 terms and six products per pair (csrc/ls_learn.h: lsim_k_linear_wgrad_split).  Against fp64 sums its error must
+    not exceed the default fp32-pipe kernel's (up to 1.25 x: the two sum in different orders); grad_pre is the same elementwise product, bit
+    for bit; ragged batches (rows past the last whole step of 32) and gradient-like operands (wide magnitude range, half the ELU units
+    saturated) included."""
+    import ctypes
+    from isaacgymloco_amd import lib
+    L = lib.load()
+    gen = torch.Generator(device="cuda:0").manual_seed(k_in + n_out + B)
+    x = torch.randn(B, k_in, device="cuda:0", generator=gen)
+    g = torch.randn(B, n_out, device="cuda:0", generator=gen) * torch.exp(2.0 * torch.randn(B, 1, device="cuda:0", generator=gen)) * 1e-3
+    z = torch.nn.functional.elu(torch.randn(B, n_out, device="cuda:0", generator=gen))
+    gp64 = g.double() * torch.where(z > 0, torch.ones_like(z), z + 1.0).double()
+    ref_w, ref_b = gp64.t() @ x.double(), gp64.sum(0)
+    s = torch.cuda.current_stream().cuda_stream
+
+    def run(on):
+        was = L.lsim_wgrad_split_bf16(on)
+        try:
+            need, parts = ctypes.c_size_t(), ctypes.c_int()
+            lib.check(L.lsim_linear_wgrad_workspace(B, k_in, n_out, ctypes.byref(need), ctypes.byref(parts)))
+            ws = torch.empty(need.value // 4, device="cuda:0")
+            dw, db, gy = torch.empty(n_out, k_in, device="cuda:0"), torch.empty(n_out, device="cuda:0"), torch.empty(B, n_out, device="cuda:0")
+            lib.check(L.lsim_linear_elu_wgrad(x.data_ptr(), k_in, g.data_ptr(), n_out, z.data_ptr(), n_out, B, k_in, n_out, dw.data_ptr(), db.data_ptr(),
+                                              gy.data_ptr(), ws.data_ptr(), need.value, s), what="lsim_linear_elu_wgrad")
+            dw2 = torch.empty_like(dw)
+            lib.check(L.lsim_linear_wgrad(x.data_ptr(), k_in, gy.data_ptr(), n_out, B, k_in, n_out, dw2.data_ptr(), None, ws.data_ptr(), need.value, s))
+            torch.cuda.synchronize()
+            return dw, db, gy, dw2, parts.value
+        finally:
+            L.lsim_wgrad_split_bf16(was)
+    dw0, db0, gy0, dwp0, parts0 = run(0)
+    dw1, db1, gy1, dwp1, parts1 = run(1)
+    assert torch.equal(gy0, gy1) and torch.equal(gy1, gp64.float())
+    mag = gp64.abs().t() @ x.double().abs()                                   # sum |a||b| per output: what a summation error scales with
+    e0, e1 = float(((dw0.double() - ref_w).abs() / mag).max()), float(((dw1.double() - ref_w).abs() / mag).max())
+    p0, p1 = float(((dwp0.double() - ref_w).abs() / mag).max()), float(((dwp1.double() - ref_w).abs() / mag).max())
+    assert e1 <= 1.25 * e0 + 1e-9 and p1 <= 1.25 * p0 + 1e-9, (e0, e1, p0, p1)
+    assert e1 < 2e-6 and p1 < 2e-6, (e1, p1)
+    bmag = gp64.abs().sum(0)
+    assert float(((db1.double() - ref_b).abs() / bmag).max()) < 2e-6
+    assert not torch.equal(dw0, dw1) or parts0 != parts1                       # the switch did select another kernel
