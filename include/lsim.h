@@ -436,6 +436,10 @@ int lsim_step_ex(lsim_handle h, const float* actions_dev, uint32_t flags, void* 
 /* host-side scalars (no device sync): common_step_counter (LR:194). */
 int lsim_get_step_counter(lsim_handle h, int64_t* counter_out);
 int lsim_set_step_counter(lsim_handle h, int64_t counter);
+/* number of lsim_reset_envs calls on this handle so far (the salt of their random draws): a resumed run that restores it together with the
+ * step counter redraws the same by-hand reset states as an uninterrupted one. */
+int lsim_get_reset_calls(lsim_handle h, uint32_t* calls_out);
+int lsim_set_reset_calls(lsim_handle h, uint32_t calls);
 /* which row (0/1) of LSIM_BUF_STATS the most recent lsim_step / lsim_reset_all filled. */
 int lsim_get_stats_row(lsim_handle h, int* row_out);
 

@@ -290,6 +290,8 @@ extern "C" int LS_API(reset_envs)(lsim_sim* s, const uint8_t* mask_dev, void* st
 
 extern "C" int LS_API(get_step_counter)(lsim_sim* s, int64_t* out) { if (!s || !out) return LSIM_E_INVALID; *out = s->step_counter; return LSIM_OK; }
 extern "C" int LS_API(set_step_counter)(lsim_sim* s, int64_t v) { if (!s) return LSIM_E_INVALID; s->step_counter = v; return LSIM_OK; }
+extern "C" int LS_API(get_reset_calls)(lsim_sim* s, uint32_t* out) { if (!s || !out) return LSIM_E_INVALID; *out = s->reset_calls; return LSIM_OK; }
+extern "C" int LS_API(set_reset_calls)(lsim_sim* s, uint32_t v) { if (!s) return LSIM_E_INVALID; s->reset_calls = v; return LSIM_OK; }
 extern "C" int LS_API(get_stats_row)(lsim_sim* s, int* row) { if (!s || !row) return LSIM_E_INVALID; *row = s->stats_row; return LSIM_OK; }
 extern "C" const char* LS_API(reward_name)(int id) { return (id >= 0 && id < LSIM_NUM_REWARD_TERMS) ? lsim_reward_names[id] : nullptr; }
 extern "C" const char* LS_API(buffer_name)(int id) { return (id >= 0 && id < LSIM_NUM_BUFFERS) ? lsim_buffer_names[id] : nullptr; }

@@ -293,18 +293,22 @@ class LeggedRobot:
     # ---- resumable simulator-side training state (the reference's checkpoints forget it: HIMR:233-240 save only the networks)
     def state_dict(self):
         """curricula and counters a resumed run needs: terrain levels/types and origins, the live command ranges (command curriculum,
-        LR:868-880), common_step_counter (push / disturbance phase, Philox step word), episode lengths"""
+        LR:868-880), common_step_counter (push / disturbance phase, Philox step word), the number of by-hand reset_idx calls
+        (salt of their draws), episode lengths"""
         from .. import abi
         c = ctypes.c_int64()
         self._L.lsim_get_step_counter(self._h, ctypes.byref(c))
+        rc = ctypes.c_uint32()
+        self._L.lsim_get_reset_calls(self._h, ctypes.byref(rc))
         S = abi.STATS["cmd_ranges"]
-        return {"step_counter": int(c.value), "terrain_levels": self.terrain_levels.cpu().clone(), "terrain_types": self.terrain_types.cpu().clone(),
+        return {"step_counter": int(c.value), "reset_calls": int(rc.value), "terrain_levels": self.terrain_levels.cpu().clone(), "terrain_types": self.terrain_types.cpu().clone(),
                 "env_origins": self.env_origins.cpu().clone(), "episode_length_buf": self.episode_length_buf.cpu().clone(),
                 "command_ranges": self.stats_row()[S:S + 8].cpu().clone()}
 
     def load_state_dict(self, d):
         from .. import abi
         self._L.lsim_set_step_counter(self._h, ctypes.c_int64(int(d["step_counter"])))
+        self._L.lsim_set_reset_calls(self._h, ctypes.c_uint32(int(d.get("reset_calls", 0))))       # (checkpoints from before round 5 do not hold it)
         self.terrain_levels.copy_(d["terrain_levels"]); self.terrain_types.copy_(d["terrain_types"])
         self.env_origins.copy_(d["env_origins"]); self.episode_length_buf.copy_(d["episode_length_buf"])
         S = abi.STATS["cmd_ranges"]

@@ -8,6 +8,7 @@ same state_dict keys, same initialisation as nn.Linear (it IS an nn.Linear); res
 """
 import ctypes
 import os
+import weakref
 
 import torch
 import torch.nn as nn
@@ -158,14 +159,20 @@ class deferred_wgrad_reduce:
         return False
 
 
-def flush_wgrad_reduces():
+def flush_wgrad_reduces(mid_backward=False):
     """sum every pending set of partial results (on the current stream: call it where the backward passes that produced them have
-    returned -- autograd has then ordered this stream behind the streams their kernels ran on)"""
+    returned -- autograd has then ordered this stream behind the streams their kernels ran on).  mid_backward: called from inside a
+    backward node instead; nothing has joined the streams yet, so this stream first waits for every other stream a pending kernel ran on"""
     if not _pending:
         return
     from .. import abi, lib
     arr = (abi.LsimWgradPending * len(_pending))(*_pending)
     dev = _pending_keep[0][0].device
+    if mid_backward:
+        cur = torch.cuda.current_stream(dev)
+        for st in {k[-1] for k in _pending_keep}:
+            if st != cur:
+                cur.wait_stream(st)
     lib.check(lib.load().lsim_wgrad_reduce_batch(arr, len(_pending), torch.cuda.current_stream(dev).cuda_stream), what="lsim_wgrad_reduce_batch")
     if _arena is not None:       # the sums went to the arena slices: they are the gradients only if autograd adopted those slices
         for wptr in _pending_params:
@@ -180,16 +187,20 @@ def _wgrad_call(L, fn_now, fn_deferred, args, weight_ptr, ws, keep, in_arena):
     sum is written after autograd has taken the returned tensor as `.grad`, which is only the same memory if autograd adopted it without a copy
     -- the arena hands out a fresh alias for exactly that, and flush_wgrad_reduces() checks it.  (`keep` must not hold dW / db: a second
     owner makes autograd clone the gradient, and the clone would be of memory that holds nothing yet.)  A second contribution to the same
-    parameter inside one block first flushes."""
+    parameter inside one block first flushes, whichever way it is computed."""
+    if _pending is not None and weight_ptr in _pending_params:
+        # a second contribution to a parameter whose first one is still a pending sum (a module applied twice inside one block): it cannot
+        # be in the arena (take() hands a slice out once per cycle), so autograd will ADD it to the slice in place -- the pending sum must be
+        # in the slice before that, not overwrite it afterwards (ADVICE r4)
+        flush_wgrad_reduces(mid_backward=True)
     if _pending is None or not in_arena:
         return getattr(L, fn_now)(*args)
-    if weight_ptr in _pending_params:
-        flush_wgrad_reduces()
     from .. import abi
     rec = abi.LsimWgradPending()
     rc = getattr(L, fn_deferred)(*args, ctypes.byref(rec))
     if rc == 0:
-        _pending.append(rec); _pending_keep.append((ws,) + tuple(keep)); _pending_params.add(weight_ptr)
+        _pending.append(rec); _pending_params.add(weight_ptr)
+        _pending_keep.append((ws,) + tuple(keep) + (torch.cuda.current_stream(ws.device),))       # last entry: the stream the kernel runs on
     return rc
 
 
@@ -483,19 +494,25 @@ def adam_clip_step_hip(optimizer, max_grad_norm, clip_params=None):
     n = len(entries)
     L = lib.load()
     dev = entries[0][0].device
-    # the C tables of one call are cached by the (parameter, gradient) pointers: with the gradients in a GradArena they repeat every minibatch
-    # and the ~40 state look-ups / 5 x 40 ctypes conversions of a call disappear (the loop is within 1.6 x of launch-bound)
-    key = (id(optimizer), n_clip, tuple(p.data_ptr() for p, _ in entries), tuple(p.grad.data_ptr() for p, _ in entries))
+    # the C tables of one call are cached: with the gradients in a GradArena every pointer repeats from minibatch to minibatch and the ~40 state
+    # look-ups / 5 x 40 ctypes conversions of a call disappear (the loop is within 1.6 x of launch-bound).  The key holds EVERY
+    # pointer and value the tables hold -- parameters, gradients, both moments, the step counters, the weight decays -- and the entry is
+    # dropped with the optimizer (weak reference; id() alone can be reused): optimizer.load_state_dict() / state.clear() replace the state
+    # tensors, and a table that still pointed at the old ones would step freed memory and leave the loaded moments untouched
+    states = [optimizer.state.get(p) for p, _ in entries]
+    for (p, _), st in zip(entries, states):
+        if (not st or not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous()
+                or not torch.is_tensor(st.get("step")) or not st["step"].is_cuda or st["step"].dtype != torch.float32):
+            return False
+    key = (n_clip, tuple(p.data_ptr() for p, _ in entries), tuple(p.grad.data_ptr() for p, _ in entries),
+           tuple(st["exp_avg"].data_ptr() for st in states), tuple(st["exp_avg_sq"].data_ptr() for st in states),
+           tuple(st["step"].data_ptr() for st in states), tuple(w for _, w in entries))
     cached = _adam_tables.get(id(optimizer))
-    if cached is not None and cached[0] == key:
+    if cached is not None and cached[0] == key and cached[2]() is optimizer:
         tables = cached[1]
     else:
         tabs = ([], [], [], [], [])
-        for p, _ in entries:
-            st = optimizer.state.get(p)
-            if (not st or not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous()
-                    or not torch.is_tensor(st.get("step")) or not st["step"].is_cuda or st["step"].dtype != torch.float32):
-                return False
+        for (p, _), st in zip(entries, states):
             for tab, t in zip(tabs, (p, p.grad, st["exp_avg"], st["exp_avg_sq"], st["step"])):
                 tab.append(t.data_ptr())
         need = ctypes.c_size_t()
@@ -503,7 +520,8 @@ def adam_clip_step_hip(optimizer, max_grad_norm, clip_params=None):
         arr = lambda v: (ctypes.c_void_p * n)(*v)
         tables = (arr(tabs[0]), arr(tabs[1]), arr(tabs[2]), arr(tabs[3]), arr(tabs[4]), (ctypes.c_int64 * n)(*[p.numel() for p, _ in entries]),
                   (ctypes.c_float * n)(*[w for _, w in entries]), need.value)
-        _adam_tables[id(optimizer)] = (key, tables)
+        oid = id(optimizer)
+        _adam_tables[oid] = (key, tables, weakref.ref(optimizer, lambda _r, oid=oid: _adam_tables.pop(oid, None)))
     ws = _workspace(("adam", id(optimizer)), dev, tables[7])
     lr = g0["lr"]
     lr_dev = lr.data_ptr() if torch.is_tensor(lr) and lr.is_cuda else None

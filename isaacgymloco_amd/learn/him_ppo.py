@@ -13,7 +13,7 @@ steps.  ONE collective per minibatch, 21 per PPO iteration (20 minibatches + the
 Round 3 reduced the estimator's bucket separately, in flight under the PPO backward; that hid 0.24 MB of transfer but paid a second
 torch.distributed call and two more stream hand-offs per minibatch in a loop that is within 1.6 x of launch-bound: a one-rank group with
 every collective issued cost 4.5 % (0.0997 vs 0.0954 s per iteration), of which the device shows 40 x ~35 us of idle around the hand-offs and
-the rest is host time (profiles/r04_trace_collectives.txt).  CPU tensors (gloo tests) keep the concatenated form of the same bucket.
+the rest is host time (profiles/r04_collective_overhead.json, profiles/r04_trace_idle_rccl.txt).  CPU tensors (gloo tests) keep the concatenated form of the same bucket.
 """
 import os
 
@@ -171,6 +171,16 @@ class DistCtx:
             p.grad = v.view_as(p.grad)
         return pieces[-1] if n_extra else None
 
+    def agree(self, flag, device):
+        """True iff `flag` is true on EVERY rank (one tiny MIN all-reduce; used once per configuration, not per iteration, and not counted in
+        `collectives`): per-rank decisions that change the launch pattern -- the update's side stream -- are taken jointly, so that all ranks
+        run the same schedule (a rank whose TunableOp table was rejected would otherwise run one stream beside ranks that run two)"""
+        if not self.enabled:
+            return bool(flag)
+        t = torch.tensor([1.0 if flag else 0.0], device=device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return bool(t.item() > 0.5)
+
     def average_scalar(self, t):
         if not self.enabled:
             return t
@@ -259,6 +269,19 @@ class HIMPPO:
         if FL._arena is not self._arena:
             FL.set_grad_arena(self._arena)
         return self._arena
+
+    def _two_streams(self, critic, rows, multi_rank):
+        """_two_streams_allowed, decided once per minibatch size -- and, with several ranks, decided JOINTLY (all ranks or none).  The side
+        stream never overlaps a collective: the one all-reduce of a minibatch is issued after both streams have joined behind the backward
+        pass, and the next minibatch's critic forward is ordered behind the optimiser step that waited for it."""
+        memo = self.__dict__.setdefault("_two_stream_decision", {})
+        key = (rows, bool(multi_rank), os.environ.get("LSIM_UPDATE_STREAMS", "auto"))
+        if key not in memo:
+            ok = _two_streams_allowed(critic, rows, multi_rank)
+            if multi_rank:
+                ok = self.dist_ctx.agree(ok, next(critic.parameters()).device)
+            memo[key] = ok
+        return memo[key]
 
     def _side_stream(self, device):
         if getattr(self, "_side", None) is None:
@@ -439,7 +462,7 @@ class HIMPPO:
         for (obs, critic_obs, actions, next_critic_obs, target_values, advantages, returns, old_logp, old_mu, old_sigma) in \
                 self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs):
             multi_rank = self.dist_ctx is not None and self.dist_ctx.enabled and self.dist_ctx.world > 1
-            two_streams = obs.is_cuda and self._lr_t is not None and _two_streams_allowed(ac.critic, obs.shape[0], multi_rank)
+            two_streams = obs.is_cuda and self._lr_t is not None and self._two_streams(ac.critic, obs.shape[0], multi_rank)
             if two_streams:
                 # The critic chain (forward here, backward inside loss.backward(): autograd runs a node on the stream of its forward) goes to a
                 # side stream; encoder + actor + estimator stay on the main one.  The two halves carry about the same matrix work (858 k vs

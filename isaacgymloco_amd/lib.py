@@ -41,6 +41,8 @@ def load_path(path):
     L.lsim_step_ex.argtypes = [vp, vp, u32, vp]
     L.lsim_get_step_counter.argtypes = [vp, ctypes.POINTER(i64)]
     L.lsim_set_step_counter.argtypes = [vp, i64]
+    L.lsim_get_reset_calls.argtypes = [vp, ctypes.POINTER(u32)]
+    L.lsim_set_reset_calls.argtypes = [vp, u32]
     L.lsim_get_stats_row.argtypes = [vp, ctypes.POINTER(i32)]
     L.lsim_last_error.argtypes = [vp]
     L.lsim_last_error.restype = ctypes.c_char_p

@@ -23,6 +23,7 @@ class _EmuApi:
                "get_buffer": [vp, i32, ctypes.POINTER(vp), ctypes.POINTER(i64), ctypes.POINTER(i32), ctypes.POINTER(i32)],
                "reset_all": [vp, vp], "reset_envs": [vp, vp, vp], "step": [vp, vp, vp], "step_ex": [vp, vp, u32, vp],
                "get_step_counter": [vp, ctypes.POINTER(i64)], "set_step_counter": [vp, i64], "get_stats_row": [vp, ctypes.POINTER(i32)],
+               "get_reset_calls": [vp, ctypes.POINTER(u32)], "set_reset_calls": [vp, u32],
                "destroy": [vp]}
         for name, argtypes in sig.items():
             fn = getattr(L, "emu_" + name)

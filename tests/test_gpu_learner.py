@@ -712,6 +712,64 @@ def test_fused_clip_adam_step_with_weight_decay_groups_matches_torch():
     assert float(net[2].weight.norm()) < float(mk()[2].weight.norm()) * 1.5
 
 
+def test_fused_clip_adam_step_follows_a_replaced_optimiser_state():
+    """the cached pointer tables of adam_clip_step_hip must not outlive the state tensors they point to.  Two steps
+    with a gradient arena (every gradient pointer repeats), then optimizer.load_state_dict() with DIFFERENT moments (what runner.load() and
+    enable_device_lr's rebuild do): the next fused step must read and update the loaded moments, exactly like torch's Adam on a twin."""
+    import copy
+    from isaacgymloco_amd.learn.fused_linear import adam_clip_step_hip
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(64, 128), torch.nn.ELU(), torch.nn.Linear(128, 19)).to("cuda:0")
+    ref = copy.deepcopy(net)
+    oa = torch.optim.Adam(net.parameters(), lr=torch.tensor(1e-3, device="cuda:0"), fused=True)
+    ob = torch.optim.Adam(ref.parameters(), lr=torch.tensor(1e-3, device="cuda:0"), fused=True)
+    grads = [torch.zeros_like(p) for p in net.parameters()]           # persistent gradient storage: the pointers repeat from step to step
+    g = torch.Generator(device="cuda:0").manual_seed(1)
+
+    def backward_both():
+        x = torch.randn(4096, 64, device="cuda:0", generator=g)
+        for n_, o_ in ((net, oa), (ref, ob)):
+            o_.zero_grad()
+            (n_(x).square().mean() * 20.0).backward()
+        for p, buf in zip(net.parameters(), grads):
+            buf.copy_(p.grad); p.grad = buf
+
+    def step_both():
+        backward_both()
+        if not adam_clip_step_hip(oa, 1.0):
+            torch.nn.utils.clip_grad_norm_(net.parameters(), 1.0); oa.step()
+        torch.nn.utils.clip_grad_norm_(ref.parameters(), 1.0); ob.step()
+    for _ in range(3):
+        step_both()
+    # a checkpoint whose moments differ: scaled copies, step counters moved on
+    sd = copy.deepcopy(ob.state_dict())
+    for st in sd["state"].values():
+        st["exp_avg"].mul_(-3.0); st["exp_avg_sq"].mul_(7.0); st["step"].add_(10.0)
+    old_ptrs = [oa.state[p]["exp_avg"].data_ptr() for p in net.parameters()]
+    oa.load_state_dict(copy.deepcopy(sd)); ob.load_state_dict(copy.deepcopy(sd))
+    for o_ in (oa, ob):
+        for grp in o_.param_groups:
+            grp["lr"] = torch.tensor(1e-3, device="cuda:0")
+    assert [oa.state[p]["exp_avg"].data_ptr() for p in net.parameters()] != old_ptrs      # load_state_dict really replaced the tensors
+    backward_both()
+    assert adam_clip_step_hip(oa, 1.0)
+    torch.nn.utils.clip_grad_norm_(ref.parameters(), 1.0); ob.step()
+    for pa, pb in zip(net.parameters(), ref.parameters()):
+        sa, sb = oa.state[pa], ob.state[pb]
+        assert float(sa["step"]) == float(sb["step"]) == 14.0
+        for k in ("exp_avg", "exp_avg_sq"):
+            scale = float(sb[k].abs().max())
+            assert float((sa[k] - sb[k]).abs().max()) < 2e-3 * scale, k          # the loaded moments were the ones updated
+        assert float((pa.detach() - pb.detach()).abs().max()) < 2e-3 * float(pb.detach().abs().max())
+    # and an optimizer that goes away takes its table with it
+    from isaacgymloco_amd.learn import fused_linear as FL
+    oid = id(oa)
+    assert oid in FL._adam_tables
+    del oa
+    import gc; gc.collect()
+    assert oid not in FL._adam_tables
+
+
 def test_amp_checkpoint_load_keeps_the_fused_optimiser_path(tmp_path):
     """after load() the param groups must carry the optimiser's own backend flags again (Adam.__setstate__ fills a
     portable checkpoint's missing `fused` with None) and the resumed AMP run must keep training"""
@@ -878,6 +936,35 @@ def test_deferred_weight_gradient_sums_change_nothing(monkeypatch):
         torch.cuda.synchronize()
         assert torch.equal(dw0, dw1) and torch.equal(db0, db1), (k_in, n_out)
         assert torch.equal(2.0 * dw0, dw2) and torch.equal(2.0 * db0, db2), (k_in, n_out)
+
+
+def test_module_applied_twice_inside_a_deferred_block_keeps_both_contributions():
+    """one HimMLP applied to two inputs inside one deferred block with a gradient arena -- the second contribution to
+    a weight cannot take the arena slice again, autograd adds it in place; the first one's pending sum must be in the slice BEFORE that
+    (it used to be written afterwards, over the accumulated value).  Against plain torch autograd on an nn.Sequential twin."""
+    import copy
+    from isaacgymloco_amd.learn import fused_linear as FL
+    torch.manual_seed(0)
+    net = FL.HimMLP(torch.nn.Linear(64, 512), torch.nn.ELU(), torch.nn.Linear(512, 256), torch.nn.ELU(), FL.SkinnyLinear(256, 12)).to("cuda:0")
+    ref = torch.nn.Sequential(*[copy.deepcopy(m) if not isinstance(m, FL.SkinnyLinear) else torch.nn.Linear(256, 12).to("cuda:0") for m in net])
+    ref[4].load_state_dict(net[4].state_dict())
+    g = torch.Generator(device="cuda:0").manual_seed(5)
+    xa, xb = torch.randn(8192, 64, device="cuda:0", generator=g), torch.randn(8192, 64, device="cuda:0", generator=g)
+    arena = FL.GradArena()
+    FL.set_grad_arena(arena)
+    try:
+        arena.bucket("all", list(net.parameters()), 0)
+        FL.grad_cycle()
+        with FL.deferred_wgrad_reduce():
+            (net(xa).square().mean() + 3.0 * net(xb).square().mean()).backward()
+        arena.bucket("all", list(net.parameters()), 0).adopt()
+        (ref(xa).square().mean() + 3.0 * ref(xb).square().mean()).backward()
+        torch.cuda.synchronize()
+        for (k, pa), pb in zip(net.named_parameters(), ref.parameters()):
+            scale = float(pb.grad.abs().max())
+            assert float((pa.grad - pb.grad).abs().max()) < 2e-4 * scale, (k, float((pa.grad - pb.grad).abs().max()), scale)
+    finally:
+        FL.set_grad_arena(None)
 
 
 def test_ppo_loss_with_the_std_vector_equals_the_broadcast_form():

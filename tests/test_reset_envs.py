@@ -200,3 +200,33 @@ def test_legged_robot_reset_idx_accepts_a_subset():
     row = be.stats_row
     env.reset_idx([])
     assert be.stats_row == row
+
+
+def test_state_dict_carries_the_by_hand_reset_salt():
+    """the per-call salt of lsim_reset_envs is part of LeggedRobot.state_dict(): a resumed run redraws the SAME by-hand
+    reset states as the uninterrupted one.  CPU leg (lane emulator behind the product's LeggedRobot class): env A resets by hand twice, a
+    fresh env B takes A's state_dict; the third by-hand reset of both draws the same joint state, and differs from a B without the salt."""
+    import torch
+    from emu_env import EmuLeggedRobot
+    cfg = _cfg()
+    cfg.env.num_envs = 8
+
+    def make():
+        return EmuLeggedRobot(cfg, seed=6)
+    a = make()
+    a.reset()
+    a.reset_idx(torch.tensor([1, 2])); a.reset_idx(torch.tensor([2]))
+    sd = a.state_dict()
+    assert sd["reset_calls"] == 2
+    b, c = make(), make()
+    b.reset(); c.reset()
+    b.load_state_dict(sd)
+    assert b.state_dict()["reset_calls"] == 2
+    sd0 = dict(sd); sd0.pop("reset_calls")
+    c.load_state_dict(sd0)                                    # a checkpoint from before round 5: salt 0
+    for e in (a, b, c):
+        e.reset_idx(torch.tensor([5]))
+    assert torch.equal(a.dof_pos[5], b.dof_pos[5]) and torch.equal(a.root_states[5], b.root_states[5])
+    assert not torch.equal(a.dof_pos[5], c.dof_pos[5])
+    for e in (a, b, c):
+        e.close()
