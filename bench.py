@@ -33,6 +33,8 @@ VALU_CYCLES_PER_WAVE_INST = 2.0    # MI355X_MICROARCH.md "Wave scheduling": a wa
                                    # tools/micro/valu_peak.hip measures 2.25-2.5 sustained (profiles/r03_valu_peak.json, wall-rate derived),
                                    # so frac priced at 2.0 is conservative
 MAX_CLOCK_HZ = 2.4e9
+WORLD1_HW_QUEUES = None            # GPU_MAX_HW_QUEUES of a single-rank run when the environment does not set it (None: the runtime's default, 4);
+                                   # chosen by measurement, see DESIGN.md section 7
 
 
 def cpu_baseline(task, budget_s=24.0):
@@ -72,6 +74,86 @@ def launch_ranks(n):
                     procs[o].terminate()
         time.sleep(0.05)
     sys.exit(rc)
+
+
+class ClockSampler:
+    """mean shader clock of this rank's GPU over a stretch of the run, read from sysfs (pp_dpm_sclk: the level marked '*') by a background
+    thread every 25 ms -- a file read, no driver call; None when the file is not there or not readable (the line then says so)"""
+
+    def __init__(self, pci_address):
+        """pci_address: '0000:xx:yy.z' of the GPU this rank computes on (a box shows every GPU of the node in sysfs, whichever one the
+        process was given: card numbers say nothing)"""
+        import glob
+        self.path = None
+        for p in glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"):
+            if os.path.basename(os.path.realpath(os.path.dirname(p))).lower() == str(pci_address).lower():
+                self.path = p
+        self.samples, self._stop, self._thread = [], False, None
+        self.error = None if self.path else f"no /sys/class/drm/card*/device -> {pci_address} with a pp_dpm_sclk"
+
+    def _read(self):
+        for line in open(self.path):
+            if "*" in line:
+                return float(line.split(":")[1].strip().split("Mhz")[0].split("MHz")[0])
+        return None
+
+    def start(self):
+        if self.path is None:
+            return self
+        import threading
+        try:
+            self._read()
+        except Exception as e:
+            self.error = f"{type(e).__name__}: {e}"
+            return self
+
+        def loop():
+            while not self._stop:
+                try:
+                    v = self._read()
+                    if v:
+                        self.samples.append(v)
+                except Exception:
+                    pass
+                time.sleep(0.025)
+        self._thread = threading.Thread(target=loop, daemon=True)
+        self._thread.start()
+        return self
+
+    def stop(self):
+        self._stop = True
+        if self._thread is not None:
+            self._thread.join(timeout=1.0)
+        if not self.samples:
+            return {"mean_mhz": None, "samples": 0, "source": self.path, "error": self.error or "no sample"}
+        return {"mean_mhz": sum(self.samples) / len(self.samples), "min_mhz": min(self.samples), "max_mhz": max(self.samples),
+                "samples": len(self.samples), "source": self.path}
+
+
+def gemm_probe(torch, dev, seconds=0.02):
+    """fp32 GEMM rate of this box right now: 4096^3 torch.mm (137 GFLOP each) for ~20 ms -- the same matrix pipe and library the update's
+    GEMMs use; a box whose probe is low explains a slow update without any change of the tree"""
+    try:
+        a = torch.randn(4096, 4096, device=dev)
+        b = torch.randn(4096, 4096, device=dev)
+        for _ in range(3):
+            torch.mm(a, b)
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = 0
+        t0 = time.perf_counter()
+        e0.record()
+        while True:
+            for _ in range(4):
+                torch.mm(a, b)
+            n += 4
+            if time.perf_counter() - t0 > seconds or n >= 64:
+                break
+        e1.record(); torch.cuda.synchronize(dev)
+        ms = e0.elapsed_time(e1)
+        return {"tflops": n * 2 * 4096 ** 3 / (ms * 1e-3) / 1e12, "shape": "4096x4096x4096 fp32 torch.mm", "launches": n, "ms": ms}
+    except Exception as e:
+        return {"tflops": None, "error": f"{type(e).__name__}: {e}"}
 
 
 def parse_args():
@@ -137,7 +219,12 @@ def main():
         import shutil, tempfile
         tdir = tempfile.mkdtemp(prefix="lsim_tunableop_")
         if os.path.exists(tuned) and os.environ.get("LSIM_TUNE_FRESH") != "1":          # LSIM_TUNE_FRESH=1: tune every shape again from scratch
-            shutil.copy(tuned, os.path.join(tdir, f"tuned{local_rank}.csv"))   # TunableOp appends the device ordinal to the name
+            mine = os.path.join(tdir, f"tuned{local_rank}.csv")                # TunableOp appends the device ordinal to the name
+            shutil.copy(tuned, mine)
+            if os.environ.get("LSIM_DEBUG_STALE_TUNE_TABLE") == "1":           # test hook: a table from "another build" (rejected at load)
+                text = open(mine).read().replace("Validator,PT_VERSION,", "Validator,PT_VERSION,0.")
+                open(mine, "w").write(text)
+            os.environ["LSIM_TUNABLEOP_TABLE"] = mine                          # the file this process really reads (bench_train reports on it)
         os.environ.setdefault("PYTORCH_TUNABLEOP_ENABLED", "1")
         os.environ.setdefault("PYTORCH_TUNABLEOP_FILENAME", os.path.join(tdir, "tuned.csv"))
         os.environ.setdefault("PYTORCH_TUNABLEOP_TUNING", "1" if os.environ.get("LSIM_TUNE") == "1" else "0")
@@ -150,6 +237,8 @@ def main():
     # 75.7 with 2 -- against 75.4 without collectives.  Must be set before the HIP runtime starts; an explicit setting wins.
     if world > 1 or (world == 1 and os.environ.get("LSIM_DEBUG_FORCE_COLLECTIVES") == "1"):
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
+    elif WORLD1_HW_QUEUES is not None:
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", WORLD1_HW_QUEUES)
     import torch
     import torch.distributed as dist
     single_dev = os.environ.get("LSIM_DEBUG_SINGLE_DEVICE") == "1"   # debugging aid: exercise the N > 1 code path on a 1-GPU box (all ranks on
@@ -216,7 +305,15 @@ def main():
                     "(no policy/learner in the loop)")
     else:
         from isaacgymloco_amd.learn.bench_train import run_train_bench   # raises if the learner is broken: no silent change of workload
-        elapsed, extra, workload = run_train_bench(env, cfg, args, dev, rank, world, barrier)
+        pr = torch.cuda.get_device_properties(dev)
+        try:
+            pci = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        except AttributeError:
+            pci = "unknown"
+        clocks = ClockSampler(pci)
+        elapsed, extra, workload = run_train_bench(env, cfg, args, dev, rank, world, barrier, clocks=clocks)
+        extra["gemm_probe_after_timed_region"] = gemm_probe(torch, dev)
+        extra["gpu_max_hw_queues"] = os.environ.get("GPU_MAX_HW_QUEUES", "unset (runtime default 4)")
         ka = extra["kernel_a_ms"]
         timed_steps = extra["timed_env_steps"]
         actions_src = "policy"

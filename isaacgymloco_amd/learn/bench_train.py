@@ -2,9 +2,10 @@
 env-steps/s over collection (policy inference + LeggedRobot.step + storage) PLUS compute_returns + update().
 
 The unit of timing is one WHOLE PPO iteration (HIMR:105-157): T = num_steps_per_env rollout steps, then GAE, then
-HIMPPO.update().  `--steps K` asks for K env-steps; max(5, ceil(K / T)) iterations are timed -- never fewer than five (0.5 s at the
-BASELINE size), so that one clock ramp or collector pause cannot move the line by several per cent (VERDICT r2) -- and `--warmup W`
-likewise runs ceil(W / T) untimed iterations (at least two: the first update carries lazy library initialisation).  `value` stays
+HIMPPO.update().  `--steps K` asks for K env-steps; max(10, ceil(K / T)) iterations are timed -- never fewer than ten (1 s at the
+BASELINE size), so that one clock ramp or collector pause cannot move the line by several per cent (VERDICT r2, r4) -- and `--warmup W`
+likewise runs ceil(W / T) untimed iterations (at least three: the first update carries lazy library initialisation and creates the
+optimiser state).  `value` stays
 whole-region throughput (all timed env-steps / barrier-to-barrier time); the per-iteration minimum / median / maximum are reported beside it."""
 import ctypes
 import os
@@ -16,7 +17,8 @@ from ..envs import config as C
 from .runner import HIMOnPolicyRunner
 
 
-MIN_TIMED_ITERATIONS = 5
+MIN_TIMED_ITERATIONS = 10
+MIN_WARMUP_ITERATIONS = 3
 
 
 def train_cfg_dict(task):
@@ -30,7 +32,7 @@ def weights_digest(module):
     return [float(flat.sum()), float((flat * flat).sum())]
 
 
-def run_train_bench(env, cfg, args, dev, rank, world, barrier):
+def run_train_bench(env, cfg, args, dev, rank, world, barrier, clocks=None):
     task = args.task if args.task in C.TASKS else "aliengo"
     tc = train_cfg_dict(task)
     torch.manual_seed(1)   # identical initial policy on every rank (then broadcast anyway)
@@ -44,7 +46,7 @@ def run_train_bench(env, cfg, args, dev, rank, world, barrier):
     use_graphs = os.environ.get("LSIM_NO_GRAPHS") != "1" and runner.enable_graphs()
     T = runner.num_steps_per_env
     iters = max(MIN_TIMED_ITERATIONS, -(-args.steps // T))
-    warm_iters = max(2, -(-args.warmup // T))
+    warm_iters = max(MIN_WARMUP_ITERATIONS, -(-args.warmup // T))
     env.episode_length_buf = torch.randint_like(env.episode_length_buf, high=int(env.max_episode_length))   # HIMR:90-91
     state = dict(obs=env.get_observations().clone(), critic=env.get_privileged_observations().clone())
     runner.alg.actor_critic.train()
@@ -69,8 +71,24 @@ def run_train_bench(env, cfg, args, dev, rank, world, barrier):
         torch.cuda.synchronize(dev)
         return t1 - t0, time.perf_counter() - t1
 
+    # The shipped GEMM table is only valid on the build it was tuned with: TunableOp rejects the whole file when one Validator line differs,
+    # every GEMM then runs the default heuristics and the update loses its second stream (him_ppo._two_streams_allowed).  The line and
+    # stderr say so (VERDICT r4 task 1d); `LSIM_TUNE=1 python bench.py` tunes a table for the build at hand (~50 s).
+    from . import him_ppo as _hp
+    tuned_table = os.environ.get("LSIM_TUNABLEOP_TABLE") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "tunableop_gfx950.csv")
     for _ in range(warm_iters):
         one_iteration()
+    # what the update really runs on (the line must explain its own learn_s_per_update): streams, TunableOp
+    tun = _hp.tunableop_status(dev, tuned_table)
+    alg = runner.alg
+    mb_rows = env.num_envs * T // alg.num_mini_batches
+    multi = alg.dist_ctx is not None and alg.dist_ctx.enabled and alg.dist_ctx.world > 1
+    two_streams = bool(alg._lr_t is not None and hasattr(alg, "_two_streams") and alg._two_streams(alg.actor_critic.critic, mb_rows, multi))
+    if tun["enabled"] and not tun["tuning"] and tun["validators_match"] is False and rank == 0:
+        import sys
+        print(f"[bench] TunableOp REJECTED the GEMM table {tuned_table} (tuned on another build: {tun['validator_mismatches']}); every GEMM "
+              f"runs the library's default heuristics and the update runs on {'two streams' if two_streams else 'ONE stream'}.  "
+              "LSIM_TUNE=1 python bench.py writes a table for this build (gpurun_out/tunableop_new.csv)", file=sys.stderr)
     # Python's cyclic collector: a full (generation 2) pass over the objects the set-up left behind -- modules, configs, the captured graphs --
     # stalls the launch-bound update for ~60 ms once every few iterations (measured: one iteration of 30 at 0.139 s instead of 0.078 s).
     # Collect once and move the survivors to the permanent generation, as the runner's learn() does after its first iteration.
@@ -81,6 +99,8 @@ def run_train_bench(env, cfg, args, dev, rank, world, barrier):
     coll = learn = 0.0
     per_iter = []
     barrier()
+    if clocks is not None:
+        clocks.start()
     t0 = time.perf_counter()
     for _ in range(iters):
         c, l = one_iteration()
@@ -89,6 +109,7 @@ def run_train_bench(env, cfg, args, dev, rank, world, barrier):
         per_iter.append([round(c, 5), round(l, 5)])
     barrier()
     elapsed = time.perf_counter() - t0
+    sclk = clocks.stop() if clocks is not None else None
     ms_a, ms_b, n = (ctypes.c_float * n_prof)(), (ctypes.c_float * n_prof)(), ctypes.c_int(n_prof)
     env._L.lsim_read_profile(env._h, ms_a, ms_b, ctypes.byref(n))
     ka = sum(ms_a[i] for i in range(n.value)) / max(n.value, 1)
@@ -115,8 +136,9 @@ def run_train_bench(env, cfg, args, dev, rank, world, barrier):
              # this rank's iterations: spread of the timed sample, and the throughput the median iteration gives (whole job, weak scaling)
              "iteration_wall_s_min_median_max": [round(walls[0], 5), round(med, 5), round(walls[-1], 5)],
              "iteration_spread_frac": (walls[-1] - walls[0]) / med,
-             "value_from_median_iteration": world * env.num_envs * T / med}
-    alg = runner.alg
+             "value_from_median_iteration": world * env.num_envs * T / med,
+             "update_two_streams": two_streams, "tunableop": tun,
+             "sclk_during_timed_region": sclk}
     workload = (f"{task}: {type(runner).__name__} loop, {iters} whole PPO iteration(s) timed, each = {T} x (policy inference + LeggedRobot.step + "
                 f"storage) + GAE + {type(alg).__name__}.update ({alg.num_learning_epochs} epochs x {alg.num_mini_batches} minibatches), "
                 f"{env.num_envs} envs/GPU")

@@ -41,6 +41,41 @@ def _loaded_tunableop_solutions(device):
     return table
 
 
+def tunableop_status(device, table_path=None):
+    """what TunableOp really does in this process (bench.py prints it; VERDICT r4: a table that is rejected at load silently costs the
+    update its second stream): enabled / tuning flags, the GEMM entries LOADED, and -- when `table_path` names the shipped table -- its
+    Validator lines against this build's (torch / HIP / hipBLASLt / rocBLAS versions, GPU architecture string): one mismatch rejects the
+    whole file."""
+    tun = getattr(torch.cuda, "tunable", None)
+    out = {"enabled": bool(tun is not None and tun.is_enabled()), "tuning": bool(tun is not None and tun.tuning_is_enabled()),
+           "entries_loaded": 0, "explicit_solutions_loaded": 0, "entries_in_table": None, "validators_match": None, "validator_mismatches": None}
+    if not out["enabled"]:
+        return out
+    try:
+        table = _loaded_tunableop_solutions(device)
+        out["entries_loaded"] = len(table)
+        out["explicit_solutions_loaded"] = sum(1 for v in table.values() if v != "Default")
+    except Exception as e:
+        out["error"] = f"{type(e).__name__}: {e}"
+    if table_path and os.path.exists(table_path):
+        want, n = {}, 0
+        for line in open(table_path):
+            f = line.rstrip("\n").split(",")
+            if f[0] == "Validator" and len(f) >= 3:
+                want[f[1]] = ",".join(f[2:])
+            elif len(f) >= 3:
+                n += 1
+        out["entries_in_table"] = n
+        try:
+            have = {str(k): str(v) for k, v in tun.get_validators()}
+            bad = {k: {"table": v, "this_build": have.get(k)} for k, v in want.items() if have.get(k) != v}
+            out["validators_match"] = not bad
+            out["validator_mismatches"] = bad or None
+        except Exception as e:
+            out["error"] = f"{type(e).__name__}: {e}"
+    return out
+
+
 def _two_streams_allowed(critic, rows, multi_rank=False, single_device_ranks=False):
     """May the critic chain of the update run on a side stream, concurrently with the actor / estimator chain?  (LSIM_UPDATE_STREAMS = 0 / 1
     forces it off / on.)  Two library GEMMs in flight at once are only safe when neither is a kernel whose workgroups wait for each other
@@ -107,9 +142,14 @@ class DistCtx:
     def reduce_bucket_async(self, params, extra=None, key=None, n_extra=None, extra_at=0):
         """start the all-reduce of one flattened bucket [gradients of `params`..., extra] WITHOUT waiting for it: RCCL works on its own stream
         (ordered behind what the compute stream has issued so far), kernels issued after this call overlap with it.  finish_bucket() waits.
-        With a gradient arena (fused_linear.GradArena: CUDA parameters) the bucket is a PERSISTENT flat buffer that the gradients already
-        live in -- the weight-gradient kernels wrote them there -- so there is no concatenation and nothing to re-view afterwards; the few
-        gradients that autograd's own kernels produced are copied into their slices by one multi-tensor launch (Bucket.adopt)."""
+        = prepare_bucket + start_reduce."""
+        return self.start_reduce(self.prepare_bucket(params, extra, key, n_extra, extra_at))
+
+    def prepare_bucket(self, params, extra=None, key=None, n_extra=None, extra_at=0):
+        """the flat bucket of one reduce, filled: -> (flat, pieces, n_extra).  With a gradient arena (fused_linear.GradArena: CUDA parameters)
+        the bucket is a PERSISTENT flat buffer that the gradients already live in -- the weight-gradient kernels wrote them there -- so there
+        is no concatenation and nothing to re-view afterwards; the few gradients that autograd's own kernels produced are copied into their
+        slices by one multi-tensor launch (Bucket.adopt).  Device work only."""
         from . import fused_linear as FL
         if n_extra is None:
             n_extra = extra.numel() if extra is not None else 0
@@ -121,15 +161,15 @@ class DistCtx:
             b.adopt()
             if extra is not None:
                 b.extra_view[extra_at:extra_at + extra.numel()].copy_(extra.detach().reshape(-1))
-            flat = b.flat
-            pieces = None
-        else:
-            parts = [p.grad.reshape(-1) for p in params]
-            n_extra = extra.numel() if extra is not None else 0
-            if extra is not None:
-                parts.append(extra.detach().reshape(-1).to(parts[0].dtype))
-            flat = torch.cat(parts)
-            pieces = params
+            return b.flat, None, n_extra
+        parts = [p.grad.reshape(-1) for p in params]
+        n_extra = extra.numel() if extra is not None else 0
+        if extra is not None:
+            parts.append(extra.detach().reshape(-1).to(parts[0].dtype))
+        return torch.cat(parts), params, n_extra
+
+    def start_reduce(self, bucket):
+        flat, pieces, n_extra = bucket
         self.collectives += 1
         avg = self._avg_op(flat)
         work = self._all_reduce_async(flat, avg if avg is not None else self.dist.ReduceOp.SUM)
@@ -404,7 +444,15 @@ class HIMPPO:
                                       est_losses=None):
         """the optimiser half of one minibatch in the data-parallel order: both backwards, ONE all-reduce of every gradient + the KL estimate,
         then the same two optimiser steps as the single-rank order (lr rule -> estimator step -> PPO step, HIMP:144-184).  Also the order of
-        the single-rank two-stream path (no collectives).  Returns the estimator's (estimation, swap) losses."""
+        the single-rank two-stream path (no collectives).  Returns the estimator's (estimation, swap) losses.  Three pieces: device work
+        up to the gradients, the collective, device work of the two optimiser steps."""
+        st = self._mb_backward(ac, obs, next_critic_obs, loss, mu, sigma, old_mu, old_sigma, kl_mean, adaptive, more_params, est_losses)
+        self._mb_reduce(st)
+        self._mb_optim(ac, st)
+        return st["est"], st["swap"]
+
+    def _mb_backward(self, ac, obs, next_critic_obs, loss, mu, sigma, old_mu, old_sigma, kl_mean, adaptive, more_params=(), est_losses=None):
+        """piece 1: both backward passes; every gradient and the KL estimate end up in the arena bucket (GPU) / a flat tensor (CPU)"""
         from . import fused_linear as FL
         ctx, est_mod = self.dist_ctx, ac.estimator
         if ctx is not None and not ctx.enabled:
@@ -426,19 +474,33 @@ class HIMPPO:
         est_ids = {id(p) for p in est_params}
         ppo_params = [p for p in ac.parameters() if p.grad is not None and id(p) not in est_ids]
         more = [p for p in more_params if p.grad is not None]
-        kl_global = extra
+        st = dict(est=est.detach(), swap=swap.detach(), est_params=est_params, ppo_params=ppo_params, adaptive=adaptive, kl=extra,
+                  dist=(mu, sigma, old_mu, old_sigma) if self._lr_t is None else None, bucket=None)
         if ctx is not None:
             slot = self._stats_slot()
             in_place = slot is not None and extra is not None and extra.data_ptr() == slot[3:4].data_ptr()     # the loss kernel already wrote it there
-            handle = ctx.reduce_bucket_async(est_live + ppo_params + more, extra=None if in_place else extra, key="all",
-                                             n_extra=5 if (extra is not None and extra.is_cuda) else None, extra_at=3)
-            got = ctx.finish_bucket(handle)                          # clip AFTER the all-reduce (HIMP:183)
-            if extra is not None:
-                kl_global = got[3:4] if got.numel() == 5 else got
+            st["bucket"] = ctx.prepare_bucket(est_live + ppo_params + more, extra=None if in_place else extra, key="all",
+                                              n_extra=5 if (extra is not None and extra.is_cuda) else None, extra_at=3)
         elif self._grad_arena() is not None:                         # single rank: the same bucket, so that the optimisers' pointer tables repeat
             self._arena.bucket("all", est_live + ppo_params + more, 0).adopt()
-        if adaptive:
-            self._adapt_lr(mu, sigma, old_mu, old_sigma, kl_global.reshape(()), already_global=True)
+        return st
+
+    def _mb_reduce(self, st):
+        """piece 2: the minibatch's ONE collective (clip AFTER the all-reduce, HIMP:183)"""
+        if st["bucket"] is None:
+            return
+        ctx = self.dist_ctx
+        got = ctx.finish_bucket(ctx.start_reduce(st["bucket"]))
+        if st["kl"] is not None:
+            st["kl"] = got[3:4] if got.numel() == 5 else got
+
+    def _mb_optim(self, ac, st):
+        """piece 3: learning-rate rule, the estimator's clipped step, the PPO group's clipped step"""
+        from . import fused_linear as FL
+        est_mod = ac.estimator
+        if st["adaptive"]:
+            mu, sigma, old_mu, old_sigma = st["dist"] if st["dist"] is not None else (None,) * 4
+            self._adapt_lr(mu, sigma, old_mu, old_sigma, st["kl"].reshape(()), already_global=True)
         if self._lr_t is None:                                       # host learning rate: the estimator steps with the PPO rate (HIMP:158)
             est_mod.learning_rate = self.learning_rate
             for g in est_mod.optimizer.param_groups:
@@ -447,76 +509,82 @@ class HIMPPO:
         if est_mod.fused_step:
             stepped = FL.adam_clip_step_hip(est_mod.optimizer, est_mod.max_grad_norm)
         if not stepped:
-            nn.utils.clip_grad_norm_(est_params, est_mod.max_grad_norm)
+            nn.utils.clip_grad_norm_(st["est_params"], est_mod.max_grad_norm)
             est_mod.optimizer.step()
-        for p in est_params:                                         # the PPO optimiser also holds these parameters: as in the reference
+        for p in st["est_params"]:                                   # the PPO optimiser also holds these parameters: as in the reference
             p.grad = None                                            # (zero_grad before the PPO backward) it must not step them
-        self._clip_and_step(self.optimizer, ppo_params, self.max_grad_norm)
-        return est.detach(), swap.detach()
+        self._clip_and_step(self.optimizer, st["ppo_params"], self.max_grad_norm)
+
+    def _mb_forward(self, ac, batch, two_streams):
+        """forward of one minibatch up to the two losses (HIMP:136-176 and the estimator's loss head) -> dict"""
+        (obs, critic_obs, actions, next_critic_obs, target_values, advantages, returns, old_logp, old_mu, old_sigma) = batch
+        if two_streams:
+            # The critic chain (forward here, backward inside loss.backward(): autograd runs a node on the stream of its forward) goes to a
+            # side stream; encoder + actor + estimator stay on the main one.  The two halves carry about the same matrix work (858 k vs
+            # 771 k multiply-adds per sample over forward + backward), and their kernels interleave on the device: one chain's
+            # bandwidth-bound passes (ELU, stores) and tile-quantisation tails run under the other chain's MFMA-bound GEMMs.
+            cur = torch.cuda.current_stream(obs.device)
+            side = self._side_stream(obs.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                value = ac.evaluate(critic_obs)
+        ac.estimator.prime(obs)        # one encoder forward serves the policy features and the estimator loss below
+        early_est = None
+        if two_streams and os.environ.get("LSIM_EARLY_EST_LOSS", "1") != "0":
+            # The estimator's loss head -- target encoder, prototype scores, three Sinkhorn rounds, log-softmax, losses and their gradients:
+            # ~15 launches that each leave most of the device idle -- depends on the encoder output alone.  Formed HERE, while the critic's
+            # GEMMs run on the side stream, it fills what they leave; behind the join it ran by itself (0.27 ms per minibatch).  Same values.
+            early_est = ac.estimator.losses(obs, next_critic_obs)
+        # the reference calls act() here (HIMP:141) and throws the sample away; torch.normal(mean, std) validates std >= 0 with a
+        # host read-back, i.e. one pipeline drain per minibatch on the GPU: only the distribution is needed
+        std_direct = obs.is_cuda and obs.dtype == torch.float32 and ac.std.dim() == 1 and ac.std.numel() <= 60 and \
+            os.environ.get("LSIM_PPO_STD_DIRECT", "1") != "0"
+        if std_direct:
+            # the policy's std is one value per action (HAC:93): the loss kernel takes it as it is (lsim_ppo_loss_std) instead of the
+            # broadcast mean * 0 + std the distribution object forms (HAC:147) -- no [B, A] sigma, no backward of the broadcast, no column sum
+            mu_direct = ac.actor(ac._actor_input(obs))
+        elif obs.is_cuda:
+            ac.update_distribution(obs)
+        else:
+            ac.act(obs)
+        if two_streams:
+            cur.wait_stream(side)
+            value.record_stream(cur)
+        else:
+            value = ac.evaluate(critic_obs)
+        mu, sigma = (mu_direct, ac.std) if std_direct else (ac.action_mean, ac.action_std)
+        loss, surrogate_loss, value_loss, kl_mean = self._ppo_loss(ac, mu, sigma, value, actions, old_logp, advantages, returns, target_values,
+                                                                   old_mu, old_sigma)
+        return dict(obs=obs, next_critic_obs=next_critic_obs, loss=loss, mu=mu, sigma=sigma, old_mu=old_mu, old_sigma=old_sigma, kl_mean=kl_mean,
+                    surrogate_loss=surrogate_loss, value_loss=value_loss, early_est=early_est)
 
     def update(self):
         ac = self.actor_critic
+        self._grad_arena()
         sums = torch.zeros(4, device=self.device)
         last_est = last_swap = None
-        self._grad_arena()
-        for (obs, critic_obs, actions, next_critic_obs, target_values, advantages, returns, old_logp, old_mu, old_sigma) in \
-                self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs):
+        adaptive = self.desired_kl is not None and self.schedule == "adaptive"
+        for batch in self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs):
+            obs = batch[0]
             multi_rank = self.dist_ctx is not None and self.dist_ctx.enabled and self.dist_ctx.world > 1
             two_streams = obs.is_cuda and self._lr_t is not None and self._two_streams(ac.critic, obs.shape[0], multi_rank)
-            if two_streams:
-                # The critic chain (forward here, backward inside loss.backward(): autograd runs a node on the stream of its forward) goes to a
-                # side stream; encoder + actor + estimator stay on the main one.  The two halves carry about the same matrix work (858 k vs
-                # 771 k multiply-adds per sample over forward + backward), and their kernels interleave on the device: one chain's
-                # bandwidth-bound passes (ELU, stores) and tile-quantisation tails run under the other chain's MFMA-bound GEMMs.
-                cur = torch.cuda.current_stream(obs.device)
-                side = self._side_stream(obs.device)
-                side.wait_stream(cur)
-                with torch.cuda.stream(side):
-                    value = ac.evaluate(critic_obs)
-            ac.estimator.prime(obs)        # one encoder forward serves the policy features and the estimator loss below
-            early_est = None
-            if two_streams and os.environ.get("LSIM_EARLY_EST_LOSS", "1") != "0":
-                # The estimator's loss head -- target encoder, prototype scores, three Sinkhorn rounds, log-softmax, losses and their gradients:
-                # ~15 launches that each leave most of the device idle -- depends on the encoder output alone.  Formed HERE, while the critic's
-                # GEMMs run on the side stream, it fills what they leave; behind the join it ran by itself (0.27 ms per minibatch).  Same values.
-                early_est = ac.estimator.losses(obs, next_critic_obs)
-            # the reference calls act() here (HIMP:141) and throws the sample away; torch.normal(mean, std) validates std >= 0 with a
-            # host read-back, i.e. one pipeline drain per minibatch on the GPU: only the distribution is needed
-            std_direct = obs.is_cuda and obs.dtype == torch.float32 and ac.std.dim() == 1 and ac.std.numel() <= 60 and \
-                os.environ.get("LSIM_PPO_STD_DIRECT", "1") != "0"
-            if std_direct:
-                # the policy's std is one value per action (HAC:93): the loss kernel takes it as it is (lsim_ppo_loss_std) instead of the
-                # broadcast mean * 0 + std the distribution object forms (HAC:147) -- no [B, A] sigma, no backward of the broadcast, no column sum
-                mu_direct = ac.actor(ac._actor_input(obs))
-            elif obs.is_cuda:
-                ac.update_distribution(obs)
-            else:
-                ac.act(obs)
-            if two_streams:
-                cur.wait_stream(side)
-                value.record_stream(cur)
-            else:
-                value = ac.evaluate(critic_obs)
-            mu, sigma = (mu_direct, ac.std) if std_direct else (ac.action_mean, ac.action_std)
-            loss, surrogate_loss, value_loss, kl_mean = self._ppo_loss(ac, mu, sigma, value, actions, old_logp, advantages, returns, target_values,
-                                                                       old_mu, old_sigma)
-            adaptive = self.desired_kl is not None and self.schedule == "adaptive"
+            f = self._mb_forward(ac, batch, two_streams)
             if (self.dist_ctx is not None and self.dist_ctx.enabled) or two_streams:
-                est, swap = self._step_minibatch_data_parallel(ac, obs, next_critic_obs, loss, mu, sigma, old_mu, old_sigma, kl_mean, adaptive,
-                                                               est_losses=early_est)
+                est, swap = self._step_minibatch_data_parallel(ac, obs, f["next_critic_obs"], f["loss"], f["mu"], f["sigma"], f["old_mu"], f["old_sigma"],
+                                                               f["kl_mean"], adaptive, est_losses=f["early_est"])
             else:
                 if adaptive:
-                    self._adapt_lr(mu, sigma, old_mu, old_sigma, kl_mean)
-                est, swap = ac.estimator.update(obs, next_critic_obs, lr=None if self._lr_t is not None else self.learning_rate)
+                    self._adapt_lr(f["mu"], f["sigma"], f["old_mu"], f["old_sigma"], f["kl_mean"])
+                est, swap = ac.estimator.update(obs, f["next_critic_obs"], lr=None if self._lr_t is not None else self.learning_rate)
                 self.optimizer.zero_grad()
                 from . import fused_linear as FL
                 FL.grad_cycle()
                 with FL.deferred_wgrad_reduce():
-                    FL.backward_losses(loss)
+                    FL.backward_losses(f["loss"])
                 if FL._arena is not None:
                     FL._arena.bucket("ppo", [p for p in ac.parameters() if p.grad is not None]).adopt()
                 self._clip_and_step(self.optimizer, ac.parameters(), self.max_grad_norm)
-            sums += torch.stack((value_loss.detach(), surrogate_loss.detach(), est, swap))
+            sums += torch.stack((f["value_loss"].detach(), f["surrogate_loss"].detach(), est, swap))
             last_est, last_swap = est, swap
         n = self.num_learning_epochs * self.num_mini_batches
         if self._lr_t is not None:

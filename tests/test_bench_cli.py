@@ -56,6 +56,24 @@ def test_driver_arguments_time_a_full_ppo_iteration():
 
 
 @pytest.mark.gpu
+def test_the_line_explains_its_update_and_announces_a_rejected_gemm_table():
+    """VERDICT r4 task 1: the train line says what the update ran on (streams, TunableOp entries and validators, hardware queues, a GEMM-rate
+    probe, the shader clock) -- and a GEMM table from another build (rejected at load: LSIM_DEBUG_STALE_TUNE_TABLE) is announced on stderr
+    and in the line instead of silently costing the update its second stream"""
+    r = _run(["--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline"], env={"LSIM_DEBUG_STALE_TUNE_TABLE": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "REJECTED the GEMM table" in r.stderr and "PT_VERSION" in r.stderr and "ONE stream" in r.stderr
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    t = j["tunableop"]
+    assert t["enabled"] and t["validators_match"] is False and "PT_VERSION" in t["validator_mismatches"]
+    assert t["explicit_solutions_loaded"] == 0 and j["update_two_streams"] is False
+    assert j["ppo_updates_timed"] >= 10 and j["iteration_spread_frac"] < 0.2
+    assert j["gemm_probe_after_timed_region"]["tflops"] > 20 and "gpu_max_hw_queues" in j
+    s = j["sclk_during_timed_region"]
+    assert s["mean_mhz"] is None or 300 < s["mean_mhz"] < 3000
+
+
+@pytest.mark.gpu
 def test_two_ranks_on_the_fused_gpu_path_stay_in_lockstep():
     """N > 1 path on the fused GPU kernels: two rank processes (both on cuda:0, gloo -- RCCL refuses two ranks on one device) shard
     the envs, all-reduce the gradients and must end with bit-identical weights; rank 0 prints n_gpus = 2"""
