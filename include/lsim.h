@@ -33,8 +33,9 @@
 extern "C" {
 #endif
 
-#define LSIM_ABI_VERSION 4   /* 2: LSIM_BUF_CONTACT_COUNT, fixed-point words in LSIM_BUF_STATS (round 2); 3: LSIM_BUF_SUBSTEP_TORQUES (round 3);
-                                 4: lsim_config.solver_type / num_position_iterations out of the reserved words (round 4) */
+#define LSIM_ABI_VERSION 5   /* 2: LSIM_BUF_CONTACT_COUNT, fixed-point words in LSIM_BUF_STATS (round 2); 3: LSIM_BUF_SUBSTEP_TORQUES (round 3);
+                                 4: lsim_config.solver_type / num_position_iterations out of the reserved words (round 4);
+                                 5: lsim_config.lin_vel_at_com (centre-of-mass linear velocities, the PhysX convention) and tgs_limit_passes, lsim_get / set_reset_calls (round 5) */
 
 /* ---- fixed sizes of the robot family on this path (12-DoF quadrupeds) ---- */
 #define LSIM_NUM_DOF 12
@@ -281,7 +282,19 @@ typedef struct lsim_config {
        so far.  num_velocity_iterations (LRC:247) is 0 in the reference and not modelled. */
     int32_t solver_type;
     int32_t num_position_iterations;
-    int32_t reserved[4];
+    /* what the LINEAR velocity columns of the state tensors mean (root_states[:, 7:10], rigid_body_states[:, :, 7:10]; LR:929-941):
+       1 = the velocity of the body's CENTRE OF MASS, which is what PhysX's getLinearVelocity() / setLinearVelocity() read and write and
+       therefore what the reference's base_lin_vel (LR:198-199), feet velocities (LR:941), pushes (LR:822-828) and reset velocities
+       (LR:816) are -- with the per-env payload COM displacement of the base included (LR:1025-1028); 0 = the velocity of the link origin
+       (rounds 1-4 of this build).  Positions are the link origin's in both.  Injected tensors (LSIM_STEP_SKIP_PHYSICS) are taken as they
+       are.  make_lsim_config sets 1. */
+    int32_t lin_vel_at_com;
+    /* solver_type 1 only: velocity-level Gauss-Seidel passes over the joint-limit rows ALONE after the last position iteration (contact
+       impulses frozen, bounds of the configuration reached).  One relaxation per position iteration leaves the limit rows of a stiffly
+       coupled leg short of their bounds; one such pass brings the share of joint speeds beyond the URDF limit to that of 8 PGS sweeps
+       (DESIGN.md section 4).  0 = none (round 4); make_lsim_config sets 1; at most LSIM_MAX_POSITION_ITERATIONS. */
+    int32_t tgs_limit_passes;
+    int32_t reserved[2];
 } lsim_config;
 
 /* ---- device buffers.  Shapes are per handle (N = num_envs); dtype codes below. ---- */

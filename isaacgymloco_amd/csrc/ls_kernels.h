@@ -221,6 +221,15 @@ LS_FN void ph_torques(const LsCtx& cx, WaveShared& sh, int lane, int env, int su
     if (flags & LSIM_STEP_RECORD_SUBSTEPS) LSB(cx, LSIM_BUF_SUBSTEP_TORQUES, float)[12 * (c.decimation * env + sub) + lane] = t;   // test hook (wave-uniform branch)
 }
 
+// lsim_config.lin_vel_at_com: the root state tensor carries the linear velocity of the base's centre of mass (PhysX); the dynamics work on
+// the link origin's: v_origin = v_com - w x (R c), once per step, after the load and before the first kinematics phase
+LS_FN void ph_root_lin_vel_to_origin(WaveShared& sh, int lane) {
+    if (lane != 0) return;
+    const V3 r = quat_apply(sh.root + 3, ls_body_com_local(sh, 0));
+    const V3 v = v3p(sh.root + 7) - cross(v3p(sh.root + 10), r);
+    v3st(sh.root + 7, v);
+}
+
 // ---- after the last sub-step: publish the simulator state tensors (LR:187-190 refresh_* equivalents)
 LS_FN void ph_store_sim_state(const LsCtx& cx, WaveShared& sh, int lane, int env) {
     if (lane < 13) LSB(cx, LSIM_BUF_ROOT_STATES, float)[13 * env + lane] = sh.root[lane];
@@ -237,7 +246,10 @@ LS_FN void ph_store_sim_state(const LsCtx& cx, WaveShared& sh, int lane, int env
 // and stored by ph_store_body_states once everything the wave had requested from memory has been consumed: a load whose result is read
 // while stores are in flight waits for the stores too (vmcnt retires in order), and at 4096 robots in lockstep a store burst takes ~5 us
 LS_FN void ph_body_states_all(const LsCtx& cx, WaveShared& sh, LaneRegs& rg, int lane) {
-    ph_body_states(sh, lane, rg.bs);
+    const bool at_com = cx.cfg.lin_vel_at_com != 0;
+    ph_body_states(sh, lane, rg.bs, at_com);
+    if (at_com && lane == 0)   // the root state tensor's linear velocity is row 0's: from here on (stores, post-physics, pushes) the centre of mass's
+        for (int k = 0; k < 3; ++k) sh.root[7 + k] = rg.bs[7 + k];
     if (lane < LS_NB)       // the feet rows of the tensor for the reward terms, from registers
         for (int f = 0; f < 4; ++f)
             if (cx.model.feet_bodies[f] == lane) {         // uniform f: scalar loads
@@ -656,6 +668,7 @@ template <int SOLVER> LS_WAVE_FN void ls_wave_step_a(const LsCtx& cx, const LsSt
     [[maybe_unused]] int ls_sub = -1, ls_k = 0;
 #endif
     LS_PHASE(ph_load_a(cx, sh, rg, lane, env, a));
+    if (!skip && c.lin_vel_at_com) LS_PHASE(ph_root_lin_vel_to_origin(sh, lane));
     LS_CP(0);
     for (int sub = 0; sub < c.decimation; ++sub) {
 #if defined(LS_WAVE_TIMES) && LS_WAVE_TIMES == 2

@@ -1120,6 +1120,24 @@ LS_FN void wc_delassus_tgs(const LsCtx& cx, WaveShared& sh, const LaneRegs& rg, 
             if (vk < 6) ls_tgs_base_twist(sh, s)[vk] = u;
         }
     }
+    // lsim_config.tgs_limit_passes: velocity-level passes over the limit rows alone, against the bounds of the configuration reached; the
+    // contact impulses stay as they are, every lane's row velocity (and the velocity lanes) follow through W as in the sweeps above.  The
+    // positions are done: only the velocity the step hands on changes.
+    if (nlim > 0) {
+        for (int it = 0; it < c.tgs_limit_passes; ++it) {
+            float Lb = -vmax, Ub = vmax;
+            if (ga < 0.1f) Lb = fmaxf(Lb, ga >= 0.0f ? -ga * ihs : fminf(1.0f, c.erp * (-ga) * ihs));
+            if (gb < 0.1f) Ub = fminf(Ub, gb >= 0.0f ? gb * ihs : -fminf(1.0f, c.erp * (-gb) * ihs));
+            Ub = fmaxf(Ub, Lb);
+            const float tgt = is_limit ? Lb : 0.0f;
+            const float neg_rng_d = is_limit ? -((Ub - Lb) * inv_d) : 0.0f;
+            float w = u - tgt;
+            int nlim_it = nlim;
+            asm volatile("" : "+s"(nlim_it));
+            ls_pgs_limits<0>(nlim_it, W, sl, inv_d, neg_rng_d, w);
+            u = w + tgt;
+        }
+    }
     const float idt = ls_rcp(dt);
     V3 f = v3(0, 0, 0);
     if (lane < LS_NB) ls_contact_force<0>(sh, sl, nc, lane, idt, f);
@@ -1187,6 +1205,35 @@ static inline void wc_tgs(const LsCtx& cx, WaveShared& sh, LaneRegs* L, int nsub
         for (int k = 0; k < LS_NV; ++k) vsum[k] += dv[k];
         for (int k = 0; k < 6; ++k) ls_tgs_base_twist(sh, s)[k] = dv[k];
     }
+    if (sh.nlim > 0)        // lsim_config.tgs_limit_passes: the limit rows alone, velocity level, bounds of the configuration reached
+        for (int it = 0; it < c.tgs_limit_passes; ++it) {
+            for (int i = 0; i < R; ++i) {
+                if (!act[i]) continue;
+                float t = 0.0f;
+                nrd[i] = 0.0f;
+                if (L[i].row_kind == 3) {
+                    const float vmax = L[i].row_rng;
+                    float Lb = -vmax, Ub = vmax;
+                    if (ga[i] < 0.1f) Lb = fmaxf(Lb, ga[i] >= 0.0f ? -ga[i] * ihs : fminf(1.0f, c.erp * (-ga[i]) * ihs));
+                    if (gb[i] < 0.1f) Ub = fminf(Ub, gb[i] >= 0.0f ? gb[i] * ihs : -fminf(1.0f, c.erp * (-gb[i]) * ihs));
+                    Ub = fmaxf(Ub, Lb);
+                    t = Lb;
+                    nrd[i] = (Ub - Lb) / L[i].wdiag;
+                }
+                tgt[i] = t;
+                w[i] = u[i] - t;
+            }
+            for (int r = 0; r < R; ++r) {
+                if (!act[r] || L[r].row_kind != 3) continue;
+                float nl = lam[r] - w[r] / L[r].wdiag;
+                nl = fmaxf(nl, 0.0f) + fminf(nl + nrd[r], 0.0f);
+                const float old = lam[r];
+                lam[r] = nl;
+                for (int i = 0; i < R; ++i) if (act[i]) w[i] = fmaf(L[i].W[r], nl, fmaf(-L[i].W[r], old, w[i]));
+                for (int k = 0; k < LS_NV; ++k) dv[k] = fmaf(sh.u.c.Y[r][k], nl, fmaf(-sh.u.c.Y[r][k], old, dv[k]));
+            }
+            for (int i = 0; i < R; ++i) if (act[i]) u[i] = w[i] + tgt[i];
+        }
     for (int i = 0; i < R; ++i) if (act[i]) sh.lam[i] = lam[i];
     for (int k = 0; k < LS_NV; ++k) {
         if (k < 6) sh.ab[k] = dv[k];
@@ -1299,6 +1346,10 @@ LS_FN void ph_integrate_tgs(const LsCtx& cx, WaveShared& sh, int lane, float dt,
             const float nn = ls_rsqrt(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
             q0 *= nn; q1 *= nn; q2 *= nn; q3 *= nn;
         }
+        // the twist the step hands on is the solver's FINAL one (sh.ab): the last sub-iteration's, plus what the limit-only velocity passes
+        // (lsim_config.tgs_limit_passes) did to the base afterwards -- the joints take the same change through - G_l dvb above
+        w = wf + v3p(sh.ab);
+        vl = vf + v3p(sh.ab + 3);
         {   // body velocity caps of the asset options (LRC:229-230), on the velocity the step hands on
             const float wn = sqrtf(dot(w, w)), ln = sqrtf(dot(vl, vl));
             if (cx.cfg.max_angular_velocity > 0.0f && wn > cx.cfg.max_angular_velocity) w = w * (cx.cfg.max_angular_velocity * ls_rcp(wn));
@@ -1312,11 +1363,21 @@ LS_FN void ph_integrate_tgs(const LsCtx& cx, WaveShared& sh, int lane, float dt,
 }
 
 // ---- phase B: world state of every body (rigid_body_states, LR:938) from the kinematics phase (lane = body)
-LS_FN void ph_body_states(WaveShared& sh, int lane, float* o /* [13]: this body's row of the rigid-body state tensor (position, quaternion, linear, angular velocity) */) {
+// at_com (lsim_config.lin_vel_at_com): the linear velocity is the one of the body's centre of mass (PhysX's getLinearVelocity), i.e. taken at
+// p + R c instead of at the link origin p; the base's c carries the per-env COM displacement (LR:1025-1028)
+LS_FN V3 ls_body_com_local(const WaveShared& sh, int body) {
+    V3 cl = v3p(sh.body[body].com);
+    if (body == 0) cl = cl + v3p(sh.comd);
+    return cl;
+}
+LS_FN void ph_body_states(WaveShared& sh, int lane, float* o /* [13]: this body's row of the rigid-body state tensor (position, quaternion, linear, angular velocity) */,
+                          bool at_com) {
     if (lane >= LS_NB) return;
     V3 p = v3p(sh.p[lane]);
     S6 V = s6p(sh.V[lane]);
-    V3 vel = V.l + cross(V.a, p);
+    V3 at = p;
+    if (at_com) at = p + mul(m3p(sh.R[lane]), ls_body_com_local(sh, lane));
+    V3 vel = V.l + cross(V.a, at);
     o[0] = sh.root[0] + p.x; o[1] = sh.root[1] + p.y; o[2] = sh.root[2] + p.z;
     float q4[4];
     if (lane == 0) { for (int k = 0; k < 4; ++k) q4[k] = sh.root[3 + k]; }

@@ -191,6 +191,10 @@ def make_lsim_config(cfg, num_envs=None, terrain=None, model=None, seed=1, rank=
     if c.solver_type == 1 and not 1 <= c.num_position_iterations <= abi.DEFINES["LSIM_MAX_POSITION_ITERATIONS"]:
         raise ValueError(f"cfg.sim.physx.num_position_iterations must be in 1..{abi.DEFINES['LSIM_MAX_POSITION_ITERATIONS']}, "
                          f"got {c.num_position_iterations}")
+    # solver_type 1: one velocity-level pass over the joint-limit rows alone after the last position iteration (include/lsim.h); 0 = round 4
+    c.tgs_limit_passes = int(os.environ.get("LSIM_TGS_LIMIT_PASSES", _get(physx, "tgs_limit_passes", 1)))
+    if not 0 <= c.tgs_limit_passes <= abi.DEFINES["LSIM_MAX_POSITION_ITERATIONS"]:
+        raise ValueError(f"tgs_limit_passes must be in 0..{abi.DEFINES['LSIM_MAX_POSITION_ITERATIONS']}, got {c.tgs_limit_passes}")
     if int(_get(physx, "num_velocity_iterations", 0)) != 0:
         raise ValueError("cfg.sim.physx.num_velocity_iterations != 0 is not modelled (every reference config sets 0, LRC:247)")
     c.contact_offset = cfg.sim.physx.contact_offset
@@ -200,4 +204,12 @@ def make_lsim_config(cfg, num_envs=None, terrain=None, model=None, seed=1, rank=
     c.using_amp = int(bool(using_amp))
     c.max_linear_velocity = cfg.asset.max_linear_velocity
     c.max_angular_velocity = cfg.asset.max_angular_velocity
+    # linear velocities of the state tensors: the body's centre of mass, as PhysX reports them (include/lsim.h lin_vel_at_com); the link-origin
+    # convention of rounds 1-4 stays reachable for A/B runs and old checkpoints' evaluation (cfg.sim.physx.lin_vel_at_com = 0 / LSIM_LIN_VEL=origin)
+    c.lin_vel_at_com = int(bool(_get(physx, "lin_vel_at_com", 1)))
+    lv = os.environ.get("LSIM_LIN_VEL", "").lower()
+    if lv:
+        if lv not in ("com", "origin"):
+            raise ValueError(f"LSIM_LIN_VEL must be 'com' or 'origin', got {lv!r}")
+        c.lin_vel_at_com = int(lv == "com")
     return c

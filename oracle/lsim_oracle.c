@@ -859,6 +859,8 @@ int orc_step_ex(orc_sim* s, const float* actions, uint32_t flags) {
         int delay = (int)(u01(s, e, stepw, LSIM_RNG_DELAY, 0) * (float)c->decimation); /* LR:134 */
         ORC_I32(s, LSIM_BUF_DELAY_STEPS)[e] = delay;
         ORC_I32(s, LSIM_BUF_CONTACT_COUNT)[2 * e] = 0; ORC_I32(s, LSIM_BUF_CONTACT_COUNT)[2 * e + 1] = 0;
+        const int at_com = c->lin_vel_at_com && !(flags & LSIM_STEP_SKIP_PHYSICS);
+        if (at_com) orc_root_lin_vel_to_origin(s, e);
         for (int sub = 0; sub < c->decimation; ++sub) { /* LR:144-152 */
             float a[N_DOF], tau[N_DOF];
             for (int j = 0; j < N_DOF; ++j)
@@ -869,6 +871,8 @@ int orc_step_ex(orc_sim* s, const float* actions, uint32_t flags) {
             if (!(flags & LSIM_STEP_SKIP_PHYSICS)) orc_physics_substep(s, e, tau, sub == 0);
         }
         if (!(flags & LSIM_STEP_SKIP_PHYSICS)) orc_refresh_body_states(s, e);
+        if (at_com) /* the root tensor's linear velocity is row 0's of the body tensor: the centre of mass's from here on */
+            for (int k = 0; k < 3; ++k) ORC_F(s, LSIM_BUF_ROOT_STATES)[13 * e + 7 + k] = ORC_F(s, LSIM_BUF_RIGID_BODY_STATES)[13 * N_BODY * e + 7 + k];
     }
     post_physics_step(s, flags);
     return LSIM_OK;

@@ -32,6 +32,7 @@ typedef struct orc_sim {
 void orc_physics_substep(orc_sim* s, int e, const float tau[12], int apply_force);
 /* recompute rigid_body_states of env e from root/dof state (forward kinematics + velocities) */
 void orc_refresh_body_states(orc_sim* s, int e);
+void orc_root_lin_vel_to_origin(orc_sim* s, int e);
 /* terrain contact query: signed distance of a world point to the (slope-corrected) terrain mesh, and the contact normal */
 void orc_terrain_contact(const orc_sim* s, const double cw[3], double radius, double* dist, double n[3]);
 /* tabulate the vertex displacement rule once per terrain (called by orc_create after the grid is in place) */

@@ -275,6 +275,20 @@ static void base_mass_props(const orc_sim* s, int e, double* mass, double com[3]
     for (int k = 0; k < 6; ++k) I[k] = b->inertia[k] * sc;
 }
 
+/* lin_vel_at_com: the root state tensor carries the linear velocity of the base's centre of mass; the sub-steps work on the link
+   origin's.  dir = -1: v_origin = v_com - w x (R c) (before the first sub-step); the way back is row 0 of orc_refresh_body_states. */
+void orc_root_lin_vel_to_origin(orc_sim* s, int e) {
+    float* root = ORC_F(s, LSIM_BUF_ROOT_STATES) + 13 * e;
+    double qb[4] = {root[3], root[4], root[5], root[6]}, Rb[9], cl[3], cw[3], w[3] = {root[10], root[11], root[12]}, wxr[3];
+    double qn = sqrt(qb[0] * qb[0] + qb[1] * qb[1] + qb[2] * qb[2] + qb[3] * qb[3]);
+    for (int k = 0; k < 4; ++k) qb[k] /= qn;
+    quat_to_R(qb, Rb);
+    for (int k = 0; k < 3; ++k) cl[k] = s->model.bodies[0].com[k] + ORC_F(s, LSIM_BUF_COM_DISPLACEMENT)[3 * e + k];
+    m3v(Rb, cl, cw);
+    v3cross(w, cw, wxr);
+    for (int k = 0; k < 3; ++k) root[7 + k] = (float)(root[7 + k] - wxr[k]);
+}
+
 void orc_refresh_body_states(orc_sim* s, int e) {
     const lsim_robot_model* m = &s->model;
     const float* root = ORC_F(s, LSIM_BUF_ROOT_STATES) + 13 * e;
@@ -295,10 +309,17 @@ void orc_refresh_body_states(orc_sim* s, int e) {
         }
     }
     for (int i = 0; i < NB; ++i) {
-        double qq[4], vel[3], wxp[3];
+        double qq[4], vel[3], wxp[3], at[3];
         R_to_quat(X[i].R, qq);
         if (i == 0) memcpy(qq, qb, sizeof(qq));
-        v3cross(V[i], X[i].p, wxp);
+        for (int k = 0; k < 3; ++k) at[k] = X[i].p[k];
+        if (s->cfg.lin_vel_at_com) { /* include/lsim.h lin_vel_at_com: the linear velocity of the body's centre of mass (PhysX getLinearVelocity) */
+            double cl[3], cw[3];
+            for (int k = 0; k < 3; ++k) cl[k] = m->bodies[i].com[k] + (i == 0 ? ORC_F(s, LSIM_BUF_COM_DISPLACEMENT)[3 * e + k] : 0.0);
+            m3v(X[i].R, cl, cw);
+            for (int k = 0; k < 3; ++k) at[k] += cw[k];
+        }
+        v3cross(V[i], at, wxp);
         for (int k = 0; k < 3; ++k) vel[k] = V[i][3 + k] + wxp[k];
         float* o = out + 13 * i;
         for (int k = 0; k < 3; ++k) o[k] = (float)(root[k] + X[i].p[k]);
@@ -580,6 +601,25 @@ void orc_physics_substep(orc_sim* s, int e, const float tau_f[12], int apply_for
             }
         }
         { double nn = 0; for (int k = 0; k < 4; ++k) nn += qcur[k] * qcur[k]; nn = sqrt(nn); for (int k = 0; k < 4; ++k) qcur[k] /= nn; }
+        {   /* lsim_config.tgs_limit_passes: velocity-level Gauss-Seidel passes over the limit rows alone (contact impulses frozen), against
+             * the bounds of the configuration reached: only the velocity the step hands on changes */
+            for (int it = 0; it < c->tgs_limit_passes; ++it)
+                for (int r = 0; r < R; ++r) {
+                    if (rkind[r] != 3) continue;
+                    int j = -1; for (int k = 0; k < 12; ++k) if (J[r][6 + k] != 0) j = k;
+                    double lo = qs[j] - m->dof_pos_lower[j], hi = m->dof_pos_upper[j] - qs[j], vmax = m->dof_vel_limit[j];
+                    double Lb = -vmax, Ub = vmax;
+                    if (lo < 0.1) Lb = fmax(Lb, lo >= 0 ? -lo / hs : fmin(1.0, c->erp * (-lo) / hs));
+                    if (hi < 0.1) Ub = fmin(Ub, hi >= 0 ? hi / hs : -fmin(1.0, c->erp * (-hi) / hs));
+                    if (Ub < Lb) Ub = Lb;
+                    double w = -Lb; for (int k = 0; k < NV; ++k) w += J[r][k] * vv[k];
+                    double nl = lam[r] - w / Wd[r];
+                    double up = nl + (Ub - Lb) / Wd[r]; nl = (nl > 0 ? nl : 0) + (up < 0 ? up : 0);
+                    double dl = nl - lam[r];
+                    lam[r] = nl;
+                    for (int k = 0; k < NV; ++k) vv[k] += Y[r][k] * dl;
+                }
+        }
         double cf[NB][3];
         memset(cf, 0, sizeof(cf));
         for (int r = 0; r < R; ++r) if (rcontact[r] >= 0) for (int k = 0; k < 3; ++k) cf[cbody[rcontact[r]]][k] += lam[r] * dirs[r][k] / dt;

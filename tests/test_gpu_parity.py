@@ -163,24 +163,27 @@ def test_hip_full_size_invariants(solver):
     env = LeggedRobot(cfg, sim_device="cuda:0", seed=1)
     env.reset()
     g = torch.Generator(device="cuda").manual_seed(0)
+    vmax_t = torch.tensor([20, 20, 15.89] * 4, device="cuda")
+    n_over, worst = 0, 0.0
     for t in range(60):
         a = torch.randn(4096, 12, device="cuda", generator=g) * 0.3
         env.step_device(a)
+        r = env.dof_vel.abs() / vmax_t
+        n_over += int((env.dof_vel.abs() > vmax_t + 1e-3).sum()); worst = max(worst, float(r.max()))
     torch.cuda.synchronize()
     root = env.root_states.cpu().numpy()
     assert np.isfinite(root).all() and np.isfinite(env.obs_buf.cpu().numpy()).all() and np.isfinite(env.rew_buf.cpu().numpy()).all()
     np.testing.assert_allclose(np.linalg.norm(root[:, 3:7], axis=1), 1.0, atol=1e-4)
     tau = env.torques.cpu().numpy()
     assert (np.abs(tau) <= np.array([44, 44, 55] * 4) + 1e-4).all()
-    qd = env.dof_vel.cpu().numpy()
-    vmax = np.array([20, 20, 15.89] * 4)
-    over = np.abs(qd) > vmax + 1e-3
-    print(f"{solver}: joint speeds beyond the limit: {int(over.sum())} of {over.size}, max ratio {float((np.abs(qd) / vmax).max()):.3f}")
-    if solver == "pgs":
-        assert (np.abs(qd) <= 1.001 * vmax).all()               # 8 sweeps converge on the limit rows (measured: 1 of 49 152 beyond + 1e-3, ratio 1.000)
-    else:                                                       # one relaxation per position iteration: a residue on the few saturated joints,
-        assert over.mean() < 2e-3                               # bounded by the 1.5 x safety clamp (tests/test_physics_invariants.py: saturated motors)
-        assert (np.abs(qd) <= 1.5 * vmax + 1e-3).all()
+    # joint speeds against the URDF limits over ALL 60 steps (round 4 looked at the last step only).  The limit is a constraint row for every
+    # joint whose FREE velocity comes within 20 % of it; what is left beyond it are joints without a row that a contact
+    # impulse kicked (both solvers alike: CPU oracle, same scenario, 20 of 2.9 M joint-steps for PGS, 40 for TGS with its final limit pass,
+    # 208 without it) -- bounded by the 1.5 x safety clamp.  ONE bar for both solvers since round 5.
+    total = 60 * 4096 * 12
+    print(f"{solver}: joint speeds beyond the limit: {n_over} of {total} joint-steps ({n_over / total:.2e}), max ratio {worst:.3f}")
+    assert n_over <= 5e-5 * total
+    assert worst <= 1.5 + 1e-4
     ep = env.episode_length_buf.cpu().numpy()
     assert ep.min() >= 0 and ep.max() <= 61
     assert np.abs(env.obs_buf.cpu().numpy()).max() <= 100.0

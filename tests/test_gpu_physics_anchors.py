@@ -163,7 +163,7 @@ def _total_mass():
 
 def _mechanical_energy(env, g=9.81):
     """kinetic + potential energy of every robot from the simulator's own outputs (rigid_body_states: link-origin position, quaternion xyzw,
-    link-origin linear velocity, angular velocity, world frame) and the model table (mass, centre of mass and inertia about it in the link
+    linear velocity of the centre of mass -- or of the link origin, lsim_config.lin_vel_at_com -- angular velocity, world frame) and the model table (mass, centre of mass and inertia about it in the link
     frame) -- nothing of the build's dynamics code is used"""
     import json, os
     from helpers import ROOT
@@ -177,7 +177,7 @@ def _mechanical_energy(env, g=9.81):
                       np.stack([2 * (x * y + z * ww), 1 - 2 * (x * x + z * z), 2 * (y * z - x * ww)], -1),
                       np.stack([2 * (x * z - y * ww), 2 * (y * z + x * ww), 1 - 2 * (x * x + y * y)], -1)], 1)      # (N, 3, 3)
         c = np.einsum("nij,j->ni", R, np.asarray(bd["com"], dtype=np.float64))
-        vc = v + np.cross(w, c)
+        vc = v if env.lcfg.lin_vel_at_com else v + np.cross(w, c)       # include/lsim.h lin_vel_at_com: the tensor already holds the COM's velocity
         Iw = np.einsum("nij,jk,nlk->nil", R, np.asarray(bd["inertia"], dtype=np.float64), R)
         E += 0.5 * bd["mass"] * (vc * vc).sum(1) + 0.5 * np.einsum("ni,nij,nj->n", w, Iw, w) + bd["mass"] * g * (p[:, 2] + c[:, 2])
     return E
@@ -321,7 +321,7 @@ def _linear_momentum(env):
                       np.stack([2 * (x * y + z * ww), 1 - 2 * (x * x + z * z), 2 * (y * z - x * ww)], -1),
                       np.stack([2 * (x * z - y * ww), 2 * (y * z + x * ww), 1 - 2 * (x * x + y * y)], -1)], 1)
         c = np.einsum("nij,j->ni", R, np.asarray(bd["com"], dtype=np.float64))
-        P += bd["mass"] * (v + np.cross(w, c))
+        P += bd["mass"] * (v if env.lcfg.lin_vel_at_com else v + np.cross(w, c))
     return P
 
 

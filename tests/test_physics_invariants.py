@@ -22,6 +22,7 @@ class _HipSim:
         from hip_backend import HipBackend
         self.be = HipBackend(cfg, N, ter, seed=seed)
         self.buf = _HipSim._Buf(self.be)
+        self.cfg = self.be.env.lcfg
 
     def step(self, a, flags=0):
         self.be.step(a, flags)
@@ -66,7 +67,7 @@ def _total_momentum(sim, model, e=0):
                       [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
         c = bs[i, 0:3] + R @ np.array(b.com)
         om = bs[i, 10:13]
-        vc = bs[i, 7:10] + np.cross(om, c - bs[i, 0:3])
+        vc = bs[i, 7:10] if sim.cfg.lin_vel_at_com else bs[i, 7:10] + np.cross(om, c - bs[i, 0:3])      # include/lsim.h: lin_vel_at_com
         I = np.array(b.inertia)
         Il = np.array([[I[0], I[1], I[2]], [I[1], I[3], I[4]], [I[2], I[4], I[5]]])
         P += b.mass * vc
@@ -158,7 +159,7 @@ def test_limits_respected(kind, solver):
         within += int((np.abs(qd) <= 1.01 * vmax).sum()); total += qd.size          # the limit itself is a constraint row (8 PGS sweeps)
         q = sim.buf["dof_state"][..., 0]
         lo = np.array([model.dof_pos_lower[j] for j in range(12)]); hi = np.array([model.dof_pos_upper[j] for j in range(12)])
-        assert (q > lo - 0.06).all() and (q < hi + 0.06).all()                      # soft: resolved at velocity level
+        assert (q > lo - 0.08).all() and (q < hi + 0.08).all()                      # soft: resolved at velocity level (measured: 0.056 without, 0.063 with the final limit pass)
         assert np.isfinite(sim.buf["root_states"]).all()
         np.testing.assert_allclose(np.linalg.norm(sim.buf["root_states"][:, 3:7], axis=1), 1.0, atol=1e-5)
     assert within >= 0.95 * total, (within, total)
@@ -190,7 +191,9 @@ def test_saturated_motors_do_not_spin_up_a_robot_in_free_flight(kind, solver):
     P1, _ = _total_momentum(sim, model)
     assert wmax < 15.0, wmax                   # the clamp version reached 54 rad/s here and kept accelerating
     # the 20 rad/s limit is held by the rows, not by the safety clamp at 30: 8 sweeps converge on it (measured 20.1); TGS relaxes every row
-    # once per position iteration, 4 passes in all, and leaves more on these stiffly coupled rows (measured 25.4; 23.8 with 8 iterations)
+    # once per position iteration, 4 passes in all, and leaves more on these stiffly coupled rows (round 4: 25.4; with the final
+    # velocity-level pass over the limit rows, lsim_config.tgs_limit_passes = 1, see the print)
+    print(f"{kind} {solver}: fastest joint {qdmax:.2f} rad/s, base spin {wmax:.2f} rad/s, momentum change {np.abs(P1 - P0).max():.3f}")
     assert qdmax < (22.0 if solver == "pgs" else 27.0), qdmax
     assert np.abs(P1 - P0).max() < 1.5, (P0, P1)
     assert np.all(np.abs(sim.buf["root_states"][:, 2] - 10.0) < 1.0)
@@ -326,3 +329,71 @@ def test_foot_contact_forces_stay_in_the_friction_pyramid(kind, solver):
         z = sim.buf["rigid_body_states"][:, [4, 8, 12, 16], 2]
         assert (z > foot_r - 0.02).all(), z.min()
     assert seen > 100           # the feet were on the ground most of the time
+
+
+def _quat_R(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+@pytest.mark.parametrize("convention", ["com", "origin"])
+@pytest.mark.parametrize("kind", KINDS)
+def test_published_linear_velocity_is_the_centre_of_mass_velocity(kind, convention, monkeypatch):
+    """P5 (LR:929-941, LR:198-199): PhysX's state tensors carry the linear velocity of each body's CENTRE OF MASS.  Robots tumbling in
+    free flight at |w| ~ 5 rad/s with the base COM displaced by the full +-5 cm payload range (LR:1025-1028): the published linear velocity of
+    the root and of all 17 bodies must equal d/dt of (link position + R c) -- a kinematic identity of the published POSITIONS, evaluated as
+    a central difference over two steps (corrected for the half-sub-step lead of a semi-implicit Euler position update) -- and must differ from the link origin's velocity by w x R c, ~0.4 m/s here.  With lin_vel_at_com = 0 (LSIM_LIN_VEL=origin: the
+    convention of rounds 1-4) the same tensors hold the link-origin velocity instead.  base_lin_vel (LR:198) is the published root value."""
+    monkeypatch.setenv("LSIM_LIN_VEL", convention)
+    cfg = _quiet("tgs")
+    cfg.init_state.pos = [0.0, 0.0, 6.0]
+    cfg.termination.fall_down = False
+    cfg.domain_rand.randomize_com_displacement = True
+    cfg.domain_rand.com_displacement_range = [0.05, 0.05]            # every env at the corner of the range
+    cfg.domain_rand.base_init_vel_range = dict(x=[0.4, 0.4], y=[-0.3, -0.3], z=[0.5, 0.5], roll=[2.0, 2.0], pitch=[-3.0, -3.0], yaw=[4.0, 4.0])
+    N = 4
+    sim, model = _make(kind, cfg, N)
+    assert bool(sim.cfg.lin_vel_at_com) == (convention == "com")
+    sim.reset_all()
+    a = np.zeros((N, 12), np.float32)
+    hist = []
+    for _ in range(7):
+        sim.step(a)
+        hist.append((sim.buf["rigid_body_states"].astype(np.float64).reshape(N, 17, 13).copy(), sim.buf["root_states"].astype(np.float64).copy(),
+                     sim.buf["base_lin_vel"].astype(np.float64).copy()))
+    assert sim.buf["reset"].sum() == 0 and np.abs(sim.buf["contact_forces"]).sum() == 0
+    comd = sim.buf["com_displacement"].astype(np.float64)
+    np.testing.assert_allclose(comd, 0.05, atol=1e-6)
+    step_dt, sub_dt = 4 * 0.005, 0.005
+
+    def point(bs, e, i, at_com):
+        c = np.array(model.bodies[i].com, dtype=np.float64) + (comd[e] if i == 0 else 0.0)
+        return bs[e, i, 0:3] + (_quat_R(bs[e, i, 3:7]) @ c if at_com else 0.0)
+    worst_own, worst_base, worst_other, sep = 0.0, 0.0, np.inf, 0.0
+    for t in range(1, 6):
+        for e in range(N):
+            for i in range(17):
+                v_pub = hist[t][0][e, i, 7:10]
+                # semi-implicit Euler: a position increment uses the velocity AFTER the sub-step's kick, so the central difference of the
+                # positions runs half a sub-step ahead of the published velocity: a dt / 2, a = the point's own acceleration (gravity +
+                # centripetal, up to 20 m/s^2 at the feet), estimated from the published velocities themselves
+                lag = 0.5 * sub_dt * (hist[t + 1][0][e, i, 7:10] - hist[t - 1][0][e, i, 7:10]) / (2 * step_dt)
+                d_com = (point(hist[t + 1][0], e, i, True) - point(hist[t - 1][0], e, i, True)) / (2 * step_dt) - lag
+                d_org = (point(hist[t + 1][0], e, i, False) - point(hist[t - 1][0], e, i, False)) / (2 * step_dt) - lag
+                own, other = (d_com, d_org) if convention == "com" else (d_org, d_com)
+                worst_own = max(worst_own, float(np.abs(v_pub - own).max()) / (0.015 + 0.012 * float(np.linalg.norm(v_pub))))
+                if i == 0:
+                    worst_base = max(worst_base, float(np.abs(v_pub - own).max()))
+                    worst_other = min(worst_other, float(np.linalg.norm(v_pub - other)))
+                    sep = max(sep, float(np.linalg.norm(d_com - d_org)))
+            np.testing.assert_array_equal(hist[t][1][e, 7:10], hist[t][0][e, 0, 7:10])              # the root tensor's velocity is row 0's
+            want = _quat_R(hist[t][1][e, 3:7]).T @ hist[t][1][e, 7:10]                              # LR:198: quat_rotate_inverse(base_quat, root_states[:, 7:10])
+            np.testing.assert_allclose(hist[t][2][e], want, atol=2e-6)
+    print(f"{kind} {convention}: base velocity vs d/dt of its own point: worst {worst_base:.4f} m/s; all bodies, in units of their bar: {worst_own:.2f}; "
+          f"base vs the OTHER point: at least {worst_other:.3f} m/s")
+    assert sep > 0.3                    # the two conventions are far apart in this motion ...
+    assert worst_base < 0.02            # ... the published base velocity follows its own point (first-order integrator: ~0.01 m/s at this spin) ...
+    assert worst_own < 1.0              # ... so does every body's (bar 0.015 m/s + 1.2 % of its speed: the feet move at 3 m/s on a 0.4 m arm)
+    assert worst_other > 0.2            # ... and none follows the other point
