@@ -48,6 +48,111 @@ def cpu_baseline(task, budget_s=24.0):
     return json.loads(out.stdout.strip().splitlines()[-1])
 
 
+def _parse_cpulist(text):
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out += list(range(int(a), int(b or a) + 1))
+    return out
+
+
+def host_cpu_plan(local_world, sysfs="/sys", allowed=None):
+    """CPU set of every local rank of an N-rank run on one node -> ([cpus of rank 0, cpus of rank 1, ...], how it was derived).
+
+    The PPO update needs 39-47 ms of host time per 71 ms (~2 200 launches, ~800 autograd nodes per update), so eight
+    rank processes are eight Python loops each within 1.6 x of host-bound: where they run decides weak scaling before xGMI does (VERDICT r4
+    task 6).  Every rank gets a DISJOINT set of hardware threads on the NUMA node its GPU hangs off -- its interpreter thread, autograd's
+    device thread, RCCL's proxy and watchdog threads and the HIP runtime's signal thread stay next to the GPU's PCIe root and never migrate
+    across sockets or on top of another rank -- and OMP_NUM_THREADS = 1 (torch's intra-op pool has nothing to do here; eight pools of 256
+    threads would only fight for the same cores).
+    GPU i's NUMA node: KFD topology node order (the HIP device order when no *_VISIBLE_DEVICES reorders it) -> PCI address -> numa_node.
+    Anything unreadable: the allowed CPUs in NUMA-node order cut into local_world equal contiguous pieces (GPU i on socket i // (N / 2) is the
+    usual 8-GPU board).  `allowed`: the CPUs this process may use (default: its current affinity mask)."""
+    allowed = sorted(os.sched_getaffinity(0)) if allowed is None else sorted(allowed)
+    nodes = {}
+    try:
+        base = os.path.join(sysfs, "devices", "system", "node")
+        for d in sorted(os.listdir(base)):
+            if d.startswith("node") and d[4:].isdigit():
+                cpus = [c for c in _parse_cpulist(open(os.path.join(base, d, "cpulist")).read()) if c in set(allowed)]
+                if cpus:
+                    nodes[int(d[4:])] = cpus
+    except OSError:
+        pass
+    if not nodes:
+        nodes = {0: allowed}
+    ordered = [c for n in sorted(nodes) for c in nodes[n]]
+
+    def even(cpus, parts):
+        k, r = divmod(len(cpus), parts)
+        out, at = [], 0
+        for i in range(parts):
+            n = k + (1 if i < r else 0)
+            out.append(cpus[at:at + n] if n else list(cpus))       # fewer CPUs than ranks: share them all
+            at += n
+        return out
+    gpu_node = []
+    try:
+        top = os.path.join(sysfs, "class", "kfd", "kfd", "topology", "nodes")
+        for d in sorted(os.listdir(top), key=int):
+            props = dict(line.split()[:2] for line in open(os.path.join(top, d, "properties")) if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) <= 0:
+                continue                                            # a CPU node
+            loc, dom = int(props["location_id"]), int(props.get("domain", "0"))
+            addr = f"{dom:04x}:{(loc >> 8) & 0xff:02x}:{(loc >> 3) & 0x1f:02x}.{loc & 7}"
+            nn = int(open(os.path.join(sysfs, "bus", "pci", "devices", addr, "numa_node")).read())
+            gpu_node.append(nn if nn in nodes else None)
+    except (OSError, ValueError, KeyError):
+        gpu_node = []
+    if len(gpu_node) >= local_world and all(n is not None for n in gpu_node[:local_world]):
+        plan = [None] * local_world
+        for n in sorted(set(gpu_node[:local_world])):
+            ranks = [r for r in range(local_world) if gpu_node[r] == n]
+            for r, cpus in zip(ranks, even(nodes[n], len(ranks))):
+                plan[r] = cpus
+        return plan, "kfd topology -> pci numa_node"
+    return even(ordered, local_world), "even split of the allowed CPUs in NUMA-node order"
+
+
+def _cpu_ranges(cpus):
+    """[0, 1, 2, 3, 8, 9] -> '0-3,8-9'"""
+    out, cpus = [], sorted(cpus)
+    i = 0
+    while i < len(cpus):
+        j = i
+        while j + 1 < len(cpus) and cpus[j + 1] == cpus[j] + 1:
+            j += 1
+        out.append(str(cpus[i]) if i == j else f"{cpus[i]}-{cpus[j]}")
+        i = j + 1
+    return ",".join(out)
+
+
+def pin_rank(local_rank, local_world):
+    """bind this rank process to its CPU set and keep torch's CPU pools small -- BEFORE torch or HIP is loaded (threads created later inherit
+    the mask).  LSIM_PIN_RANKS=0 leaves the process alone.  -> what the JSON line reports"""
+    info = {"pinned": False, "omp_num_threads": os.environ.get("OMP_NUM_THREADS")}
+    if os.environ.get("LSIM_PIN_RANKS", "1") == "0" or local_world <= 1:
+        return info
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    os.environ.setdefault("MKL_NUM_THREADS", "1")
+    info["omp_num_threads"] = os.environ["OMP_NUM_THREADS"]
+    try:
+        plan, how = host_cpu_plan(local_world)
+        os.sched_setaffinity(0, plan[local_rank])
+        info.update(pinned=True, source=how, cpu_affinity_by_local_rank=[_cpu_ranges(c) for c in plan])
+    except (OSError, ValueError, IndexError) as e:
+        info["error"] = f"{type(e).__name__}: {e}"
+    return info
+
+
+def task_of_rank(task, rank, world, mixed_robots):
+    """BASELINE config 5's mapping (--mixed-robots): the upper half of the ranks simulate Go2 (same observation / action layout, its own model
+    table and gains: envs/config.py GO2_OVERRIDES), the lower half --task's robot; one asset per process as in the reference (LR:1133-1135)"""
+    return "go2" if (mixed_robots and world > 1 and rank >= world // 2) else task
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` without a launcher: start N fresh rank processes (this parent never imports torch or touches a device),
     relay rank 0's JSON line, exit with the worst return code."""
@@ -204,6 +309,9 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch one rank per GPU (or plain `python bench.py --gpus N`)")
 
+    # host side of a multi-rank run: this rank's CPU set next to its GPU, small CPU thread pools -- before torch / HIP create their threads
+    host = pin_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+
     # CPU baseline first: a child process on the host cores, while this process has not initialised the GPU yet (rank 0 at N = 1 only)
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
@@ -261,9 +369,8 @@ def main():
     from isaacgymloco_amd.envs.legged_robot import LeggedRobot
     mode = args.mode
     base_task = args.task
-    if args.mixed_robots and world > 1 and rank >= world // 2:
-        args.task = "go2"           # same observation / action layout, different model table and gains (envs/config.py GO2_OVERRIDES:
-                                    # kinematics fitted to the reference's Go2 mocap clips, inertial values nominal; rounds 1-3 used Go1 here)
+    args.task = task_of_rank(base_task, rank, world, args.mixed_robots)     # (Go2: kinematics fitted to the reference's Go2 mocap clips, inertial
+                                                                             # values nominal; rounds 1-3 used Go1 here)
     cfg = C.TASKS[args.task][0]()
     cfg.env.num_envs = args.envs
     env = LeggedRobot(cfg, sim_device=f"cuda:{local_rank}", seed=1, rank=rank, using_amp=(args.task == "aliengo_amp"))
@@ -314,6 +421,7 @@ def main():
         elapsed, extra, workload = run_train_bench(env, cfg, args, dev, rank, world, barrier, clocks=clocks)
         extra["gemm_probe_after_timed_region"] = gemm_probe(torch, dev)
         extra["gpu_max_hw_queues"] = os.environ.get("GPU_MAX_HW_QUEUES", "unset (runtime default 4)")
+        extra["host"] = host
         ka = extra["kernel_a_ms"]
         timed_steps = extra["timed_env_steps"]
         actions_src = "policy"

@@ -202,3 +202,98 @@ def test_hybrid_ppo_data_parallel_order_equals_the_single_rank_order(tmp_path):
                 torch.testing.assert_close(d[part][k], single[part][k], rtol=0, atol=0, msg=f"{part}.{k}")
         for a, b in zip(d["nz"], single["nz"]):
             torch.testing.assert_close(a, b, rtol=0, atol=0)
+
+
+def _worker8(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), OMP_NUM_THREADS="1")
+    sys.path.insert(0, ROOT)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from isaacgymloco_amd.learn.bench_train import train_cfg_dict, weights_digest
+    from isaacgymloco_amd.learn.runner import HIMOnPolicyRunner
+    tc = train_cfg_dict("aliengo")                       # the reference's update: 5 epochs x 4 minibatches (AGC:316-317)
+    tc["runner"]["num_steps_per_env"] = 4
+    torch.manual_seed(100 + rank)                         # different initial weights per rank: the broadcast must fix that
+    runner = HIMOnPolicyRunner(FakeEnv(4, seed=7 + rank), tc, log_dir=None, device="cpu")
+    torch.manual_seed(5 + rank)
+    per_iter = []
+    for _ in range(2):
+        c0 = runner.dist_ctx.collectives
+        runner.learn(1, init_at_random_ep_len=False)
+        per_iter.append(runner.dist_ctx.collectives - c0)
+    torch.save({"digest": weights_digest(runner.alg.actor_critic), "lr": runner.alg.learning_rate, "collectives": per_iter, "world": runner.dist_ctx.world},
+               os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_stay_in_lockstep_with_21_collectives_per_iteration(tmp_path):
+    """SURVEY.md 8(e) / BASELINE config 5 at its real width (VERDICT r4 task 6): eight rank processes (gloo, CPU) with the reference's
+    5 x 4 minibatches take identical optimiser steps -- bit-identical weight digests and learning rate on all eight -- and issue exactly
+    21 collectives per PPO iteration each (20 merged gradient + KL buckets, one advantage-statistics sum); nothing else crosses ranks."""
+    port = 35500 + (os.getpid() % 2000)
+    mp.spawn(_worker8, args=(8, port, str(tmp_path)), nprocs=8, join=True)
+    outs = [torch.load(os.path.join(tmp_path, f"rank{r}.pt")) for r in range(8)]
+    assert all(o["world"] == 8 for o in outs)
+    assert all(o["collectives"] == [21, 21] for o in outs), [o["collectives"] for o in outs]
+    assert all(o["digest"] == outs[0]["digest"] and o["lr"] == outs[0]["lr"] for o in outs), [o["digest"] for o in outs]
+
+
+def test_mixed_robot_mapping_puts_ranks_4_to_7_on_the_go2_table():
+    """bench.py --mixed-robots at world size 8: ranks 0-3 simulate --task's robot, ranks 4-7 Go2 -- a different model table (total mass), the
+    same observation / action layout -- one asset per process as in the reference (LR:1133-1135)"""
+    import bench
+    from isaacgymloco_amd.envs import config as C
+    from isaacgymloco_amd.envs.legged_robot import build_robot_model
+    tasks = [bench.task_of_rank("aliengo", r, 8, True) for r in range(8)]
+    assert tasks == ["aliengo"] * 4 + ["go2"] * 4
+    assert [bench.task_of_rank("aliengo", r, 8, False) for r in range(8)] == ["aliengo"] * 8 and bench.task_of_rank("aliengo", 0, 1, True) == "aliengo"
+    mass = {}
+    for t in ("aliengo", "go2"):
+        cfg = C.TASKS[t][0]()
+        m = build_robot_model(cfg.asset)
+        mass[t] = sum(m.bodies[i].mass for i in range(17))
+        assert (cfg.env.num_observations, cfg.env.num_privileged_obs, cfg.env.num_actions) == (270, 238, 12)
+    assert abs(mass["aliengo"] - mass["go2"]) > 5.0, mass
+
+
+def _fake_sysfs(root, numa_cpus, gpu_numa):
+    """a node with len(numa_cpus) NUMA nodes and len(gpu_numa) GPUs behind a KFD topology (CPU nodes first, as the driver lists them)"""
+    for n, cl in enumerate(numa_cpus):
+        d = os.path.join(root, "devices", "system", "node", f"node{n}")
+        os.makedirs(d)
+        open(os.path.join(d, "cpulist"), "w").write(cl + "\n")
+    top = os.path.join(root, "class", "kfd", "kfd", "topology", "nodes")
+    for n in range(len(numa_cpus)):
+        os.makedirs(os.path.join(top, str(n)))
+        open(os.path.join(top, str(n), "properties"), "w").write("cpu_cores_count 64\nsimd_count 0\nlocation_id 0\ndomain 0\n")
+    for i, nn in enumerate(gpu_numa):
+        d = os.path.join(top, str(len(numa_cpus) + i))
+        os.makedirs(d)
+        bus = 0x05 + 0x10 * i
+        open(os.path.join(d, "properties"), "w").write(f"cpu_cores_count 0\nsimd_count 1024\nlocation_id {bus << 8}\ndomain 0\n")
+        pd = os.path.join(root, "bus", "pci", "devices", f"0000:{bus:02x}:00.0")
+        os.makedirs(pd)
+        open(os.path.join(pd, "numa_node"), "w").write(f"{nn}\n")
+
+
+def test_host_cpu_plan_gives_every_rank_its_own_cpus_next_to_its_gpu(tmp_path):
+    """bench.host_cpu_plan (the CPU set a rank process binds to before torch / HIP start): disjoint sets, on the GPU's NUMA node when the KFD
+    topology says which one that is, otherwise an even split in NUMA order; eight ranks on a 2 x 64-core, 256-thread host"""
+    import bench
+    root = str(tmp_path / "sys")
+    # sockets interleave their SMT siblings: node0 = 0-63,128-191; GPUs 0-3 on socket 1 (!), 4-7 on socket 0: the plan must follow the topology
+    _fake_sysfs(root, ["0-63,128-191", "64-127,192-255"], [1, 1, 1, 1, 0, 0, 0, 0])
+    plan, how = bench.host_cpu_plan(8, sysfs=root, allowed=range(256))
+    assert how.startswith("kfd topology")
+    node0, node1 = set(bench._parse_cpulist("0-63,128-191")), set(bench._parse_cpulist("64-127,192-255"))
+    assert all(len(p) == 32 for p in plan) and len(set().union(*map(set, plan))) == 256          # disjoint, everything used
+    assert all(set(plan[r]) <= node1 for r in range(4)) and all(set(plan[r]) <= node0 for r in range(4, 8))
+    # a container that only allows 64 CPUs of socket 0: the GPUs of socket 1 cannot get local CPUs -> even split of what is allowed
+    plan, how = bench.host_cpu_plan(8, sysfs=root, allowed=range(64))
+    assert how.startswith("even split") and [len(p) for p in plan] == [8] * 8 and sorted(sum(plan, [])) == list(range(64))
+    # no topology at all (this container): even split; more ranks than CPUs: everybody shares
+    plan, how = bench.host_cpu_plan(2, sysfs=str(tmp_path / "nothing"), allowed=[3, 4, 5, 9])
+    assert plan == [[3, 4], [5, 9]] and how.startswith("even split")
+    plan, _ = bench.host_cpu_plan(4, sysfs=str(tmp_path / "nothing"), allowed=[0, 1])
+    assert plan[0] == [0] and plan[1] == [1] and plan[2] == [0, 1] and plan[3] == [0, 1]
+    assert bench._cpu_ranges([0, 1, 2, 3, 8, 9, 11]) == "0-3,8-9,11"
