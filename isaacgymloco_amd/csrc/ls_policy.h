@@ -11,9 +11,21 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#define LS_POL_PAD 4              // floats of row padding in LDS (spreads the rows over the banks)
 #define LS_POL_MAX_HIDDEN 512
 #define LS_POL_MAX_IN 272
+// LDS layout of an activation buffer: row stride = 16 (mod 64) floats -- 272 (inputs, buffer B) and 528 (buffer A) -- and inside every
+// 16-float chunk the four 4-float groups of row r sit at group index q ^ g[(r >> 2) & 3], g = {0, 3, 2, 1}.  A layer's B-operand read is a
+// ds_read_b128 of lane (i = row, q = k group); the hardware serves it in four 16-lane groups {q = 0: rows 0-3, 12-15; q = 1: rows 4-11} etc.
+// (MI355X_MICROARCH.md, LDS), 16 slots of 16 bytes per cycle.  With a stride of 4 slots, rows r, r + 4, r + 8, r + 12 share a block of 4
+// slots and the XOR by g spreads them over it: every lane group reads 16 distinct slots.  [Rounds 2-4 padded rows by 4 floats (stride 516 /
+// 276): slot = (row + q) mod 16, two lanes of every group on one slot -- SQ_LDS_BANK_CONFLICT = 53 % of the kernel's LDS cycles, VERDICT r4.]
+#define LS_POL_STRIDE_IN 272
+#define LS_POL_STRIDE_A 528
+#define LS_POL_STRIDE_B 272
+static_assert(LS_POL_STRIDE_IN % 64 == 16 && LS_POL_STRIDE_A % 64 == 16 && LS_POL_STRIDE_B % 64 == 16, "row strides of 4 slots (mod 16 slots)");
+static_assert(LS_POL_STRIDE_IN >= LS_POL_MAX_IN && LS_POL_STRIDE_A >= LS_POL_MAX_HIDDEN && LS_POL_STRIDE_B >= LS_POL_MAX_IN, "strides hold the widest row");
+__device__ __forceinline__ int ls_pol_swz(int row) { return (0x1230 >> (4 * ((row >> 2) & 3))) & 3; }       // g = {0, 3, 2, 1}
+__device__ __forceinline__ int ls_pol_col(int row, int c) { return c ^ (ls_pol_swz(row) << 2); }            // column c of row `row` -> its float index in the row
 
 extern __shared__ float ls_pol_lds[];
 // The weight / bias pointers arrive inside a struct passed by value, so the compiler cannot tell their address space and emits FLAT loads --
@@ -32,79 +44,114 @@ __device__ __forceinline__ float ls_elu(float x) { return x > 0.0f ? x : expm1f(
 
 // one layer for this wave's NTW output tiles [tile0, tile0 + valid) and all RH * 16 rows of the block: every weight vector fetched from
 // L2 feeds RH MFMAs (one per 16-row half), so a block of 32 environments streams half the weight bytes per environment of a block of 16
-template <int NTW, int RH>
-__device__ __noinline__ void ls_pol_layer(const float* __restrict__ W, const float* __restrict__ bias, int k_pad, int x_off, int x_stride,
-                                          int y_off, int y_stride, int tile0, int valid, int elu, int lane) {
+// one layer for this wave's NTW output tiles [tile0, tile0 + valid) and all RH * 16 rows of the block: every weight vector fetched from
+// L2 feeds RH MFMAs (one per 16-row half), so a block of 32 environments streams half the weight bytes per environment of a block of 16.
+// The k loop runs over THREE register stages used round-robin (chunk j computes from stage j % 3 while the weight vectors of chunk j + 2 load
+// into stage (j + 2) % 3 and the activation vectors of chunk j + 1 are read from LDS into stage (j + 1) % 3): no register is copied.
+// [Rounds 3-4 rotated w0 <- w1 <- w2 at the end of every chunk; the copy of the vector requested in that same chunk put an
+// `s_waitcnt vmcnt(0)` there -- the prefetch distance was one chunk's MFMAs, not two chunks, and a deeper ring (measured in round 5: depth 4
+// / 5 / 6 = 70.7 / 70.7 / 73.3 us against 63.4) only added copies in front of the same wait; the LDS operand of a chunk was read and waited
+// for at its top.  The ISA of the loop showed both.]
+// FULL: the wave owns all NTW tiles (every layer of the shipped networks: tile counts are powers of two) -- no per-tile predicate, so the
+// loop body is straight-line code and the compiler's s_waitcnt counters see every load (a load inside a branch makes it wait for all of them)
+template <int NTW, int RH, bool FULL>
+__device__ __noinline__ void ls_pol_layer(const float* __restrict__ W, const float* __restrict__ bias, int k_pad_in, int x_off, int x_stride,
+                                          int y_off, int y_stride, int tile0_in, int valid_in, int elu_in, int lane) {
+    // arguments of a non-inlined function arrive in vector registers; these are wave-uniform: scalar registers make the loop's bounds tests
+    // scalar branches (s_cbranch_scc) instead of exec-mask manipulation around every guarded load
+    const int k_pad = __builtin_amdgcn_readfirstlane(k_pad_in), tile0 = __builtin_amdgcn_readfirstlane(tile0_in), elu = __builtin_amdgcn_readfirstlane(elu_in);
+    const int valid = FULL ? NTW : __builtin_amdgcn_readfirstlane(valid_in);
     const int i = lane & 15, q = lane >> 4;
     ls_v4f acc[NTW][RH];
 #pragma unroll
     for (int t = 0; t < NTW; ++t)
 #pragma unroll
         for (int h = 0; h < RH; ++h) acc[t][h] = (ls_v4f){0.0f, 0.0f, 0.0f, 0.0f};
+    float4 b[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) b[t] = make_float4(0, 0, 0, 0);
     if (valid > 0) {
-        const float* xrow = ls_pol_lds + x_off + i * x_stride + 4 * q;            // B operand: row i (+ 16 h) of the block, k group q
+        const float* xrow = ls_pol_lds + x_off + i * x_stride + 4 * (q ^ ls_pol_swz(i));   // B operand: row i (+ 16 h: same swizzle) of the block, k group q
         ls_pol_gptr wrow = (ls_pol_gptr)W + (size_t)(tile0 * 16 + i) * k_pad + 4 * q;   // A operand: output tile0*16 + i, k group q
-        // weight vectors of the current k chunk and of the next two (register triple buffer: the loads issued in an iteration are
-        // consumed two iterations later; a block keeps only a few waves per SIMD, so this is what hides the L2 latency)
-        float4 w0[NTW], w1[NTW], w2[NTW];
+        float4 wa[NTW], wb[NTW], wc[NTW], xa[RH], xb[RH], xc[RH];
+        // G = guarded against the end of the row (prologue and the last <= 4 chunks), U = unguarded (steady state: every request is in range;
+        // a request inside a branch would make the compiler wait for ALL outstanding loads at the next use)
+#define LS_POL_LDW_U(ST, KC) do { _Pragma("unroll") for (int t = 0; t < NTW; ++t)                                            \
+            if (FULL || t < valid) ST[t] = ls_pol_ld4(wrow + (size_t)t * 16 * k_pad + (KC)); } while (0)
+#define LS_POL_LDW_G(ST, KC) do { _Pragma("unroll") for (int t = 0; t < NTW; ++t)                                            \
+            ST[t] = ((FULL || t < valid) && (KC) < k_pad) ? ls_pol_ld4(wrow + (size_t)t * 16 * k_pad + (KC)) : make_float4(0, 0, 0, 0); } while (0)
+#define LS_POL_LDX_U(ST, KC) do { _Pragma("unroll") for (int h = 0; h < RH; ++h) ST[h] = *(const float4*)(xrow + 16 * h * x_stride + (KC)); } while (0)
+#define LS_POL_LDX_G(ST, KC) do { if ((KC) < k_pad) LS_POL_LDX_U(ST, KC); } while (0)
+#define LS_POL_MMA(WS, XS) do { _Pragma("unroll") for (int t = 0; t < NTW; ++t) { if (FULL || t < valid) { _Pragma("unroll") for (int h = 0; h < RH; ++h) {   \
+            acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(WS[t].x, XS[h].x, acc[t][h], 0, 0, 0);                          \
+            acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(WS[t].y, XS[h].y, acc[t][h], 0, 0, 0);                          \
+            acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(WS[t].z, XS[h].z, acc[t][h], 0, 0, 0);                          \
+            acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(WS[t].w, XS[h].w, acc[t][h], 0, 0, 0); } } } } while (0)
+        // chunk KC from (WS, XS); requests: weights of chunk KC + 32 into WL (the stage the previous chunk consumed), activations of chunk
+        // KC + 16 into XL  (scheduling barriers: left alone, hipcc sinks the requests behind the MFMAs, to two instructions in front of
+        // their first use)
+#define LS_POL_CHUNK(V, WS, XS, WL, XL, KC) do { LS_POL_LDW_##V(WL, (KC) + 32); LS_POL_LDX_##V(XL, (KC) + 16); __builtin_amdgcn_sched_barrier(0);    \
+                                                 LS_POL_MMA(WS, XS); __builtin_amdgcn_sched_barrier(0); } while (0)
+        LS_POL_LDW_G(wa, 0);
+        LS_POL_LDW_G(wb, 16);
+        LS_POL_LDX_G(xa, 0);
+        // the bias vectors now, not behind the loop (one L2 round trip less in front of the epilogue)
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) {
-            const bool ok = t < valid;
-            w0[t] = ok ? ls_pol_ld4(wrow + (size_t)t * 16 * k_pad) : make_float4(0, 0, 0, 0);
-            w1[t] = (ok && 16 < k_pad) ? ls_pol_ld4(wrow + (size_t)t * 16 * k_pad + 16) : make_float4(0, 0, 0, 0);
+        for (int t = 0; t < NTW; ++t)
+            if (FULL || t < valid) b[t] = ls_pol_ld4((ls_pol_gptr)bias + (tile0 + t) * 16 + 4 * q);
+        int kc = 0;
+        for (; kc + 80 <= k_pad; kc += 48) {            // every request of these three chunks (up to kc + 64 .. + 79) is inside the row
+            LS_POL_CHUNK(U, wa, xa, wc, xb, kc);
+            LS_POL_CHUNK(U, wb, xb, wa, xc, kc + 16);
+            LS_POL_CHUNK(U, wc, xc, wb, xa, kc + 32);
         }
-        for (int kc = 0; kc < k_pad; kc += 16) {
-            if (kc + 32 < k_pad) {
-#pragma unroll
-                for (int t = 0; t < NTW; ++t)
-                    if (t < valid) w2[t] = ls_pol_ld4(wrow + (size_t)t * 16 * k_pad + kc + 32);
-            }
-            float4 x[RH];
-#pragma unroll
-            for (int h = 0; h < RH; ++h) x[h] = *(const float4*)(xrow + 16 * h * x_stride + kc);
-#pragma unroll
-            for (int t = 0; t < NTW; ++t) {
-                if (t < valid) {
-#pragma unroll
-                    for (int h = 0; h < RH; ++h) {
-                        acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[t].x, x[h].x, acc[t][h], 0, 0, 0);
-                        acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[t].y, x[h].y, acc[t][h], 0, 0, 0);
-                        acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[t].z, x[h].z, acc[t][h], 0, 0, 0);
-                        acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[t].w, x[h].w, acc[t][h], 0, 0, 0);
-                    }
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < NTW; ++t) { w0[t] = w1[t]; w1[t] = w2[t]; }
-        }
+        if (kc < k_pad) { LS_POL_CHUNK(G, wa, xa, wc, xb, kc); kc += 16; }     // one to four chunks left; the stages are aligned again
+        if (kc < k_pad) { LS_POL_CHUNK(G, wb, xb, wa, xc, kc); kc += 16; }
+        if (kc < k_pad) { LS_POL_CHUNK(G, wc, xc, wb, xa, kc); kc += 16; }
+        if (kc < k_pad) { LS_POL_CHUNK(G, wa, xa, wc, xb, kc); }
+#undef LS_POL_CHUNK
+#undef LS_POL_MMA
+#undef LS_POL_LDX_G
+#undef LS_POL_LDX_U
+#undef LS_POL_LDW_G
+#undef LS_POL_LDW_U
     }
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
-        if (t < valid) {
-            const int n = (tile0 + t) * 16 + 4 * q;                               // D[n .. n+3][row i + 16 h]
-            const float4 b = ls_pol_ld4((ls_pol_gptr)bias + n);
+        if (FULL || t < valid) {
+            const int n_lds = (tile0 + t) * 16 + 4 * (q ^ ls_pol_swz(i));         // D[n .. n+3][row i + 16 h], n = (tile0 + t) * 16 + 4 q: where that group of four lives in the row
 #pragma unroll
             for (int h = 0; h < RH; ++h) {
-                float4 y = make_float4(acc[t][h][0] + b.x, acc[t][h][1] + b.y, acc[t][h][2] + b.z, acc[t][h][3] + b.w);
+                float4 y = make_float4(acc[t][h][0] + b[t].x, acc[t][h][1] + b[t].y, acc[t][h][2] + b[t].z, acc[t][h][3] + b[t].w);
                 if (elu) { y.x = ls_elu(y.x); y.y = ls_elu(y.y); y.z = ls_elu(y.z); y.w = ls_elu(y.w); }
-                *(float4*)(ls_pol_lds + y_off + (i + 16 * h) * y_stride + n) = y;
+                *(float4*)(ls_pol_lds + y_off + (i + 16 * h) * y_stride + n_lds) = y;
             }
         }
     }
 }
 
+// this wave's output tiles of a layer: [tile0, tile0 + valid), at most `per` of them
+template <int WAVES>
+__device__ __forceinline__ void ls_pol_split(const lsim_mlp_layer& L, int wave, int& per, int& tile0, int& valid) {
+    const int tiles = L.n_pad >> 4;
+    per = (tiles + WAVES - 1) / WAVES;
+    tile0 = wave * per;
+    valid = tiles - tile0;
+    if (valid > per) valid = per;
+    if (valid < 0) valid = 0;
+}
+
 template <int ROWS, int WAVES>
 __device__ __forceinline__ void ls_pol_run_layer(const lsim_mlp_layer& L, int x_off, int x_stride, int y_off, int y_stride, int elu, int wave, int lane) {
     constexpr int RH = ROWS / 16;
-    const int tiles = L.n_pad >> 4;
-    const int per = (tiles + WAVES - 1) / WAVES;                               // output tiles per wave
-    const int tile0 = wave * per;
-    int valid = tiles - tile0;
-    if (valid > per) valid = per;
-    if (valid < 0) valid = 0;
-    if constexpr (32 / WAVES > 2) { if (per > 2) { ls_pol_layer<4, RH>(L.weight, L.bias, L.k_pad, x_off, x_stride, y_off, y_stride, tile0, valid, elu, lane); __syncthreads(); return; } }
-    if (per > 1) ls_pol_layer<2, RH>(L.weight, L.bias, L.k_pad, x_off, x_stride, y_off, y_stride, tile0, valid, elu, lane);
-    else ls_pol_layer<1, RH>(L.weight, L.bias, L.k_pad, x_off, x_stride, y_off, y_stride, tile0, valid, elu, lane);
+    int per, tile0, valid;
+    ls_pol_split<WAVES>(L, wave, per, tile0, valid);
+#define LS_POL_CALL(NTW) do { if (valid == NTW) ls_pol_layer<NTW, RH, true>(L.weight, L.bias, L.k_pad, x_off, x_stride, y_off, y_stride, tile0, valid, elu, lane); \
+                              else if (valid > 0) ls_pol_layer<NTW, RH, false>(L.weight, L.bias, L.k_pad, x_off, x_stride, y_off, y_stride, tile0, valid, elu, lane); } while (0)
+    if constexpr (32 / WAVES > 2) { if (per > 2) { LS_POL_CALL(4); __syncthreads(); return; } }
+    if (per > 1) LS_POL_CALL(2);
+    else LS_POL_CALL(1);
+#undef LS_POL_CALL
     __syncthreads();
 }
 
@@ -133,24 +180,47 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4
     const long r0 = (long)blockIdx.x * ROWS;
     // blockIdx.y = 0: estimator encoder + actor on the observation history; 1: critic on the privileged observation.  The two halves are
     // independent: separate blocks halve the serial layer chain.
-    // LDS map (floats): input rows | buffer A (<= 512 wide) | buffer B (<= 272 wide)
+    // LDS map (floats): input rows (stride 272) | buffer A (<= 512 wide, stride 528) | buffer B (<= 272 wide, stride 272); columns swizzled: ls_pol_col
     const bool critic = blockIdx.y != 0;
+#if defined(LS_POL_EXP) && LS_POL_EXP == 1      // timing probes (tools/policy_ab.sh): one half of the blocks returns at once
+    if (critic) return;
+#elif defined(LS_POL_EXP) && LS_POL_EXP == 2
+    if (!critic) return;
+#endif
     const lsim_mlp_layer& first = critic ? p.critic[0] : p.encoder[0];
     const int n_in = critic ? p.num_priv_obs : p.num_obs;
     const float* __restrict__ src = critic ? priv : obs;
-    const int s_in = first.k_pad + LS_POL_PAD, s_a = LS_POL_MAX_HIDDEN + LS_POL_PAD, s_b = LS_POL_MAX_IN + LS_POL_PAD;
-    const int o_in = 0, o_a = o_in + ROWS * (LS_POL_MAX_IN + LS_POL_PAD), o_b = o_a + ROWS * s_a;
-    for (int e = tid; e < ROWS * first.k_pad; e += 64 * WAVES) {
-        const int r = e / first.k_pad, c = e - r * first.k_pad;
-        const long env = r0 + r;
-        const float v = (env < num_envs && c < n_in) ? src[env * n_in + c] : 0.0f;
-        ls_pol_lds[o_in + r * s_in + c] = v;
-        if (ACT && env < num_envs && c < n_in) {
-            float* dst = critic ? act.st.privileged_observations : act.st.observations;
-            dst[((size_t)act.step * act.st.num_envs + env) * n_in + c] = v;
-            if (critic && act.prev_step >= 0)       // next critic observation of the previous step, termination rows patched in (HIMR:119-121)
-                act.st.next_privileged_observations[((size_t)act.prev_step * act.st.num_envs + env) * n_in + c] =
-                    act.prev_dones[env] ? act.prev_term_priv[env * n_in + c] : v;
+    constexpr int s_in = LS_POL_STRIDE_IN, s_a = LS_POL_STRIDE_A, s_b = LS_POL_STRIDE_B;
+    constexpr int o_in = 0, o_a = o_in + ROWS * s_in, o_b = o_a + ROWS * s_a;
+    {   // stage the block's input rows: every thread's loads first, all in flight together (one memory round trip), then the LDS writes and
+        // the rollout's stores (a load-store-load-store loop paid a round trip per pass: 9 passes)
+        constexpr int T = 64 * WAVES, PER = (ROWS * LS_POL_MAX_IN + T - 1) / T;
+        const int kp = first.k_pad, total = ROWS * kp;
+        float v[PER], vt[PER];
+        int rr[PER], cc[PER];
+        const bool patch = ACT && critic && act.prev_step >= 0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int e = tid + j * T;
+            const int r = e / kp, c = e - r * kp;
+            rr[j] = r; cc[j] = c;
+            const long env = r0 + r;
+            const bool ok = e < total && env < num_envs && c < n_in;
+            v[j] = ok ? src[env * n_in + c] : 0.0f;
+            vt[j] = (ok && patch && act.prev_dones[env]) ? act.prev_term_priv[env * n_in + c] : v[j];
+        }
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int e = tid + j * T, r = rr[j], c = cc[j];
+            if (e >= total) continue;
+            const long env = r0 + r;
+            ls_pol_lds[o_in + r * s_in + ls_pol_col(r, c)] = v[j];
+            if (ACT && env < num_envs && c < n_in) {
+                float* dst = critic ? act.st.privileged_observations : act.st.observations;
+                dst[((size_t)act.step * act.st.num_envs + env) * n_in + c] = v[j];
+                if (patch)       // next critic observation of the previous step, termination rows patched in (HIMR:119-121)
+                    act.st.next_privileged_observations[((size_t)act.prev_step * act.st.num_envs + env) * n_in + c] = vt[j];
+            }
         }
     }
     if (ACT && critic && act.prev_step >= 0 && tid < ROWS && r0 + tid < num_envs) {
@@ -162,7 +232,12 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4
         act.st.dones[row] = act.prev_dones[env];
     }
     __syncthreads();
+#if defined(LS_POL_STOP_AFTER)      // timing probe (tools/gpu_r5_f.sh): every block returns after that many layers (0: after the staging)
+    int ls_layers_left = LS_POL_STOP_AFTER;
+#define LS_RUN(L, XO, XS, YO, YS, ELU) do { if (ls_layers_left-- <= 0) return; ls_pol_run_layer<ROWS, WAVES>(L, XO, XS, YO, YS, ELU, wave, lane); } while (0)
+#else
 #define LS_RUN(L, XO, XS, YO, YS, ELU) ls_pol_run_layer<ROWS, WAVES>(L, XO, XS, YO, YS, ELU, wave, lane)
+#endif
     if (critic) {
         // ---- critic (HAC:82-95)
         LS_RUN(p.critic[0], o_in, s_in, o_a, s_a, 1);
@@ -170,7 +245,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4
         LS_RUN(p.critic[2], o_b, s_b, o_a, s_a, 1);
         LS_RUN(p.critic[3], o_a, s_a, o_b, s_b, 0);
         if (tid < ROWS && r0 + tid < num_envs) {
-            const float v = ls_pol_lds[o_b + tid * s_b];
+            const float v = ls_pol_lds[o_b + tid * s_b + ls_pol_col(tid, 0)];
             values_out[r0 + tid] = v;
             if (ACT) act.st.values[(size_t)act.step * act.st.num_envs + r0 + tid] = v;
         }
@@ -186,14 +261,14 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4
         for (int e = tid; e < ROWS * kin; e += 64 * WAVES) {
             const int r = e / kin, c = e - r * kin;
             float v = 0.0f;
-            if (c < n1) v = ls_pol_lds[o_in + r * s_in + c];
-            else if (c < n1 + 3) v = ls_pol_lds[o_a + r * s_a + (c - n1)];
+            if (c < n1) v = ls_pol_lds[o_in + r * s_in + ls_pol_col(r, c)];
+            else if (c < n1 + 3) v = ls_pol_lds[o_a + r * s_a + ls_pol_col(r, c - n1)];
             else if (c < n1 + 3 + nl) {
                 float ss = 0.0f;
-                for (int k = 0; k < nl; ++k) { const float z = ls_pol_lds[o_a + r * s_a + 3 + k]; ss += z * z; }
-                v = ls_pol_lds[o_a + r * s_a + 3 + (c - n1 - 3)] / fmaxf(sqrtf(ss), 1e-12f);      // F.normalize(p=2, eps=1e-12)
+                for (int k = 0; k < nl; ++k) { const float z = ls_pol_lds[o_a + r * s_a + ls_pol_col(r, 3 + k)]; ss += z * z; }
+                v = ls_pol_lds[o_a + r * s_a + ls_pol_col(r, 3 + (c - n1 - 3))] / fmaxf(sqrtf(ss), 1e-12f);      // F.normalize(p=2, eps=1e-12)
             }
-            ls_pol_lds[o_b + r * s_b + c] = v;
+            ls_pol_lds[o_b + r * s_b + ls_pol_col(r, c)] = v;
         }
         __syncthreads();
     }
@@ -205,7 +280,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4
 #undef LS_RUN
     for (int e = tid; e < ROWS * p.num_actions; e += 64 * WAVES) {
         const int r = e / p.num_actions, c = e - r * p.num_actions;
-        if (r0 + r < num_envs) mean_out[(r0 + r) * p.num_actions + c] = ls_pol_lds[o_b + r * s_b + c];
+        if (r0 + r < num_envs) mean_out[(r0 + r) * p.num_actions + c] = ls_pol_lds[o_b + r * s_b + ls_pol_col(r, c)];
     }
     if constexpr (ACT) {
         const int A = p.num_actions;                    // <= 16 (checked by the host)
@@ -215,7 +290,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4
             const long env = r0 + r;
             float lp = 0.0f;
             if (c < A && env < num_envs) {
-                const float mu = ls_pol_lds[o_b + r * s_b + c], sd = act.std[c];
+                const float mu = ls_pol_lds[o_b + r * s_b + ls_pol_col(r, c)], sd = act.std[c];
                 const float a = ls_sample_action(act.seed, act.rank, (uint32_t)env, (uint32_t)act.draw, c, mu, sd);
                 const size_t row = (size_t)act.step * act.st.num_envs + env;
                 act.actions_out[env * A + c] = a;
@@ -264,7 +339,7 @@ static int ls_policy_launch(const lsim_him_policy* p, const float* obs, const fl
     k = p->num_priv_obs;
     for (int l = 0; l < 4; ++l) { bad |= ls_pol_check_layer(&p->critic[l], k); k = p->critic[l].n_out; }
     if (p->critic[3].n_out != 1 || p->critic[0].k_pad > LS_POL_MAX_IN) bad = 1;
-    // layers whose output lands in LDS buffer B (row stride LS_POL_MAX_IN + pad): second and last layer of each network
+    // layers whose output lands in LDS buffer B (row stride LS_POL_STRIDE_B): second and last layer of each network
     if (p->encoder[1].n_pad > LS_POL_MAX_IN || p->actor[1].n_pad > LS_POL_MAX_IN || p->actor[3].n_pad > LS_POL_MAX_IN ||
         p->critic[1].n_pad > LS_POL_MAX_IN || p->critic[3].n_pad > LS_POL_MAX_IN) bad = 1;
     if (bad) return LSIM_E_UNSUPPORTED;
@@ -272,7 +347,7 @@ static int ls_policy_launch(const lsim_him_policy* p, const float* obs, const fl
     static const bool force16 = getenv("LSIM_POLICY_ROWS16") != nullptr;      // A/B switch (tools/policy_time.py), read once
     const bool wide = num_envs >= 2048 && !force16;
     const int rows = wide ? 32 : 16;
-    const size_t lds = (size_t)rows * (2 * (LS_POL_MAX_IN + LS_POL_PAD) + (LS_POL_MAX_HIDDEN + LS_POL_PAD)) * sizeof(float);
+    const size_t lds = (size_t)rows * (LS_POL_STRIDE_IN + LS_POL_STRIDE_A + LS_POL_STRIDE_B) * sizeof(float);
     static size_t configured[4][64] = {{0}};     // per kernel and device: the attribute belongs to the device's copy of the kernel
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LSIM_E_HIP;
