@@ -526,12 +526,15 @@ int lsim_rollout_gae(const lsim_rollout_storage* st, const float* last_values, f
 /* ---- fused rollout-time forward of the HIM policy (HAC:136-163, HES:64-68, HIMP:90-96): estimator encoder
  * (observation history -> 3 velocity + latent), L2-normalised latent, actor on [one-step obs, velocity, latent], critic on the
  * privileged observation -- 11 Linear layers with ELU between them -- in one launch, MFMA fp32, activations in LDS.
- * Weights are passed PADDED: weight [n_pad][k_pad] row-major and bias [n_pad], both dimensions multiples of 16, zero filled beyond
- * [n_out][k_in], 16-byte aligned (the caller packs torch's nn.Linear parameters once per policy update).
+ * Weights are passed PADDED and TILED: both dimensions rounded up to multiples of 16 (zero filled beyond [n_out][k_in]) and stored as
+ * 16 x 16 blocks, weight[(n / 16) * (k_pad / 16) + k / 16][n % 16][k % 16] -- the 1 KB block of output tile n / 16 and k chunk k / 16 is
+ * contiguous, so the wave that owns an output tile reads whole cache lines, each once (ABI v5; v4 took [n_pad][k_pad] row-major: half a
+ * line per row and chunk, with the second half evicted from the CU's 32 KB vector cache before its turn when a wave owned two tiles) --
+ * bias [n_pad]; 16-byte aligned (the caller packs torch's nn.Linear parameters once per policy update).
  * mean_out [num_envs, num_actions], values_out [num_envs, 1].  LSIM_E_UNSUPPORTED for other topologies / sizes (hidden widths > 512,
  * inputs > 272): run the networks in the host framework then. */
 typedef struct lsim_mlp_layer {
-    const float* weight;      /* [n_pad][k_pad] */
+    const float* weight;      /* [n_pad / 16][k_pad / 16][16][16]: see above */
     const float* bias;        /* [n_pad] */
     int32_t k_pad, n_pad, k_in, n_out;
 } lsim_mlp_layer;

@@ -3,7 +3,7 @@
 // kernel instead of 29 launches (HAC:136-163, HES:64-68).  A workgroup owns 32 environments (16 for small batches); activations never leave LDS.
 //
 // Layer = Y[16 x N] = act(X[16 x K] W^T + b) on v_mfma_f32_16x16x4_f32 with A = W tile (16 outputs x 4 k) read straight from
-// global memory (the weights, 2.2 MB, stay L2 resident) and B = X (4 k x 16 rows) from LDS.  Both operands are fetched as 16-byte
+// global memory (the weights, 2.2 MB, stay L2 resident; stored as 16 x 16 blocks) and B = X (4 k x 16 rows) from LDS.  Both operands are fetched as 16-byte
 // vectors: lane (i, q) takes k = 16 kc + 4 q .. + 3 of its weight row / activation row and feeds component c to MFMA step c, so a
 // 16-wide k chunk costs one global and one LDS vector load per 4 MFMAs.  The result tile lands as D[n = 4 q + r][row = lane % 16],
 // i.e. four consecutive outputs of one row per lane: bias + ELU + one ds_write_b128.  The four waves of the block split the output
@@ -72,14 +72,16 @@ __device__ __noinline__ void ls_pol_layer(const float* __restrict__ W, const flo
     for (int t = 0; t < NTW; ++t) b[t] = make_float4(0, 0, 0, 0);
     if (valid > 0) {
         const float* xrow = ls_pol_lds + x_off + i * x_stride + 4 * (q ^ ls_pol_swz(i));   // B operand: row i (+ 16 h: same swizzle) of the block, k group q
-        ls_pol_gptr wrow = (ls_pol_gptr)W + (size_t)(tile0 * 16 + i) * k_pad + 4 * q;   // A operand: output tile0*16 + i, k group q
+        // A operand: output tile0*16 + i, k group q.  The weights are stored as 16 x 16 blocks (include/lsim.h): tile T, chunk KC / 16 at
+        // (T * k_pad + KC) * 16 floats, row i, k group q inside it -- a wave's request is one contiguous kilobyte
+        ls_pol_gptr wrow = (ls_pol_gptr)W + (size_t)tile0 * 16 * k_pad + 16 * i + 4 * q;
         float4 wa[NTW], wb[NTW], wc[NTW], xa[RH], xb[RH], xc[RH];
         // G = guarded against the end of the row (prologue and the last <= 4 chunks), U = unguarded (steady state: every request is in range;
         // a request inside a branch would make the compiler wait for ALL outstanding loads at the next use)
 #define LS_POL_LDW_U(ST, KC) do { _Pragma("unroll") for (int t = 0; t < NTW; ++t)                                            \
-            if (FULL || t < valid) ST[t] = ls_pol_ld4(wrow + (size_t)t * 16 * k_pad + (KC)); } while (0)
+            if (FULL || t < valid) ST[t] = ls_pol_ld4(wrow + (size_t)t * 16 * k_pad + 16 * (KC)); } while (0)
 #define LS_POL_LDW_G(ST, KC) do { _Pragma("unroll") for (int t = 0; t < NTW; ++t)                                            \
-            ST[t] = ((FULL || t < valid) && (KC) < k_pad) ? ls_pol_ld4(wrow + (size_t)t * 16 * k_pad + (KC)) : make_float4(0, 0, 0, 0); } while (0)
+            ST[t] = ((FULL || t < valid) && (KC) < k_pad) ? ls_pol_ld4(wrow + (size_t)t * 16 * k_pad + 16 * (KC)) : make_float4(0, 0, 0, 0); } while (0)
 #define LS_POL_LDX_U(ST, KC) do { _Pragma("unroll") for (int h = 0; h < RH; ++h) ST[h] = *(const float4*)(xrow + 16 * h * x_stride + (KC)); } while (0)
 #define LS_POL_LDX_G(ST, KC) do { if ((KC) < k_pad) LS_POL_LDX_U(ST, KC); } while (0)
 #define LS_POL_MMA(WS, XS) do { _Pragma("unroll") for (int t = 0; t < NTW; ++t) { if (FULL || t < valid) { _Pragma("unroll") for (int h = 0; h < RH; ++h) {   \
@@ -192,37 +194,46 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4
     const float* __restrict__ src = critic ? priv : obs;
     constexpr int s_in = LS_POL_STRIDE_IN, s_a = LS_POL_STRIDE_A, s_b = LS_POL_STRIDE_B;
     constexpr int o_in = 0, o_a = o_in + ROWS * s_in, o_b = o_a + ROWS * s_a;
-    {   // stage the block's input rows: every thread's loads first, all in flight together (one memory round trip), then the LDS writes and
-        // the rollout's stores (a load-store-load-store loop paid a round trip per pass: 9 passes)
-        constexpr int T = 64 * WAVES, PER = (ROWS * LS_POL_MAX_IN + T - 1) / T;
-        const int kp = first.k_pad, total = ROWS * kp;
-        float v[PER], vt[PER];
-        int rr[PER], cc[PER];
-        const bool patch = ACT && critic && act.prev_step >= 0;
+    constexpr int T_STAGE = 64 * WAVES, PER_STAGE = (ROWS * LS_POL_MAX_IN + T_STAGE - 1) / T_STAGE;
+    const int kp = first.k_pad, total = ROWS * kp;
+    {   // stage the block's input rows: every thread's loads first, all in flight together (one memory round trip), then the LDS writes
+        // (a load-store-load-store loop paid a round trip per pass: 9 passes)
+        float v[PER_STAGE];
+        int rr[PER_STAGE], cc[PER_STAGE];
 #pragma unroll
-        for (int j = 0; j < PER; ++j) {
-            const int e = tid + j * T;
+        for (int j = 0; j < PER_STAGE; ++j) {
+            const int e = tid + j * T_STAGE;
             const int r = e / kp, c = e - r * kp;
             rr[j] = r; cc[j] = c;
             const long env = r0 + r;
-            const bool ok = e < total && env < num_envs && c < n_in;
-            v[j] = ok ? src[env * n_in + c] : 0.0f;
-            vt[j] = (ok && patch && act.prev_dones[env]) ? act.prev_term_priv[env * n_in + c] : v[j];
+            v[j] = (e < total && env < num_envs && c < n_in) ? src[env * n_in + c] : 0.0f;
         }
 #pragma unroll
-        for (int j = 0; j < PER; ++j) {
-            const int e = tid + j * T, r = rr[j], c = cc[j];
-            if (e >= total) continue;
-            const long env = r0 + r;
-            ls_pol_lds[o_in + r * s_in + ls_pol_col(r, c)] = v[j];
-            if (ACT && env < num_envs && c < n_in) {
-                float* dst = critic ? act.st.privileged_observations : act.st.observations;
-                dst[((size_t)act.step * act.st.num_envs + env) * n_in + c] = v[j];
-                if (patch)       // next critic observation of the previous step, termination rows patched in (HIMR:119-121)
-                    act.st.next_privileged_observations[((size_t)act.prev_step * act.st.num_envs + env) * n_in + c] = vt[j];
+        for (int j = 0; j < PER_STAGE; ++j)
+            if (tid + j * T_STAGE < total) ls_pol_lds[o_in + rr[j] * s_in + ls_pol_col(rr[j], cc[j])] = v[j];
+    }
+    // The rollout's copies of the staged rows (storage row `step` of the observations / privileged observations; the previous step's next
+    // critic observation with the termination rows patched in, HIMR:119-121) are written at the END of the block, from the input rows that
+    // stay in LDS: issued here they sat in front of the staging barrier, whose s_waitcnt vmcnt(0) waits for stores too -- every block paid
+    // the store round trip before its first layer
+    auto store_rows = [&]() {
+        if constexpr (ACT) {
+            const bool patch = critic && act.prev_step >= 0;
+            float* dst = critic ? act.st.privileged_observations : act.st.observations;
+#pragma unroll
+            for (int j = 0; j < PER_STAGE; ++j) {
+                const int e = tid + j * T_STAGE;
+                const int r = e / kp, c = e - r * kp;
+                const long env = r0 + r;
+                if (e >= total || env >= num_envs || c >= n_in) continue;
+                const float v = ls_pol_lds[o_in + r * s_in + ls_pol_col(r, c)];
+                dst[((size_t)act.step * act.st.num_envs + env) * n_in + c] = v;
+                if (patch)
+                    act.st.next_privileged_observations[((size_t)act.prev_step * act.st.num_envs + env) * n_in + c] =
+                        act.prev_dones[env] ? act.prev_term_priv[env * n_in + c] : v;
             }
         }
-    }
+    };
     if (ACT && critic && act.prev_step >= 0 && tid < ROWS && r0 + tid < num_envs) {
         const long env = r0 + tid;
         const size_t row = (size_t)act.prev_step * act.st.num_envs + env;
@@ -249,6 +260,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4
             values_out[r0 + tid] = v;
             if (ACT) act.st.values[(size_t)act.step * act.st.num_envs + r0 + tid] = v;
         }
+        store_rows();
         return;
     }
     // ---- estimator encoder (HES:64-68): history -> (velocity 3, latent 16)
@@ -312,6 +324,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4
             act.st.actions_log_prob[(size_t)act.step * act.st.num_envs + r0 + tid] = (t4[0] + t4[2]) + (t4[1] + t4[3]);
         }
     }
+    store_rows();
 }
 
 static int ls_pol_check_layer(const lsim_mlp_layer* L, int k_in_expected) {

@@ -1,7 +1,7 @@
 """Rollout-time forward of the HIM policy through the library's fused MFMA kernel (include/lsim.h, lsim_policy_forward).
 
 `PackedHimPolicy` keeps zero-padded copies of the eleven nn.Linear parameter pairs in the layout the kernel wants (both dimensions
-multiples of 16) at fixed device addresses; `refresh()` re-copies them after every policy update (11 small copies per PPO
+multiples of 16, cut into 16 x 16 blocks) at fixed device addresses; `refresh()` re-copies them after every policy update (22 small copies per PPO
 iteration).  Same arithmetic as HIMActorCritic.update_distribution / evaluate (HAC:136-163) up to fp32 summation order.
 """
 import ctypes
@@ -38,13 +38,16 @@ class PackedHimPolicy:
         self._L = lib.load()
         self.layers = _linears(ac.estimator.encoder) + _linears(ac.actor) + _linears(ac.critic)
         pad = lambda v: (v + 15) // 16 * 16
-        self.w = [torch.zeros(pad(l.out_features), pad(l.in_features), device=self.dev) for l in self.layers]
+        # weights as the kernel reads them: 16 x 16 blocks, [n_pad / 16][k_pad / 16][16][16] (include/lsim.h) -- self.w holds the blocks, the
+        # row-major padded image they are cut from is scratch
+        self._rows = [torch.zeros(pad(l.out_features), pad(l.in_features), device=self.dev) for l in self.layers]
+        self.w = [torch.zeros(r.shape[0] // 16, r.shape[1] // 16, 16, 16, device=self.dev) for r in self._rows]
         self.b = [torch.zeros(pad(l.out_features), device=self.dev) for l in self.layers]
         P = abi.LsimHimPolicy()
         for idx, l in enumerate(self.layers):
             dst = P.encoder[idx] if idx < 3 else (P.actor[idx - 3] if idx < 7 else P.critic[idx - 7])
             dst.weight, dst.bias = self.w[idx].data_ptr(), self.b[idx].data_ptr()
-            dst.k_pad, dst.n_pad, dst.k_in, dst.n_out = self.w[idx].shape[1], self.w[idx].shape[0], l.in_features, l.out_features
+            dst.k_pad, dst.n_pad, dst.k_in, dst.n_out = self._rows[idx].shape[1], self._rows[idx].shape[0], l.in_features, l.out_features
         P.num_obs, P.num_priv_obs = ac.num_actor_obs, self.layers[7].in_features
         P.num_one_step_obs, P.num_actions = ac.num_one_step_obs, ac.num_actions
         self._P = P
@@ -53,8 +56,9 @@ class PackedHimPolicy:
     @torch.no_grad()
     def refresh(self):
         """copy the current parameters into the padded buffers (call after every optimiser step that the rollout should see)"""
-        for l, w, b in zip(self.layers, self.w, self.b):
-            w[:l.out_features, :l.in_features].copy_(l.weight)
+        for l, r, w, b in zip(self.layers, self._rows, self.w, self.b):
+            r[:l.out_features, :l.in_features].copy_(l.weight)
+            w.copy_(r.view(r.shape[0] // 16, 16, r.shape[1] // 16, 16).permute(0, 2, 1, 3))
             b[:l.out_features].copy_(l.bias)
 
     def forward(self, obs, priv_obs, mean_out, values_out):
