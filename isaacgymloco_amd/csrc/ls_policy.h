@@ -194,23 +194,32 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4
     const float* __restrict__ src = critic ? priv : obs;
     constexpr int s_in = LS_POL_STRIDE_IN, s_a = LS_POL_STRIDE_A, s_b = LS_POL_STRIDE_B;
     constexpr int o_in = 0, o_a = o_in + ROWS * s_in, o_b = o_a + ROWS * s_a;
-    constexpr int T_STAGE = 64 * WAVES, PER_STAGE = (ROWS * LS_POL_MAX_IN + T_STAGE - 1) / T_STAGE;
-    const int kp = first.k_pad, total = ROWS * kp;
+    // rows of the block are dealt to the waves (ROWS / WAVES each), a row's columns to the lanes: no index division, coalesced rows
+    constexpr int RPW = ROWS / WAVES, CPL = (LS_POL_MAX_IN + 63) / 64;
+    static_assert(ROWS % WAVES == 0, "whole rows per wave");
+    const int kp = first.k_pad;
     {   // stage the block's input rows: every thread's loads first, all in flight together (one memory round trip), then the LDS writes
         // (a load-store-load-store loop paid a round trip per pass: 9 passes)
-        float v[PER_STAGE];
-        int rr[PER_STAGE], cc[PER_STAGE];
+        float v[RPW][CPL];
 #pragma unroll
-        for (int j = 0; j < PER_STAGE; ++j) {
-            const int e = tid + j * T_STAGE;
-            const int r = e / kp, c = e - r * kp;
-            rr[j] = r; cc[j] = c;
+        for (int a = 0; a < RPW; ++a) {
+            const int r = wave * RPW + a;
             const long env = r0 + r;
-            v[j] = (e < total && env < num_envs && c < n_in) ? src[env * n_in + c] : 0.0f;
+#pragma unroll
+            for (int m = 0; m < CPL; ++m) {
+                const int c = lane + 64 * m;
+                v[a][m] = (env < num_envs && c < n_in) ? src[env * n_in + c] : 0.0f;
+            }
         }
 #pragma unroll
-        for (int j = 0; j < PER_STAGE; ++j)
-            if (tid + j * T_STAGE < total) ls_pol_lds[o_in + rr[j] * s_in + ls_pol_col(rr[j], cc[j])] = v[j];
+        for (int a = 0; a < RPW; ++a) {
+            const int r = wave * RPW + a;
+#pragma unroll
+            for (int m = 0; m < CPL; ++m) {
+                const int c = lane + 64 * m;
+                if (c < kp) ls_pol_lds[o_in + r * s_in + ls_pol_col(r, c)] = v[a][m];
+            }
+        }
     }
     // The rollout's copies of the staged rows (storage row `step` of the observations / privileged observations; the previous step's next
     // critic observation with the termination rows patched in, HIMR:119-121) are written at the END of the block, from the input rows that
@@ -221,16 +230,21 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4
             const bool patch = critic && act.prev_step >= 0;
             float* dst = critic ? act.st.privileged_observations : act.st.observations;
 #pragma unroll
-            for (int j = 0; j < PER_STAGE; ++j) {
-                const int e = tid + j * T_STAGE;
-                const int r = e / kp, c = e - r * kp;
+            for (int a = 0; a < RPW; ++a) {
+                const int r = wave * RPW + a;
                 const long env = r0 + r;
-                if (e >= total || env >= num_envs || c >= n_in) continue;
-                const float v = ls_pol_lds[o_in + r * s_in + ls_pol_col(r, c)];
-                dst[((size_t)act.step * act.st.num_envs + env) * n_in + c] = v;
-                if (patch)
-                    act.st.next_privileged_observations[((size_t)act.prev_step * act.st.num_envs + env) * n_in + c] =
-                        act.prev_dones[env] ? act.prev_term_priv[env * n_in + c] : v;
+                if (env >= num_envs) continue;
+                const bool term = patch && act.prev_dones[env];                 // wave-uniform: one row per wave at a time
+                float* d0 = dst + ((size_t)act.step * act.st.num_envs + env) * n_in;
+                float* d1 = patch ? act.st.next_privileged_observations + ((size_t)act.prev_step * act.st.num_envs + env) * n_in : nullptr;
+#pragma unroll
+                for (int m = 0; m < CPL; ++m) {
+                    const int c = lane + 64 * m;
+                    if (c >= n_in) continue;
+                    const float v = ls_pol_lds[o_in + r * s_in + ls_pol_col(r, c)];
+                    d0[c] = v;
+                    if (patch) d1[c] = term ? act.prev_term_priv[env * n_in + c] : v;
+                }
             }
         }
     };
