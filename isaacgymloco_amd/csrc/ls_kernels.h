@@ -149,7 +149,7 @@ LS_FN void ph_load_a(const LsCtx& cx, WaveShared& sh, LaneRegs& rg, int lane, in
     // ---- LDS writes
     // the tail of the row array Y that no spatial inertia ever overlays (ls_shared.h, union u): the solver reads whole triples of limit slots,
     // i.e. up to two slots that hold no row yet, and multiplies what it finds by a zero impulse -- harmless only if it is finite
-    static_assert(sizeof(sh.u.c.Y) - sizeof(sh.u.I6) == 2 * LS_NV * sizeof(float), "rows of Y beyond the inertias");
+    static_assert(sizeof(sh.u.I6) <= sizeof(sh.u.c.Y) && sizeof(sh.u.c.Y) - sizeof(sh.u.I6) <= 2 * LS_NV * sizeof(float), "rows of Y beyond the inertias: at most the two zeroed here");
     if (lane < 2 * LS_NV) (&sh.u.c.Y[LS_MAXR - 2][0])[lane] = 0.0f;
     if (lane < LSIM_MAX_HEIGHT_PTS_X) sh.mpx[lane] = v_mp; else sh.mpy[lane - LSIM_MAX_HEIGHT_PTS_X] = v_mp;
     if (lane < 13) sh.root[lane] = v_root;

@@ -13,6 +13,12 @@
 #include "ls_math.h"
 
 #define LS_NB LSIM_NUM_BODIES
+// row stride of the spatial-inertia array (lane = body).  36 floats put bodies b, b + 8 and b + 16 on the same LDS banks (36 b mod 32 = 4 b);
+// 38 keeps the 8-byte alignment of the rows (two-float stores and loads stay) and leaves only bodies 0 and 16 on one bank (38 b mod 32 = 6 b).
+// The array lives in a union with the constraint rows Y, which are larger: the padding costs no LDS.
+#ifndef LS_I6_STRIDE
+#define LS_I6_STRIDE 38
+#endif
 #define LS_NV 18
 #define LS_MAXC LSIM_MAX_CONTACTS
 #define LS_MAXR (3 * LSIM_MAX_CONTACTS + LSIM_NUM_DOF)  // 60 <= 64 lanes
@@ -130,7 +136,7 @@ struct WaveShared {
     };
     float com0[3];           // base COM (world axes)
     union {
-        float I6[LS_NB][36];                 // spatial inertias (dead after the composite pass)
+        float I6[LS_NB][LS_I6_STRIDE];       // spatial inertias, 6 x 6 row-major in the first 36 floats of a row (dead after the composite pass)
         struct {
             // Per constraint row i, M^-1 J_i^T WITHOUT its base-coupling leg terms: [0..5] z = Sb^-1 (Jb - Mbl y), [6 + 3l + k] = y[k] = (Mll^-1 Jl)[k]
             // on the row's own leg and 0 on the others.  The full vector has - G_l z on every leg; the solver never needs it:
