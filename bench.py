@@ -193,7 +193,7 @@ class ClockSampler:
         for p in glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"):
             if os.path.basename(os.path.realpath(os.path.dirname(p))).lower() == str(pci_address).lower():
                 self.path = p
-        self.samples, self._stop, self._thread = [], False, None
+        self.samples, self.times, self._stop, self._thread = [], [], False, None
         self.error = None if self.path else f"no /sys/class/drm/card*/device -> {pci_address} with a pp_dpm_sclk"
 
     def _read(self):
@@ -218,6 +218,7 @@ class ClockSampler:
                     v = self._read()
                     if v:
                         self.samples.append(v)
+                        self.times.append(time.perf_counter())
                 except Exception:
                     pass
                 time.sleep(0.025)
@@ -225,14 +226,22 @@ class ClockSampler:
         self._thread.start()
         return self
 
-    def stop(self):
+    def stop(self, phases=None):
+        """phases: {name: [(t0, t1), ...]} in time.perf_counter() seconds -> also the mean clock over the samples that fall inside each phase
+        (the rollout's short kernels and the update's GEMMs need not run at the same clock: one box of round 5 ran kernel A 1.7 x slower
+        than every other while its update was the fastest)"""
         self._stop = True
         if self._thread is not None:
             self._thread.join(timeout=1.0)
         if not self.samples:
             return {"mean_mhz": None, "samples": 0, "source": self.path, "error": self.error or "no sample"}
-        return {"mean_mhz": sum(self.samples) / len(self.samples), "min_mhz": min(self.samples), "max_mhz": max(self.samples),
-                "samples": len(self.samples), "source": self.path}
+        out = {"mean_mhz": sum(self.samples) / len(self.samples), "min_mhz": min(self.samples), "max_mhz": max(self.samples),
+               "samples": len(self.samples), "source": self.path}
+        for name, spans in (phases or {}).items():
+            vals = [v for v, t in zip(self.samples, self.times) if any(a <= t < b for a, b in spans)]
+            out[f"mean_mhz_{name}"] = sum(vals) / len(vals) if vals else None
+            out[f"samples_{name}"] = len(vals)
+        return out
 
 
 def gemm_probe(torch, dev, seconds=0.02):
@@ -422,6 +431,7 @@ def main():
         extra["gemm_probe_after_timed_region"] = gemm_probe(torch, dev)
         extra["gpu_max_hw_queues"] = os.environ.get("GPU_MAX_HW_QUEUES", "unset (runtime default 4)")
         extra["host"] = host
+        extra["device"] = {"name": pr.name, "compute_units": pr.multi_processor_count, "pci": pci, "arch": getattr(pr, "gcnArchName", None)}
         ka = extra["kernel_a_ms"]
         timed_steps = extra["timed_env_steps"]
         actions_src = "policy"

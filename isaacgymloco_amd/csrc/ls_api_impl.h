@@ -256,7 +256,11 @@ extern "C" int LS_API(step_ex)(lsim_sim* s, const float* actions_dev, uint32_t f
     lsbk_prof_mark(s, 0, stream);
     if (lsbk_launch_a(s, a, stream) != 0) LS_FAIL(s, LSIM_E_HIP, "kernel A launch failed");
     lsbk_prof_mark(s, 1, stream);
+#if defined(LS_EXP_NO_FINISH)      // timing probe only (wrong statistics): what the finish launch costs on the rollout's critical path
+    if (a.fuse_tail) { }
+#else
     if (a.fuse_tail) { if (lsbk_launch_finish(s, a, stream) != 0) LS_FAIL(s, LSIM_E_HIP, "finish kernel launch failed"); }
+#endif
     else if (lsbk_launch_b(s, a, stream) != 0) LS_FAIL(s, LSIM_E_HIP, "kernel B launch failed");
     lsbk_prof_mark(s, 2, stream);
     return LSIM_OK;

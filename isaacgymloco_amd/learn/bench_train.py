@@ -51,6 +51,8 @@ def run_train_bench(env, cfg, args, dev, rank, world, barrier, clocks=None):
     state = dict(obs=env.get_observations().clone(), critic=env.get_privileged_observations().clone())
     runner.alg.actor_critic.train()
 
+    spans = {"collection": [], "update": []}      # wall-clock intervals of the two halves of every iteration (the clock sampler splits its samples by them)
+
     def one_iteration():
         """HIMR:105-157 without the logging: returns (collection seconds, learn seconds), each closed by a device sync"""
         t0 = time.perf_counter()
@@ -69,7 +71,9 @@ def run_train_bench(env, cfg, args, dev, rank, world, barrier, clocks=None):
             runner.graphs.end_iteration()
         runner.alg.update()
         torch.cuda.synchronize(dev)
-        return t1 - t0, time.perf_counter() - t1
+        t2 = time.perf_counter()
+        spans["collection"].append((t0, t1)); spans["update"].append((t1, t2))
+        return t1 - t0, t2 - t1
 
     # The shipped GEMM table is only valid on the build it was tuned with: TunableOp rejects the whole file when one Validator line differs,
     # every GEMM then runs the default heuristics and the update loses its second stream (him_ppo._two_streams_allowed).  The line and
@@ -109,7 +113,7 @@ def run_train_bench(env, cfg, args, dev, rank, world, barrier, clocks=None):
         per_iter.append([round(c, 5), round(l, 5)])
     barrier()
     elapsed = time.perf_counter() - t0
-    sclk = clocks.stop() if clocks is not None else None
+    sclk = clocks.stop(phases=spans) if clocks is not None else None
     ms_a, ms_b, n = (ctypes.c_float * n_prof)(), (ctypes.c_float * n_prof)(), ctypes.c_int(n_prof)
     env._L.lsim_read_profile(env._h, ms_a, ms_b, ctypes.byref(n))
     ka = sum(ms_a[i] for i in range(n.value)) / max(n.value, 1)
