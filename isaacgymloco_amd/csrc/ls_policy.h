@@ -40,7 +40,11 @@ __device__ __forceinline__ float4 ls_pol_ld4(ls_pol_gptr p) {
     return make_float4(v.x, v.y, v.z, v.w);
 }
 
+#if defined(LS_POL_FAST_ELU)      // timing probe: what the library expm1f costs in the layer epilogues
+__device__ __forceinline__ float ls_elu(float x) { return x > 0.0f ? x : __builtin_amdgcn_exp2f(x * 1.44269504f) - 1.0f; }
+#else
 __device__ __forceinline__ float ls_elu(float x) { return x > 0.0f ? x : expm1f(x); }
+#endif
 
 // one layer for this wave's NTW output tiles [tile0, tile0 + valid) and all RH * 16 rows of the block: every weight vector fetched from
 // L2 feeds RH MFMAs (one per 16-row half), so a block of 32 environments streams half the weight bytes per environment of a block of 16
