@@ -27,8 +27,8 @@ static int lsbk_launch_a(lsim_sim* s, const LsStepArgs& a, void*) {
     static WaveShared sh;
     static LaneRegs L[64];
     for (int env = 0; env < s->cfg.num_envs; ++env) {
-        memset(&sh, 0xCD, sizeof(sh));   // poison: phases must not rely on stale LDS
-        memset(L, 0xCD, sizeof(L));
+        memset(&sh, 0xFF, sizeof(sh));   // poison with NaNs (0xFFFFFFFF): phases must not rely on stale LDS -- not even "times zero" (round 5: a finite poison hid exactly that)
+        memset(L, 0xFF, sizeof(L));
         if (s->cfg.solver_type == LSIM_SOLVER_TGS) ls_wave_step_a<LSIM_SOLVER_TGS>(*s->dev_ctx, a, env, sh, L);
         else ls_wave_step_a<LSIM_SOLVER_PGS>(*s->dev_ctx, a, env, sh, L);
     }
@@ -38,8 +38,8 @@ static int lsbk_launch_b(lsim_sim* s, const LsStepArgs& a, void*) {
     static WaveShared sh;
     static LaneRegs L[64];
     for (int env = 0; env < s->cfg.num_envs; ++env) {
-        memset(&sh, 0xCD, sizeof(sh));
-        memset(L, 0xCD, sizeof(L));
+        memset(&sh, 0xFF, sizeof(sh));
+        memset(L, 0xFF, sizeof(L));
         ls_wave_step_b(*s->dev_ctx, a, env, sh, L);
     }
     return 0;
