@@ -1269,9 +1269,50 @@ __global__ __launch_bounds__(256) void lsim_k_gather_rows(const uint32_t* __rest
     uint32_t* d = dst + (size_t)r * cols;
     for (long c = threadIdx.x & (cpt - 1); c < cols; c += cpt) d[c] = s[c];
 }
+// wide rows (the observation fields: 238 / 270 floats): one WAVE per row, 8-byte elements, four rows of a wave in flight at once, a resident
+// grid that strides over the rows.  [The form above gives every wide row a 256-thread block of its own: 409 600 blocks of two 4-byte
+// copies each ran at 2.2 TB/s over the ten fields of a shuffle (1.18 ms per update, r05_kernel_stats_train.csv).]
+#define LS_GATHER_MAXC 3          // 64-lane chunks of 8-byte elements per row: rows up to 384 floats
+__global__ __launch_bounds__(256) void lsim_k_gather_rows_wide(const uint2* __restrict__ src, long cols2, const long long* __restrict__ index, long n,
+                                                               uint2* __restrict__ dst) {
+    constexpr int U = 4;
+    const int lane = threadIdx.x & 63;
+    const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+    for (long r0 = wave * U; r0 < n; r0 += nwaves * U) {
+        uint2 v[U][LS_GATHER_MAXC];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long r = r0 + u < n ? r0 + u : n - 1;
+            const uint2* s = src + (size_t)index[r] * cols2;
+#pragma unroll
+            for (int m = 0; m < LS_GATHER_MAXC; ++m) {
+                const long c = lane + 64 * m;
+                if (c < cols2) v[u][m] = s[c];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (r0 + u >= n) break;
+            uint2* d = dst + (size_t)(r0 + u) * cols2;
+#pragma unroll
+            for (int m = 0; m < LS_GATHER_MAXC; ++m) {
+                const long c = lane + 64 * m;
+                if (c < cols2) d[c] = v[u][m];
+            }
+        }
+    }
+}
 extern "C" int lsim_gather_rows(const void* src, int64_t cols, const int64_t* index, int64_t n, void* dst, void* stream) {
     if (!src || !index || !dst || cols <= 0 || n < 0) return LSIM_E_INVALID;
     if (n == 0) return LSIM_OK;
+    if (cols >= 64 && cols % 2 == 0 && cols <= 128 * LS_GATHER_MAXC && (((uintptr_t)src | (uintptr_t)dst) & 7) == 0) {
+        const long waves = (n + 3) / 4;
+        long blocks = (waves + 3) / 4;
+        if (blocks > 2048) blocks = 2048;           // 8 192 waves: 32 per CU
+        hipLaunchKernelGGL(lsim_k_gather_rows_wide, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint2*)src, (long)(cols / 2),
+                           (const long long*)index, (long)n, (uint2*)dst);
+        return hipGetLastError() == hipSuccess ? LSIM_OK : LSIM_E_HIP;
+    }
     int lg = 0;
     while ((1 << lg) < cols && lg < 8) ++lg;
     const long rpb = 256 >> lg;

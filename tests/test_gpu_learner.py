@@ -1013,7 +1013,8 @@ def test_backward_from_the_loss_kernels_gradients_changes_nothing(monkeypatch):
 def test_gather_rows_equals_advanced_indexing():
     from isaacgymloco_amd.learn.storage import _gather_rows
     g = torch.Generator(device="cuda:0").manual_seed(1)
-    for shape in ((4096, 270), (5000, 238), (4096, 12), (4097, 1), (3000,), (1000, 3, 5)):
+    for shape in ((4096, 270), (5000, 238), (4096, 12), (4097, 1), (3000,), (1000, 3, 5), (409600, 270), (8, 238), (9, 270), (10, 64), (12, 384), (50, 386),
+                  (40, 271)):       # wide even rows take the wave-per-row kernel (four rows in flight: ragged tails of 1-3 rows included), the rest the block form
         f = torch.randn(*shape, device="cuda:0", generator=g)
         perm = torch.randperm(shape[0] - 7, device="cuda:0")
         assert torch.equal(_gather_rows(f, perm), f[perm]), shape
