@@ -111,7 +111,10 @@ __global__ __launch_bounds__(64 * LS_WGRAD_WAVES_PER_BLOCK) void lsim_k_linear_w
 // (65 us).  Every output is still added up in the same order: (s0 + s1) + (s2 + s3) over the partials w = s, s + 16, ..., then the 16 slices.
 #define LS_LEARN_HD static __host__ __device__ __forceinline__
 LS_LEARN_HD int ls_reduce_vec4(const float* part, int count) { return (count % 4 == 0) && ((((uintptr_t)part) & 15) == 0); }
-LS_LEARN_HD int ls_reduce_blocks(const float* part, int count) { return ls_reduce_vec4(part, count) ? (count + 63) / 64 : (count + 15) / 16; }
+#ifndef LS_REDUCE_QUADS
+#define LS_REDUCE_QUADS 1          // output quads per thread of the vector form.  Measured in round 5 (train line, three interleaved runs): 1 -> update
+#endif                             // 70.3-70.9 ms, 2 -> 71.9-74.5, 4 -> 73.5-75.0: the summing launch wants more blocks, not more loads per thread
+LS_LEARN_HD int ls_reduce_blocks(const float* part, int count) { return ls_reduce_vec4(part, count) ? (count + 64 * LS_REDUCE_QUADS - 1) / (64 * LS_REDUCE_QUADS) : (count + 15) / 16; }
 __device__ __forceinline__ void ls_wgrad_reduce_body(const float* __restrict__ part, int num_waves, int count, float* __restrict__ out,
                                                      const float* __restrict__ part2, int count2, float* __restrict__ out2, int block) {
     // one launch serves the weight-gradient partials (count outputs) and, in the blocks after them, the bias-gradient partials (count2)
@@ -121,25 +124,45 @@ __device__ __forceinline__ void ls_wgrad_reduce_body(const float* __restrict__ p
     const int nb1 = ls_reduce_blocks(part, count);
     const bool second = block >= nb1;
     if (!second && ls_reduce_vec4(part, count)) {          // block-uniform
-        const int o = block * 64 + 4 * ol;
-        float4 s0 = make_float4(0, 0, 0, 0), s1 = s0, s2 = s0, s3 = s0;
+        // LS_REDUCE_QUADS quads of outputs per thread, 64 outputs apart; every output is added up exactly as before (the mapping of outputs to
+        // threads changed in round 5, the order of additions did not)
         auto add = [](float4& a, const float4 v) { a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; };
-        if (o < count) {
-            int w = sl;
-            for (; w + 48 < num_waves; w += 64) {
-                add(s0, *(const float4*)(part + (size_t)w * count + o)); add(s1, *(const float4*)(part + (size_t)(w + 16) * count + o));
-                add(s2, *(const float4*)(part + (size_t)(w + 32) * count + o)); add(s3, *(const float4*)(part + (size_t)(w + 48) * count + o));
-            }
-            for (; w < num_waves; w += 16) add(s0, *(const float4*)(part + (size_t)w * count + o));
-        }
-        red4[sl][ol] = make_float4((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z), (s0.w + s1.w) + (s2.w + s3.w));
-        __syncthreads();
-        if (sl == 0 && o < count) {
-            float4 t = make_float4(0, 0, 0, 0);
+        int oq[LS_REDUCE_QUADS];
+        float4 s0[LS_REDUCE_QUADS], s1[LS_REDUCE_QUADS], s2[LS_REDUCE_QUADS], s3[LS_REDUCE_QUADS];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) add(t, red4[k][ol]);
-            if ((((uintptr_t)out) & 15) == 0) *(float4*)(out + o) = t;       // a gradient-arena slice starts wherever the previous parameter ended
-            else { out[o] = t.x; out[o + 1] = t.y; out[o + 2] = t.z; out[o + 3] = t.w; }
+        for (int q = 0; q < LS_REDUCE_QUADS; ++q) {
+            oq[q] = (block * LS_REDUCE_QUADS + q) * 64 + 4 * ol;
+            s0[q] = s1[q] = s2[q] = s3[q] = make_float4(0, 0, 0, 0);
+        }
+        int w = sl;
+        for (; w + 48 < num_waves; w += 64) {
+#pragma unroll
+            for (int q = 0; q < LS_REDUCE_QUADS; ++q) {
+                if (oq[q] >= count) continue;
+                const float* p0 = part + (size_t)w * count + oq[q];
+                add(s0[q], *(const float4*)p0); add(s1[q], *(const float4*)(p0 + (size_t)16 * count));
+                add(s2[q], *(const float4*)(p0 + (size_t)32 * count)); add(s3[q], *(const float4*)(p0 + (size_t)48 * count));
+            }
+        }
+        for (; w < num_waves; w += 16) {
+#pragma unroll
+            for (int q = 0; q < LS_REDUCE_QUADS; ++q)
+                if (oq[q] < count) add(s0[q], *(const float4*)(part + (size_t)w * count + oq[q]));
+        }
+#pragma unroll
+        for (int q = 0; q < LS_REDUCE_QUADS; ++q) {
+            if (q > 0) __syncthreads();
+            red4[sl][ol] = make_float4((s0[q].x + s1[q].x) + (s2[q].x + s3[q].x), (s0[q].y + s1[q].y) + (s2[q].y + s3[q].y),
+                                       (s0[q].z + s1[q].z) + (s2[q].z + s3[q].z), (s0[q].w + s1[q].w) + (s2[q].w + s3[q].w));
+            __syncthreads();
+            const int o = oq[q];
+            if (sl == 0 && o < count) {
+                float4 t = make_float4(0, 0, 0, 0);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) add(t, red4[k][ol]);
+                if ((((uintptr_t)out) & 15) == 0) *(float4*)(out + o) = t;       // a gradient-arena slice starts wherever the previous parameter ended
+                else { out[o] = t.x; out[o + 1] = t.y; out[o + 2] = t.z; out[o + 3] = t.w; }
+            }
         }
         return;
     }
