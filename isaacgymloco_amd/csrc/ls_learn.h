@@ -956,24 +956,31 @@ __global__ __launch_bounds__(256) void lsim_k_sinkhorn_last(const float* __restr
     ls_row_store<KMAX>(out + (m * batch + b) * K, K, (K & 3) == 0, v);
 }
 
-// u[k] = 1 / (K * sum over blocks of part[block][k]); 16 interleaved slices per prototype, combined in LDS in a fixed order
+// u[k] = 1 / (K * sum over blocks of part[block][k]): 1024 threads = 32 (K <= 32) or 16 interleaved slices per prototype, eight partial
+// rows in flight per thread (one block, nothing else to hide the loads behind: the 1600 rows the estimator's score kernel leaves took
+// 15 us with two in flight), the slices combined in LDS; every order is fixed
 __global__ __launch_bounds__(1024) void lsim_k_sinkhorn_scale(const float* __restrict__ part, int blocks, int K, float* __restrict__ u) {
-    __shared__ float red[16][64];
-    const int k = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    __shared__ float red[32][65];
+    const int kp = K <= 32 ? 32 : 64, slices = 1024 / kp;
+    const int k = threadIdx.x & (kp - 1), sl = threadIdx.x / kp;
     part += (size_t)blockIdx.y * blocks * K;
     u += blockIdx.y * 64;
-    float s0 = 0.0f, s1 = 0.0f;
+    float s[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = 0.0f;
     if (k < K) {
         int i = sl;
-        for (; i + 16 < blocks; i += 32) { s0 += part[(size_t)i * K + k]; s1 += part[(size_t)(i + 16) * K + k]; }
-        if (i < blocks) s0 += part[(size_t)i * K + k];
+        for (; i + 7 * slices < blocks; i += 8 * slices) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] += part[(size_t)(i + j * slices) * K + k];
+        }
+        for (; i < blocks; i += slices) s[0] += part[(size_t)i * K + k];
     }
-    red[sl][k] = s0 + s1;
+    red[sl][k] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
     __syncthreads();
     if (sl == 0 && k < K) {
         float t = 0.0f;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) t += red[j][k];
+        for (int j = 0; j < slices; ++j) t += red[j][k];
         u[k] = 1.0f / ((float)K * t);
     }
 }
@@ -999,9 +1006,10 @@ extern "C" int lsim_sinkhorn_workspace(long batch, int K, size_t* bytes) {
 }
 
 // the column / row rescaling rounds after `first` has filled E and its partial sums: leaves the final u (E and u define the result)
-template <int KMAX> static void ls_sinkhorn_rounds(const LsSkBufs& w, long batch, int K, int mats, int iters, hipStream_t s) {
+// (`first_blocks`: rows of partial sums the producer of E left in w.part, w.blocks unless it used another block size)
+template <int KMAX> static void ls_sinkhorn_rounds(const LsSkBufs& w, long batch, int K, int mats, int iters, hipStream_t s, int first_blocks = 0) {
     const dim3 grid(w.blocks, mats), one(1, mats);
-    hipLaunchKernelGGL(lsim_k_sinkhorn_scale, one, dim3(1024), 0, s, (const float*)w.part, w.blocks, K, w.u);
+    hipLaunchKernelGGL(lsim_k_sinkhorn_scale, one, dim3(1024), 0, s, (const float*)w.part, first_blocks ? first_blocks : w.blocks, K, w.u);
     for (int it = 1; it < iters; ++it) {
         hipLaunchKernelGGL(lsim_k_sinkhorn_mid<KMAX>, grid, dim3(256), 0, s, (const float*)w.E, (const float*)w.u, batch, K, w.part);
         hipLaunchKernelGGL(lsim_k_sinkhorn_scale, one, dim3(1024), 0, s, (const float*)w.part, w.blocks, K, w.u);
@@ -1037,54 +1045,134 @@ extern "C" int lsim_sinkhorn(const float* scores, int64_t lds, int64_t batch, in
 // and d (est + swap) / d enc [B, 3 + D], / d tgt [B, D], / d P [K, D].  Launches: scores + first Sinkhorn pass of both matrices (1),
 // the remaining Sinkhorn rounds of both together (2 iters - 1), loss + row gradients with the last Sinkhorn step folded in (1), finish
 // (1), prototype gradient through lsim_linear_wgrad's single-wave kernel (2): 10 instead of the ~75 torch kernels of the same
-// arithmetic.  One thread per sample row, the row's K <= 64 scores and D <= 32 latents in registers.
+// arithmetic.
+// Scores and loss: FOUR LANES (one DPP quad) per sample row, lane q of the quad owns prototypes [q K/4, (q + 1) K/4).  One thread per
+// row (rounds 2-4) left 1.5 waves per SIMD on the chip, every row load and store strided by the row length, 32 + 32 row values in
+// registers: 48 + 49 us per call at the minibatch of 102 400.  With the quad a wave reads and writes 16 CONSECUTIVE rows (2 KB
+// contiguous per instruction group), row reductions are two quad_perm DPP steps, and 4x the waves hide the latency.
+#define LS_EST_ROWS 64                      // sample rows per block of 256 threads
+#if !defined(LS_EST_WAVES_PER_EU)
+#define LS_EST_WAVES_PER_EU 4
+#endif
+template <int CTRL> __device__ __forceinline__ float ls_est_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float ls_quad_x1(float v) { return ls_est_dpp<0xB1>(v); }     // quad_perm [1, 0, 3, 2]: from lane ^ 1
+__device__ __forceinline__ float ls_quad_x2(float v) { return ls_est_dpp<0x4E>(v); }     // quad_perm [2, 3, 0, 1]: from lane ^ 2
+__device__ __forceinline__ float ls_quad_sum(float v) { v += ls_quad_x1(v); v += ls_quad_x2(v); return v; }   // same bits on all four lanes
+__device__ __forceinline__ float ls_quad_max(float v) { v = fmaxf(v, ls_quad_x1(v)); v = fmaxf(v, ls_quad_x2(v)); return v; }
+
+// prototypes in LDS: row k at (k * DMAX + (k / KQ) * 4) floats -- the four lanes of a quad read rows KQ apart with ds_read_b128, and
+// KQ * DMAX is a multiple of the 64 banks; one float4 of padding per quarter puts the four addresses on different bank quads
+#define LS_EST_P_FLOATS(KMAX, DMAX) ((KMAX) * (DMAX) + 16)
 template <int KMAX, int DMAX>
-__device__ __forceinline__ void ls_load_proto_lds(const float* __restrict__ proto, int K, int D, float* __restrict__ P /* [KMAX][DMAX] */) {
-    for (int i = threadIdx.x; i < KMAX * DMAX; i += 256) {
+__device__ __forceinline__ void ls_load_proto_lds(const float* __restrict__ proto, int K, int D, float* __restrict__ P) {
+    constexpr int KQ = KMAX / 4;
+    for (int i = threadIdx.x; i < KMAX * DMAX; i += blockDim.x) {
         const int k = i / DMAX, d = i - k * DMAX;
-        P[i] = (k < K && d < D) ? proto[k * D + d] : 0.0f;
+        P[i + (k / KQ) * 4] = (k < K && d < D) ? proto[k * D + d] : 0.0f;
+    }
+}
+
+// a lane's KQ consecutive values of a row segment p[0 .. KQ) that starts at prototype k0: 16-byte accesses when K % 4 == 0
+template <int KQ>
+__device__ __forceinline__ void ls_seg_load(const float* __restrict__ p, int k0, int K, bool vec, float fill, float (&v)[KQ]) {
+    if (vec) {
+#pragma unroll
+        for (int j = 0; j < KQ; j += 4) {
+            const bool in = k0 + j < K;
+            const float4 t = *(const float4*)(p + (in ? j : -k0));         // clamped to the row start: always inside the row
+            v[j] = in ? t.x : fill; v[j + 1] = in ? t.y : fill; v[j + 2] = in ? t.z : fill; v[j + 3] = in ? t.w : fill;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < KQ; ++j) { const bool in = k0 + j < K; const float t = p[in ? j : -k0]; v[j] = in ? t : fill; }
+    }
+}
+template <int KQ>
+__device__ __forceinline__ void ls_seg_store(float* __restrict__ p, int k0, int K, bool vec, const float (&v)[KQ]) {
+    if (vec) {
+#pragma unroll
+        for (int j = 0; j < KQ; j += 4) if (k0 + j < K) *(float4*)(p + j) = make_float4(v[j], v[j + 1], v[j + 2], v[j + 3]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < KQ; ++j) if (k0 + j < K) p[j] = v[j];
     }
 }
 
 template <int KMAX, int DMAX>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void lsim_k_est_scores(const float* __restrict__ enc, long ld_o, const float* __restrict__ tgt, long ld_t,
+__global__ __launch_bounds__(4 * LS_EST_ROWS) __attribute__((amdgpu_waves_per_eu(LS_EST_WAVES_PER_EU, 8))) void lsim_k_est_scores(const float* __restrict__ enc, long ld_o, const float* __restrict__ tgt, long ld_t,
                                                          const float* __restrict__ proto, long batch, int D, int K, float inv_eps,
                                                          float* __restrict__ z /* [2][B][D] */, float* __restrict__ inv_n /* [2][B] */,
                                                          float* __restrict__ S /* [2][B][K] */, float* __restrict__ E /* [2][B][K] */,
-                                                         float* __restrict__ part /* [2][blocks][K] */) {
-    __shared__ float tile[LS_COLSUM_TILE(KMAX)];
-    __shared__ __attribute__((aligned(16))) float P[KMAX * DMAX];
+                                                         float* __restrict__ part /* [2][gridDim.x][K] */) {
+    constexpr int KQ = KMAX / 4, DQ = DMAX / 4, GROUPS = LS_EST_ROWS / 4;      // GROUPS: 16-lane DPP rows per block (4 sample rows each)
+    __shared__ __attribute__((aligned(16))) float P[LS_EST_P_FLOATS(KMAX, DMAX)];
+    __shared__ float gsum[2][GROUPS][KMAX];
     ls_load_proto_lds<KMAX, DMAX>(proto, K, D, P);
     __syncthreads();
-    const long b = (long)blockIdx.x * LS_SK_ROWS + threadIdx.x;
-    const bool vec = (K & 3) == 0;
-    for (int m = 0; m < 2; ++m) {            // student, target
-        float sc[KMAX];
+    const int q = threadIdx.x & 3, k0 = q * KQ;
+    const long b = (long)blockIdx.x * LS_EST_ROWS + (threadIdx.x >> 2);
+    const bool live = b < batch, vec = (K & 3) == 0, zvec = (D & 3) == 0;
+    const long bb = live ? b : batch - 1;           // rows past the batch compute on the last row (all lanes stay in the DPP steps), store nothing
+    float zz[2][DMAX];
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k) sc[k] = 0.0f;
-        if (b < batch) {
-            const float* src = m ? tgt + b * ld_t : enc + b * ld_o + 3;
-            float zz[DMAX], ss = 0.0f;
+    for (int m = 0; m < 2; ++m) {                   // student, target
+        const float* src = m ? tgt + bb * ld_t : enc + bb * ld_o + 3;
+        float ss = 0.0f;
 #pragma unroll
-            for (int d = 0; d < DMAX; ++d) { const float t = src[d < D ? d : 0]; zz[d] = d < D ? t : 0.0f; ss = fmaf(zz[d], zz[d], ss); }
-            const float n = sqrtf(ss), inv = 1.0f / fmaxf(n, 1e-12f);
-            inv_n[(long)m * batch + b] = n < 1e-12f ? -inv : inv;          // sign flags the clamped branch of F.normalize
-            float* zdst = z + ((long)m * batch + b) * D;
+        for (int d = 0; d < DMAX; ++d) { const float t = src[d < D ? d : 0]; zz[m][d] = d < D ? t : 0.0f; ss = fmaf(zz[m][d], zz[m][d], ss); }
+        const float n = sqrtf(ss), inv = 1.0f / fmaxf(n, 1e-12f);
+        if (live && q == 0) inv_n[(long)m * batch + b] = n < 1e-12f ? -inv : inv;          // sign flags the clamped branch of F.normalize
 #pragma unroll
-            for (int d = 0; d < DMAX; ++d) { zz[d] *= inv; if (d < D) zdst[d] = zz[d]; }
+        for (int d = 0; d < DMAX; ++d) zz[m][d] *= inv;
+        // lane q writes latents [q DQ, (q + 1) DQ) of the normalised row
+        float o[DQ];
 #pragma unroll
-            for (int k = 0; k < KMAX; ++k) {
-                float a = 0.0f;
+        for (int i = 0; i < DQ; ++i) o[i] = q == 0 ? zz[m][i] : q == 1 ? zz[m][DQ + i] : q == 2 ? zz[m][2 * DQ + i] : zz[m][3 * DQ + i];
+        float* zdst = z + ((long)m * batch + bb) * D + q * DQ;
+        if (live) ls_seg_store<DQ>(zdst, q * DQ, D, zvec, o);
+    }
+    float sc[2][KQ];
+    const float* pq = P + q * (KQ * DMAX + 4);
 #pragma unroll
-                for (int d = 0; d < DMAX; ++d) a = fmaf(zz[d], P[k * DMAX + d], a);
-                sc[k] = a;
-            }
-            ls_row_store<KMAX>(S + ((long)m * batch + b) * K, K, vec, sc);
+    for (int j = 0; j < KQ; ++j) {
+        float a0 = 0.0f, a1 = 0.0f;
 #pragma unroll
-            for (int k = 0; k < KMAX; ++k) sc[k] = k < K ? expf(sc[k] * inv_eps) : 0.0f;
-            ls_row_store<KMAX>(E + ((long)m * batch + b) * K, K, vec, sc);
+        for (int d = 0; d < DMAX; d += 4) {
+            const float4 pr = *(const float4*)(pq + j * DMAX + d);
+            a0 = fmaf(zz[0][d], pr.x, a0); a0 = fmaf(zz[0][d + 1], pr.y, a0); a0 = fmaf(zz[0][d + 2], pr.z, a0); a0 = fmaf(zz[0][d + 3], pr.w, a0);
+            a1 = fmaf(zz[1][d], pr.x, a1); a1 = fmaf(zz[1][d + 1], pr.y, a1); a1 = fmaf(zz[1][d + 2], pr.z, a1); a1 = fmaf(zz[1][d + 3], pr.w, a1);
         }
-        ls_block_colsum<KMAX>(sc, tile, part + ((long)m * gridDim.x + blockIdx.x) * K, K);
+        asm volatile("" : "+v"(a0), "+v"(a1));      // both dot products finish HERE: left free, the target's half sinks below the student's stores
+        sc[0][j] = a0; sc[1][j] = a1;                  // and all K/4 prototype rows wait for it in 128 registers (174 in all, 2 waves per SIMD)
+    }
+    const int lane = threadIdx.x & 63, group = threadIdx.x >> 4;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const long row = ((long)m * batch + bb) * K + k0;
+        if (live) ls_seg_store<KQ>(S + row, k0, K, vec, sc[m]);
+#pragma unroll
+        for (int j = 0; j < KQ; ++j) sc[m][j] = (live && k0 + j < K) ? expf(sc[m][j] * inv_eps) : 0.0f;
+        if (live) ls_seg_store<KQ>(E + row, k0, K, vec, sc[m]);
+        // column sums of the group's 4 rows: the quads of a 16-lane DPP row hold the same columns
+#pragma unroll
+        for (int j = 0; j < KQ; ++j) {
+            float t = sc[m][j];
+            t += ls_est_dpp<0x120 + 8>(t);          // row_ror:8
+            t += ls_est_dpp<0x120 + 4>(t);          // row_ror:4
+            if ((lane & 12) == 0) gsum[m][group][k0 + j] = t;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * KMAX) {                   // the block's partial column sums, groups added in a fixed order
+        const int m = threadIdx.x / KMAX, k = threadIdx.x % KMAX;
+        if (k < K) {
+            float a = 0.0f;
+#pragma unroll
+            for (int g = 0; g < GROUPS; ++g) a += gsum[m][g][k];
+            part[((long)m * gridDim.x + blockIdx.x) * K + k] = a;
+        }
     }
 }
 
@@ -1094,112 +1182,159 @@ static __device__ __forceinline__ float ls_wave_sum64(float t) {
 }
 
 template <int KMAX, int DMAX>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void lsim_k_est_loss(const float* __restrict__ enc, long ld_o, const float* __restrict__ vel, long ld_v,
+__global__ __launch_bounds__(4 * LS_EST_ROWS) __attribute__((amdgpu_waves_per_eu(KMAX * DMAX > 512 ? 2 : LS_EST_WAVES_PER_EU, 8))) void lsim_k_est_loss(const float* __restrict__ enc, long ld_o, const float* __restrict__ vel, long ld_v,
                                                        const float* __restrict__ proto, float* __restrict__ S /* in: scores, out: d loss / d scores */,
                                                        const float* __restrict__ E, const float* __restrict__ u, const float* __restrict__ z,
                                                        const float* __restrict__ inv_n, long batch, int D, int K, float inv_T,
                                                        float* __restrict__ d_enc /* [B][3 + D] */, float* __restrict__ d_tgt /* [B][D] */,
-                                                       float* __restrict__ part /* [blocks][2] */) {
-    __shared__ __attribute__((aligned(16))) float P[KMAX * DMAX];
+                                                       float* __restrict__ part /* [gridDim.x][2] */) {
+    constexpr int KQ = KMAX / 4, DQ = DMAX / 4, DH = DMAX / 2, WAVES = 4 * LS_EST_ROWS / 64;
+    __shared__ __attribute__((aligned(16))) float P[LS_EST_P_FLOATS(KMAX, DMAX)];
     __shared__ float us[2][KMAX];
-    __shared__ float red[4][2];
-    __shared__ float xt[32 * 256];
+    __shared__ float red[WAVES][2];
     ls_load_proto_lds<KMAX, DMAX>(proto, K, D, P);
     if (threadIdx.x < 2 * KMAX) { const int m = threadIdx.x / KMAX, k = threadIdx.x % KMAX; us[m][k] = k < K ? u[m * 64 + k] : 0.0f; }
     __syncthreads();
-    const long b = (long)blockIdx.x * LS_SK_ROWS + threadIdx.x;
-    const bool vec = (K & 3) == 0;
+    const int q = threadIdx.x & 3, k0 = q * KQ;
+    const long b = (long)blockIdx.x * LS_EST_ROWS + (threadIdx.x >> 2);
+    const bool live = b < batch, vec = (K & 3) == 0;
+    const long bb = live ? b : batch - 1;
     const float c = -0.5f / ((float)batch * (float)K), ce = 2.0f / (3.0f * (float)batch);
+    const float* pq = P + q * (KQ * DMAX + 4);
+    const int d0 = (q & 1) * DH + (q >> 1) * DQ;    // the latents this lane ends up with after the two exchange steps below
     float est_acc = 0.0f, swap_acc = 0.0f;
-    if (b < batch) {
-        // m = 0: the target's assignment q_t weights the student's log-softmax -> gradient to the student scores; m = 1 the other way
-#pragma unroll 1
-        for (int m = 0; m < 2; ++m) {
-            float q[KMAX], x[KMAX];
-            ls_row_load<KMAX>(E + ((long)(1 - m) * batch + b) * K, K, vec, 0.0f, q);
-            float qsum = 0.0f;
+    // m = 0: the target's assignment q_t weights the student's log-softmax -> gradient to the student scores; m = 1 the other way
 #pragma unroll
-            for (int k = 0; k < KMAX; ++k) { q[k] *= us[1 - m][k]; qsum += q[k]; }
-            const float qn = 1.0f / qsum;                        // last Sinkhorn step: B E u v = E u / sum_k E u
-            float* srow = S + ((long)m * batch + b) * K;
-            ls_row_load<KMAX>(srow, K, vec, -INFINITY, x);
-            float mx = -INFINITY;
+    for (int m = 0; m < 2; ++m) {
+        float qv[KQ], x[KQ];
+        ls_seg_load<KQ>(E + ((long)(1 - m) * batch + bb) * K + k0, k0, K, vec, 0.0f, qv);
+        float* srow = S + ((long)m * batch + bb) * K + k0;
+        ls_seg_load<KQ>(srow, k0, K, vec, -INFINITY, x);
+        float qsum = 0.0f;
 #pragma unroll
-            for (int k = 0; k < KMAX; ++k) { x[k] *= inv_T; mx = fmaxf(mx, x[k]); }
-            float se = 0.0f;
+        for (int j = 0; j < KQ; ++j) { qv[j] *= us[1 - m][k0 + j]; qsum += qv[j]; }
+        const float qn = 1.0f / ls_quad_sum(qsum);              // last Sinkhorn step: B E u v = E u / sum_k E u
+        float mx = -INFINITY;
 #pragma unroll
-            for (int k = 0; k < KMAX; ++k) se += expf(x[k] - mx);
-            const float lse = mx + logf(se);
-            float gsum = 0.0f, dot = 0.0f;
+        for (int j = 0; j < KQ; ++j) { x[j] *= inv_T; mx = fmaxf(mx, x[j]); }
+        mx = ls_quad_max(mx);
+        float se = 0.0f;
 #pragma unroll
-            for (int k = 0; k < KMAX; ++k) {
-                q[k] *= qn;
-                const float lp = k < K ? x[k] - lse : 0.0f;
-                dot = fmaf(q[k], lp, dot);
-                gsum += c * q[k];
-                x[k] = lp;
+        for (int j = 0; j < KQ; ++j) se += expf(x[j] - mx);
+        const float lse = mx + logf(ls_quad_sum(se));
+        float gs = 0.0f, dot = 0.0f;
+#pragma unroll
+        for (int j = 0; j < KQ; ++j) {
+            qv[j] *= qn;
+            const float lp = k0 + j < K ? x[j] - lse : 0.0f;
+            dot = fmaf(qv[j], lp, dot);
+            gs += c * qv[j];
+            x[j] = lp;
+        }
+        gs = ls_quad_sum(gs);
+        if (live) swap_acc += dot;                              // the quad's four partial dots meet in the wave sum
+#pragma unroll
+        for (int j = 0; j < KQ; ++j) x[j] = k0 + j < K ? (c * qv[j] - expf(x[j]) * gs) * inv_T : 0.0f;      // d loss / d score
+        if (live) ls_seg_store<KQ>(srow, k0, K, vec, x);
+        // d z = dS P: every lane over its K/4 prototypes, then the quad adds up AND splits the D latents (lane ^ 1: halves, lane ^ 2: quarters)
+        float dz[DMAX];
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) dz[d] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < KQ; ++j) {
+#pragma unroll
+            for (int d = 0; d < DMAX; d += 4) {
+                const float4 pr = *(const float4*)(pq + j * DMAX + d);
+                dz[d] = fmaf(x[j], pr.x, dz[d]); dz[d + 1] = fmaf(x[j], pr.y, dz[d + 1]); dz[d + 2] = fmaf(x[j], pr.z, dz[d + 2]); dz[d + 3] = fmaf(x[j], pr.w, dz[d + 3]);
             }
-            swap_acc += dot;
+        }
+        float h[DH], g[DQ];
 #pragma unroll
-            for (int k = 0; k < KMAX; ++k) x[k] = k < K ? (c * q[k] - expf(x[k]) * gsum) * inv_T : 0.0f;      // d loss / d score
-            ls_row_store<KMAX>(srow, K, vec, x);
-            // d z = dS P, then F.normalize backward
-            float dz[DMAX];
-#pragma unroll
-            for (int d = 0; d < DMAX; ++d) dz[d] = 0.0f;
-            // the row goes through a thread-private LDS column so that k can be a rolled loop (an unrolled K x D block of prototype
-            // reads blows the register allocation up): xt[j][t], 32 prototypes at a time
-#pragma unroll
-            for (int c0 = 0; c0 < KMAX; c0 += 32) {
-#pragma unroll
-                for (int j = 0; j < 32; ++j) xt[j * 256 + threadIdx.x] = x[c0 + j];
-#pragma unroll 4
-                for (int j = 0; j < 32; ++j) {
-                    const float xk = xt[j * 256 + threadIdx.x];
-                    const float* pr = P + (c0 + j) * DMAX;
-#pragma unroll
-                    for (int d = 0; d < DMAX; ++d) dz[d] = fmaf(xk, pr[d], dz[d]);
-                }
-            }
-            const float* zrow = z + ((long)m * batch + b) * D;
-            float zz[DMAX], zd = 0.0f;
-#pragma unroll
-            for (int d = 0; d < DMAX; ++d) { const float t = zrow[d < D ? d : 0]; zz[d] = d < D ? t : 0.0f; zd = fmaf(zz[d], dz[d], zd); }
-            const float inv = inv_n[(long)m * batch + b];
-            float* dst = m ? d_tgt + b * D : d_enc + b * (3 + D) + 3;
-#pragma unroll
-            for (int d = 0; d < DMAX; ++d)
-                if (d < D) dst[d] = inv < 0.0f ? dz[d] * -inv : (dz[d] - zz[d] * zd) * inv;      // clamped branch: plain scale
+        for (int i = 0; i < DH; ++i) {
+            const float give = (q & 1) ? dz[i] : dz[DH + i], keep = (q & 1) ? dz[DH + i] : dz[i];
+            h[i] = keep + ls_quad_x1(give);
         }
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const float e = enc[b * ld_o + j] - vel[b * ld_v + j];
-            est_acc = fmaf(e, e, est_acc);
-            d_enc[b * (3 + D) + j] = ce * e;
+        for (int i = 0; i < DQ; ++i) {
+            const float give = (q & 2) ? h[i] : h[DQ + i], keep = (q & 2) ? h[DQ + i] : h[i];
+            g[i] = keep + ls_quad_x2(give);
         }
+        // F.normalize backward on latents [d0, d0 + DQ)
+        const float* zrow = z + ((long)m * batch + bb) * D;
+        float zz[DQ], zd = 0.0f;
+#pragma unroll
+        for (int i = 0; i < DQ; ++i) { const bool in = d0 + i < D; const float t = zrow[in ? d0 + i : 0]; zz[i] = in ? t : 0.0f; zd = fmaf(zz[i], g[i], zd); }
+        zd = ls_quad_sum(zd);
+        const float inv = inv_n[(long)m * batch + bb];
+        float* dst = m ? d_tgt + bb * D : d_enc + bb * (3 + D) + 3;
+#pragma unroll
+        for (int i = 0; i < DQ; ++i)
+            if (live && d0 + i < D) dst[d0 + i] = inv < 0.0f ? g[i] * -inv : (g[i] - zz[i] * zd) * inv;      // clamped branch: plain scale
+    }
+    if (live && q < 3) {
+        const float e = enc[b * ld_o + q] - vel[b * ld_v + q];
+        est_acc = e * e;
+        d_enc[b * (3 + D) + q] = ce * e;
     }
     est_acc = ls_wave_sum64(est_acc);
     swap_acc = ls_wave_sum64(swap_acc);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (lane == 0) { red[w][0] = est_acc; red[w][1] = swap_acc; }
     __syncthreads();
-    if (threadIdx.x < 2) part[(size_t)blockIdx.x * 2 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (threadIdx.x < 2) {
+        float a = 0.0f;
+#pragma unroll
+        for (int i = 0; i < WAVES; ++i) a += red[i][threadIdx.x];
+        part[(size_t)blockIdx.x * 2 + threadIdx.x] = a;
+    }
 }
 
-// losses[0] = est, [1] = swap, [2] = est + swap; partial sums added in a fixed order
-__global__ __launch_bounds__(256) void lsim_k_est_finish(const float* __restrict__ part, int blocks, long batch, int K, float* __restrict__ losses) {
-    __shared__ float red[256][2];
-    float a = 0.0f, s = 0.0f;
-    for (int i = threadIdx.x; i < blocks; i += 256) { a += part[(size_t)i * 2]; s += part[(size_t)i * 2 + 1]; }
-    red[threadIdx.x][0] = a; red[threadIdx.x][1] = s;
-    __syncthreads();
-    for (int st = 128; st > 0; st >>= 1) {
-        if ((int)threadIdx.x < st) { red[threadIdx.x][0] += red[threadIdx.x + st][0]; red[threadIdx.x][1] += red[threadIdx.x + st][1]; }
+// the last launch of the loss head, two jobs side by side:
+//   block 0             losses[0] = est, [1] = swap, [2] = est + swap from the loss kernel's per-block sums
+//   blocks 1 ..         d P = sum of the prototype weight-gradient partials [num_partials][count]: 64 outputs (16 float4 columns) x 64 slices
+//                       per block, eight rows in flight per thread -- the general lsim_k_wgrad_reduce (16 slices, four rows in flight) needed
+//                       12.8 us for these 1024 partial rows of 512 outputs, as a launch of its own behind a 5 us finish launch
+// every sum in a fixed order
+__global__ __launch_bounds__(1024) void lsim_k_est_tail(const float* __restrict__ part, int blocks, long batch, int K, float* __restrict__ losses,
+                                                        const float* __restrict__ wpart, int num_partials, int count, float* __restrict__ d_proto) {
+    __shared__ float4 red4[64][17];
+    if (blockIdx.x == 0) {
+        float (*red)[2] = (float (*)[2])&red4[0][0];           // 1024 x 2 floats
+        float a = 0.0f, s = 0.0f;
+        for (int i = threadIdx.x; i < blocks; i += 1024) { a += part[(size_t)i * 2]; s += part[(size_t)i * 2 + 1]; }
+        red[threadIdx.x][0] = a; red[threadIdx.x][1] = s;
         __syncthreads();
+        for (int st = 512; st > 0; st >>= 1) {
+            if ((int)threadIdx.x < st) { red[threadIdx.x][0] += red[threadIdx.x + st][0]; red[threadIdx.x][1] += red[threadIdx.x + st][1]; }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            const float est = red[0][0] / (3.0f * (float)batch), swap = -0.5f * red[0][1] / ((float)batch * (float)K);
+            losses[0] = est; losses[1] = swap; losses[2] = est + swap;
+        }
+        return;
     }
-    if (threadIdx.x == 0) {
-        const float est = red[0][0] / (3.0f * (float)batch), swap = -0.5f * red[0][1] / ((float)batch * (float)K);
-        losses[0] = est; losses[1] = swap; losses[2] = est + swap;
+    const int ol = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int o = ((int)blockIdx.x - 1) * 64 + 4 * ol;         // count % 4 == 0 (checked by the caller)
+    auto add = [](float4& a, const float4 v) { a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; };
+    float4 s[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = make_float4(0, 0, 0, 0);
+    if (o < count) {
+        int w = sl;
+        for (; w + 7 * 64 < num_partials; w += 8 * 64) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) add(s[j], *(const float4*)(wpart + (size_t)(w + j * 64) * count + o));
+        }
+        for (; w < num_partials; w += 64) add(s[0], *(const float4*)(wpart + (size_t)w * count + o));
+    }
+    add(s[0], s[1]); add(s[2], s[3]); add(s[4], s[5]); add(s[6], s[7]); add(s[0], s[2]); add(s[4], s[6]); add(s[0], s[4]);
+    red4[sl][ol] = s[0];
+    __syncthreads();
+    if (sl == 0 && o < count) {
+        float4 t = make_float4(0, 0, 0, 0);
+        for (int j = 0; j < 64; ++j) add(t, red4[j][ol]);
+        d_proto[o] = t.x; d_proto[o + 1] = t.y; d_proto[o + 2] = t.z; d_proto[o + 3] = t.w;
     }
 }
 
@@ -1209,13 +1344,13 @@ static int ls_est_plan(long batch, int D, int K, LsEstPlan* p) {
     size_t wg_bytes; int np;
     int rc = lsim_linear_wgrad_workspace(2 * batch, D, K, &wg_bytes, &np);
     if (rc != LSIM_OK) return rc;
-    const size_t blocks = (size_t)((batch + LS_SK_ROWS - 1) / LS_SK_ROWS);
+    const size_t blocks = (size_t)((batch + LS_EST_ROWS - 1) / LS_EST_ROWS);      // of the score and loss kernels; the Sinkhorn rounds use LS_SK_ROWS
     size_t o = 0;
     auto take = [&o](size_t floats) { const size_t at = o; o += (floats + 63) & ~(size_t)63; return at; };    // 256-byte aligned pieces
     p->z = take(2 * (size_t)batch * D);
     p->inv_n = take(2 * (size_t)batch);
     p->S = take(2 * (size_t)batch * K);
-    p->sk = take(ls_sinkhorn_floats(batch, K, 2));
+    p->sk = take(((size_t)2 * batch * K + 63) / 64 * 64 + 2 * blocks * K + 128);          // E of both matrices, partial column sums, u
     p->part = take(blocks * 2);
     p->wg = take((wg_bytes + 3) / 4);
     p->total = o;
@@ -1243,16 +1378,16 @@ template <int KMAX, int DMAX> static void ls_est_launch(const LsEstArgs& a, floa
     // batch * K is; the kernels index [m * batch + b], so use the unpadded layout: E for both matrices is contiguous)
     LsSkBufs w;
     w.blocks = (int)((a.batch + LS_SK_ROWS - 1) / LS_SK_ROWS);
+    const int eb = (int)((a.batch + LS_EST_ROWS - 1) / LS_EST_ROWS);
     w.E = ws + p.sk;
     w.part = w.E + (((size_t)2 * a.batch * a.K + 63) / 64 * 64);
-    w.u = w.part + (size_t)2 * w.blocks * a.K;
-    hipLaunchKernelGGL((lsim_k_est_scores<KMAX, DMAX>), dim3(w.blocks), dim3(256), 0, s, a.enc, a.ld_enc, a.tgt, a.ld_tgt, a.proto, a.batch, a.D, a.K,
+    w.u = w.part + (size_t)2 * eb * a.K;
+    hipLaunchKernelGGL((lsim_k_est_scores<KMAX, DMAX>), dim3(eb), dim3(4 * LS_EST_ROWS), 0, s, a.enc, a.ld_enc, a.tgt, a.ld_tgt, a.proto, a.batch, a.D, a.K,
                        1.0f / a.eps, ws + p.z, ws + p.inv_n, ws + p.S, w.E, w.part);
-    ls_sinkhorn_rounds<KMAX>(w, a.batch, a.K, 2, a.iters, s);
-    hipLaunchKernelGGL((lsim_k_est_loss<KMAX, DMAX>), dim3(w.blocks), dim3(256), 0, s, a.enc, a.ld_enc, a.vel, a.ld_vel, a.proto, ws + p.S,
+    ls_sinkhorn_rounds<KMAX>(w, a.batch, a.K, 2, a.iters, s, eb);
+    hipLaunchKernelGGL((lsim_k_est_loss<KMAX, DMAX>), dim3(eb), dim3(4 * LS_EST_ROWS), 0, s, a.enc, a.ld_enc, a.vel, a.ld_vel, a.proto, ws + p.S,
                        (const float*)w.E, (const float*)w.u, (const float*)(ws + p.z), (const float*)(ws + p.inv_n), a.batch, a.D, a.K, a.inv_T,
                        a.g_enc, a.g_tgt, ws + p.part);
-    hipLaunchKernelGGL(lsim_k_est_finish, dim3(1), dim3(256), 0, s, (const float*)(ws + p.part), w.blocks, a.batch, a.K, a.losses);
 }
 
 extern "C" int lsim_estimator_loss(const float* enc_out, int64_t ld_enc, const float* tgt_out, int64_t ld_tgt, const float* proto, const float* vel,
@@ -1274,11 +1409,18 @@ extern "C" int lsim_estimator_loss(const float* enc_out, int64_t ld_enc, const f
     else if (K <= 32) ls_est_launch<32, 32>(a, ws, p, s);
     else if (latent <= 16) ls_est_launch<64, 16>(a, ws, p, s);
     else ls_est_launch<64, 32>(a, ws, p, s);
-    // d P[k][d] = sum over both halves of dS[b][k] z[b][d]: a Linear weight gradient with x = z [2B, D], g = dS [2B, K]
+    // d P[k][d] = sum over both halves of dS[b][k] z[b][d]: a Linear weight gradient with x = z [2B, D], g = dS [2B, K]; its partial results
+    // are added up by the tail launch, next to the loss sums
     size_t wg_bytes; int np;
     lsim_linear_wgrad_workspace(2 * batch, latent, K, &wg_bytes, &np);
-    rc = ls_linear_wgrad_impl(ws + p.z, latent, ws + p.S, K, nullptr, 0, nullptr, 2 * batch, latent, K, grad_proto, nullptr, ws + p.wg, wg_bytes, s);
+    const int eb = (int)((batch + LS_EST_ROWS - 1) / LS_EST_ROWS);
+    lsim_wgrad_pending pend;
+    const bool fold = (latent * K) % 4 == 0;
+    rc = ls_linear_wgrad_impl(ws + p.z, latent, ws + p.S, K, nullptr, 0, nullptr, 2 * batch, latent, K, grad_proto, nullptr, ws + p.wg, wg_bytes, s, fold ? &pend : nullptr);
     if (rc != LSIM_OK) return rc;
+    if (fold && (((uintptr_t)pend.part & 15) != 0 || pend.count != latent * K)) return LSIM_E_INVALID;        // the workspace piece is 256-byte aligned
+    hipLaunchKernelGGL(lsim_k_est_tail, dim3(fold ? 1 + (pend.count + 63) / 64 : 1), dim3(1024), 0, s, (const float*)(ws + p.part), eb, (long)batch, K, losses3,
+                       fold ? pend.part : nullptr, fold ? pend.num_partials : 0, fold ? pend.count : 0, grad_proto);
     return hipGetLastError() == hipSuccess ? LSIM_OK : LSIM_E_HIP;
 }
 
