@@ -1006,10 +1006,9 @@ extern "C" int lsim_sinkhorn_workspace(long batch, int K, size_t* bytes) {
 }
 
 // the column / row rescaling rounds after `first` has filled E and its partial sums: leaves the final u (E and u define the result)
-// (`first_blocks`: rows of partial sums the producer of E left in w.part, w.blocks unless it used another block size)
-template <int KMAX> static void ls_sinkhorn_rounds(const LsSkBufs& w, long batch, int K, int mats, int iters, hipStream_t s, int first_blocks = 0) {
+template <int KMAX> static void ls_sinkhorn_rounds(const LsSkBufs& w, long batch, int K, int mats, int iters, hipStream_t s) {
     const dim3 grid(w.blocks, mats), one(1, mats);
-    hipLaunchKernelGGL(lsim_k_sinkhorn_scale, one, dim3(1024), 0, s, (const float*)w.part, first_blocks ? first_blocks : w.blocks, K, w.u);
+    hipLaunchKernelGGL(lsim_k_sinkhorn_scale, one, dim3(1024), 0, s, (const float*)w.part, w.blocks, K, w.u);
     for (int it = 1; it < iters; ++it) {
         hipLaunchKernelGGL(lsim_k_sinkhorn_mid<KMAX>, grid, dim3(256), 0, s, (const float*)w.E, (const float*)w.u, batch, K, w.part);
         hipLaunchKernelGGL(lsim_k_sinkhorn_scale, one, dim3(1024), 0, s, (const float*)w.part, w.blocks, K, w.u);
@@ -1100,12 +1099,39 @@ __device__ __forceinline__ void ls_seg_store(float* __restrict__ p, int k0, int 
     }
 }
 
+// partial column sums of a block's LS_EST_ROWS rows on the quad layout (lane q of a quad: columns [k0, k0 + K/4) of its row): the four quads
+// of a 16-lane DPP row hold the same columns of four rows -> two row rotations; then one LDS line per 16-lane group, added in a fixed order
+template <int KMAX>
+__device__ __forceinline__ void ls_est_group_colsum(const float (&e)[KMAX / 4], float (*__restrict__ gs)[KMAX] /* [GROUPS][KMAX] */, int k0) {
+    const int lane = threadIdx.x & 63, group = threadIdx.x >> 4;
+#pragma unroll
+    for (int j = 0; j < KMAX / 4; ++j) {
+        float t = e[j];
+        t += ls_est_dpp<0x120 + 8>(t);          // row_ror:8
+        t += ls_est_dpp<0x120 + 4>(t);          // row_ror:4
+        if ((lane & 12) == 0) gs[group][k0 + j] = t;
+    }
+}
+template <int KMAX>
+__device__ __forceinline__ void ls_est_block_colsum(const float (*__restrict__ gsum)[LS_EST_ROWS / 4][KMAX] /* [2][GROUPS][KMAX] */,
+                                                    float* __restrict__ part /* [2][gridDim.x][K] */, int K) {
+    __syncthreads();
+    if (threadIdx.x < 2 * KMAX) {
+        const int m = threadIdx.x / KMAX, k = threadIdx.x % KMAX;
+        if (k < K) {
+            float a = 0.0f;
+#pragma unroll
+            for (int g = 0; g < LS_EST_ROWS / 4; ++g) a += gsum[m][g][k];
+            part[((long)m * gridDim.x + blockIdx.x) * K + k] = a;
+        }
+    }
+}
+
 template <int KMAX, int DMAX>
 __global__ __launch_bounds__(4 * LS_EST_ROWS) __attribute__((amdgpu_waves_per_eu(LS_EST_WAVES_PER_EU, 8))) void lsim_k_est_scores(const float* __restrict__ enc, long ld_o, const float* __restrict__ tgt, long ld_t,
                                                          const float* __restrict__ proto, long batch, int D, int K, float inv_eps,
                                                          float* __restrict__ z /* [2][B][D] */, float* __restrict__ inv_n /* [2][B] */,
-                                                         float* __restrict__ S /* [2][B][K] */, float* __restrict__ E /* [2][B][K] */,
-                                                         float* __restrict__ part /* [2][gridDim.x][K] */) {
+                                                         float* __restrict__ S /* [2][B][K] */, float* __restrict__ part /* [2][gridDim.x][K] */) {
     constexpr int KQ = KMAX / 4, DQ = DMAX / 4, GROUPS = LS_EST_ROWS / 4;      // GROUPS: 16-lane DPP rows per block (4 sample rows each)
     __shared__ __attribute__((aligned(16))) float P[LS_EST_P_FLOATS(KMAX, DMAX)];
     __shared__ float gsum[2][GROUPS][KMAX];
@@ -1147,33 +1173,44 @@ __global__ __launch_bounds__(4 * LS_EST_ROWS) __attribute__((amdgpu_waves_per_eu
         asm volatile("" : "+v"(a0), "+v"(a1));      // both dot products finish HERE: left free, the target's half sinks below the student's stores
         sc[0][j] = a0; sc[1][j] = a1;                  // and all K/4 prototype rows wait for it in 128 registers (174 in all, 2 waves per SIMD)
     }
-    const int lane = threadIdx.x & 63, group = threadIdx.x >> 4;
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-        const long row = ((long)m * batch + bb) * K + k0;
-        if (live) ls_seg_store<KQ>(S + row, k0, K, vec, sc[m]);
+        if (live) ls_seg_store<KQ>(S + ((long)m * batch + bb) * K + k0, k0, K, vec, sc[m]);
+        // E = exp(S / eps) is not stored: the Sinkhorn rounds and the loss kernel form it again from S with this same expression (26 MB less
+        // to write here and 26 MB less to read in each of them)
 #pragma unroll
         for (int j = 0; j < KQ; ++j) sc[m][j] = (live && k0 + j < K) ? expf(sc[m][j] * inv_eps) : 0.0f;
-        if (live) ls_seg_store<KQ>(E + row, k0, K, vec, sc[m]);
-        // column sums of the group's 4 rows: the quads of a 16-lane DPP row hold the same columns
-#pragma unroll
-        for (int j = 0; j < KQ; ++j) {
-            float t = sc[m][j];
-            t += ls_est_dpp<0x120 + 8>(t);          // row_ror:8
-            t += ls_est_dpp<0x120 + 4>(t);          // row_ror:4
-            if ((lane & 12) == 0) gsum[m][group][k0 + j] = t;
-        }
+        ls_est_group_colsum<KMAX>(sc[m], gsum[m], k0);
     }
+    ls_est_block_colsum<KMAX>(gsum, part, K);
+}
+
+// the Sinkhorn round between two rescalings, on the quad layout: v[b] = 1 / (B * sum_k E[b, k] u[k]), partial column sums of E * v
+template <int KMAX>
+__global__ __launch_bounds__(4 * LS_EST_ROWS) void lsim_k_est_mid(const float* __restrict__ S, const float* __restrict__ u, long batch, int K, float inv_eps,
+                                                                  float* __restrict__ part /* [2][gridDim.x][K] */) {
+    constexpr int KQ = KMAX / 4, GROUPS = LS_EST_ROWS / 4;
+    __shared__ float us[2][KMAX];
+    __shared__ float gsum[2][GROUPS][KMAX];
+    if (threadIdx.x < 2 * KMAX) { const int m = threadIdx.x / KMAX, k = threadIdx.x % KMAX; us[m][k] = k < K ? u[m * 64 + k] : 0.0f; }
     __syncthreads();
-    if (threadIdx.x < 2 * KMAX) {                   // the block's partial column sums, groups added in a fixed order
-        const int m = threadIdx.x / KMAX, k = threadIdx.x % KMAX;
-        if (k < K) {
-            float a = 0.0f;
+    const int q = threadIdx.x & 3, k0 = q * KQ;
+    const long b = (long)blockIdx.x * LS_EST_ROWS + (threadIdx.x >> 2);
+    const bool live = b < batch, vec = (K & 3) == 0;
+    const long bb = live ? b : batch - 1;
 #pragma unroll
-            for (int g = 0; g < GROUPS; ++g) a += gsum[m][g][k];
-            part[((long)m * gridDim.x + blockIdx.x) * K + k] = a;
-        }
+    for (int m = 0; m < 2; ++m) {
+        float v[KQ];
+        ls_seg_load<KQ>(S + ((long)m * batch + bb) * K + k0, k0, K, vec, 0.0f, v);
+        float t = 0.0f;
+#pragma unroll
+        for (int j = 0; j < KQ; ++j) { v[j] = k0 + j < K ? expf(v[j] * inv_eps) : 0.0f; t = fmaf(v[j], us[m][k0 + j], t); }
+        const float vb = live ? 1.0f / ((float)batch * ls_quad_sum(t)) : 0.0f;
+#pragma unroll
+        for (int j = 0; j < KQ; ++j) v[j] *= vb;
+        ls_est_group_colsum<KMAX>(v, gsum[m], k0);
     }
+    ls_est_block_colsum<KMAX>(gsum, part, K);
 }
 
 static __device__ __forceinline__ float ls_wave_sum64(float t) {
@@ -1184,8 +1221,8 @@ static __device__ __forceinline__ float ls_wave_sum64(float t) {
 template <int KMAX, int DMAX>
 __global__ __launch_bounds__(4 * LS_EST_ROWS) __attribute__((amdgpu_waves_per_eu(KMAX * DMAX > 512 ? 2 : LS_EST_WAVES_PER_EU, 8))) void lsim_k_est_loss(const float* __restrict__ enc, long ld_o, const float* __restrict__ vel, long ld_v,
                                                        const float* __restrict__ proto, float* __restrict__ S /* in: scores, out: d loss / d scores */,
-                                                       const float* __restrict__ E, const float* __restrict__ u, const float* __restrict__ z,
-                                                       const float* __restrict__ inv_n, long batch, int D, int K, float inv_T,
+                                                       const float* __restrict__ u, const float* __restrict__ z,
+                                                       const float* __restrict__ inv_n, long batch, int D, int K, float inv_T, float inv_eps,
                                                        float* __restrict__ d_enc /* [B][3 + D] */, float* __restrict__ d_tgt /* [B][D] */,
                                                        float* __restrict__ part /* [gridDim.x][2] */) {
     constexpr int KQ = KMAX / 4, DQ = DMAX / 4, DH = DMAX / 2, WAVES = 4 * LS_EST_ROWS / 64;
@@ -1204,15 +1241,20 @@ __global__ __launch_bounds__(4 * LS_EST_ROWS) __attribute__((amdgpu_waves_per_eu
     const int d0 = (q & 1) * DH + (q >> 1) * DQ;    // the latents this lane ends up with after the two exchange steps below
     float est_acc = 0.0f, swap_acc = 0.0f;
     // m = 0: the target's assignment q_t weights the student's log-softmax -> gradient to the student scores; m = 1 the other way
+    float s01[2][KQ];                               // the row's scores of both matrices: each is the other's assignment input, and d loss / d score replaces them below
+#pragma unroll
+    for (int m = 0; m < 2; ++m) ls_seg_load<KQ>(S + ((long)m * batch + bb) * K + k0, k0, K, vec, -INFINITY, s01[m]);
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
         float qv[KQ], x[KQ];
-        ls_seg_load<KQ>(E + ((long)(1 - m) * batch + bb) * K + k0, k0, K, vec, 0.0f, qv);
         float* srow = S + ((long)m * batch + bb) * K + k0;
-        ls_seg_load<KQ>(srow, k0, K, vec, -INFINITY, x);
         float qsum = 0.0f;
 #pragma unroll
-        for (int j = 0; j < KQ; ++j) { qv[j] *= us[1 - m][k0 + j]; qsum += qv[j]; }
+        for (int j = 0; j < KQ; ++j) {
+            x[j] = s01[m][j];
+            qv[j] = k0 + j < K ? expf(s01[1 - m][j] * inv_eps) * us[1 - m][k0 + j] : 0.0f;      // E = exp(S / eps) as the score kernel formed it
+            qsum += qv[j];
+        }
         const float qn = 1.0f / ls_quad_sum(qsum);              // last Sinkhorn step: B E u v = E u / sum_k E u
         float mx = -INFINITY;
 #pragma unroll
@@ -1350,7 +1392,7 @@ static int ls_est_plan(long batch, int D, int K, LsEstPlan* p) {
     p->z = take(2 * (size_t)batch * D);
     p->inv_n = take(2 * (size_t)batch);
     p->S = take(2 * (size_t)batch * K);
-    p->sk = take(((size_t)2 * batch * K + 63) / 64 * 64 + 2 * blocks * K + 128);          // E of both matrices, partial column sums, u
+    p->sk = take(2 * blocks * K + 128);                                                     // partial column sums of both matrices, u [2][64]
     p->part = take(blocks * 2);
     p->wg = take((wg_bytes + 3) / 4);
     p->total = o;
@@ -1374,20 +1416,19 @@ struct LsEstArgs {
     float *losses, *g_enc, *g_tgt;
 };
 template <int KMAX, int DMAX> static void ls_est_launch(const LsEstArgs& a, float* ws, const LsEstPlan& p, hipStream_t s) {
-    // the matrix pair of the Sinkhorn workspace: E of student and target back to back (a multiple of 64 floats apart only when
-    // batch * K is; the kernels index [m * batch + b], so use the unpadded layout: E for both matrices is contiguous)
-    LsSkBufs w;
-    w.blocks = (int)((a.batch + LS_SK_ROWS - 1) / LS_SK_ROWS);
     const int eb = (int)((a.batch + LS_EST_ROWS - 1) / LS_EST_ROWS);
-    w.E = ws + p.sk;
-    w.part = w.E + (((size_t)2 * a.batch * a.K + 63) / 64 * 64);
-    w.u = w.part + (size_t)2 * eb * a.K;
-    hipLaunchKernelGGL((lsim_k_est_scores<KMAX, DMAX>), dim3(eb), dim3(4 * LS_EST_ROWS), 0, s, a.enc, a.ld_enc, a.tgt, a.ld_tgt, a.proto, a.batch, a.D, a.K,
-                       1.0f / a.eps, ws + p.z, ws + p.inv_n, ws + p.S, w.E, w.part);
-    ls_sinkhorn_rounds<KMAX>(w, a.batch, a.K, 2, a.iters, s, eb);
-    hipLaunchKernelGGL((lsim_k_est_loss<KMAX, DMAX>), dim3(eb), dim3(4 * LS_EST_ROWS), 0, s, a.enc, a.ld_enc, a.vel, a.ld_vel, a.proto, ws + p.S,
-                       (const float*)w.E, (const float*)w.u, (const float*)(ws + p.z), (const float*)(ws + p.inv_n), a.batch, a.D, a.K, a.inv_T,
-                       a.g_enc, a.g_tgt, ws + p.part);
+    float *part = ws + p.sk, *u = part + (size_t)2 * eb * a.K;
+    const dim3 grid(eb), one(1, 2), threads(4 * LS_EST_ROWS);
+    const float inv_eps = 1.0f / a.eps;
+    hipLaunchKernelGGL((lsim_k_est_scores<KMAX, DMAX>), grid, threads, 0, s, a.enc, a.ld_enc, a.tgt, a.ld_tgt, a.proto, a.batch, a.D, a.K, inv_eps, ws + p.z,
+                       ws + p.inv_n, ws + p.S, part);
+    hipLaunchKernelGGL(lsim_k_sinkhorn_scale, one, dim3(1024), 0, s, (const float*)part, eb, a.K, u);
+    for (int it = 1; it < a.iters; ++it) {
+        hipLaunchKernelGGL((lsim_k_est_mid<KMAX>), grid, threads, 0, s, (const float*)(ws + p.S), (const float*)u, a.batch, a.K, inv_eps, part);
+        hipLaunchKernelGGL(lsim_k_sinkhorn_scale, one, dim3(1024), 0, s, (const float*)part, eb, a.K, u);
+    }
+    hipLaunchKernelGGL((lsim_k_est_loss<KMAX, DMAX>), grid, threads, 0, s, a.enc, a.ld_enc, a.vel, a.ld_vel, a.proto, ws + p.S, (const float*)u,
+                       (const float*)(ws + p.z), (const float*)(ws + p.inv_n), a.batch, a.D, a.K, a.inv_T, inv_eps, a.g_enc, a.g_tgt, ws + p.part);
 }
 
 extern "C" int lsim_estimator_loss(const float* enc_out, int64_t ld_enc, const float* tgt_out, int64_t ld_tgt, const float* proto, const float* vel,
