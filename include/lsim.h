@@ -575,6 +575,15 @@ int lsim_linear_wgrad_workspace(long batch, int k_in, int n_out, size_t* bytes, 
 int lsim_linear_wgrad(const float* x, int64_t ldx, const float* g, int64_t ldg, int64_t batch, int k_in, int n_out,
                       float* dw, float* db, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Forward of a Linear layer followed by ELU (alpha = 1): out[b, :] = elu(x[b, :] W^T + bias), the hidden layers of the actor, critic and
+ * estimator MLPs (rsl_rl/modules/him_actor_critic.py:52-76, him_estimator.py:40-62 build them as nn.Linear + nn.ELU pairs; HIMPPO.update
+ * runs them on minibatches of 102 400 rows, him_ppo.py:136-150).  fp32 MFMA with the activation applied to the accumulators: the layer's
+ * output is written once instead of BLAS output + elementwise read + write.  x [batch, k_in] with leading dimension ldx, weight
+ * [n_out, k_in] contiguous (nn.Linear.weight), bias [n_out] or NULL, out [batch, n_out] with leading dimension ldo.
+ * LSIM_E_UNSUPPORTED unless n_out % 4 == 0, ldo % 4 == 0 and out is 16-byte aligned (use BLAS + ELU). */
+int lsim_linear_elu_forward(const float* x, int64_t ldx, const float* weight, const float* bias, int64_t batch, int k_in, int n_out,
+                            float* out, int64_t ldo, void* stream);
+
 /* Backward of a Linear layer followed by ELU (y = x W^T + b, z = elu(y), alpha = 1) given the gradient of z: the gradient of the
  * pre-activation  grad_pre = grad_out * (z > 0 ? 1 : z + 1)  (torch's elu_backward on the saved OUTPUT) is formed on the fly as the MFMA
  * operand of the weight-gradient kernel and written once -- [batch, n_out] contiguous -- for the caller's input-gradient GEMM

@@ -10,4 +10,5 @@
 #include "../../include/lsim.h"
 #include "ls_rollout.h"
 #include "ls_learn.h"
+#include "ls_gemm.h"
 #include "ls_policy.h"

@@ -266,13 +266,42 @@ def _eligible_fused_elu(batch, k_in, n_out):
     return _eligible(batch, k_in, n_out) and k_in * n_out > 4096
 
 
+def _fused_forward_wanted(k_in, n_out):
+    """LSIM_ELU_FORWARD: 0 = BLAS + torch ELU everywhere, all = the library kernel wherever it runs, unset = where it measured faster than
+    BLAS + ELU at the minibatch of 102 400 rows (tools/fwd_time.py, profiles/r05_linear_elu_forward.txt)"""
+    mode = os.environ.get("LSIM_ELU_FORWARD", "auto")
+    if mode == "0":
+        return False
+    if mode == "all":
+        return True
+    return k_in <= 128 or (n_out <= 128 and k_in % 4 == 0)
+
+
+def linear_elu_forward(x, weight, bias):
+    """elu(x W^T + b): lsim_linear_elu_forward (fp32 MFMA, the activation applied to the accumulators, one write of the output) where it is
+    the faster form, else BLAS + torch's elementwise ELU"""
+    if (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and weight.dtype == torch.float32 and weight.is_contiguous() and weight.shape[0] % 4 == 0
+            and _fused_forward_wanted(weight.shape[1], weight.shape[0])):
+        from .. import abi, lib
+        xx = x if x.stride(1) == 1 else x.contiguous()
+        z = torch.empty(x.shape[0], weight.shape[0], device=x.device, dtype=torch.float32)
+        b = bias.detach() if bias is not None else None
+        rc = lib.load().lsim_linear_elu_forward(xx.data_ptr(), xx.stride(0), weight.data_ptr(), b.data_ptr() if b is not None else None, x.shape[0],
+                                                weight.shape[1], weight.shape[0], z.data_ptr(), z.stride(0), torch.cuda.current_stream(x.device).cuda_stream)
+        if rc == 0:
+            return z
+        if rc != abi.E_UNSUPPORTED:
+            lib.check(rc, what="lsim_linear_elu_forward")
+    return F.elu(F.linear(x, weight, bias))
+
+
 class _LinearEluFn(torch.autograd.Function):
     """z = elu(x W^T + b) whose backward runs ONE fused pass (lsim_linear_elu_wgrad): grad_pre = g * elu'(z) formed on the fly as the
     MFMA operand of the weight-gradient kernel (and written once), then the usual BLAS input gradient grad_pre @ W."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
-        z = F.elu(F.linear(x, weight, bias))
+        z = linear_elu_forward(x, weight, bias)
         ctx.save_for_backward(x, weight, z)
         ctx.has_bias = bias is not None
         ctx.bias_ptr = bias.data_ptr() if bias is not None else None

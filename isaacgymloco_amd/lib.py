@@ -77,6 +77,7 @@ def load_path(path):
     L.lsim_ppo_loss_std.argtypes = [vp] * 10 + [i64, i32, f32, f32, f32, i32, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
     L.lsim_adaptive_lr.argtypes = [vp, f32, f32, f32, f32, vp, vp]
     L.lsim_linear_elu_wgrad.argtypes = [vp, i64, vp, i64, vp, i64, i64, i32, i32, vp, vp, vp, vp, ctypes.c_size_t, vp]
+    L.lsim_linear_elu_forward.argtypes = [vp, i64, vp, vp, i64, i32, i32, vp, i64, vp]
     pend = ctypes.POINTER(abi.LsimWgradPending)
     L.lsim_linear_wgrad_deferred.argtypes = [vp, i64, vp, i64, i64, i32, i32, vp, vp, vp, ctypes.c_size_t, vp, pend]
     L.lsim_linear_elu_wgrad_deferred.argtypes = [vp, i64, vp, i64, vp, i64, i64, i32, i32, vp, vp, vp, vp, ctypes.c_size_t, vp, pend]

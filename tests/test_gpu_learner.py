@@ -1,4 +1,5 @@
 """GPU: the hipGraph-captured rollout step writes the same storage as the eager runner step (same ops); full PPO iteration runs."""
+import os
 import pytest
 import torch
 
@@ -498,6 +499,41 @@ def test_fused_linear_elu_backward_matches_torch(k_in, n_out):
     (fus(xb.detach()) * w).sum().backward()
     for (n1, p1), (n2, p2) in zip(ref.named_parameters(), fus.named_parameters()):
         torch.testing.assert_close(p2.grad, p1.grad, rtol=2e-4, atol=2e-5 * float(p1.grad.abs().max()), msg=n1 + " (no input gradient)")
+
+
+@pytest.mark.parametrize("rows,k_in,n_out", [(102400, 64, 512), (20480 + 12, 512, 256), (20480 + 12, 256, 128), (4096, 238, 512), (4099, 270, 128), (1000, 45, 128),
+                                             (161, 128, 64), (7, 33, 12)])
+def test_fused_linear_elu_forward_matches_torch(rows, k_in, n_out):
+    """lsim_linear_elu_forward (fp32 MFMA product with bias and ELU applied to the accumulators) against F.elu(F.linear) in fp64, through the C-ABI: every
+    hidden-layer shape of the learner (16-byte, 8-byte and 4-byte aligned rows; partial sample, feature and K tiles), strided input rows, with and without bias.
+    Tolerance: 2e-5 absolute on O(1) activations (an fp32 sum of <= 512 products; the order of the additions differs from BLAS)"""
+    import torch.nn.functional as F
+    from isaacgymloco_amd import abi, lib
+    from isaacgymloco_amd.learn.fused_linear import linear_elu_forward
+    L = lib.load()
+    g = torch.Generator(device="cuda:0").manual_seed(rows + k_in + n_out)
+    big = torch.randn(rows, k_in + 5, device="cuda:0", generator=g)
+    W = torch.randn(n_out, k_in, device="cuda:0", generator=g) / k_in ** 0.5
+    b = torch.randn(n_out, device="cuda:0", generator=g) * 0.3
+    for x, bias in ((big[:, :k_in].contiguous(), b), (big[:, 1:1 + k_in], None)):          # the second: rows k_in + 5 apart, starting 4 bytes into the allocation
+        out = torch.full((rows, n_out), float("nan"), device="cuda:0")
+        rc = L.lsim_linear_elu_forward(x.data_ptr(), x.stride(0), W.data_ptr(), bias.data_ptr() if bias is not None else None, rows, k_in, n_out, out.data_ptr(),
+                                       out.stride(0), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, rc
+        want = F.elu(F.linear(x.double(), W.double(), bias.double() if bias is not None else None))
+        assert torch.isfinite(out).all()
+        assert float((out.double() - want).abs().max()) < 2e-5
+    # the learner's entry point: the library kernel under LSIM_ELU_FORWARD=all, BLAS + ELU under =0, the same values either way
+    os.environ["LSIM_ELU_FORWARD"] = "all"
+    try:
+        z1 = linear_elu_forward(big[:, :k_in], W, b)
+        os.environ["LSIM_ELU_FORWARD"] = "0"
+        z0 = linear_elu_forward(big[:, :k_in], W, b)
+    finally:
+        os.environ.pop("LSIM_ELU_FORWARD", None)
+    assert float((z1 - z0).abs().max()) < 2e-5
+    # n_out % 4 != 0 is the caller's to run through BLAS
+    assert L.lsim_linear_elu_forward(big.data_ptr(), big.stride(0), W.data_ptr(), None, rows, k_in, 10, out.data_ptr(), 12, torch.cuda.current_stream().cuda_stream) == abi.E_UNSUPPORTED
 
 
 def test_reference_style_step_tuple_and_strict_runner_path():
