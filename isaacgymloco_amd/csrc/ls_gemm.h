@@ -17,9 +17,6 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#if !defined(LS_FWD_TN128)
-#define LS_FWD_TN128 2
-#endif
 
 
 // stage one BK-wide chunk of ROWS rows (global, row-major, leading dimension ld) in registers: thread t takes k-quad (t & 7) of rows
@@ -60,7 +57,8 @@ __device__ __forceinline__ void ls_fwd_stage(float* __restrict__ tile, const flo
 }
 
 // waves 2 (samples) x 2 (features), per wave TM x TN MFMA tiles of 16 x 16: BM = 32 TM samples, BN = 32 TN features per block.
-// TM = 5 (160 samples): 102 400 rows = 640 sample tiles, and with BN = N / 4 every layer width gives 2560 tiles = 10 per CU exactly.
+// TM = 5 (160 samples): 102 400 rows = 640 sample tiles; 512 and 128 features then give 2560 and 1280 tiles = 5 and 2.5 per block (the
+// host picks the feature tile, see lsim_linear_elu_forward).
 // PERSISTENT blocks, two per CU (the launch asks for enough LDS that a third does not fit): a block walks its list of tiles with the
 // (tile, chunk) sequence flattened -- the first chunk of the next tile is fetched during the last MFMAs of the current one and is in
 // flight during its epilogue, instead of a 2 us fetch with nothing to hide behind at the start of each of the 2560 blocks.
@@ -223,9 +221,10 @@ extern "C" int lsim_linear_elu_forward(const float* x, int64_t ldx, const float*
     if (!ls_linear_fwd_supported((long)batch, k_in, n_out) || ldo % 4 != 0 || (((uintptr_t)out & 15) != 0))
         return LSIM_E_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    // feature tile = a quarter of the layer (see the kernel's comment), at most 128 wide
-    if (n_out > 256) ls_linear_fwd_launch<5, 4, 32, true>(x, (long)ldx, weight, bias, (long)batch, k_in, n_out, out, (long)ldo, s);
-    else if (n_out > 128) ls_linear_fwd_launch<5, 2, 64, true>(x, (long)ldx, weight, bias, (long)batch, k_in, n_out, out, (long)ldo, s);
-    else ls_linear_fwd_launch<5, LS_FWD_TN128, 64, true>(x, (long)ldx, weight, bias, (long)batch, k_in, n_out, out, (long)ldo, s);
+    // feature tile: 128 wide from 256 features on -- 512 -> 256 with 64-wide tiles (2560 tiles, 5 per block) read the sample rows through L2
+    // four times and ran at 267 us next to 246 with 128-wide ones (1280 tiles, 3 or 2 per block): the L2 -> LDS traffic costs more than
+    // the uneven split.  Narrow layers keep 64 (128 would leave 640 tiles for 512 blocks).
+    if (n_out > 128) ls_linear_fwd_launch<5, 4, 32, true>(x, (long)ldx, weight, bias, (long)batch, k_in, n_out, out, (long)ldo, s);
+    else ls_linear_fwd_launch<5, 2, 64, true>(x, (long)ldx, weight, bias, (long)batch, k_in, n_out, out, (long)ldo, s);
     return hipGetLastError() == hipSuccess ? LSIM_OK : LSIM_E_HIP;
 }

@@ -267,14 +267,10 @@ def _eligible_fused_elu(batch, k_in, n_out):
 
 
 def _fused_forward_wanted(k_in, n_out):
-    """LSIM_ELU_FORWARD: 0 = BLAS + torch ELU everywhere, all = the library kernel wherever it runs, unset = where it measured faster than
-    BLAS + ELU at the minibatch of 102 400 rows (tools/fwd_time.py, profiles/r05_linear_elu_forward.txt)"""
-    mode = os.environ.get("LSIM_ELU_FORWARD", "auto")
-    if mode == "0":
-        return False
-    if mode == "all":
-        return True
-    return k_in <= 128 or (n_out <= 128 and k_in % 4 == 0)
+    """LSIM_ELU_FORWARD=0: BLAS + torch ELU everywhere (A/B hook).  Default: the library kernel for every hidden layer it runs -- alone it is 0.94x to
+    1.66x of BLAS + ELU depending on the layer, in the training loop the update measured 69.8-70.3 ms with it on every layer, 70.2-70.9 ms with BLAS
+    everywhere and 72.5-72.9 ms with it only on the layers where it wins alone (profiles/r05_linear_elu_forward.txt)"""
+    return os.environ.get("LSIM_ELU_FORWARD", "all") != "0"
 
 
 def linear_elu_forward(x, weight, bias):
