@@ -1527,19 +1527,27 @@ extern "C" int lsim_gather_rows(const void* src, int64_t cols, const int64_t* in
     return hipGetLastError() == hipSuccess ? LSIM_OK : LSIM_E_HIP;
 }
 
-// ---- F.normalize(w, dim=-1) in place for a small matrix: one thread per row
-__global__ __launch_bounds__(256) void lsim_k_normalize_rows(float* __restrict__ w, int rows, int cols, float eps) {
-    const int r = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (r >= rows) return;
-    float* p = w + (size_t)r * cols;
-    float ss = 0.0f;
-    for (int c = 0; c < cols; ++c) ss += p[c] * p[c];
+// ---- F.normalize(w, dim=-1) in place for a small matrix: one wave per row, lane = column (+ 64 i): one round trip to memory instead of a
+// serial loop of `cols` dependent iterations per thread (13 us for the 32 x 16 prototypes, in front of every estimator loss)
+__global__ __launch_bounds__(64) void lsim_k_normalize_rows(float* __restrict__ w, int rows, int cols, float eps) {
+    float* p = w + (size_t)blockIdx.x * cols;
+    float v[4], ss = 0.0f;                       // rows * cols <= 4096 and rows >= 1: cols <= 4096 -> looped in chunks of 256
+    for (int c0 = 0; c0 < cols; c0 += 256) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const int c = c0 + threadIdx.x + 64 * i; v[i] = c < cols ? p[c] : 0.0f; ss = fmaf(v[i], v[i], ss); }
+    }
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
     const float d = fmaxf(sqrtf(ss), eps);
-    for (int c = 0; c < cols; ++c) p[c] = p[c] / d;
+    if (cols <= 256) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const int c = threadIdx.x + 64 * i; if (c < cols) p[c] = v[i] / d; }
+    } else {
+        for (int c = threadIdx.x; c < cols; c += 64) p[c] = p[c] / d;
+    }
 }
 extern "C" int lsim_normalize_rows(float* w, int rows, int cols, float eps, void* stream) {
     if (!w || rows <= 0 || cols <= 0 || (long)rows * cols > 4096 || !(eps > 0.0f)) return LSIM_E_INVALID;
-    hipLaunchKernelGGL(lsim_k_normalize_rows, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, rows, cols, eps);
+    hipLaunchKernelGGL(lsim_k_normalize_rows, dim3(rows), dim3(64), 0, (hipStream_t)stream, w, rows, cols, eps);
     return hipGetLastError() == hipSuccess ? LSIM_OK : LSIM_E_HIP;
 }
 
@@ -1661,9 +1669,16 @@ __global__ __launch_bounds__(256) void lsim_k_ppo_loss_finish_std(const float* _
         if (threadIdx.x < 4) m[k] = s / (float)batch;
     } else {
         const int j = threadIdx.x & 63, part = (threadIdx.x >> 6) - 1;
-        float s = 0.0f;
-        if (j < A) for (int i = part; i < blocks; i += 3) s += partial[(size_t)i * nq + 4 + j];
-        acc[part][j] = s;
+        float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};                      // four partial rows in flight (one at a time: 13.6 us for 400 blocks)
+        if (j < A) {
+            int i = part;
+            for (; i + 9 < blocks; i += 12) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) s[u] += partial[(size_t)(i + 3 * u) * nq + 4 + j];
+            }
+            for (; i < blocks; i += 3) s[0] += partial[(size_t)i * nq + 4 + j];
+        }
+        acc[part][j] = (s[0] + s[1]) + (s[2] + s[3]);
     }
     __syncthreads();
     if (threadIdx.x < 4) out[threadIdx.x] = m[threadIdx.x];

@@ -536,6 +536,20 @@ def test_fused_linear_elu_forward_matches_torch(rows, k_in, n_out):
     assert L.lsim_linear_elu_forward(big.data_ptr(), big.stride(0), W.data_ptr(), None, rows, k_in, 10, out.data_ptr(), 12, torch.cuda.current_stream().cuda_stream) == abi.E_UNSUPPORTED
 
 
+@pytest.mark.parametrize("rows,cols", [(32, 16), (64, 32), (5, 300), (1, 4096), (3, 1)])
+def test_normalize_rows_matches_torch(rows, cols):
+    """lsim_normalize_rows = F.normalize(w, dim=-1) in place (HIMEstimator's prototype normalisation before every loss, HES:83-86), one wave per row"""
+    import torch.nn.functional as F
+    from isaacgymloco_amd import lib
+    g = torch.Generator(device="cuda:0").manual_seed(rows * 131 + cols)
+    w = torch.randn(rows, cols, device="cuda:0", generator=g) * 3.0
+    if rows > 2:
+        w[1].zero_()                                   # a zero row stays zero (the 1e-12 floor of F.normalize)
+    want = F.normalize(w.double(), dim=-1, p=2, eps=1e-12)
+    lib.check(lib.load().lsim_normalize_rows(w.data_ptr(), rows, cols, 1e-12, torch.cuda.current_stream().cuda_stream), what="lsim_normalize_rows")
+    assert float((w.double() - want).abs().max()) < 5e-7
+
+
 def test_reference_style_step_tuple_and_strict_runner_path():
     """LeggedRobot.step (LR:122-176): the 7-tuple (8 with AMP) with data-dependent shapes, consistent with step_device on a twin env; and
     the runner's strict path (fast=False: the reference's call sequence incl. the next_critic_obs[termination_ids] patch, HIMR:119-123)
