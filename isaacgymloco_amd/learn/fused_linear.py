@@ -267,10 +267,15 @@ def _eligible_fused_elu(batch, k_in, n_out):
 
 
 def _fused_forward_wanted(k_in, n_out):
-    """LSIM_ELU_FORWARD=0: BLAS + torch ELU everywhere (A/B hook).  Default: the library kernel for every hidden layer it runs -- alone it is 0.94x to
-    1.66x of BLAS + ELU depending on the layer, in the training loop the update measured 69.8-70.3 ms with it on every layer, 70.2-70.9 ms with BLAS
-    everywhere and 72.5-72.9 ms with it only on the layers where it wins alone (profiles/r05_linear_elu_forward.txt)"""
-    return os.environ.get("LSIM_ELU_FORWARD", "all") != "0"
+    """Default: the library kernel for the hidden layers whose rows are 16-byte aligned (k_in % 4 == 0: 64 -> 512, 512 -> 256, 256 -> 128, 128 -> 64); the
+    238- / 270- / 45-wide first layers stay on BLAS + torch ELU -- their 8- and 4-byte loads double and quadruple the kernel's fetch instructions, and the
+    fetch is what bounds it (in the training loop's trace 238 -> 512 took 415 us against ~325 for BLAS + ELU).  Update in the loop, interleaved on one lease:
+    66.9-67.3 ms this way, 69.0-71.4 with the kernel on every hidden layer, 69.8-70.5 with BLAS + ELU everywhere (profiles/r05_linear_elu_forward.txt).
+    LSIM_ELU_FORWARD=0 / all: A/B switches"""
+    mode = os.environ.get("LSIM_ELU_FORWARD", "aligned")
+    if mode == "aligned":
+        return k_in % 4 == 0
+    return mode != "0"
 
 
 def linear_elu_forward(x, weight, bias):
