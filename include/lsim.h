@@ -623,6 +623,9 @@ int lsim_wgrad_reduce_batch(const lsim_wgrad_pending* items, int n, void* stream
  * shuffle of the rollout storage through the minibatch permutation (HST:140-164) at copy bandwidth -- torch's advanced indexing computes an
  * offset per element (2.6 TB/s on these row widths). */
 int lsim_gather_rows(const void* src, int64_t cols, const int64_t* index, int64_t n, void* dst, void* stream);
+/* the same with destination rows `dst_ld` elements apart (dst_ld >= cols; elements cols .. dst_ld - 1 of a row are left alone): HIMRolloutStorage keeps its
+ * shuffled observation fields in rows padded to 16 bytes so that the first layers of the networks read aligned rows */
+int lsim_gather_rows_ld(const void* src, int64_t cols, const int64_t* index, int64_t n, void* dst, int64_t dst_ld, void* stream);
 
 /* w[r, :] /= max(||w[r, :]||_2, eps) in place for a small matrix (rows * cols <= 4096): torch.nn.functional.normalize(w, dim=-1, p=2, eps) written
  * back, as HIMEstimator.update does with its prototypes before every loss evaluation (HES:80-81) -- one launch instead of clone, norm, clamp,

@@ -1467,12 +1467,12 @@ extern "C" int lsim_estimator_loss(const float* enc_out, int64_t ld_enc, const f
 
 // ---- row gather: block = 256 / CPT rows x CPT column lanes (CPT = the row width rounded up to a power of two, at most 256)
 __global__ __launch_bounds__(256) void lsim_k_gather_rows(const uint32_t* __restrict__ src, long cols, const long long* __restrict__ index, long n,
-                                                          uint32_t* __restrict__ dst, int cpt_log2) {
+                                                          uint32_t* __restrict__ dst, long dst_ld, int cpt_log2) {
     const int cpt = 1 << cpt_log2, rpb = 256 >> cpt_log2;
     const long r = (long)blockIdx.x * rpb + (threadIdx.x >> cpt_log2);
     if (r >= n) return;
     const uint32_t* s = src + (size_t)index[r] * cols;
-    uint32_t* d = dst + (size_t)r * cols;
+    uint32_t* d = dst + (size_t)r * dst_ld;
     for (long c = threadIdx.x & (cpt - 1); c < cols; c += cpt) d[c] = s[c];
 }
 // wide rows (the observation fields: 238 / 270 floats): one WAVE per row, 8-byte elements, four rows of a wave in flight at once, a resident
@@ -1480,7 +1480,7 @@ __global__ __launch_bounds__(256) void lsim_k_gather_rows(const uint32_t* __rest
 // copies each ran at 2.2 TB/s over the ten fields of a shuffle (1.18 ms per update, r05_kernel_stats_train.csv).]
 #define LS_GATHER_MAXC 3          // 64-lane chunks of 8-byte elements per row: rows up to 384 floats
 __global__ __launch_bounds__(256) void lsim_k_gather_rows_wide(const uint2* __restrict__ src, long cols2, const long long* __restrict__ index, long n,
-                                                               uint2* __restrict__ dst) {
+                                                               uint2* __restrict__ dst, long dst_ld2) {
     constexpr int U = 4;
     const int lane = threadIdx.x & 63;
     const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
@@ -1499,7 +1499,7 @@ __global__ __launch_bounds__(256) void lsim_k_gather_rows_wide(const uint2* __re
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (r0 + u >= n) break;
-            uint2* d = dst + (size_t)(r0 + u) * cols2;
+            uint2* d = dst + (size_t)(r0 + u) * dst_ld2;
 #pragma unroll
             for (int m = 0; m < LS_GATHER_MAXC; ++m) {
                 const long c = lane + 64 * m;
@@ -1508,23 +1508,26 @@ __global__ __launch_bounds__(256) void lsim_k_gather_rows_wide(const uint2* __re
         }
     }
 }
-extern "C" int lsim_gather_rows(const void* src, int64_t cols, const int64_t* index, int64_t n, void* dst, void* stream) {
-    if (!src || !index || !dst || cols <= 0 || n < 0) return LSIM_E_INVALID;
+extern "C" int lsim_gather_rows_ld(const void* src, int64_t cols, const int64_t* index, int64_t n, void* dst, int64_t dst_ld, void* stream) {
+    if (!src || !index || !dst || cols <= 0 || n < 0 || dst_ld < cols) return LSIM_E_INVALID;
     if (n == 0) return LSIM_OK;
-    if (cols >= 64 && cols % 2 == 0 && cols <= 128 * LS_GATHER_MAXC && (((uintptr_t)src | (uintptr_t)dst) & 7) == 0) {
+    if (cols >= 64 && cols % 2 == 0 && dst_ld % 2 == 0 && cols <= 128 * LS_GATHER_MAXC && (((uintptr_t)src | (uintptr_t)dst) & 7) == 0) {
         const long waves = (n + 3) / 4;
         long blocks = (waves + 3) / 4;
         if (blocks > 2048) blocks = 2048;           // 8 192 waves: 32 per CU
         hipLaunchKernelGGL(lsim_k_gather_rows_wide, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint2*)src, (long)(cols / 2),
-                           (const long long*)index, (long)n, (uint2*)dst);
+                           (const long long*)index, (long)n, (uint2*)dst, (long)(dst_ld / 2));
         return hipGetLastError() == hipSuccess ? LSIM_OK : LSIM_E_HIP;
     }
     int lg = 0;
     while ((1 << lg) < cols && lg < 8) ++lg;
     const long rpb = 256 >> lg;
     hipLaunchKernelGGL(lsim_k_gather_rows, dim3((unsigned)((n + rpb - 1) / rpb)), dim3(256), 0, (hipStream_t)stream, (const uint32_t*)src, (long)cols,
-                       (const long long*)index, (long)n, (uint32_t*)dst, lg);
+                       (const long long*)index, (long)n, (uint32_t*)dst, (long)dst_ld, lg);
     return hipGetLastError() == hipSuccess ? LSIM_OK : LSIM_E_HIP;
+}
+extern "C" int lsim_gather_rows(const void* src, int64_t cols, const int64_t* index, int64_t n, void* dst, void* stream) {
+    return lsim_gather_rows_ld(src, cols, index, n, dst, cols, stream);
 }
 
 // ---- F.normalize(w, dim=-1) in place for a small matrix: one wave per row, lane = column (+ 64 i): one round trip to memory instead of a

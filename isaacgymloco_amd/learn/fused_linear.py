@@ -266,7 +266,7 @@ def _eligible_fused_elu(batch, k_in, n_out):
     return _eligible(batch, k_in, n_out) and k_in * n_out > 4096
 
 
-def _fused_forward_wanted(k_in, n_out):
+def _fused_forward_wanted(x, k_in):
     """Default: the library kernel for the hidden layers whose rows are 16-byte aligned (k_in % 4 == 0: 64 -> 512, 512 -> 256, 256 -> 128, 128 -> 64); the
     238- / 270- / 45-wide first layers stay on BLAS + torch ELU -- their 8- and 4-byte loads double and quadruple the kernel's fetch instructions, and the
     fetch is what bounds it (in the training loop's trace 238 -> 512 took 415 us against ~325 for BLAS + ELU).  Update in the loop, interleaved on one lease:
@@ -274,7 +274,7 @@ def _fused_forward_wanted(k_in, n_out):
     LSIM_ELU_FORWARD=0 / all: A/B switches"""
     mode = os.environ.get("LSIM_ELU_FORWARD", "aligned")
     if mode == "aligned":
-        return k_in % 4 == 0
+        return k_in % 4 == 0 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
     return mode != "0"
 
 
@@ -282,9 +282,9 @@ def linear_elu_forward(x, weight, bias):
     """elu(x W^T + b): lsim_linear_elu_forward (fp32 MFMA, the activation applied to the accumulators, one write of the output) where it is
     the faster form, else BLAS + torch's elementwise ELU"""
     if (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and weight.dtype == torch.float32 and weight.is_contiguous() and weight.shape[0] % 4 == 0
-            and _fused_forward_wanted(weight.shape[1], weight.shape[0])):
+            and x.stride(1) == 1 and _fused_forward_wanted(x, weight.shape[1])):
         from .. import abi, lib
-        xx = x if x.stride(1) == 1 else x.contiguous()
+        xx = x
         z = torch.empty(x.shape[0], weight.shape[0], device=x.device, dtype=torch.float32)
         b = bias.detach() if bias is not None else None
         rc = lib.load().lsim_linear_elu_forward(xx.data_ptr(), xx.stride(0), weight.data_ptr(), b.data_ptr() if b is not None else None, x.shape[0],

@@ -143,7 +143,9 @@ class HIMRolloutStorage:
 
     def _shuffle(self, fields, perm):
         """every field gathered through the permutation.  On the GPU the destinations are PERSISTENT buffers (allocated at the first call):
-        minibatch i of every update lives at the same addresses and the update stops allocating 0.4 GB per call"""
+        minibatch i of every update lives at the same addresses and the update stops allocating 0.4 GB per call.
+        (Rows of the 238- / 270-wide observation fields padded to 16 bytes, so that the first layers read aligned rows, were measured in round 5
+        and cost the update 1 ms: the BLAS kernels of those layers are TunableOp-selected per leading dimension)"""
         if not fields[0].is_cuda:
             return tuple(_gather_rows(f, perm) for f in fields)
         bufs = getattr(self, "_shuffled", None)
@@ -156,7 +158,7 @@ class HIMRolloutStorage:
 
 def _gather_rows(f, perm, out=None):
     """f[perm] for a contiguous tensor of 4-byte elements on the GPU through lsim_gather_rows (rows at copy bandwidth); anything else: f[perm].
-    `out`: destination to fill (and return) instead of a fresh tensor"""
+    `out`: destination to fill (and return) instead of a fresh tensor; a 2-D `out` may have rows further apart than its width"""
     if not (f.is_cuda and f.is_contiguous() and f.element_size() == 4 and f.dim() >= 1 and perm.dtype == torch.int64 and perm.is_contiguous()):
         if out is None:
             return f[perm]
@@ -166,7 +168,11 @@ def _gather_rows(f, perm, out=None):
     cols = f[0].numel() if f.dim() > 1 else 1
     if out is None:
         out = torch.empty((perm.numel(),) + tuple(f.shape[1:]), dtype=f.dtype, device=f.device)
-    lib.check(lib.load().lsim_gather_rows(f.data_ptr(), cols, perm.data_ptr(), perm.numel(), out.data_ptr(), torch.cuda.current_stream(f.device).cuda_stream),
-              what="lsim_gather_rows")
+    if out.is_contiguous():
+        ld = cols
+    else:
+        assert out.dim() == 2 and out.stride(1) == 1 and out.stride(0) >= cols, "destination rows must be dense"
+        ld = out.stride(0)
+    lib.check(lib.load().lsim_gather_rows_ld(f.data_ptr(), cols, perm.data_ptr(), perm.numel(), out.data_ptr(), ld, torch.cuda.current_stream(f.device).cuda_stream),
+              what="lsim_gather_rows_ld")
     return out
-

@@ -84,6 +84,7 @@ def load_path(path):
     L.lsim_wgrad_reduce_batch.argtypes = [pend, i32, vp]
     L.lsim_normalize_rows.argtypes = [vp, i32, i32, f32, vp]
     L.lsim_gather_rows.argtypes = [vp, i64, vp, i64, vp, vp]
+    L.lsim_gather_rows_ld.argtypes = [vp, i64, vp, i64, vp, i64, vp]
     L.lsim_destroy.argtypes = [vp]
     L.lsim_destroy.restype = None
     return L

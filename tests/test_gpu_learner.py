@@ -515,7 +515,9 @@ def test_fused_linear_elu_forward_matches_torch(rows, k_in, n_out):
     big = torch.randn(rows, k_in + 5, device="cuda:0", generator=g)
     W = torch.randn(n_out, k_in, device="cuda:0", generator=g) / k_in ** 0.5
     b = torch.randn(n_out, device="cuda:0", generator=g) * 0.3
-    for x, bias in ((big[:, :k_in].contiguous(), b), (big[:, 1:1 + k_in], None)):          # the second: rows k_in + 5 apart, starting 4 bytes into the allocation
+    padded = torch.full((rows, (k_in + 3) // 4 * 4 + 4), float("nan"), device="cuda:0")       # rows further apart than their width: what lies behind a row is not read as data
+    padded[:, :k_in] = big[:, :k_in]
+    for x, bias in ((big[:, :k_in].contiguous(), b), (big[:, 1:1 + k_in], None), (padded[:, :k_in], b)):    # the second: rows k_in + 5 apart, starting 4 bytes into the allocation
         out = torch.full((rows, n_out), float("nan"), device="cuda:0")
         rc = L.lsim_linear_elu_forward(x.data_ptr(), x.stride(0), W.data_ptr(), bias.data_ptr() if bias is not None else None, rows, k_in, n_out, out.data_ptr(),
                                        out.stride(0), torch.cuda.current_stream().cuda_stream)
@@ -1071,7 +1073,13 @@ def test_gather_rows_equals_advanced_indexing():
     b = torch.randint(0, 2, (500, 1), device="cuda:0", dtype=torch.uint8)          # not 4-byte elements: the torch statement
     perm = torch.randperm(500, device="cuda:0")
     assert torch.equal(_gather_rows(b, perm), b[perm])
-
+    # destination rows further apart than their width (lsim_gather_rows_ld): the columns in between are left alone
+    for rows, cols, ld in ((4099, 238, 240), (5000, 270, 272), (1000, 45, 48), (77, 12, 16)):
+        f = torch.randn(rows, cols, device="cuda:0", generator=g)
+        perm = torch.randperm(rows - 3, device="cuda:0")
+        buf = torch.full((rows - 3, ld), 7.0, device="cuda:0")
+        out = _gather_rows(f, perm, out=buf[:, :cols])
+        assert out.data_ptr() == buf.data_ptr() and torch.equal(out, f[perm]) and bool((buf[:, cols:] == 7.0).all()), (rows, cols, ld)
 
 
 @pytest.mark.parametrize("k_in,n_out,B", [(512, 256, 102400), (256, 128, 102400), (128, 128, 20480 + 12), (512, 256, 4099)])
