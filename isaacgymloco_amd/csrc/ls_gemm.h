@@ -17,6 +17,15 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// exp of the ELU epilogue: the hardware exponential (v_exp_f32 of x log2 e: 1 ulp of 2^x, absolute error of elu(x) <= 2e-7 for x <= 0) instead of
+// the library expf (a dozen instructions with range reduction): 80 accumulators per wave and tile make the epilogue 5 % (512 -> 256) to 40 %
+// (64 -> 512, K = 64: 320 MFMAs per tile) of a tile's instruction stream.  -DLS_FWD_PRECISE_EXP: expf
+#if defined(LS_FWD_PRECISE_EXP)
+#define LS_FWD_EXP(x) expf(x)
+#else
+#define LS_FWD_EXP(x) __expf(x)
+#endif
+
 
 
 // stage one BK-wide chunk of ROWS rows (global, row-major, leading dimension ld) in registers: thread t takes k-quad (t & 7) of rows
@@ -177,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void lsim_k_linear_fwd(const float* __restr
                 float e[4] = {acc[a][b][0] + bv.x, acc[a][b][1] + bv.y, acc[a][b][2] + bv.z, acc[a][b][3] + bv.w};
                 if (ELU) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) e[j] = e[j] > 0.0f ? e[j] : expf(e[j]) - 1.0f;       // torch's elu_kernel: exp(x) - 1, not expm1
+                    for (int j = 0; j < 4; ++j) e[j] = e[j] > 0.0f ? e[j] : LS_FWD_EXP(e[j]) - 1.0f;  // torch's elu_kernel: exp(x) - 1, not expm1
                 }
                 if (nok && m < M) *(float4*)(out + m * ldo + n) = make_float4(e[0], e[1], e[2], e[3]);
                 acc[a][b] = (ls_v4f){0.0f, 0.0f, 0.0f, 0.0f};
