@@ -1,3 +1,5 @@
+#!/bin/bash
+# eight consecutive default-size train lines with the per-iteration update times (is the update stable from run to run on this lease?)   usage: bash tools/gpu_multi_train.sh
 for i in 1 2 3 4 5 6 7 8; do python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "
 import sys, json
 j = json.loads(sys.stdin.read().strip().splitlines()[-1])
