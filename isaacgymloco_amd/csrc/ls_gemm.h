@@ -214,10 +214,8 @@ static void ls_linear_fwd_launch(const float* x, long ldx, const float* W, const
     const int vw = ((K % 4 == 0) && (((uintptr_t)W & 15) == 0)) ? 2 : ((K % 2 == 0) && (((uintptr_t)W & 7) == 0)) ? 1 : 0;
     constexpr size_t tile_bytes = (size_t)(BM + BN) * (BK + 4) * sizeof(float);
     constexpr size_t lds = tile_bytes > 56 * 1024 ? tile_bytes : 56 * 1024;       // three blocks would need 168 KB: exactly two per CU
-#define LS_F(VX, VW) do { \
-        static bool big = false;       /* more than 64 KB of LDS per block has to be asked for once per kernel */ \
-        if (!big) { (void)hipFuncSetAttribute((const void*)lsim_k_linear_fwd<TM, TN, BK, VX, VW, ELU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); big = true; } \
-        hipLaunchKernelGGL((lsim_k_linear_fwd<TM, TN, BK, VX, VW, ELU>), grid, threads, lds, s, x, ldx, W, bias, M, K, N, out, ldo, n_tiles, total); } while (0)
+    static_assert(lds <= 64 * 1024, "above 64 KB of dynamic LDS the kernel needs hipFuncAttributeMaxDynamicSharedMemorySize, per device");
+#define LS_F(VX, VW) hipLaunchKernelGGL((lsim_k_linear_fwd<TM, TN, BK, VX, VW, ELU>), grid, threads, lds, s, x, ldx, W, bias, M, K, N, out, ldo, n_tiles, total)
     if (vx == 2 && vw == 2) LS_F(2, 2);
     else if (vx >= 1 && vw >= 1) LS_F(1, 1);
     else LS_F(0, 0);
