@@ -142,6 +142,9 @@ def run_train_bench(env, cfg, args, dev, rank, world, barrier, clocks=None):
              "iteration_spread_frac": (walls[-1] - walls[0]) / med,
              "value_from_median_iteration": world * env.num_envs * T / med,
              "update_two_streams": two_streams, "tunableop": tun,
+             # which form the hidden layers' forward ran in (learn/fused_linear.py: linear_elu_forward): "aligned" = the library's MFMA kernel with bias + ELU in
+             # the epilogue on the layers with 16-byte-aligned rows, BLAS + torch ELU on the rest; "0" = BLAS + ELU everywhere; "all"
+             "linear_elu_forward": os.environ.get("LSIM_ELU_FORWARD", "aligned"),
              "sclk_during_timed_region": sclk}
     workload = (f"{task}: {type(runner).__name__} loop, {iters} whole PPO iteration(s) timed, each = {T} x (policy inference + LeggedRobot.step + "
                 f"storage) + GAE + {type(alg).__name__}.update ({alg.num_learning_epochs} epochs x {alg.num_mini_batches} minibatches), "

@@ -68,7 +68,7 @@ def test_the_line_explains_its_update_and_announces_a_rejected_gemm_table():
     assert t["enabled"] and t["validators_match"] is False and "PT_VERSION" in t["validator_mismatches"]
     assert t["explicit_solutions_loaded"] == 0 and j["update_two_streams"] is False
     assert j["ppo_updates_timed"] >= 10 and j["iteration_spread_frac"] < 0.2
-    assert j["gemm_probe_after_timed_region"]["tflops"] > 20 and "gpu_max_hw_queues" in j
+    assert j["gemm_probe_after_timed_region"]["tflops"] > 20 and "gpu_max_hw_queues" in j and j["linear_elu_forward"] == "aligned"
     s = j["sclk_during_timed_region"]
     assert s["mean_mhz"] is None or 300 < s["mean_mhz"] < 3000
 
