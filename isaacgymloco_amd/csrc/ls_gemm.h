@@ -20,6 +20,9 @@
 // exp of the ELU epilogue: the hardware exponential (v_exp_f32 of x log2 e: 1 ulp of 2^x, absolute error of elu(x) <= 2e-7 for x <= 0) instead of
 // the library expf (a dozen instructions with range reduction): 80 accumulators per wave and tile make the epilogue 5 % (512 -> 256) to 40 %
 // (64 -> 512, K = 64: 320 MFMAs per tile) of a tile's instruction stream.  -DLS_FWD_PRECISE_EXP: expf
+#if !defined(LS_FWD_NARROW_BK)
+#define LS_FWD_NARROW_BK 32          // K chunk of the 64-wide feature tiles (64 measured 2-7 % slower on 256 -> 128 and 128 -> 64, 1.6 x slower on the scalar-load form)
+#endif
 #if defined(LS_FWD_PRECISE_EXP)
 #define LS_FWD_EXP(x) expf(x)
 #else
@@ -232,6 +235,6 @@ extern "C" int lsim_linear_elu_forward(const float* x, int64_t ldx, const float*
     // four times and ran at 267 us next to 246 with 128-wide ones (1280 tiles, 3 or 2 per block): the L2 -> LDS traffic costs more than
     // the uneven split.  Narrow layers keep 64 (128 would leave 640 tiles for 512 blocks).
     if (n_out > 128) ls_linear_fwd_launch<5, 4, 32, true>(x, (long)ldx, weight, bias, (long)batch, k_in, n_out, out, (long)ldo, s);
-    else ls_linear_fwd_launch<5, 2, 64, true>(x, (long)ldx, weight, bias, (long)batch, k_in, n_out, out, (long)ldo, s);
+    else ls_linear_fwd_launch<5, 2, LS_FWD_NARROW_BK, true>(x, (long)ldx, weight, bias, (long)batch, k_in, n_out, out, (long)ldo, s);
     return hipGetLastError() == hipSuccess ? LSIM_OK : LSIM_E_HIP;
 }
