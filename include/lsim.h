@@ -564,6 +564,37 @@ int lsim_policy_act_post_at(const lsim_him_policy* p, const lsim_rollout_storage
                             int64_t prev_step, const uint8_t* prev_dones, const uint8_t* prev_time_outs, const float* prev_rewards,
                             const float* prev_term_priv_obs, float gamma, void* stream);
 
+/* ---- the AMP rollout step in one launch (SURVEY.md 8f rank 4 "discriminator reward fused after the step"): what HybridPolicyRunner does between
+ * env.step() and process_env_step() (rsl_rl/runners/hybrid_runner.py:183-200) --
+ *   next' = where(dones, terminal_amp_states, next_amp_obs)                                  HYBR:191-192
+ *   d = head(relu(W2 relu(W1 [norm(amp_obs) | norm(next')] + b1) + b2))                      amp_discriminator.py:55-62, utils/utils.py:124-130
+ *   reward = reward_coef * max(1 - (d - 1)^2 / 4, 0);  lerp > 0: (1 - lerp) * reward + lerp * task_reward     amp_discriminator.py:63-72
+ *   replay ring rows (cursor + env) % capacity <- (amp_obs, next')                            storage/replay_buffer.py:52-68
+ *   amp_obs_carry <- next_amp_obs (the NEXT step's amp_obs, un-patched)                       HYBR:196
+ * The two trunk layers use lsim_mlp_layer's padded 16 x 16-block layout (see lsim_him_policy); head_weight [hidden[1].n_pad] zero padded, head_bias [1];
+ * norm_mean / norm_var: the running moments as the reference keeps them (float64 [amp_dim]; both NULL = no normaliser).
+ * amp_dim <= 32, hidden[0].n_pad <= 1024, hidden[1].n_pad <= 1024; fp32 MFMA, activations in LDS, nothing but the outputs written. */
+typedef struct lsim_amp_disc {
+    lsim_mlp_layer hidden[2];    /* DISC:18-25: Linear + ReLU, Linear + ReLU */
+    const float* head_weight;    /* DISC:27 amp_linear.weight */
+    const float* head_bias;      /* amp_linear.bias [1], device */
+    const double* norm_mean;     /* UT:78-106 */
+    const double* norm_var;
+    double norm_eps, norm_clip;  /* UT:114-116: 1e-4, 10 */
+    double reward_coef, task_reward_lerp;   /* DISC:14-15 (python floats) */
+    int32_t amp_dim, reserved;
+} lsim_amp_disc;
+/* workspace: lsim_amp_step_workspace() bytes, 16-byte aligned, ZERO-FILLED by the caller before its first use (every call leaves it ready for the next).
+ * amp_obs, next_amp_obs, terminal_amp_states [num_envs, amp_dim]; dones u8 [num_envs] or NULL (no patching); task_rewards [num_envs] (may be NULL when
+ * lerp == 0); rewards_out [num_envs]; disc_out [num_envs] or NULL (the discriminator's raw output d); amp_obs_carry [num_envs, amp_dim] or NULL, must not
+ * alias amp_obs; replay_states / replay_next_states [replay_capacity, amp_dim] or both NULL, replay_capacity >= num_envs, 0 <= replay_cursor < capacity
+ * (the caller advances its cursor by num_envs modulo capacity, RB:66-68). */
+int lsim_amp_step_workspace(int64_t num_envs, size_t* bytes);
+int lsim_amp_step(const lsim_amp_disc* d, const float* amp_obs, const float* next_amp_obs, const uint8_t* dones, const float* terminal_amp_states,
+                  const float* task_rewards, int64_t num_envs, float* rewards_out, float* disc_out, float* amp_obs_carry,
+                  float* replay_states, float* replay_next_states, int64_t replay_capacity, int64_t replay_cursor,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- learner-side kernel: weight / bias gradient of a small Linear layer over a tall minibatch,
  *   dw[n, k] = sum_b g[b, n] * x[b, k],   db[n] = sum_b g[b, n]      (torch.nn.Linear backward: grad_weight = g^T x, grad_bias = g.sum(0))
  * for ceil(n_out / 16) * ceil(k_in / 16) <= 32 (each <= 8): the heads and narrow layers of HAC:66-95 / HES:36-54 / DISC:18-25, whose

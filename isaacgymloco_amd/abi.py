@@ -101,6 +101,7 @@ LsimRolloutStorage = STRUCTS["lsim_rollout_storage"]
 LsimMlpLayer = STRUCTS["lsim_mlp_layer"]
 LsimHimPolicy = STRUCTS["lsim_him_policy"]
 LsimWgradPending = STRUCTS["lsim_wgrad_pending"]
+LsimAmpDisc = STRUCTS["lsim_amp_disc"]
 
 REWARD_IDS = {k[len("LSIM_R_"):].lower(): v for k, v in ENUMS["lsim_reward_id"].items() if k.startswith("LSIM_R_")}
 NUM_REWARD_TERMS = ENUMS["lsim_reward_id"]["LSIM_NUM_REWARD_TERMS"]

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 LIB = os.path.join(HERE, "liblsim.so")
 # two translation units, two flag sets: (source, headers it depends on, extra flags)
 SIM_HEADERS = ["ls_math.h", "ls_shared.h", "ls_physics.h", "ls_post.h", "ls_kernels.h", "ls_api_impl.h"]
-LEARN_HEADERS = ["ls_math.h", "ls_rollout.h", "ls_learn.h", "ls_gemm.h", "ls_policy.h"]
+LEARN_HEADERS = ["ls_math.h", "ls_rollout.h", "ls_learn.h", "ls_gemm.h", "ls_policy.h", "ls_amp.h"]
 # The simulator kernels' time is their vector instruction count, so ITS flags (SIM_FLAGS) are chosen for that:
 # -fno-hip-fp32-correctly-rounded-divide-sqrt: ~150 divisions per sub-step cost ~12 instructions each when IEEE-rounded; quotients that
 #   must be exact use ls_div_exact (ls_math.h)

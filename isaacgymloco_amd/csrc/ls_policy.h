@@ -47,8 +47,6 @@ __device__ __forceinline__ float ls_elu(float x) { return x > 0.0f ? x : expm1f(
 #endif
 
 // one layer for this wave's NTW output tiles [tile0, tile0 + valid) and all RH * 16 rows of the block: every weight vector fetched from
-// L2 feeds RH MFMAs (one per 16-row half), so a block of 32 environments streams half the weight bytes per environment of a block of 16
-// one layer for this wave's NTW output tiles [tile0, tile0 + valid) and all RH * 16 rows of the block: every weight vector fetched from
 // L2 feeds RH MFMAs (one per 16-row half), so a block of 32 environments streams half the weight bytes per environment of a block of 16.
 // The k loop runs over THREE register stages used round-robin (chunk j computes from stage j % 3 while the weight vectors of chunk j + 2 load
 // into stage (j + 2) % 3 and the activation vectors of chunk j + 1 are read from LDS into stage (j + 1) % 3): no register is copied.
@@ -59,19 +57,13 @@ __device__ __forceinline__ float ls_elu(float x) { return x > 0.0f ? x : expm1f(
 // FULL: the wave owns all NTW tiles (every layer of the shipped networks: tile counts are powers of two) -- no per-tile predicate, so the
 // loop body is straight-line code and the compiler's s_waitcnt counters see every load (a load inside a branch makes it wait for all of them)
 template <int NTW, int RH, bool FULL>
-__device__ __noinline__ void ls_pol_layer(const float* __restrict__ W, const float* __restrict__ bias, int k_pad_in, int x_off, int x_stride,
-                                          int y_off, int y_stride, int tile0_in, int valid_in, int elu_in, int lane) {
-    // arguments of a non-inlined function arrive in vector registers; these are wave-uniform: scalar registers make the loop's bounds tests
-    // scalar branches (s_cbranch_scc) instead of exec-mask manipulation around every guarded load
-    const int k_pad = __builtin_amdgcn_readfirstlane(k_pad_in), tile0 = __builtin_amdgcn_readfirstlane(tile0_in), elu = __builtin_amdgcn_readfirstlane(elu_in);
-    const int valid = FULL ? NTW : __builtin_amdgcn_readfirstlane(valid_in);
+__device__ __forceinline__ void ls_pol_accumulate(const float* __restrict__ W, const float* __restrict__ bias, int k_pad, int x_off, int x_stride,
+                                                  int tile0, int valid, int lane, ls_v4f (&acc)[NTW][RH], float4 (&b)[NTW]) {
     const int i = lane & 15, q = lane >> 4;
-    ls_v4f acc[NTW][RH];
 #pragma unroll
     for (int t = 0; t < NTW; ++t)
 #pragma unroll
         for (int h = 0; h < RH; ++h) acc[t][h] = (ls_v4f){0.0f, 0.0f, 0.0f, 0.0f};
-    float4 b[NTW];
 #pragma unroll
     for (int t = 0; t < NTW; ++t) b[t] = make_float4(0, 0, 0, 0);
     if (valid > 0) {
@@ -122,6 +114,23 @@ __device__ __noinline__ void ls_pol_layer(const float* __restrict__ W, const flo
 #undef LS_POL_LDW_G
 #undef LS_POL_LDW_U
     }
+}
+
+// activation codes of a layer's epilogue
+#define LS_POL_ACT_NONE 0
+#define LS_POL_ACT_ELU 1
+#define LS_POL_ACT_RELU 2      /* the AMP discriminator's trunk (ls_amp.h) */
+template <int NTW, int RH, bool FULL>
+__device__ __noinline__ void ls_pol_layer(const float* __restrict__ W, const float* __restrict__ bias, int k_pad_in, int x_off, int x_stride,
+                                          int y_off, int y_stride, int tile0_in, int valid_in, int elu_in, int lane) {
+    // arguments of a non-inlined function arrive in vector registers; these are wave-uniform: scalar registers make the loop's bounds tests
+    // scalar branches (s_cbranch_scc) instead of exec-mask manipulation around every guarded load
+    const int k_pad = __builtin_amdgcn_readfirstlane(k_pad_in), tile0 = __builtin_amdgcn_readfirstlane(tile0_in), elu = __builtin_amdgcn_readfirstlane(elu_in);
+    const int valid = FULL ? NTW : __builtin_amdgcn_readfirstlane(valid_in);
+    const int i = lane & 15, q = lane >> 4;
+    ls_v4f acc[NTW][RH];
+    float4 b[NTW];
+    ls_pol_accumulate<NTW, RH, FULL>(W, bias, k_pad, x_off, x_stride, tile0, valid, lane, acc, b);
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
         if (FULL || t < valid) {
@@ -129,7 +138,8 @@ __device__ __noinline__ void ls_pol_layer(const float* __restrict__ W, const flo
 #pragma unroll
             for (int h = 0; h < RH; ++h) {
                 float4 y = make_float4(acc[t][h][0] + b[t].x, acc[t][h][1] + b[t].y, acc[t][h][2] + b[t].z, acc[t][h][3] + b[t].w);
-                if (elu) { y.x = ls_elu(y.x); y.y = ls_elu(y.y); y.z = ls_elu(y.z); y.w = ls_elu(y.w); }
+                if (elu == LS_POL_ACT_ELU) { y.x = ls_elu(y.x); y.y = ls_elu(y.y); y.z = ls_elu(y.z); y.w = ls_elu(y.w); }
+                else if (elu == LS_POL_ACT_RELU) { y.x = fmaxf(y.x, 0.0f); y.y = fmaxf(y.y, 0.0f); y.z = fmaxf(y.z, 0.0f); y.w = fmaxf(y.w, 0.0f); }
                 *(float4*)(ls_pol_lds + y_off + (i + 16 * h) * y_stride + n_lds) = y;
             }
         }

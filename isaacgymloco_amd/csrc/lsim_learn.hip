@@ -12,3 +12,4 @@
 #include "ls_learn.h"
 #include "ls_gemm.h"
 #include "ls_policy.h"
+#include "ls_amp.h"

@@ -182,6 +182,15 @@ class ReplayBuffer:
         self.num_samples = min(self.buffer_size, max(end, self.num_samples))
         self.step = (self.step + n) % self.buffer_size
 
+    def reserve(self, n):
+        """the bookkeeping of insert() for n rows written by someone else (lsim_amp_step fills ring rows (cursor + i) % size): returns the cursor"""
+        if n > self.buffer_size:
+            raise ValueError("more rows than the ring holds")
+        cur = self.step
+        self.num_samples = min(self.buffer_size, max(cur + n, self.num_samples))
+        self.step = (cur + n) % self.buffer_size
+        return cur
+
     def feed_forward_generator(self, num_mini_batch, mini_batch_size):   # RB:70-74
         for _ in range(num_mini_batch):
             idx = torch.from_numpy(np.random.choice(self.num_samples, size=mini_batch_size)).to(self.device)

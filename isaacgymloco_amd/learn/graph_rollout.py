@@ -160,26 +160,53 @@ class GraphedRollout:
 class HybridFusedRollout(GraphedRollout):
     """The same device-side rollout step for HybridPolicyRunner (AMP, HYBR:118-152): between the simulator step and the storage write
     the task reward is blended with the discriminator's style reward on (amp_obs, next_amp_obs) -- terminal AMP states patched in for
-    resetting envs (HYBR:136-140) -- and the pair goes into the AMP replay buffer (HYBP:121-124).  Those pieces stay torch ops."""
+    resetting envs (HYBR:136-140) -- and the pair goes into the AMP replay buffer (HYBP:121-124).  ONE launch: lsim_amp_step
+    (learn/fused_amp.py; csrc/ls_amp.h) normalises, runs the discriminator on the matrix cores, writes the blended reward row the next policy
+    launch stores, the replay ring rows and the next step's AMP observation.  Discriminator shapes the kernel does not take (or
+    LSIM_AMP_FUSED_STEP=0, the A/B switch) run the same statements as torch ops."""
 
     def __init__(self, runner):
         super().__init__(runner)
-        self._amp_obs = self.env.get_amp_observations().clone()
-        self.rewards = torch.zeros(self.env.num_envs, device=self.dev)
+        import os
+        from .fused_amp import PackedAmpDisc
+        N = self.env.num_envs
+        first = self.env.get_amp_observations()
+        self._amp_bufs = [first.clone(), torch.empty_like(first)]      # ping-pong: the kernel reads one as amp_obs and fills the other with next_amp_obs
+        self._cur = 0
+        self.rewards = torch.zeros(N, device=self.dev)
+        self.disc_out = torch.zeros(N, device=self.dev)
+        disc = self.alg.discriminator
+        ok = os.environ.get("LSIM_AMP_FUSED_STEP") != "0" and PackedAmpDisc.supported(disc) and self.alg.amp_storage.buffer_size >= N
+        self.packed_disc = PackedAmpDisc(disc, self.alg.amp_normalizer, N) if ok else None
+
+    @property
+    def _amp_obs(self):
+        return self._amp_bufs[self._cur]
+
+    def _sync_weights(self):
+        if self._weights_stale and self.packed_disc is not None:
+            self.packed_disc.refresh()
+        super()._sync_weights()
 
     def step(self):
         env, alg = self.env, self.alg
-        amp_obs = self._amp_obs
+        amp_obs = self._amp_bufs[self._cur]
         self._sync_weights()
         if self.packed is not None:
             self._act()
         else:
             self.graph_a.replay()
         env.step_device(self.actions)
-        next_amp = env.get_amp_observations().clone()
-        next_with_term = torch.where(env.reset_buf.unsqueeze(1), env.terminal_amp_states_buf, next_amp)
-        self.rewards.copy_(alg.discriminator.predict_amp_reward(amp_obs, next_with_term, env.rew_buf, normalizer=alg.amp_normalizer)[0])
-        alg.amp_storage.insert(amp_obs, next_with_term)
+        if self.packed_disc is not None:
+            with lib.roctx_range("amp_step"):
+                self.packed_disc.step(amp_obs, env.get_amp_observations(), env.reset_buf, env.terminal_amp_states_buf, env.rew_buf, self.rewards,
+                                      disc_out=self.disc_out, carry=self._amp_bufs[self._cur ^ 1], replay=alg.amp_storage)
+        else:
+            next_amp = env.get_amp_observations()
+            next_with_term = torch.where(env.reset_buf.unsqueeze(1), env.terminal_amp_states_buf, next_amp)
+            self.rewards.copy_(alg.discriminator.predict_amp_reward(amp_obs, next_with_term, env.rew_buf, normalizer=alg.amp_normalizer)[0])
+            alg.amp_storage.insert(amp_obs, next_with_term)
+            self._amp_bufs[self._cur ^ 1].copy_(next_amp)
+        self._cur ^= 1
         self._post(self.rewards)
-        self._amp_obs = next_amp
         self.storage.step += 1

@@ -85,6 +85,8 @@ def load_path(path):
     L.lsim_normalize_rows.argtypes = [vp, i32, i32, f32, vp]
     L.lsim_gather_rows.argtypes = [vp, i64, vp, i64, vp, vp]
     L.lsim_gather_rows_ld.argtypes = [vp, i64, vp, i64, vp, i64, vp]
+    L.lsim_amp_step_workspace.argtypes = [i64, ctypes.POINTER(ctypes.c_size_t)]
+    L.lsim_amp_step.argtypes = [ctypes.POINTER(abi.LsimAmpDisc), vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, i64, i64, vp, ctypes.c_size_t, vp]
     L.lsim_destroy.argtypes = [vp]
     L.lsim_destroy.restype = None
     return L
