@@ -625,6 +625,35 @@ int lsim_linear_elu_forward(const float* x, int64_t ldx, const float* weight, co
 int lsim_linear_elu_wgrad(const float* x, int64_t ldx, const float* grad_out, int64_t ldg, const float* elu_out, int64_t ldz, int64_t batch,
                           int k_in, int n_out, float* dw, float* db, float* grad_pre, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same for a Linear layer followed by ReLU (the AMP discriminator's trunk, amp_discriminator.py:18-25), given the saved ReLU OUTPUT:
+ * grad_pre = grad_out * [relu_out > 0] (torch's threshold_backward). */
+int lsim_linear_relu_wgrad(const float* x, int64_t ldx, const float* grad_out, int64_t ldg, const float* relu_out, int64_t ldz, int64_t batch,
+                           int k_in, int n_out, float* dw, float* db, float* grad_pre, void* workspace, size_t workspace_bytes, void* stream);
+
+/* out[b, n] = mask_src[b, n] > 0 ? sum_k x[b, k] weight[n, k] : 0: a product consumed by a ReLU's backward, mask applied to the accumulators (no
+ * separate threshold_backward pass).  Limits as lsim_linear_elu_forward; mask_src [batch, n_out] with leading dimension ldm % 4 == 0, 16-byte aligned. */
+int lsim_linear_masked_forward(const float* x, int64_t ldx, const float* weight, const float* mask_src, int64_t ldm, int64_t batch, int k_in, int n_out,
+                               float* out, int64_t ldo, void* stream);
+
+/* ---- discriminator update (HybridPPO.update, hybrid_ppo.py:236-281): the elementwise passes between the GEMMs of the LSGAN loss / gradient penalty.
+ * lsim_relu_head_backward: for the head d = relu_out . head_weight + b on relu_out [batch, n] (leading dimension ld) and grad_d [batch] = d loss / d d:
+ *   grad_pre[b, j] = relu_out[b, j] > 0 ? grad_d[b] * head_weight[j] : 0  ([batch, n] contiguous),  grad_bias[j] = sum_b grad_pre[b, j],
+ *   grad_head [n + 4]: [j < n] = sum_b relu_out[b, j] * grad_d[b],  [n] = sum_b grad_d[b], three zeros  -- one pass, sums in a fixed order.
+ * lsim_masked_colsum: out[j] = sum_b (mask_src[b, j] > 0 ? v[b, j] : 0).
+ * n % 4 == 0, n <= 1024, n / 4 a divisor of 256; 16-byte aligned rows; workspace lsim_relu_cols_workspace() bytes.  LSIM_E_UNSUPPORTED otherwise. */
+int lsim_relu_cols_workspace(int64_t batch, int n, size_t* bytes);
+int lsim_relu_head_backward(const float* relu_out, int64_t ld, const float* grad_d, const float* head_weight, int64_t batch, int n,
+                            float* grad_pre, float* grad_bias, float* grad_head, void* workspace, size_t workspace_bytes, void* stream);
+int lsim_masked_colsum(const float* v, int64_t ldv, const float* mask_src, int64_t ldm, int64_t batch, int n, float* out,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* Normalizer.update (utils/utils.py:86-106; twice per minibatch at hybrid_ppo.py:279-281): the batch moments of x [batch, dim <= 64] merged into the
+ * float64 running mean / var / count (device arrays [dim], [dim], [1], updated in place) with the parallel-variance formula; batch sums in float64.
+ * Two launches, no host round trip.  workspace: lsim_running_moments_workspace() bytes, 8-byte aligned. */
+int lsim_running_moments_workspace(size_t* bytes);
+int lsim_running_moments_update(const float* x, int64_t ldx, int64_t batch, int dim, double* mean, double* var, double* count,
+                                void* workspace, size_t workspace_bytes, void* stream);
+
 /* Opt-in form of the two calls above for layers whose k_in and n_out are multiples of 128 (and whose operands are 16-byte aligned): the same fp32
  * sums on the bf16 matrix pipe.  Every fp32 operand is split exactly into three bf16 terms (3 x 8 significand bits) and the six products of
  * order <= 2 are accumulated in fp32: products exact, truncation 2^-24 |a||b| per product -- fp32's own rounding (measured against fp64 sums:
@@ -648,6 +677,9 @@ int lsim_linear_wgrad_deferred(const float* x, int64_t ldx, const float* g, int6
 int lsim_linear_elu_wgrad_deferred(const float* x, int64_t ldx, const float* grad_out, int64_t ldg, const float* elu_out, int64_t ldz, int64_t batch,
                                    int k_in, int n_out, float* dw, float* db, float* grad_pre, void* workspace, size_t workspace_bytes, void* stream,
                                    lsim_wgrad_pending* pending);
+int lsim_linear_relu_wgrad_deferred(const float* x, int64_t ldx, const float* grad_out, int64_t ldg, const float* relu_out, int64_t ldz, int64_t batch,
+                                    int k_in, int n_out, float* dw, float* db, float* grad_pre, void* workspace, size_t workspace_bytes, void* stream,
+                                    lsim_wgrad_pending* pending);
 int lsim_wgrad_reduce_batch(const lsim_wgrad_pending* items, int n, void* stream);
 
 /* dst[r, :] = src[index[r], :] for 4-byte elements (rows of `cols` elements, both contiguous; index: int64 [n] on the device): the once-per-update

@@ -253,3 +253,187 @@ extern "C" int lsim_amp_step(const lsim_amp_disc* d, const float* amp_obs, const
     else hipLaunchKernelGGL(lsim_k_amp_step<1>, dim3((unsigned)groups, 1), dim3(64 * LS_AMP_WAVES), lds, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? LSIM_OK : LSIM_E_HIP;
 }
+
+// =====================================================================================================================================
+// Discriminator UPDATE side (HybridPPO.update, rsl_rl/algorithms/hybrid_ppo.py:236-281): the elementwise passes between the big GEMMs of the
+// LSGAN loss and of the gradient penalty, each folded into the one kernel that has to touch the activation anyway.
+//
+// lsim_relu_head_backward -- everything between d loss / d d and the gradient of the LAST trunk layer's pre-activation, for the head
+//   d = a2 . w3 + b3 on a2 = relu(z2) (DISC:27, DISC:61):
+//     g2[b, n] = a2[b, n] > 0 ? gd[b] * w3[n] : 0            (outer product + threshold_backward: was a K = 1 "GEMM" of 182 us + a 93 us mask pass)
+//     db2[n]   = sum_b g2[b, n]                               (was a 68 us column sum)
+//     dw3[n]   = sum_b a2[b, n] * gd[b],  db3 = sum_b gd[b]   (was a 33 us GEMV + a reduction)
+//   in one pass over a2 (read) and g2 (written).
+// lsim_masked_colsum -- out[n] = sum_b (m[b, n] > 0 ? v[b, n] : 0): the gradient penalty's d w3 (amp.py _GradPenFn: threshold_backward + sum).
+// Both: a block owns a slice of rows, thread (row lane, column quad) keeps its column sums in registers, the row lanes of a block add up
+// through LDS, one partial row per block, summed over the blocks in a fixed order by lsim_k_wgrad_reduce (deterministic, no atomics).
+#define LS_COLK_SLICES 1024
+template <int MODE /* 0: head backward, 1: masked column sum */>
+__global__ __launch_bounds__(256) void lsim_k_relu_cols(const float* __restrict__ a, long lda, const float* __restrict__ v, long ldv, const float* __restrict__ gd,
+                                                       const float* __restrict__ w3, long batch, int n, long rows_per_slice, float* __restrict__ g2,
+                                                       float* __restrict__ part1, float* __restrict__ part2) {
+    const int quads = n >> 2, rl = 256 / quads;                 // row lanes per block (host: quads divides 256)
+    const int q = (int)threadIdx.x % quads, lane_r = (int)threadIdx.x / quads;
+    const long s0 = (long)blockIdx.x * rows_per_slice;
+    long s1 = s0 + rows_per_slice;
+    if (s1 > batch) s1 = batch;
+    float4 c1 = make_float4(0, 0, 0, 0), c2 = make_float4(0, 0, 0, 0);
+    float cg = 0.0f;
+    float4 w = make_float4(0, 0, 0, 0);
+    if (MODE == 0) w = *(const float4*)(w3 + 4 * q);
+    for (long r = s0 + lane_r; r < s1; r += rl) {
+        const float4 av = *(const float4*)(a + r * lda + 4 * q);
+        if (MODE == 0) {
+            const float g = gd[r];
+            const float4 o = make_float4(av.x > 0.0f ? g * w.x : 0.0f, av.y > 0.0f ? g * w.y : 0.0f, av.z > 0.0f ? g * w.z : 0.0f, av.w > 0.0f ? g * w.w : 0.0f);
+            *(float4*)(g2 + r * (long)n + 4 * q) = o;
+            c1.x += o.x; c1.y += o.y; c1.z += o.z; c1.w += o.w;
+            c2.x += av.x * g; c2.y += av.y * g; c2.z += av.z * g; c2.w += av.w * g;
+            if (q == 0) cg += g;
+        } else {
+            const float4 vv = *(const float4*)(v + r * ldv + 4 * q);
+            c1.x += av.x > 0.0f ? vv.x : 0.0f; c1.y += av.y > 0.0f ? vv.y : 0.0f; c1.z += av.z > 0.0f ? vv.z : 0.0f; c1.w += av.w > 0.0f ? vv.w : 0.0f;
+        }
+    }
+    __shared__ float4 r1[256], r2[256];
+    __shared__ float rg[256];
+    r1[threadIdx.x] = c1;
+    if (MODE == 0) { r2[threadIdx.x] = c2; rg[threadIdx.x] = cg; }
+    __syncthreads();
+    if (lane_r != 0) return;
+    for (int l = 1; l < rl; ++l) {                               // fixed order
+        const float4 o = r1[l * quads + q];
+        c1.x += o.x; c1.y += o.y; c1.z += o.z; c1.w += o.w;
+        if (MODE == 0) {
+            const float4 p = r2[l * quads + q];
+            c2.x += p.x; c2.y += p.y; c2.z += p.z; c2.w += p.w;
+            if (q == 0) cg += rg[l * quads];
+        }
+    }
+    *(float4*)(part1 + (size_t)blockIdx.x * n + 4 * q) = c1;
+    if (MODE == 0) {
+        float* p2 = part2 + (size_t)blockIdx.x * (n + 4);        // dw3 [n] | db3 | 3 unused
+        *(float4*)(p2 + 4 * q) = c2;
+        if (q == 0) *(float4*)(p2 + n) = make_float4(cg, 0.0f, 0.0f, 0.0f);
+    }
+}
+
+static int ls_colk_plan(int64_t batch, int n, int* slices, long* rows) {
+    if (batch <= 0 || n <= 0 || (n & 3) || n > 1024 || 256 % (n >> 2) != 0) return LSIM_E_UNSUPPORTED;
+    const int rl = 256 / (n >> 2);
+    long rps = (batch + LS_COLK_SLICES - 1) / LS_COLK_SLICES;
+    rps = (rps + rl - 1) / rl * rl;
+    if (rps < 4L * rl) rps = 4L * rl;
+    *rows = rps;
+    *slices = (int)((batch + rps - 1) / rps);
+    return LSIM_OK;
+}
+extern "C" int lsim_relu_cols_workspace(int64_t batch, int n, size_t* bytes) {
+    int slices; long rows;
+    if (!bytes) return LSIM_E_INVALID;
+    int rc = ls_colk_plan(batch, n, &slices, &rows);
+    if (rc != LSIM_OK) return rc;
+    *bytes = (size_t)slices * (2 * (size_t)n + 4) * sizeof(float);
+    return LSIM_OK;
+}
+extern "C" int lsim_relu_head_backward(const float* relu_out, int64_t ld, const float* grad_d, const float* head_weight, int64_t batch, int n,
+                                       float* grad_pre, float* grad_bias, float* grad_head /* [n + 4]: d head_weight | d head_bias | 3 zeros */,
+                                       void* workspace, size_t workspace_bytes, void* stream) {
+    if (!relu_out || !grad_d || !head_weight || !grad_pre || !grad_bias || !grad_head || !workspace || ld < n) return LSIM_E_INVALID;
+    int slices; long rows; size_t need;
+    int rc = ls_colk_plan(batch, n, &slices, &rows);
+    if (rc != LSIM_OK) return rc;
+    if ((ld & 3) || ((uintptr_t)relu_out & 15) || ((uintptr_t)grad_pre & 15) || ((uintptr_t)head_weight & 15)) return LSIM_E_UNSUPPORTED;
+    (void)lsim_relu_cols_workspace(batch, n, &need);
+    if (workspace_bytes < need || ((uintptr_t)workspace & 15)) return LSIM_E_INVALID;
+    float* p1 = (float*)workspace;
+    float* p2 = p1 + (size_t)slices * n;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(lsim_k_relu_cols<0>, dim3(slices), dim3(256), 0, s, relu_out, (long)ld, (const float*)nullptr, 0L, grad_d, head_weight, (long)batch, n, rows,
+                       grad_pre, p1, p2);
+    // the two partial arrays have different row lengths (n and n + 4): two small fixed-order sums
+    hipLaunchKernelGGL(lsim_k_wgrad_reduce, dim3(ls_reduce_blocks(p1, n)), dim3(256), 0, s, (const float*)p1, slices, n, grad_bias, (const float*)nullptr, 0, (float*)nullptr);
+    hipLaunchKernelGGL(lsim_k_wgrad_reduce, dim3(ls_reduce_blocks(p2, n + 4)), dim3(256), 0, s, (const float*)p2, slices, n + 4, grad_head, (const float*)nullptr, 0, (float*)nullptr);
+    return hipGetLastError() == hipSuccess ? LSIM_OK : LSIM_E_HIP;
+}
+extern "C" int lsim_masked_colsum(const float* v, int64_t ldv, const float* mask_src, int64_t ldm, int64_t batch, int n, float* out,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+    if (!v || !mask_src || !out || !workspace || ldv < n || ldm < n) return LSIM_E_INVALID;
+    int slices; long rows; size_t need;
+    int rc = ls_colk_plan(batch, n, &slices, &rows);
+    if (rc != LSIM_OK) return rc;
+    if ((ldv & 3) || (ldm & 3) || ((uintptr_t)v & 15) || ((uintptr_t)mask_src & 15)) return LSIM_E_UNSUPPORTED;
+    (void)lsim_relu_cols_workspace(batch, n, &need);
+    if (workspace_bytes < need || ((uintptr_t)workspace & 15)) return LSIM_E_INVALID;
+    float* p1 = (float*)workspace;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(lsim_k_relu_cols<1>, dim3(slices), dim3(256), 0, s, mask_src, (long)ldm, v, (long)ldv, (const float*)nullptr, (const float*)nullptr, (long)batch, n,
+                       rows, (float*)nullptr, p1, (float*)nullptr);
+    hipLaunchKernelGGL(lsim_k_wgrad_reduce, dim3(ls_reduce_blocks(p1, n)), dim3(256), 0, s, (const float*)p1, slices, n, out, (const float*)nullptr, 0, (float*)nullptr);
+    return hipGetLastError() == hipSuccess ? LSIM_OK : LSIM_E_HIP;
+}
+
+// lsim_running_moments_update -- Normalizer.update (rsl_rl/utils/utils.py:86-106, called twice per minibatch at HYBP:279-281): batch mean /
+// variance of x [batch, dim] merged into the float64 running (mean, var, count) with the parallel-variance formula, in two launches and
+// without a host round trip (the torch statement was ~25 launches of 1-2 us and one pageable host -> device copy, i.e. a pipeline drain, per call).
+// Batch sums are formed in float64 (the reference forms them in float32 with numpy's pairwise summation: agreement to ~1e-7 relative).
+#define LS_MOM_SLICES 256
+#define LS_MOM_MAX_DIM 64
+__global__ __launch_bounds__(256) void lsim_k_moments_partial(const float* __restrict__ x, long ldx, long batch, int dim, long rows_per_slice, double* __restrict__ part) {
+    const int c = (int)threadIdx.x & 63, lane_r = (int)threadIdx.x >> 6;           // 4 row lanes x 64 columns
+    const long s0 = (long)blockIdx.x * rows_per_slice;
+    long s1 = s0 + rows_per_slice;
+    if (s1 > batch) s1 = batch;
+    double a = 0.0, b = 0.0;
+    if (c < dim)
+        for (long r = s0 + lane_r; r < s1; r += 4) { const double t = (double)x[r * ldx + c]; a += t; b += t * t; }
+    __shared__ double sa[256], sb[256];
+    sa[threadIdx.x] = a; sb[threadIdx.x] = b;
+    __syncthreads();
+    if (lane_r == 0 && c < dim) {
+        for (int l = 1; l < 4; ++l) { a += sa[64 * l + c]; b += sb[64 * l + c]; }
+        part[((size_t)blockIdx.x * 2) * LS_MOM_MAX_DIM + c] = a;
+        part[((size_t)blockIdx.x * 2 + 1) * LS_MOM_MAX_DIM + c] = b;
+    }
+}
+__global__ __launch_bounds__(256) void lsim_k_moments_merge(const double* __restrict__ part, int slices, long batch, int dim, double* __restrict__ mean,
+                                                           double* __restrict__ var, double* __restrict__ count) {
+    const int c = (int)threadIdx.x & 63, grp = (int)threadIdx.x >> 6;             // four groups take every fourth slice, then add up in group order
+    double a = 0.0, b = 0.0;
+    if (c < dim)
+        for (int s = grp; s < slices; s += 4) { a += part[((size_t)s * 2) * LS_MOM_MAX_DIM + c]; b += part[((size_t)s * 2 + 1) * LS_MOM_MAX_DIM + c]; }
+    __shared__ double sa[256], sb[256];
+    sa[threadIdx.x] = a; sb[threadIdx.x] = b;
+    __syncthreads();
+    if (grp != 0) return;
+    const double cnt = count[0], n = (double)batch, tot = cnt + n;
+    if (c < dim) {
+        for (int l = 1; l < 4; ++l) { a += sa[64 * l + c]; b += sb[64 * l + c]; }
+        const double bmean = a / n, bvar = b / n - bmean * bmean;
+        const double delta = bmean - mean[c];                                                           // UT:96-106
+        const double m2 = var[c] * cnt + bvar * n + delta * delta * cnt * n / tot;
+        mean[c] += delta * n / tot;
+        var[c] = m2 / tot;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (c == 0) count[0] = tot;          // after this wave's reads of count[0] above (one wave: program order)
+}
+extern "C" int lsim_running_moments_workspace(size_t* bytes) {
+    if (!bytes) return LSIM_E_INVALID;
+    *bytes = (size_t)LS_MOM_SLICES * 2 * LS_MOM_MAX_DIM * sizeof(double);
+    return LSIM_OK;
+}
+extern "C" int lsim_running_moments_update(const float* x, int64_t ldx, int64_t batch, int dim, double* mean, double* var, double* count,
+                                           void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !mean || !var || !count || !workspace || batch <= 0 || dim <= 0 || ldx < dim) return LSIM_E_INVALID;
+    if (dim > LS_MOM_MAX_DIM) return LSIM_E_UNSUPPORTED;
+    if (workspace_bytes < (size_t)LS_MOM_SLICES * 2 * LS_MOM_MAX_DIM * sizeof(double) || ((uintptr_t)workspace & 7)) return LSIM_E_INVALID;
+    long rps = ((long)batch + LS_MOM_SLICES - 1) / LS_MOM_SLICES;
+    rps = (rps + 3) & ~3L;
+    if (rps < 16) rps = 16;
+    const int slices = (int)(((long)batch + rps - 1) / rps);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(lsim_k_moments_partial, dim3(slices), dim3(256), 0, s, x, (long)ldx, (long)batch, dim, rps, (double*)workspace);
+    hipLaunchKernelGGL(lsim_k_moments_merge, dim3(1), dim3(256), 0, s, (const double*)workspace, slices, (long)batch, dim, mean, var, count);
+    return hipGetLastError() == hipSuccess ? LSIM_OK : LSIM_E_HIP;
+}

@@ -77,9 +77,15 @@ __device__ __forceinline__ void ls_fwd_stage(float* __restrict__ tile, const flo
 // Workgroups go round-robin to the 8 XCDs (each with its own L2): XCD j takes the j-th eighth of the tile list, feature tile fastest, and
 // its 64 blocks stride through it together, so that the blocks sharing a sample tile read it through ONE L2 at about the same time.
 // One LDS buffer: the next chunk is fetched into registers before the MFMAs of the current one and stored behind a barrier.
-template <int TM, int TN, int BK, int VX, int VW, bool ELU>
+// ACT: the epilogue -- LS_FWD_ACT_ELU: elu(acc + bias); LS_FWD_ACT_MASK: aux[m, n] > 0 ? acc + bias : 0 (the ReLU mask of a saved activation `aux`, leading
+// dimension ldaux: the product and torch's threshold_backward in one pass -- lsim_linear_masked_forward); LS_FWD_ACT_NONE: acc + bias
+#define LS_FWD_ACT_NONE 0
+#define LS_FWD_ACT_ELU 1
+#define LS_FWD_ACT_MASK 2
+template <int TM, int TN, int BK, int VX, int VW, int ACT>
 __global__ __launch_bounds__(256, 2) void lsim_k_linear_fwd(const float* __restrict__ x, long ldx, const float* __restrict__ W, const float* __restrict__ bias,
-                                                             long M, int K, int N, float* __restrict__ out, long ldo, int n_tiles, unsigned total_tiles) {
+                                                             long M, int K, int N, float* __restrict__ out, long ldo, int n_tiles, unsigned total_tiles,
+                                                             const float* __restrict__ aux, long ldaux) {
     constexpr int BM = 32 * TM, BN = 32 * TN, LS_FWD_PITCH = BK + 4, LS_FWD_BK = BK;
     extern __shared__ __attribute__((aligned(16))) float ls_fwd_lds[];
     float* Xs = ls_fwd_lds;
@@ -187,9 +193,15 @@ __global__ __launch_bounds__(256, 2) void lsim_k_linear_fwd(const float* __restr
             for (int b = 0; b < TM; ++b) {
                 const long m = m0 + wm + 16 * b + c16;
                 float e[4] = {acc[a][b][0] + bv.x, acc[a][b][1] + bv.y, acc[a][b][2] + bv.z, acc[a][b][3] + bv.w};
-                if (ELU) {
+                if (ACT == LS_FWD_ACT_ELU) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) e[j] = e[j] > 0.0f ? e[j] : LS_FWD_EXP(e[j]) - 1.0f;  // torch's elu_kernel: exp(x) - 1, not expm1
+                }
+                if (ACT == LS_FWD_ACT_MASK) {
+                    if (nok && m < M) {
+                        const float4 mk = *(const float4*)(aux + m * ldaux + n);
+                        e[0] = mk.x > 0.0f ? e[0] : 0.0f; e[1] = mk.y > 0.0f ? e[1] : 0.0f; e[2] = mk.z > 0.0f ? e[2] : 0.0f; e[3] = mk.w > 0.0f ? e[3] : 0.0f;
+                    }
                 }
                 if (nok && m < M) *(float4*)(out + m * ldo + n) = make_float4(e[0], e[1], e[2], e[3]);
                 acc[a][b] = (ls_v4f){0.0f, 0.0f, 0.0f, 0.0f};
@@ -202,15 +214,19 @@ __global__ __launch_bounds__(256, 2) void lsim_k_linear_fwd(const float* __restr
 
 static int ls_linear_fwd_supported(long batch, int k_in, int n_out) { return batch > 0 && k_in > 0 && n_out > 0 && n_out % 4 == 0; }
 
-template <int TM, int TN, int BK, bool ELU>
-static void ls_linear_fwd_launch(const float* x, long ldx, const float* W, const float* bias, long M, int K, int N, float* out, long ldo, hipStream_t s) {
+template <int TM, int TN, int BK, int ACT>
+static void ls_linear_fwd_launch(const float* x, long ldx, const float* W, const float* bias, long M, int K, int N, float* out, long ldo, hipStream_t s,
+                                 const float* aux = nullptr, long ldaux = 0) {
     constexpr int BM = 32 * TM, BN = 32 * TN;
     const int n_tiles = (N + BN - 1) / BN;
     const long m_tiles = (M + BM - 1) / BM;
     const unsigned total = (unsigned)(m_tiles * n_tiles);
-    static int cus = 0;
-    if (!cus) { int dev = 0; hipDeviceProp_t pr; cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }
-    unsigned blocks = (unsigned)(2 * cus) & ~7u;                                 // two persistent blocks per CU
+    static int cus_of[64] = {0};                                                  // per device ordinal (one process may drive several devices)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!cus_of[dev]) { hipDeviceProp_t pr; cus_of[dev] = hipGetDeviceProperties(&pr, dev) == hipSuccess ? pr.multiProcessorCount : 256; }
+    unsigned blocks = (unsigned)(2 * cus_of[dev]) & ~7u;                          // two persistent blocks per CU; the kernel wants a multiple of 8 (block & 7 = XCD)
+    if (blocks < 8u) blocks = 8u;
     if (blocks > ((total + 7) & ~7u)) blocks = (total + 7) & ~7u;
     const dim3 grid(blocks), threads(256);
     const int vx = ((ldx % 4 == 0) && (K % 4 == 0) && (((uintptr_t)x & 15) == 0)) ? 2 : ((ldx % 2 == 0) && (K % 2 == 0) && (((uintptr_t)x & 7) == 0)) ? 1 : 0;
@@ -218,7 +234,7 @@ static void ls_linear_fwd_launch(const float* x, long ldx, const float* W, const
     constexpr size_t tile_bytes = (size_t)(BM + BN) * (BK + 4) * sizeof(float);
     constexpr size_t lds = tile_bytes > 56 * 1024 ? tile_bytes : 56 * 1024;       // three blocks would need 168 KB: exactly two per CU
     static_assert(lds <= 64 * 1024, "above 64 KB of dynamic LDS the kernel needs hipFuncAttributeMaxDynamicSharedMemorySize, per device");
-#define LS_F(VX, VW) hipLaunchKernelGGL((lsim_k_linear_fwd<TM, TN, BK, VX, VW, ELU>), grid, threads, lds, s, x, ldx, W, bias, M, K, N, out, ldo, n_tiles, total)
+#define LS_F(VX, VW) hipLaunchKernelGGL((lsim_k_linear_fwd<TM, TN, BK, VX, VW, ACT>), grid, threads, lds, s, x, ldx, W, bias, M, K, N, out, ldo, n_tiles, total, aux, ldaux)
     if (vx == 2 && vw == 2) LS_F(2, 2);
     else if (vx >= 1 && vw >= 1) LS_F(1, 1);
     else LS_F(0, 0);
@@ -234,7 +250,21 @@ extern "C" int lsim_linear_elu_forward(const float* x, int64_t ldx, const float*
     // feature tile: 128 wide from 256 features on -- 512 -> 256 with 64-wide tiles (2560 tiles, 5 per block) read the sample rows through L2
     // four times and ran at 267 us next to 246 with 128-wide ones (1280 tiles, 3 or 2 per block): the L2 -> LDS traffic costs more than
     // the uneven split.  Narrow layers keep 64 (128 would leave 640 tiles for 512 blocks).
-    if (n_out > 128) ls_linear_fwd_launch<5, 4, 32, true>(x, (long)ldx, weight, bias, (long)batch, k_in, n_out, out, (long)ldo, s);
-    else ls_linear_fwd_launch<5, 2, LS_FWD_NARROW_BK, true>(x, (long)ldx, weight, bias, (long)batch, k_in, n_out, out, (long)ldo, s);
+    if (n_out > 128) ls_linear_fwd_launch<5, 4, 32, LS_FWD_ACT_ELU>(x, (long)ldx, weight, bias, (long)batch, k_in, n_out, out, (long)ldo, s);
+    else ls_linear_fwd_launch<5, 2, LS_FWD_NARROW_BK, LS_FWD_ACT_ELU>(x, (long)ldx, weight, bias, (long)batch, k_in, n_out, out, (long)ldo, s);
+    return hipGetLastError() == hipSuccess ? LSIM_OK : LSIM_E_HIP;
+}
+
+// out[b, n] = mask_src[b, n] > 0 ? sum_k x[b, k] W[n, k] : 0 -- a product whose consumer is a ReLU's backward (torch: the GEMM, then
+// threshold_backward(grad, saved_output, 0) reading both and writing a third [batch, n_out] array): the gradient penalty's
+// d u1 = m1 * (dg W1^T) (learn/amp.py _GradPenFn).  Same kernel and limits as lsim_linear_elu_forward; mask_src [batch, n_out], leading dimension ldm % 4 == 0.
+extern "C" int lsim_linear_masked_forward(const float* x, int64_t ldx, const float* weight, const float* mask_src, int64_t ldm, int64_t batch, int k_in, int n_out,
+                                          float* out, int64_t ldo, void* stream) {
+    if (!x || !weight || !mask_src || !out || ldx < k_in || ldo < n_out || ldm < n_out) return LSIM_E_INVALID;
+    if (!ls_linear_fwd_supported((long)batch, k_in, n_out) || ldo % 4 != 0 || ldm % 4 != 0 || (((uintptr_t)out & 15) != 0) || (((uintptr_t)mask_src & 15) != 0))
+        return LSIM_E_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    if (n_out > 128) ls_linear_fwd_launch<5, 4, 32, LS_FWD_ACT_MASK>(x, (long)ldx, weight, nullptr, (long)batch, k_in, n_out, out, (long)ldo, s, mask_src, (long)ldm);
+    else ls_linear_fwd_launch<5, 2, LS_FWD_NARROW_BK, LS_FWD_ACT_MASK>(x, (long)ldx, weight, nullptr, (long)batch, k_in, n_out, out, (long)ldo, s, mask_src, (long)ldm);
     return hipGetLastError() == hipSuccess ? LSIM_OK : LSIM_E_HIP;
 }

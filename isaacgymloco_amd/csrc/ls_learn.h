@@ -249,7 +249,7 @@ template <int VX, int VG, int KG, bool FULL, bool FZ>
 __device__ __forceinline__ void ls_wgrad_tile_loop(const float* __restrict__ x, long ldx, const float* __restrict__ g, long ldg,
                                                    const float* __restrict__ z, long ldz, float* __restrict__ gy, bool write_gy, long b0, long b1,
                                                    long safe, int n_base, int k_base, int n_out, int k_in, int sub, int col,
-                                                   ls_v4f (&acc)[4][4 * KG], float (&dbacc)[4]) {
+                                                   ls_v4f (&acc)[4][4 * KG], float (&dbacc)[4], float zoff) {
     float a0[4], x0[KG][4], a1[4], x1[KG][4], a2[4], x2[KG][4], z1[4], z2[4];
     // wave-uniform, loop-invariant: does the second 64-column k group of an edge tile exist at all
     const bool live_k1 = FULL || k_base + 64 < k_in;
@@ -280,7 +280,7 @@ __device__ __forceinline__ void ls_wgrad_tile_loop(const float* __restrict__ x, 
     for (long b = b0; b < b1; b += 4) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            a0[j] = FZ ? a1[j] * (z1[j] > 0.0f ? 1.0f : z1[j] + 1.0f) : a1[j];
+            a0[j] = FZ ? a1[j] * (z1[j] > 0.0f ? 1.0f : z1[j] + zoff) : a1[j];
             a1[j] = a2[j];
             if (FZ) z1[j] = z2[j];
 #pragma unroll
@@ -330,7 +330,7 @@ template <int VX, int VG, int KG, bool FZ, bool LIVE1 /* the second 64-column k 
 __device__ __forceinline__ long ls_wgrad_tile_loop3(const float* __restrict__ x, long ldx, const float* __restrict__ g, long ldg,
                                                     const float* __restrict__ z, long ldz, float* __restrict__ gy, long b0, long b1,
                                                     bool full, int n_base, int k_base, int n_out, int k_in, int sub, int col,
-                                                    ls_v4f (&acc)[4][4 * KG], float (&dbacc)[4]) {
+                                                    ls_v4f (&acc)[4][4 * KG], float (&dbacc)[4], float zoff) {
     if (b1 - b0 < 20) return b0;
     int og[4], ox0[4], ox1[4];
     ls_wgrad_offsets<VG>(n_base + 4 * col, n_out, full, og);
@@ -349,7 +349,7 @@ __device__ __forceinline__ long ls_wgrad_tile_loop3(const float* __restrict__ x,
         if (live_k1) ls_wgrad_ld<VX>(x + r_ * ldx, ox1, ST.x[KG - 1]); } while (0)
 #define LS_CMP(ST, ROW) do {                                                                                                 \
         if (FZ) {                                                                                                            \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j) ST.a[j] *= ST.z[j] > 0.0f ? 1.0f : ST.z[j] + 1.0f;                 \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) ST.a[j] *= ST.z[j] > 0.0f ? 1.0f : ST.z[j] + zoff;                 \
             if (WGY) *(float4*)(gy + (ROW) * (long)n_out + n_base + 4 * col) = make_float4(ST.a[0], ST.a[1], ST.a[2], ST.a[3]);     \
         }                                                                                                                    \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                      \
@@ -377,7 +377,7 @@ __device__ __forceinline__ long ls_wgrad_tile_loop3(const float* __restrict__ x,
         __builtin_amdgcn_s_setprio(0); } while (0)
 #define LS_STEP(CS, CROW, LS, LROW) do { const long lr_ = (LROW);                                                            \
         if (FZ) {     /* g_z * elu'(z) for the whole step up front: spread between the MFMA groups it costs 10 % (measured) */   \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j) CS.a[j] *= CS.z[j] > 0.0f ? 1.0f : CS.z[j] + 1.0f;                 \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) CS.a[j] *= CS.z[j] > 0.0f ? 1.0f : CS.z[j] + zoff;                 \
             if (WGY) *(float4*)(gy + (CROW) * (long)n_out + n_base + 4 * col) = make_float4(CS.a[0], CS.a[1], CS.a[2], CS.a[3]);  \
         }                                                                                                                    \
         LS_SB(); LS_GRP(CS, 0); LS_SB();                                                                                     \
@@ -412,7 +412,9 @@ template <int VX, int VG, int KG, bool FZ>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void lsim_k_linear_wgrad_tiled(const float* __restrict__ x, long ldx, const float* __restrict__ g, long ldg, const float* __restrict__ z, long ldz,
                                float* __restrict__ gy, long batch, int k_in, int n_out,
-                               int k_blocks, int tiles, int slices, long rows_per_slice, float* __restrict__ part_dw, float* __restrict__ part_db) {
+                               int k_blocks, int tiles, int slices, long rows_per_slice, float* __restrict__ part_dw, float* __restrict__ part_db, float zoff) {
+    // zoff: the activation whose saved OUTPUT z is: d act / d pre = z > 0 ? 1 : z + zoff -- 1 for ELU (alpha = 1: torch's elu_backward on the result), 0 for
+    // ReLU (its output is exactly 0 where the unit is off: torch's threshold_backward)
     // one BLOCK per (output tile, batch slice): its four waves split the slice's rows four ways and add their accumulators in LDS at the
     // end, so there is one partial result per block but four times as many waves in flight (two per SIMD: one wave's operand loads,
     // register rotation and waits hide behind the other's MFMAs)
@@ -446,13 +448,13 @@ void lsim_k_linear_wgrad_tiled(const float* __restrict__ x, long ldx, const floa
     {
         const bool live1 = KG == 1 || k_base + 64 < k_in;
         const bool wgy = FZ && kb == 0 && gy != nullptr, wgy_vec = (n_out & 3) == 0 && n_base + 64 <= n_out;      // gy == NULL: nobody needs grad_pre (a network's first layer)
-#define LS_L3(LIVE1, WGY) b0 = ls_wgrad_tile_loop3<VX, VG, KG, FZ, LIVE1, WGY>(x, ldx, g, ldg, z, ldz, gy, b0, b1, full, n_base, k_base, n_out, k_in, sub, col, acc, dbacc)
+#define LS_L3(LIVE1, WGY) b0 = ls_wgrad_tile_loop3<VX, VG, KG, FZ, LIVE1, WGY>(x, ldx, g, ldg, z, ldz, gy, b0, b1, full, n_base, k_base, n_out, k_in, sub, col, acc, dbacc, zoff)
         if (!wgy) { if (live1) LS_L3(true, false); else LS_L3(false, false); }
         else if (wgy_vec) { if (live1) LS_L3(true, true); else LS_L3(false, true); }
         // (g_y rows of an edge n tile: everything goes through the guarded loop below)
 #undef LS_L3
     }
-    ls_wgrad_tile_loop<VX, VG, KG, false, FZ>(x, ldx, g, ldg, z, ldz, gy, kb == 0 && gy != nullptr, b0, b1, safe, n_base, k_base, n_out, k_in, sub, col, acc, dbacc);   // the last < 12 rows
+    ls_wgrad_tile_loop<VX, VG, KG, false, FZ>(x, ldx, g, ldg, z, ldz, gy, kb == 0 && gy != nullptr, b0, b1, safe, n_base, k_base, n_out, k_in, sub, col, acc, dbacc, zoff);   // the last < 12 rows
     // block reduction: wave 0 stores its accumulators to LDS (lane-major, 16-byte vectors: no bank conflicts), waves 1-3 add theirs in
     // turn; wave 3 ends up with the block's sums and writes the partial tile
     __shared__ float4 red[4 * 4 * KG][64];
@@ -730,7 +732,7 @@ extern "C" int lsim_linear_wgrad_workspace(long batch, int k_in, int n_out, size
 
 static int ls_linear_wgrad_impl(const float* x, int64_t ldx, const float* g, int64_t ldg, const float* z, int64_t ldz, float* gy, int64_t batch,
                                 int k_in, int n_out, float* dw, float* db, void* workspace, size_t workspace_bytes, void* stream,
-                                lsim_wgrad_pending* pending = nullptr) {
+                                lsim_wgrad_pending* pending = nullptr, float zoff = 1.0f) {
     if (!x || !g || !dw || !workspace) return LSIM_E_INVALID;
     LsWgradPlan p;
     int rc = ls_wgrad_plan(batch, k_in, n_out, &p);
@@ -760,7 +762,7 @@ static int ls_linear_wgrad_impl(const float* x, int64_t ldx, const float* g, int
         int vg = ((ldg % 4 == 0) && (((uintptr_t)g & 15) == 0)) ? 2 : 0;
         if (fz && !((ldz % 4 == 0) && (((uintptr_t)z & 15) == 0))) vg = 0;
         const int kg = k_in <= 64 ? 1 : 2;
-        if (p.split && vx == 2 && vg == 2 && (!gy || (((uintptr_t)gy & 15) == 0))) {
+        if (p.split && zoff == 1.0f && vx == 2 && vg == 2 && (!gy || (((uintptr_t)gy & 15) == 0))) {      // (the bf16-pipe kernel hard-codes ELU)
             const int kb128 = k_in / 128, tiles128 = (n_out / 128) * kb128;
             if (fz) hipLaunchKernelGGL((lsim_k_linear_wgrad_split<true>), dim3(tiles128 * p.partials), dim3(256), 0, s, x, (long)ldx, g, (long)ldg, z, (long)ldz,
                                        gy, (long)batch, k_in, n_out, kb128, tiles128, p.partials, p.rows, pdw, pdb);
@@ -768,7 +770,7 @@ static int ls_linear_wgrad_impl(const float* x, int64_t ldx, const float* g, int
                                     gy, (long)batch, k_in, n_out, kb128, tiles128, p.partials, p.rows, pdw, pdb);
         } else {
 #define LS_T(VX, VG, KG, FZ) hipLaunchKernelGGL((lsim_k_linear_wgrad_tiled<VX, VG, KG, FZ>), dim3(blocks), dim3(256), 0, s, x, (long)ldx, g, (long)ldg, z, (long)ldz, \
-                                                gy, (long)batch, k_in, n_out, p.k_blocks, tiles, p.partials, p.rows, pdw, pdb)
+                                                gy, (long)batch, k_in, n_out, p.k_blocks, tiles, p.partials, p.rows, pdw, pdb, zoff)
 #define LS_TZ(VX, VG, KG) do { if (fz) LS_T(VX, VG, KG, true); else LS_T(VX, VG, KG, false); } while (0)
 #define LS_TK(VX, VG) do { if (kg == 1) LS_TZ(VX, VG, 1); else LS_TZ(VX, VG, 2); } while (0)
         if (vg == 2) { if (vx == 2) LS_TK(2, 2); else if (vx == 1) LS_TK(1, 2); else LS_TK(0, 2); }
@@ -828,6 +830,19 @@ extern "C" int lsim_linear_elu_wgrad(const float* x, int64_t ldx, const float* g
                                      int k_in, int n_out, float* dw, float* db, float* grad_pre, void* workspace, size_t workspace_bytes, void* stream) {
     if (!elu_out) return LSIM_E_INVALID;
     return ls_linear_wgrad_impl(x, ldx, grad_out, ldg, elu_out, ldz, grad_pre, batch, k_in, n_out, dw, db, workspace, workspace_bytes, stream);
+}
+
+// Linear + ReLU (the AMP discriminator's trunk, DISC:18-25): the same kernels with d act / d pre = [output > 0] (zoff = 0)
+extern "C" int lsim_linear_relu_wgrad(const float* x, int64_t ldx, const float* grad_out, int64_t ldg, const float* relu_out, int64_t ldz, int64_t batch,
+                                      int k_in, int n_out, float* dw, float* db, float* grad_pre, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!relu_out) return LSIM_E_INVALID;
+    return ls_linear_wgrad_impl(x, ldx, grad_out, ldg, relu_out, ldz, grad_pre, batch, k_in, n_out, dw, db, workspace, workspace_bytes, stream, nullptr, 0.0f);
+}
+extern "C" int lsim_linear_relu_wgrad_deferred(const float* x, int64_t ldx, const float* grad_out, int64_t ldg, const float* relu_out, int64_t ldz, int64_t batch,
+                                               int k_in, int n_out, float* dw, float* db, float* grad_pre, void* workspace, size_t workspace_bytes, void* stream,
+                                               lsim_wgrad_pending* pending) {
+    if (!relu_out || !pending) return LSIM_E_INVALID;
+    return ls_linear_wgrad_impl(x, ldx, grad_out, ldg, relu_out, ldz, grad_pre, batch, k_in, n_out, dw, db, workspace, workspace_bytes, stream, pending, 0.0f);
 }
 
 // ---- Sinkhorn-Knopp assignment of HIMEstimator (HES:119-133): Q = exp(scores / eps)^T, then `iters` x {rows sum to 1/K, columns

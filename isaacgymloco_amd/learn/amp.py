@@ -117,6 +117,11 @@ class AMPLoader:
                 yield self.get_frame_at_time_batch(ti, t), self.get_frame_at_time_batch(ti, t + self.time_between_frames)
 
 
+def _fused_update_wanted():
+    """LSIM_AMP_FUSED_UPDATE=0: the discriminator update's torch statements (A/B switch)"""
+    return os.environ.get("LSIM_AMP_FUSED_UPDATE") != "0"
+
+
 class Normalizer:
     """Running mean / variance (parallel algorithm), float64, clip +-clip_obs (UT:78-130)."""
 
@@ -129,7 +134,7 @@ class Normalizer:
 
     mean = property(lambda self: self._mean.cpu().numpy())
     var = property(lambda self: self._var.cpu().numpy())
-    count = property(lambda self: float(self._count))
+    count = property(lambda self: float(self._count.reshape(-1)[0]))
 
     def to(self, device):
         self._mean, self._var, self._count = self._mean.to(device), self._var.to(device), self._count.to(device)
@@ -145,6 +150,24 @@ class Normalizer:
 
     def update(self, arr):
         a = torch.as_tensor(arr).to(device=self._mean.device)
+        if self.moment_sync is None and a.is_cuda and a.dim() == 2 and a.dtype == torch.float32 and a.stride(1) == 1 and _fused_update_wanted():
+            # lsim_running_moments_update: two launches, the running state updated IN PLACE (no host round trip: the torch statements below
+            # start with a pageable host -> device copy of the row count, i.e. one pipeline drain per call, twice per minibatch)
+            import ctypes
+            from .. import abi, lib
+            L = lib.load()
+            if getattr(self, "_ws", None) is None or self._ws.device != a.device:
+                need = ctypes.c_size_t()
+                lib.check(L.lsim_running_moments_workspace(ctypes.byref(need)), what="lsim_running_moments_workspace")
+                self._ws = torch.empty(need.value // 8, dtype=torch.float64, device=a.device)
+            if self._count.dim() == 0:
+                self._count = self._count.reshape(1)
+            rc = L.lsim_running_moments_update(a.data_ptr(), a.stride(0), a.shape[0], a.shape[1], self._mean.data_ptr(), self._var.data_ptr(),
+                                               self._count.data_ptr(), self._ws.data_ptr(), self._ws.numel() * 8, torch.cuda.current_stream(a.device).cuda_stream)
+            if rc == 0:
+                return
+            if rc != abi.E_UNSUPPORTED:
+                lib.check(rc, what="lsim_running_moments_update")
         n = torch.tensor(float(a.shape[0]), dtype=torch.float64, device=a.device)
         if self.moment_sync is None:
             # the reference feeds float32 arrays to np.mean / np.var (HYBP:280-281): batch moments are formed in the input
@@ -219,7 +242,7 @@ class _GradPenFn(autograd.Function):
         # on the fp32 activation itself: one pass per mask instead of compare + cast / not + multiply / fill
         tb = torch.ops.aten.threshold_backward
         a1 = _linear_relu(b1, x, W1)                       # relu(z1) straight from the GEMM epilogue; z1 > 0  <=>  a1 > 0
-        z2 = torch.addmm(b2, a1, W2.t())
+        z2 = _linear_relu(b2, a1, W2)                      # relu(z2): only its sign pattern is used below (z2 > 0 <=> relu(z2) > 0)
         u2 = tb(w3.expand_as(z2), z2, 0.0)                  # (B, H2): m2 * w3
         u1 = tb(u2 @ W2, a1, 0.0)                           # (B, H1): m1 * (W2^T u2)
         g = u1 @ W1                                         # (B, D): dD/dx
@@ -232,11 +255,131 @@ class _GradPenFn(autograd.Function):
         tb = torch.ops.aten.threshold_backward
         W1, W2, a1, z2, u2, u1, g = ctx.saved_tensors
         dg = g * (ctx.scale * grad_out)                     # d penalty / d g
+        B, n1 = a1.shape
+        n2 = z2.shape[1]
+        fused = _fused_update_wanted() and B >= 16384 and n1 % 4 == 0 and dg.shape[1] % 4 == 0
+        if fused:
+            # lsim_linear_wgrad: u1^T dg with K = B as MFMA tiles (was a split-K BLAS GEMM + its post-sum); lsim_linear_masked_forward: dg W1^T with the
+            # mask of a1 applied to the accumulators (was a GEMM + a mask pass over (B, H1)); lsim_masked_colsum: mask of z2 + column sum in one pass
+            import ctypes
+            from .. import abi, lib
+            from . import fused_linear as FL
+            L = lib.load()
+            st = torch.cuda.current_stream(a1.device).cuda_stream
+            dW1 = FL.linear_wgrad(dg, u1, want_bias=False)[0] if FL._eligible(B, dg.shape[1], n1) else u1.t() @ dg
+            du1 = torch.empty_like(a1)
+            rc = L.lsim_linear_masked_forward(dg.data_ptr(), dg.stride(0), W1.data_ptr(), a1.data_ptr(), a1.stride(0), B, dg.shape[1], n1, du1.data_ptr(), du1.stride(0), st)
+            if rc == abi.E_UNSUPPORTED:
+                du1 = tb(dg @ W1.t(), a1, 0.0)
+            else:
+                lib.check(rc, what="lsim_linear_masked_forward")
+            dW2 = u2.t() @ du1
+            t = du1 @ W2.t()
+            ws = _cols_ws(B, n2, a1.device)
+            dw3 = torch.empty(1, n2, device=a1.device)
+            if ws is None or L.lsim_masked_colsum(t.data_ptr(), t.stride(0), z2.data_ptr(), z2.stride(0), B, n2, dw3.data_ptr(), ws.data_ptr(), ws.numel(), st) != 0:
+                dw3 = tb(t, z2, 0.0).sum(dim=0, keepdim=True)
+            return None, dW1, None, dW2, None, dw3, None
         dW1 = u1.t() @ dg                                   # g = u1 W1
         du1 = tb(dg @ W1.t(), a1, 0.0)                      # through the mask m1 (a constant)
         dW2 = u2.t() @ du1                                  # u1 = m1 * (u2 W2)
         dw3 = tb(du1 @ W2.t(), z2, 0.0).sum(dim=0, keepdim=True)   # u2 = m2 * w3
         return None, dW1, None, dW2, None, dw3, None
+
+
+def _cols_ws(batch, n, device):
+    import ctypes
+    from .. import lib
+    from . import fused_linear as FL
+    need = ctypes.c_size_t()
+    if lib.load().lsim_relu_cols_workspace(batch, n, ctypes.byref(need)) != 0:
+        return None
+    return FL._workspace("relu_cols", device, need.value)
+
+
+def _relu_wgrad(x, g, a, weight, bias):
+    """(dW, db) of relu(x W^T + b) from the gradient g of its OUTPUT a: the mask is applied to g as the MFMA operand is formed (lsim_linear_relu_wgrad);
+    the masked gradient is never written.  Falls back to the torch statements for shapes the library leaves to BLAS."""
+    import ctypes
+    from .. import lib
+    from . import fused_linear as FL
+    L = lib.load()
+    batch, k_in = x.shape
+    n_out = weight.shape[0]
+    need, parts = ctypes.c_size_t(), ctypes.c_int()
+    if FL._eligible_fused_elu(batch, k_in, n_out) and L.lsim_linear_wgrad_workspace(batch, k_in, n_out, ctypes.byref(need), ctypes.byref(parts)) == 0:
+        # plain output tensors, summed at once: the discriminator's parameters receive a second contribution from the gradient penalty in the same
+        # backward pass, so their gradient-arena slices (whose deferred sums assume a single contribution, fused_linear._wgrad_call) are not used here
+        ws = FL._workspace("wgrad_relu", x.device, need.value, floor=1 << 20)
+        dw, db = torch.empty(n_out, k_in, device=x.device), torch.empty(n_out, device=x.device)
+        lib.check(L.lsim_linear_relu_wgrad(x.data_ptr(), x.stride(0), g.data_ptr(), g.stride(0), a.data_ptr(), a.stride(0), batch, k_in, n_out, dw.data_ptr(),
+                                           db.data_ptr(), None, ws.data_ptr(), ws.numel(), torch.cuda.current_stream(x.device).cuda_stream),
+                  what="lsim_linear_relu_wgrad")
+        return dw, db
+    gy = torch.ops.aten.threshold_backward(g, a, 0.0)
+    return gy.t() @ x, gy.sum(dim=0)
+
+
+def _fused_disc_ok(x, trunk, head):
+    if not (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[0] >= 16384 and _fused_update_wanted() and len(trunk) == 4):
+        return False
+    if not (isinstance(trunk[0], nn.Linear) and isinstance(trunk[1], nn.ReLU) and isinstance(trunk[2], nn.Linear) and isinstance(trunk[3], nn.ReLU)):
+        return False
+    n2 = trunk[2].out_features
+    return (trunk[0].bias is not None and trunk[2].bias is not None and head.bias is not None and head.out_features == 1 and n2 % 4 == 0 and n2 <= 1024
+            and 256 % (n2 // 4) == 0 and trunk[0].out_features % 4 == 0)
+
+
+class _LsganFn(autograd.Function):
+    """sum_i mean_b (D(x_i)[b] - target_i)^2 for row blocks x_i stacked in x (HYBP:258-261: expert block with target +1, policy block with -1), D = the
+    two-layer ReLU trunk + linear head; forward and backward in closed form.  Backward is five GEMMs (hipBLASLt) and three passes of the build's kernels:
+      lsim_relu_head_backward   gd x w3 masked by a2 -> g2, with db2, d w3 and d b3 summed in the same pass (was an outer-product "GEMM", a mask pass, a GEMV and two sums)
+      lsim_linear_relu_wgrad    dW1, db1 from (g2 W2, a1, x): the mask of a1 applied as the MFMA operand is formed (was a mask pass, a split-K GEMM and a column sum)
+    Returns (the loss, mean D per block [detached])."""
+    _targets = {}
+
+    @staticmethod
+    def forward(ctx, x, W1, b1, W2, b2, w3, b3, targets, block):
+        a1 = _linear_relu(b1, x, W1)
+        a2 = _linear_relu(b2, a1, W2)
+        d = torch.addmm(b3, a2, w3.t()).view(-1)            # (the GEMM path: rocBLAS's gemv reads the 420 MB at 2 TB/s)
+        nb = x.shape[0] // block
+        key = (x.device, tuple(targets), block)
+        t = _LsganFn._targets.get(key)
+        if t is None:                                       # built once with fills (a host list -> device tensor would be a pageable copy: one pipeline drain per minibatch)
+            t = torch.empty(nb, block, device=x.device)
+            for i, v in enumerate(targets):
+                t[i].fill_(float(v))
+            t = _LsganFn._targets[key] = t.view(-1)
+        err = d - t
+        ctx.save_for_backward(x, W1, b1, W2, b2, w3, a1, a2, err)
+        ctx.block = block
+        means = d.view(nb, block).mean(dim=1)
+        ctx.mark_non_differentiable(means)
+        return err.pow(2).sum() / block, means
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_means):
+        import ctypes
+        from .. import lib
+        x, W1, b1, W2, b2, w3, a1, a2, err = ctx.saved_tensors
+        L = lib.load()
+        B, n2 = a2.shape
+        gd = err * (g_loss * (2.0 / ctx.block))
+        g2 = torch.empty_like(a2)
+        db2 = torch.empty(n2, device=x.device)
+        dhead = torch.empty(n2 + 4, device=x.device)
+        ws = _cols_ws(B, n2, x.device)
+        lib.check(L.lsim_relu_head_backward(a2.data_ptr(), a2.stride(0), gd.data_ptr(), w3.data_ptr(), B, n2, g2.data_ptr(), db2.data_ptr(), dhead.data_ptr(),
+                                            ws.data_ptr(), ws.numel(), torch.cuda.current_stream(x.device).cuda_stream), what="lsim_relu_head_backward")
+        # block by block: K = one minibatch is the shape the shipped GEMM table is tuned for (the stacked K ran an untuned kernel at 79 TFLOP/s)
+        blk = ctx.block
+        dW2 = g2[:blk].t() @ a1[:blk]
+        for i in range(blk, B, blk):
+            dW2.addmm_(g2[i:i + blk].t(), a1[i:i + blk])
+        g1 = g2 @ W2                                        # gradient of a1 (the mask of a1 is applied inside the weight-gradient kernel)
+        dW1, db1 = _relu_wgrad(x, g1, a1, W1, b1)
+        return None, dW1, db1, dW2, db2, dhead[:n2].view(1, n2), dhead[n2:n2 + 1], None, None
 
 
 class _LinearReluFn(autograd.Function):
@@ -291,6 +434,18 @@ class AMPDiscriminator(nn.Module):
     def forward(self, x):
         h = _trunk_fused(self.trunk, x)
         return self.amp_linear(h if h is not None else self.trunk(x))
+
+    def lsgan_loss(self, expert_in, policy_in):
+        """0.5 * (mse(D(expert), 1) + mse(D(policy), -1)) (HYBP:258-261) -> (loss, mean D(policy), mean D(expert)); both blocks through ONE closed-form
+        forward / backward (_LsganFn) on the GPU, else the reference's statements"""
+        if expert_in.shape == policy_in.shape and _fused_disc_ok(expert_in, self.trunk, self.amp_linear):
+            l1, l2, h = self.trunk[0], self.trunk[2], self.amp_linear
+            loss, means = _LsganFn.apply(torch.cat([expert_in, policy_in], dim=0), l1.weight, l1.bias, l2.weight, l2.bias, h.weight, h.bias, (1.0, -1.0),
+                                         expert_in.shape[0])
+            return 0.5 * loss, means[1], means[0]
+        policy_d, expert_d = self(policy_in), self(expert_in)
+        loss = 0.5 * (torch.nn.functional.mse_loss(expert_d, torch.ones_like(expert_d)) + torch.nn.functional.mse_loss(policy_d, -torch.ones_like(policy_d)))
+        return loss, policy_d.mean().detach(), expert_d.mean().detach()
 
     def compute_grad_pen(self, expert_state, expert_next_state, lambda_=10):   # DISC:36-53
         data = torch.cat([expert_state, expert_next_state], dim=-1)

@@ -78,10 +78,7 @@ class HybridPPO(HIMPPO):
                 with torch.no_grad():
                     nz = self.amp_normalizer.normalize_torch
                     pol_s, pol_ns, exp_s, exp_ns = nz(pol_s, dev), nz(pol_ns, dev), nz(exp_s, dev), nz(exp_ns, dev)
-            policy_d = disc(torch.cat([pol_s, pol_ns], dim=-1))
-            expert_d = disc(torch.cat([exp_s, exp_ns], dim=-1))
-            amp_loss = 0.5 * (torch.nn.functional.mse_loss(expert_d, torch.ones_like(expert_d)) +
-                              torch.nn.functional.mse_loss(policy_d, -torch.ones_like(policy_d)))
+            amp_loss, policy_d_mean, expert_d_mean = disc.lsgan_loss(torch.cat([exp_s, exp_ns], dim=-1), torch.cat([pol_s, pol_ns], dim=-1))   # HYBP:252-261
             grad_pen = disc.compute_grad_pen(exp_s_raw, exp_ns_raw, lambda_=10)     # on the un-normalised expert pair (HYBP:262-263)
             loss = ppo_loss + amp_loss + grad_pen
             if dist_on:      # two collectives per minibatch, the estimator's in flight during this backward (him_ppo.py)
@@ -102,7 +99,7 @@ class HybridPPO(HIMPPO):
                 self.amp_normalizer.update(pol_s)
                 self.amp_normalizer.update(exp_s)
             sums += torch.stack((value_loss.detach(), surrogate_loss.detach(), amp_loss.detach(), grad_pen.detach(),
-                                 policy_d.mean().detach(), expert_d.mean().detach()))
+                                 policy_d_mean, expert_d_mean))
         if self._lr_t is not None:
             self.learning_rate = float(self._lr_t)
         s = (sums / n_updates).tolist()

@@ -85,6 +85,14 @@ def load_path(path):
     L.lsim_normalize_rows.argtypes = [vp, i32, i32, f32, vp]
     L.lsim_gather_rows.argtypes = [vp, i64, vp, i64, vp, vp]
     L.lsim_gather_rows_ld.argtypes = [vp, i64, vp, i64, vp, i64, vp]
+    L.lsim_linear_relu_wgrad.argtypes = [vp, i64, vp, i64, vp, i64, i64, i32, i32, vp, vp, vp, vp, ctypes.c_size_t, vp]
+    L.lsim_linear_relu_wgrad_deferred.argtypes = [vp, i64, vp, i64, vp, i64, i64, i32, i32, vp, vp, vp, vp, ctypes.c_size_t, vp, pend]
+    L.lsim_linear_masked_forward.argtypes = [vp, i64, vp, vp, i64, i64, i32, i32, vp, i64, vp]
+    L.lsim_relu_cols_workspace.argtypes = [i64, i32, ctypes.POINTER(ctypes.c_size_t)]
+    L.lsim_relu_head_backward.argtypes = [vp, i64, vp, vp, i64, i32, vp, vp, vp, vp, ctypes.c_size_t, vp]
+    L.lsim_masked_colsum.argtypes = [vp, i64, vp, i64, i64, i32, vp, vp, ctypes.c_size_t, vp]
+    L.lsim_running_moments_workspace.argtypes = [ctypes.POINTER(ctypes.c_size_t)]
+    L.lsim_running_moments_update.argtypes = [vp, i64, i64, i32, vp, vp, vp, vp, ctypes.c_size_t, vp]
     L.lsim_amp_step_workspace.argtypes = [i64, ctypes.POINTER(ctypes.c_size_t)]
     L.lsim_amp_step.argtypes = [ctypes.POINTER(abi.LsimAmpDisc), vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, i64, i64, vp, ctypes.c_size_t, vp]
     L.lsim_destroy.argtypes = [vp]
