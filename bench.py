@@ -71,12 +71,13 @@ def host_cpu_plan(local_world, sysfs="/sys", allowed=None):
     Anything unreadable: the allowed CPUs in NUMA-node order cut into local_world equal contiguous pieces (GPU i on socket i // (N / 2) is the
     usual 8-GPU board).  `allowed`: the CPUs this process may use (default: its current affinity mask)."""
     allowed = sorted(os.sched_getaffinity(0)) if allowed is None else sorted(allowed)
+    allowed_set = set(allowed)
     nodes = {}
     try:
         base = os.path.join(sysfs, "devices", "system", "node")
         for d in sorted(os.listdir(base)):
             if d.startswith("node") and d[4:].isdigit():
-                cpus = [c for c in _parse_cpulist(open(os.path.join(base, d, "cpulist")).read()) if c in set(allowed)]
+                cpus = [c for c in _parse_cpulist(open(os.path.join(base, d, "cpulist")).read()) if c in allowed_set]
                 if cpus:
                     nodes[int(d[4:])] = cpus
     except OSError:
@@ -94,6 +95,12 @@ def host_cpu_plan(local_world, sysfs="/sys", allowed=None):
             at += n
         return out
     gpu_node = []
+    # KFD node order is the HIP device order only while nothing re-maps devices: under HIP_ / ROCR_ / CUDA_VISIBLE_DEVICES (or the single-device debug
+    # mode, where every rank shares device 0) rank i's GPU is not the i-th KFD node, and pinning by it would put ranks next to the WRONG GPU's NUMA node
+    # while the line still said "kfd topology" (ADVICE r5): fall back to the even split and say why
+    remap = [v for v in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "LSIM_DEBUG_SINGLE_DEVICE") if os.environ.get(v)]
+    if remap:
+        return even(ordered, local_world), "even split of the allowed CPUs in NUMA-node order (" + ", ".join(remap) + " set: KFD order is not the device order)"
     try:
         top = os.path.join(sysfs, "class", "kfd", "kfd", "topology", "nodes")
         for d in sorted(os.listdir(top), key=int):
@@ -403,11 +410,13 @@ def main():
             env.step_device(acts[i % 16])
         env._L.lsim_set_profiling(env._h, K)
         barrier()
+        nf0 = int(env.nonfinite_envs)            # (a host read: outside the timed region)
         t0 = time.perf_counter()
         for i in range(K):
             env.step_device(acts[i % 16])
         barrier()
         elapsed = time.perf_counter() - t0
+        nonfinite = int(env.nonfinite_envs) - nf0
         timed_steps = K
         ms_a = (ctypes.c_float * K)()
         ms_b = (ctypes.c_float * K)()
@@ -415,7 +424,7 @@ def main():
         env._L.lsim_read_profile(env._h, ms_a, ms_b, ctypes.byref(n))
         ka = sum(ms_a[i] for i in range(n.value)) / max(n.value, 1)
         kb = sum(ms_b[i] for i in range(n.value)) / max(n.value, 1)
-        extra = {"kernel_a_ms": ka, "kernel_b_ms": kb, "timed_env_steps": K}
+        extra = {"kernel_a_ms": ka, "kernel_b_ms": kb, "timed_env_steps": K, "nonfinite_envs": nonfinite}
         actions_src = args.actions
         workload = (f"{args.task}: LeggedRobot.step() back-to-back, {'N(0,1)' if args.actions == 'normal' else 'zero'} actions, {N} envs/GPU "
                     "(no policy/learner in the loop)")
@@ -437,9 +446,16 @@ def main():
         actions_src = "policy"
 
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    nf = torch.tensor([float(extra.get("nonfinite_envs", 0))], device=dev, dtype=torch.float64)
     if world > 1 or forced:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(nf, op=dist.ReduceOp.SUM)
     elapsed = float(t.item())
+    extra["nonfinite_envs"] = int(nf.item())
+    if extra["nonfinite_envs"] != 0:
+        # env-steps of the timed region in which a robot's simulated state held a NaN / infinity (LSIM_BUF_NONFINITE): the number that would be printed
+        # is then not a measurement of the workload (non-finite robots also run slower: until round 6 this was only noticed as a slow kernel A)
+        raise SystemExit(f"bench.py: {extra['nonfinite_envs']} env-steps of the timed region had a non-finite robot state (solver blow-up): no line printed")
 
     if rank == 0:
         value = world * N * timed_steps / elapsed

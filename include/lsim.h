@@ -33,9 +33,10 @@
 extern "C" {
 #endif
 
-#define LSIM_ABI_VERSION 5   /* 2: LSIM_BUF_CONTACT_COUNT, fixed-point words in LSIM_BUF_STATS (round 2); 3: LSIM_BUF_SUBSTEP_TORQUES (round 3);
+#define LSIM_ABI_VERSION 6   /* 2: LSIM_BUF_CONTACT_COUNT, fixed-point words in LSIM_BUF_STATS (round 2); 3: LSIM_BUF_SUBSTEP_TORQUES (round 3);
                                  4: lsim_config.solver_type / num_position_iterations out of the reserved words (round 4);
-                                 5: lsim_config.lin_vel_at_com (centre-of-mass linear velocities, the PhysX convention) and tgs_limit_passes, lsim_get / set_reset_calls (round 5) */
+                                 5: lsim_config.lin_vel_at_com (centre-of-mass linear velocities, the PhysX convention) and tgs_limit_passes, lsim_get / set_reset_calls (round 5);
+                                 6: LSIM_BUF_NONFINITE + LSIM_STATS_NONFINITE (robots whose simulated state is not finite), lsim_amp_step and the discriminator-update kernels (round 6) */
 
 /* ---- fixed sizes of the robot family on this path (12-DoF quadrupeds) ---- */
 #define LSIM_NUM_DOF 12
@@ -357,6 +358,10 @@ enum lsim_buffer_id {
                                                   (LR:146 keeps only the last), i.e. _compute_torques(delayed_actions[:, i]) of LR:138-146 -- what
                                                   makes the action-delay model observable from outside */
     LSIM_BUF_STATS,              /* f32 [2,LSIM_STATS_SIZE] device-side per-step reductions, see below */
+    LSIM_BUF_NONFINITE,          /* i64 [2]       [0] env-steps since lsim_create in which a robot's simulated state (root 13, joint angles 12, joint velocities 12, after the
+                                                  last sub-step) held a NaN or an infinity -- CUMULATIVE, never cleared by the library (the caller may zero it); [1] the
+                                                  step counter of the latest such step.  A robot that went non-finite stays so until its episode times out: it is
+                                                  counted in every step.  Must stay 0: anything else is a solver blow-up, and until round 6 it was only visible as a slow kernel A */
     LSIM_BUF_HEIGHT_GRID,        /* i16 [rows,cols] */
     LSIM_BUF_TERRAIN_ORIGINS,    /* f32 [levels,types,3] */
     LSIM_BUF_TERRAIN_MESH,       /* i32 [rows,cols] per grid vertex of the reference's triangle mesh: bits 0-15 = height sample (int16);
@@ -375,6 +380,7 @@ enum lsim_buffer_id {
  *   [2+T .. 10+T)            command_ranges[4][2] live values (LR:877-880)
  *   [10+T]                   reserved (the tracking sum of LR:875 is kept in fixed point, below)
  *   [11+T]                   reserved
+ *   [12+T]                   number of envs whose simulated state was not finite in THIS step (see LSIM_BUF_NONFINITE for the running total)
  *   [LSIM_STATS_FIX ..)      internal, not for the host: int64 fixed-point (2^-32, each addend clamped to +-2^20) accumulators of [1 .. 1+T) and of the sum over reset envs of
  *                            episode_sums[tracking_lin_vel] (LR:875), and a ticket counter.  Waves add to them with integer atomics, so the sums
  *                            -- extras["episode"] and the command-curriculum decision -- do not depend on the order the waves arrive in; the last
@@ -386,6 +392,7 @@ enum lsim_buffer_id {
 #define LSIM_STATS_CMD_RANGES (2 + LSIM_NUM_REWARD_TERMS)
 #define LSIM_STATS_TRACK_SUM (10 + LSIM_NUM_REWARD_TERMS)
 #define LSIM_STATS_RESET_STEPS (11 + LSIM_NUM_REWARD_TERMS)
+#define LSIM_STATS_NONFINITE (12 + LSIM_NUM_REWARD_TERMS)
 #define LSIM_STATS_FIX ((17 + LSIM_NUM_REWARD_TERMS) & ~1)      /* even float index: the int64 words are 8-byte aligned (rows are too) */
 #define LSIM_STATS_FIX_TRACK LSIM_NUM_REWARD_TERMS             /* word index of the tracking sum */
 #define LSIM_STATS_FIX_TICKET (LSIM_NUM_REWARD_TERMS + 1)      /* word index of the ticket counter */

@@ -97,6 +97,7 @@ static inline int lsim_buffer_desc(const lsim_config* cfg, int id, int64_t shape
         case LSIM_BUF_CONTACT_COUNT: s1 = 2; nd = 2; dt = LSIM_DT_I32; break;
         case LSIM_BUF_SUBSTEP_TORQUES: s1 = cfg->decimation > 0 ? cfg->decimation : 1; s2 = LSIM_NUM_DOF; nd = 3; break;
         case LSIM_BUF_STATS: s0 = 2; s1 = LSIM_STATS_SIZE; nd = 2; break;
+        case LSIM_BUF_NONFINITE: s0 = 2; dt = LSIM_DT_I64; break;
         case LSIM_BUF_HEIGHT_GRID:
             s0 = cfg->grid_rows > 0 ? cfg->grid_rows : 1; s1 = cfg->grid_cols > 0 ? cfg->grid_cols : 1;
             nd = 2; dt = LSIM_DT_I16; break;
@@ -126,7 +127,7 @@ static const char* const lsim_buffer_names[LSIM_NUM_BUFFERS] = {
     "feet_air_time", "last_contacts", "contact_filt", "measured_heights", "pending_force", "terrain_levels",
     "terrain_types", "env_origins", "kp_factors", "kd_factors", "motor_strength", "motor_strength_factors", "friction",
     "restitution", "payload", "com_displacement", "episode_sums", "term_priv_obs", "term_amp_obs", "amp_obs",
-    "delay_steps", "contact_count", "substep_torques", "stats", "height_grid", "terrain_origins", "terrain_mesh"};
+    "delay_steps", "contact_count", "substep_torques", "stats", "nonfinite", "height_grid", "terrain_origins", "terrain_mesh"};
 
 static const char* const lsim_reward_names[LSIM_NUM_REWARD_TERMS] = {
     "action_rate", "ang_vel_xy", "ang_vel_xy_up", "base_height", "base_height_up", "calf_pose", "calf_pose_up",

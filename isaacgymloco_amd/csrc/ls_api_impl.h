@@ -44,6 +44,8 @@ static int ls_check_cfg(const lsim_config* c) {
     if (c->terrain_num_rows > LSIM_TERRAIN_LEVELS_MAX || c->terrain_num_cols > LSIM_TERRAIN_TYPES_MAX) return LSIM_E_INVALID;
     if (c->solver_type != LSIM_SOLVER_PGS && c->solver_type != LSIM_SOLVER_TGS) return LSIM_E_INVALID;
     if (c->solver_type == LSIM_SOLVER_TGS && (c->num_position_iterations < 1 || c->num_position_iterations > LSIM_MAX_POSITION_ITERATIONS)) return LSIM_E_INVALID;
+    // (a direct C-ABI caller with a large value would get an unbounded per-sub-step loop in the limit pass)
+    if (c->tgs_limit_passes < 0 || c->tgs_limit_passes > LSIM_MAX_POSITION_ITERATIONS || (c->lin_vel_at_com != 0 && c->lin_vel_at_com != 1)) return LSIM_E_INVALID;
     return LSIM_OK;
 }
 
@@ -142,8 +144,26 @@ static std::vector<int32_t> ls_terrain_mesh_flags(const lsim_config& c, const in
     return out;
 }
 
+static int ls_create_impl(const lsim_config* cfg, const lsim_robot_model* model, const int16_t* height_grid,
+                          const float* terrain_origins, void* arena_dev, int device_id, lsim_sim** out, lsim_sim** partial);
+// include/lsim.h promises that no exception crosses the ABI: the set-up below fills std::vectors (the init-time draws, the terrain mesh words),
+// whose allocation failure is a C++ exception -- caught here, what had been allocated is released, LSIM_E_NOMEM returned
 extern "C" int LS_API(create)(const lsim_config* cfg, const lsim_robot_model* model, const int16_t* height_grid,
                               const float* terrain_origins, void* arena_dev, int device_id, lsim_sim** out) {
+    lsim_sim* partial = nullptr;
+    try {
+        return ls_create_impl(cfg, model, height_grid, terrain_origins, arena_dev, device_id, out, &partial);
+    } catch (...) {
+        if (partial) {
+            if (partial->owns_arena && partial->arena) lsbk_free(partial->arena);
+            if (partial->dev_ctx) lsbk_free(partial->dev_ctx);
+            free(partial);
+        }
+        return LSIM_E_NOMEM;
+    }
+}
+static int ls_create_impl(const lsim_config* cfg, const lsim_robot_model* model, const int16_t* height_grid,
+                          const float* terrain_origins, void* arena_dev, int device_id, lsim_sim** out, lsim_sim** partial) {
     if (!cfg || !model || !out) return LSIM_E_INVALID;
     int rc = ls_check_cfg(cfg);
     if (rc != LSIM_OK) return rc;
@@ -162,6 +182,7 @@ extern "C" int LS_API(create)(const lsim_config* cfg, const lsim_robot_model* mo
         s->owns_arena = true;
     }
     if (lsbk_memset(s->arena, 0, total) != 0) { if (s->owns_arena) lsbk_free(s->arena); free(s); return LSIM_E_HIP; }
+    *partial = s;        // from here on an exception (std::bad_alloc of the vectors below) is cleaned up by the caller
 
     // ---- init-time draws (LR:999-1032, LR:1172-1179, LR:506-513, LR:1232-1239), identical to the oracle's
     const uint32_t W = 0xFFFFFFFFu;
@@ -222,11 +243,12 @@ extern "C" int LS_API(create)(const lsim_config* cfg, const lsim_robot_model* mo
     }
     if (lsbk_malloc((void**)&s->dev_ctx, sizeof(LsCtx)) != 0) bad = 1;
     else bad |= lsbk_h2d(s->dev_ctx, &h, sizeof(LsCtx));
-    if (bad) { if (s->owns_arena) lsbk_free(s->arena); if (s->dev_ctx) lsbk_free(s->dev_ctx); free(s); return LSIM_E_HIP; }
+    if (bad) { *partial = nullptr; if (s->owns_arena) lsbk_free(s->arena); if (s->dev_ctx) lsbk_free(s->dev_ctx); free(s); return LSIM_E_HIP; }
     s->step_counter = 0;
     s->priority_max_envs = 32768;
     if (const char* e = getenv("LSIM_PRIORITY_MAX_ENVS")) s->priority_max_envs = atoi(e);
     s->init_done = 1;   // construction completes before the runner's first reset (LR:116, HIMR:84)
+    *partial = nullptr;
     *out = s;
     return LSIM_OK;
 }
@@ -239,15 +261,16 @@ extern "C" int LS_API(get_buffer)(lsim_sim* s, int id, void** dev_ptr, int64_t s
 
 extern "C" int LS_API(step_ex)(lsim_sim* s, const float* actions_dev, uint32_t flags, void* stream) {
     if (!s || !actions_dev) return LSIM_E_INVALID;
-    s->step_counter += 1;   // LR:194
+    // the host-side state (step counter, stats row) advances only AFTER every launch of the step was accepted: a failed launch (invalid stream,
+    // device lost) leaves the handle where it was -- nothing ran, the call can be repeated
+    const int64_t step = s->step_counter + 1;   // LR:194
     LsStepArgs a;
     memset(&a, 0, sizeof(a));
-    a.actions = actions_dev; a.step_counter = s->step_counter; a.flags = flags; a.init_done = s->init_done;
+    a.actions = actions_dev; a.step_counter = step; a.flags = flags; a.init_done = s->init_done;
     a.row_in = s->stats_row; a.row_out = s->stats_row ^ 1; a.reset_all = 0;
-    s->stats_row = a.row_out;
     // Kernel B exists for the step's one global dependency; it only bites when the command curriculum evaluates (LR:307: one step in
     // max_episode_length).  On every other step kernel A runs B's per-env work itself and a few blocks finish the step (ls_kernels.h).
-    const bool curriculum_step = s->cfg.commands_curriculum && (s->step_counter % s->cfg.max_episode_length == 0);
+    const bool curriculum_step = s->cfg.commands_curriculum && (step % s->cfg.max_episode_length == 0);
     a.fuse_tail = (!curriculum_step && !(flags & LSIM_STEP_TWO_KERNELS)) ? 1 : 0;
     // contact-count wave priorities pay while a launch is a few rounds of waves (4096 resident at a time): +6.5 % at N = 4096, +3.7 % at 8192,
     // +2.1 % at 12 288, +1.2 % at 16 384, nothing at 32 768; with many rounds in flight the slowest wave of a round hides behind the next
@@ -256,6 +279,10 @@ extern "C" int LS_API(step_ex)(lsim_sim* s, const float* actions_dev, uint32_t f
     lsbk_prof_mark(s, 0, stream);
     if (lsbk_launch_a(s, a, stream) != 0) LS_FAIL(s, LSIM_E_HIP, "kernel A launch failed");
     lsbk_prof_mark(s, 1, stream);
+    // (kernel A was accepted: from here on the step HAS begun on the device, so the counters advance even if the second launch fails --
+    // the error is reported, and the handle's state matches what the device will have done)
+    s->step_counter = step;
+    s->stats_row = a.row_out;
 #if defined(LS_EXP_NO_FINISH)      // timing probe only (wrong statistics): what the finish launch costs on the rollout's critical path
     if (a.fuse_tail) { }
 #else
@@ -273,8 +300,8 @@ extern "C" int LS_API(reset_all)(lsim_sim* s, void* stream) {
     memset(&a, 0, sizeof(a));
     a.actions = nullptr; a.step_counter = s->step_counter; a.flags = 0; a.init_done = s->init_done;
     a.row_in = s->stats_row; a.row_out = s->stats_row ^ 1; a.reset_all = 1;
-    s->stats_row = a.row_out;
     if (lsbk_launch_reduce(s, a, stream) != 0) LS_FAIL(s, LSIM_E_HIP, "reduction kernel launch failed");
+    s->stats_row = a.row_out;      // (after the first accepted launch, as in lsim_step_ex)
     if (lsbk_launch_b(s, a, stream) != 0) LS_FAIL(s, LSIM_E_HIP, "reset kernel launch failed");
     return LSIM_OK;
 }
@@ -285,9 +312,10 @@ extern "C" int LS_API(reset_envs)(lsim_sim* s, const uint8_t* mask_dev, void* st
     memset(&a, 0, sizeof(a));
     a.actions = nullptr; a.step_counter = s->step_counter; a.flags = 0; a.init_done = s->init_done;
     a.row_in = s->stats_row; a.row_out = s->stats_row ^ 1; a.reset_all = 2; a.reset_mask = mask_dev;
-    a.rng_salt = (++s->reset_calls) * 0x9E3779B9u;
-    s->stats_row = a.row_out;
+    a.rng_salt = (s->reset_calls + 1) * 0x9E3779B9u;
     if (lsbk_launch_reduce(s, a, stream) != 0) LS_FAIL(s, LSIM_E_HIP, "reduction kernel launch failed");
+    s->reset_calls += 1;
+    s->stats_row = a.row_out;
     if (lsbk_launch_b(s, a, stream) != 0) LS_FAIL(s, LSIM_E_HIP, "reset kernel launch failed");
     return LSIM_OK;
 }

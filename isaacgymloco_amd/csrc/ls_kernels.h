@@ -242,6 +242,28 @@ LS_FN void ph_store_sim_state(const LsCtx& cx, WaveShared& sh, int lane, int env
     if (lane < 3 * LS_NB) LSB(cx, LSIM_BUF_CONTACT_FORCES, float)[3 * LS_NB * env + lane] = sh.cf[lane / 3][lane % 3];
     if (lane == 52) { LSB(cx, LSIM_BUF_CONTACT_COUNT, int32_t)[2 * env] = sh.nact_max; LSB(cx, LSIM_BUF_CONTACT_COUNT, int32_t)[2 * env + 1] = sh.nact; }
 }
+// A robot whose root / joint state holds a NaN or an infinity after the last sub-step (a solver blow-up; it stays that way until the episode times out):
+// +1 in this step's stats row and in the running total of LSIM_BUF_NONFINITE.  Integer-valued float / integer atomics: exact in any order; issued only
+// by the waves concerned (none in a healthy run).
+LS_FN bool ls_not_finite(float v) { return (ls_float_bits(v) & 0x7f800000u) == 0x7f800000u; }
+LS_FN void ls_report_nonfinite(const LsCtx& cx, const LsStepArgs& a) {
+    LS_ATOMIC_ADD(LS_G(float, cx.accum) + a.row_out * LSIM_STATS_SIZE + LSIM_STATS_NONFINITE, 1.0f);
+    LS_ATOMIC_ADD_I64(LSB(cx, LSIM_BUF_NONFINITE, long long), 1);
+    LSB(cx, LSIM_BUF_NONFINITE, long long)[1] = (long long)a.step_counter;       // racing writers store the same value
+}
+#if defined(LS_EMU)
+static inline void emu_count_nonfinite(const LsCtx& cx, WaveShared& sh, const LsStepArgs& a) {
+    bool bad = false;
+    for (int k = 0; k < 13; ++k) bad |= ls_not_finite(sh.root[k]);
+    for (int k = 0; k < 12; ++k) bad |= ls_not_finite(sh.q[k]) || ls_not_finite(sh.qd[k]);
+    if (bad) ls_report_nonfinite(cx, a);
+}
+#else
+__device__ __forceinline__ void wc_count_nonfinite(const LsCtx& cx, WaveShared& sh, int lane, const LsStepArgs& a) {
+    const float v = lane < 13 ? sh.root[lane] : (lane >= 16 && lane < 28 ? sh.q[lane - 16] : (lane >= 32 && lane < 44 ? sh.qd[lane - 32] : 0.0f));
+    if (__ballot(ls_not_finite(v)) != 0ull && lane == 0) ls_report_nonfinite(cx, a);
+}
+#endif
 // the rigid-body state rows into registers (LaneRegs::bs) while the kinematics arrays are still alive -- the height samples overlay them --
 // and stored by ph_store_body_states once everything the wave had requested from memory has been consumed: a load whose result is read
 // while stores are in flight waits for the stores too (vmcnt retires in order), and at 4096 robots in lockstep a store burst takes ~5 us
@@ -392,7 +414,7 @@ LS_FN void ph_b_housekeeping(const LsCtx& cx, WaveShared& sh, int lane, int env,
     if (lane < 8) out[LSIM_STATS_CMD_RANGES + lane] = sh.ranges[lane];
     if (a.reset_all == 1 && lane == 8) out[LSIM_STATS_RESET_COUNT] = (float)cx.cfg.num_envs;
     LS_GLOBAL float* nxt = LS_G(float, cx.accum) + a.row_in * LSIM_STATS_SIZE;   // the next call accumulates into the row this call read
-    if (lane == 9) nxt[LSIM_STATS_RESET_COUNT] = 0.0f;
+    if (lane == 9) { nxt[LSIM_STATS_RESET_COUNT] = 0.0f; nxt[LSIM_STATS_NONFINITE] = 0.0f; }
     LS_GLOBAL long long* fnxt = LS_G(long long, ls_fix_row(cx, a.row_in));
     LS_STRIDED(k, lane, LSIM_STATS_FIX_WORDS) fnxt[k] = 0;
     LS_STRIDED(k, lane, LSIM_NUM_REWARD_TERMS) nxt[LSIM_STATS_EPISODE_SUMS + k] = 0.0f;
@@ -729,7 +751,8 @@ template <int SOLVER> LS_WAVE_FN void ls_wave_step_a(const LsCtx& cx, const LsSt
         LS_PHASE(ph_body_states_all(cx, sh, rg, lane));
         LS_PHASE(ph_heights_finish(cx, sh, rg, lane, env); ph_late_stage(sh, rg, lane, fuse));   // the loads' results, before the first store; Mbl .. vnew are dead from here on
         LS_CP(6);
-        LS_PHASE(ph_store_body_states(cx, rg, lane, env); ph_store_sim_state(cx, sh, lane, env));
+        LS_COLLECTIVE(ph_store_body_states(cx, rg, lane, env); ph_store_sim_state(cx, sh, lane, env); wc_count_nonfinite(cx, sh, lane, a),
+                      LS_PHASE(ph_store_body_states(cx, rg, lane, env); ph_store_sim_state(cx, sh, lane, env)); emu_count_nonfinite(cx, sh, a));
         LS_CP(7);
     } else {
         LS_PHASE(ph_late_load(cx, rg, lane, env, fuse); ph_heights_issue(cx, sh, rg, lane));
@@ -821,5 +844,5 @@ LS_FN void ls_step_finish_rows(const LsCtx& cx, const LsStepArgs& a, int t) {
         nxt[LSIM_STATS_EPISODE_SUMS + t] = 0.0f;
     }
     if (t < LSIM_STATS_FIX_WORDS) LS_G(long long, ls_fix_row(cx, a.row_in))[t] = 0;
-    if (t == 0) nxt[LSIM_STATS_RESET_COUNT] = 0.0f;
+    if (t == 0) { nxt[LSIM_STATS_RESET_COUNT] = 0.0f; nxt[LSIM_STATS_NONFINITE] = 0.0f; }
 }

@@ -64,6 +64,14 @@ static inline void ls_uniform_load3(const float* p, float out[3]) { out[0] = p[0
 #endif
 
 struct alignas(8) LsF2 { float x, y; };   // one 8-byte global store
+// float -> int as the GPU converts it (v_cvt_i32_f32: NaN -> 0, out-of-range values saturate); the C++ cast is undefined there and x86 returns
+// INT_MIN, with which the lane emulator indexed the height grid when a robot's state was NaN (the GPU did not: tests/test_nonfinite_counter.py)
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ int ls_f2i(float v) { return (int)v; }
+#else
+static inline int ls_f2i(float v) { return v != v ? 0 : (v >= 2147483648.0f ? 2147483647 : (v <= -2147483648.0f ? (-2147483647 - 1) : (int)v)); }
+#endif
+LS_FN unsigned int ls_float_bits(float v) { union { float f; unsigned int u; } c; c.f = v; return c.u; }
 
 struct V3 {
     float x, y, z;

@@ -370,7 +370,7 @@ LS_FN void ls_terrain_query(const LsCtx& cx, float x, float y, float& h, V3& n) 
     const float ihs = ls_rcp(hs);
     float gx = (x + c.border_size) * ihs, gy = (y + c.border_size) * ihs;
     float fi = clampf(floorf(gx), 0.0f, (float)(c.grid_rows - 2)), fj = clampf(floorf(gy), 0.0f, (float)(c.grid_cols - 2));
-    int i = (int)fi, j = (int)fj;
+    int i = ls_f2i(fi), j = ls_f2i(fj);
     float u = clampf(gx - fi, 0.0f, 1.0f), v = clampf(gy - fj, 0.0f, 1.0f);
     float h00 = g[i * c.grid_cols + j] * vs, h10 = g[(i + 1) * c.grid_cols + j] * vs;
     float h01 = g[i * c.grid_cols + j + 1] * vs, h11 = g[(i + 1) * c.grid_cols + j + 1] * vs;
@@ -434,7 +434,7 @@ LS_FN bool ls_terrain_fast(const LsCtx& cx, V3 cw, float radius, float& dist, V3
     const float ihs = ls_rcp(hs);
     float gx = (cw.x + c.border_size) * ihs, gy = (cw.y + c.border_size) * ihs;
     float fi = clampf(floorf(gx), 0.0f, (float)(c.grid_rows - 2)), fj = clampf(floorf(gy), 0.0f, (float)(c.grid_cols - 2));
-    int i = (int)fi, j = (int)fj;
+    int i = ls_f2i(fi), j = ls_f2i(fj);
     gi = i; gj = j;
     const int w00 = mesh[i * c.grid_cols + j];
     {   // nothing within the 4 x 4 vertex block reaches up to the sphere (ls_api_impl.h: bits 24-31 = the block's highest vertex above this

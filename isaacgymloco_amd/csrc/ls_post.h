@@ -26,7 +26,7 @@ LS_FN float ls_sample_height_min3(const LsCtx& cx, float x, float y) {
     const lsim_config& c = cx.cfg;
     float fx = ls_div_exact(x + c.border_size, c.horizontal_scale);
     float fy = ls_div_exact(y + c.border_size, c.horizontal_scale);
-    int px = (int)fx, py = (int)fy;
+    int px = ls_f2i(fx), py = ls_f2i(fy);
     px = px < 0 ? 0 : (px > c.grid_rows - 2 ? c.grid_rows - 2 : px);
     py = py < 0 ? 0 : (py > c.grid_cols - 2 ? c.grid_cols - 2 : py);
     LS_GLOBAL const int16_t* g = LSB(cx, LSIM_BUF_HEIGHT_GRID, const int16_t);
@@ -74,7 +74,7 @@ LS_FN void ls_height_samples3(const LsCtx& cx, float x, float y, int* h2) {
     const lsim_config& c = cx.cfg;
     float fx = ls_div_exact(x + c.border_size, c.horizontal_scale);
     float fy = ls_div_exact(y + c.border_size, c.horizontal_scale);
-    int px = (int)fx, py = (int)fy;
+    int px = ls_f2i(fx), py = ls_f2i(fy);
     px = px < 0 ? 0 : (px > c.grid_rows - 2 ? c.grid_rows - 2 : px);
     py = py < 0 ? 0 : (py > c.grid_cols - 2 ? c.grid_cols - 2 : py);
     // two registers per point and NO arithmetic on them here (anything that looks at a loaded value makes the compiler wait for it in this
@@ -311,7 +311,7 @@ LS_FN float ls_foot_clearance_terrain_part(const LsCtx& cx, const WaveShared& sh
     else {
         float px = bs[0], py = bs[1], pz = bs[2];
         for (int s = 0; s < shifts; ++s) { px += c.border_size; py += c.border_size; pz += c.border_size; }
-        int ix = (int)ls_div_exact(px, c.horizontal_scale), iy = (int)ls_div_exact(py, c.horizontal_scale);
+        int ix = ls_f2i(ls_div_exact(px, c.horizontal_scale)), iy = ls_f2i(ls_div_exact(py, c.horizontal_scale));
         ix = ix < 0 ? 0 : (ix > c.grid_rows - 2 ? c.grid_rows - 2 : ix);
         iy = iy < 0 ? 0 : (iy > c.grid_cols - 2 ? c.grid_cols - 2 : iy);
         LS_GLOBAL const int16_t* g = LSB(cx, LSIM_BUF_HEIGHT_GRID, const int16_t);

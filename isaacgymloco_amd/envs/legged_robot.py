@@ -100,6 +100,7 @@ class LeggedRobot:
         self.reward_curriculum_coef = []
         if cfg.env.send_timeouts:
             self.extras["time_outs"] = self._extras_time_outs
+        self.extras["nonfinite_envs"] = self.nonfinite_envs
         self.common_step_counter = 0
         self.init_done = True
 
@@ -154,6 +155,9 @@ class LeggedRobot:
         self.payload, self.com_displacement = b["payload"].view(N, 1), b["com_displacement"]
         self.episode_sums = {name: b["episode_sums"][:, abi.REWARD_IDS[name]] for name in self.reward_scales}
         self.termination_privileged_obs_buf, self.terminal_amp_states_buf, self.amp_obs_buf = b["term_priv_obs"], b["term_amp_obs"], b["amp_obs"]
+        # running count of env-steps whose simulated state held a NaN / infinity (LSIM_BUF_NONFINITE: cumulative since creation, never cleared by the
+        # library) -- a live 0-d device tensor, so carrying it in `extras` costs no host sync; anything but 0 means the solver blew up
+        self.nonfinite_envs = b["nonfinite"][0]
         dev = self._arena.device
         self.feet_indices = torch.tensor(list(self.model.feet_bodies), dtype=torch.long, device=dev)
         self.penalised_contact_indices = torch.tensor([i for i in range(17) if (self.model.penalised_body_mask >> i) & 1], dtype=torch.long, device=dev)
@@ -303,10 +307,27 @@ class LeggedRobot:
         S = abi.STATS["cmd_ranges"]
         return {"step_counter": int(c.value), "reset_calls": int(rc.value), "terrain_levels": self.terrain_levels.cpu().clone(), "terrain_types": self.terrain_types.cpu().clone(),
                 "env_origins": self.env_origins.cpu().clone(), "episode_length_buf": self.episode_length_buf.cpu().clone(),
-                "command_ranges": self.stats_row()[S:S + 8].cpu().clone()}
+                "command_ranges": self.stats_row()[S:S + 8].cpu().clone(),
+                # the simulator conventions the run was made under: observations / rewards of a policy depend on them
+                "conventions": self._conventions()}
+
+    def _conventions(self):
+        from .. import abi
+        c = self.lcfg
+        return {"abi_version": int(abi.ABI_VERSION), "lin_vel_at_com": int(c.lin_vel_at_com), "tgs_limit_passes": int(c.tgs_limit_passes),
+                "solver_type": int(c.solver_type), "num_position_iterations": int(c.num_position_iterations)}
 
     def load_state_dict(self, d):
         from .. import abi
+        import warnings
+        conv, live = d.get("conventions"), self._conventions()
+        if conv is None:
+            warnings.warn("simulator state saved before round 6: it does not record the conventions it was trained under (centre-of-mass vs link-origin "
+                          f"linear velocities, TGS limit passes); this simulator runs {live} -- LSIM_LIN_VEL=origin LSIM_TGS_LIMIT_PASSES=0 restore rounds 1-4")
+        else:
+            diff = {k: (conv[k], live[k]) for k in ("lin_vel_at_com", "tgs_limit_passes", "solver_type", "num_position_iterations") if conv.get(k) != live[k]}
+            if diff:
+                warnings.warn(f"simulator state was saved under other conventions (saved, live): {diff}; base_lin_vel observations / contact behaviour differ")
         self._L.lsim_set_step_counter(self._h, ctypes.c_int64(int(d["step_counter"])))
         self._L.lsim_set_reset_calls(self._h, ctypes.c_uint32(int(d.get("reset_calls", 0))))       # (checkpoints from before round 5 do not hold it)
         self.terrain_levels.copy_(d["terrain_levels"]); self.terrain_types.copy_(d["terrain_types"])
@@ -325,6 +346,7 @@ class LeggedRobot:
         with at least one reset; values are device tensors (no host sync here)."""
         if self.cfg.env.send_timeouts:
             self.extras["time_outs"] = self._extras_time_outs
+        self.extras["nonfinite_envs"] = self.nonfinite_envs
         if not force_valid:
             return
         S = abi.STATS

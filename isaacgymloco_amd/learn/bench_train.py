@@ -103,6 +103,7 @@ def run_train_bench(env, cfg, args, dev, rank, world, barrier, clocks=None):
     coll = learn = 0.0
     per_iter = []
     barrier()
+    nf0 = int(env.nonfinite_envs)                # (a host read: outside the timed region)
     if clocks is not None:
         clocks.start()
     t0 = time.perf_counter()
@@ -113,6 +114,7 @@ def run_train_bench(env, cfg, args, dev, rank, world, barrier, clocks=None):
         per_iter.append([round(c, 5), round(l, 5)])
     barrier()
     elapsed = time.perf_counter() - t0
+    nonfinite = int(env.nonfinite_envs) - nf0
     sclk = clocks.stop(phases=spans) if clocks is not None else None
     ms_a, ms_b, n = (ctypes.c_float * n_prof)(), (ctypes.c_float * n_prof)(), ctypes.c_int(n_prof)
     env._L.lsim_read_profile(env._h, ms_a, ms_b, ctypes.byref(n))
@@ -132,7 +134,7 @@ def run_train_bench(env, cfg, args, dev, rank, world, barrier, clocks=None):
         digests, masses = [digest], [mass]
     walls = sorted(c + l for c, l in per_iter)
     med = walls[len(walls) // 2] if len(walls) % 2 else 0.5 * (walls[len(walls) // 2 - 1] + walls[len(walls) // 2])
-    extra = {"kernel_a_ms": ka, "kernel_b_ms": kb, "timed_env_steps": iters * T, "ppo_updates_timed": iters, "warmup_iterations": warm_iters,
+    extra = {"kernel_a_ms": ka, "kernel_b_ms": kb, "timed_env_steps": iters * T, "nonfinite_envs": nonfinite, "ppo_updates_timed": iters, "warmup_iterations": warm_iters,
              "ppo_iteration_wall_s": elapsed / iters, "collection_s_per_iteration": coll / iters, "learn_s_per_update": learn / iters,
              "collection_env_steps_per_s": world * env.num_envs * iters * T / max(coll, 1e-9),
              "collection_learn_s_by_iteration": per_iter[:32], "rollout_hip_graphs": bool(use_graphs), "weights_digest_by_rank": digests,

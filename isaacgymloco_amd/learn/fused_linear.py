@@ -281,7 +281,9 @@ def _fused_forward_wanted(x, k_in):
 def linear_elu_forward(x, weight, bias):
     """elu(x W^T + b): lsim_linear_elu_forward (fp32 MFMA, the activation applied to the accumulators, one write of the output) where it is
     the faster form, else BLAS + torch's elementwise ELU"""
+    # (x wider than k_in would be silently truncated by the kernel where F.linear raises: shapes, bias dtype and layout are checked here, ADVICE r5)
     if (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and weight.dtype == torch.float32 and weight.is_contiguous() and weight.shape[0] % 4 == 0
+            and x.shape[1] == weight.shape[1] and (bias is None or (bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == weight.shape[0]))
             and x.stride(1) == 1 and _fused_forward_wanted(x, weight.shape[1])):
         from .. import abi, lib
         xx = x

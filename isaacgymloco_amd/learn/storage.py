@@ -122,7 +122,11 @@ class HIMRolloutStorage:
         return (idx[1:] - idx[:-1]).float().mean(), self.rewards.mean()
 
     def mini_batch_generator(self, num_mini_batches, num_epochs=8):
+        """HST:129-177.  ALIASING CONTRACT (GPU): the minibatch tensors are slices of persistent per-storage buffers (_shuffle), not fresh tensors -- they
+        are overwritten by the NEXT call's shuffle, so a caller that keeps one across update() calls must clone it, and only ONE generator of a
+        storage may be live at a time (a second one re-shuffles under the first: asserted on every yield).  release_shuffle_buffers() frees them."""
         self._no_pending_store()
+        gen_id = self._shuffle_generation = getattr(self, "_shuffle_generation", 0) + 1
         batch = self.num_envs * self.num_transitions_per_env
         mb = batch // num_mini_batches
         perm = torch.randperm(num_mini_batches * mb, requires_grad=False, device=self.device)
@@ -139,7 +143,13 @@ class HIMRolloutStorage:
         shuffled = self._shuffle(fields, perm)
         for _ in range(num_epochs):
             for i in range(num_mini_batches):
+                if self._shuffle_generation != gen_id:
+                    raise RuntimeError("a second mini_batch_generator of this storage re-shuffled the buffers this one hands out (one live generator per storage)")
                 yield tuple(f[i * mb:(i + 1) * mb] for f in shuffled)
+
+    def release_shuffle_buffers(self):
+        """free the persistent shuffle destinations (~0.4 GB at 4096 x 100): after the last update of a run, before an evaluation-only phase"""
+        self._shuffled = None
 
     def _shuffle(self, fields, perm):
         """every field gathered through the permutation.  On the GPU the destinations are PERSISTENT buffers (allocated at the first call):
@@ -150,7 +160,7 @@ class HIMRolloutStorage:
             return tuple(_gather_rows(f, perm) for f in fields)
         bufs = getattr(self, "_shuffled", None)
         ok = bufs is not None and len(bufs) == len(fields) and all(b.shape[0] == perm.numel() and b.shape[1:] == f.shape[1:] and b.dtype == f.dtype
-                                                                      for b, f in zip(bufs, fields))
+                                                                      and b.device == f.device for b, f in zip(bufs, fields))
         if not ok:
             bufs = self._shuffled = tuple(torch.empty((perm.numel(),) + tuple(f.shape[1:]), dtype=f.dtype, device=f.device) for f in fields)
         return tuple(_gather_rows(f, perm, out=b) for f, b in zip(fields, bufs))

@@ -739,6 +739,7 @@ static int check_cfg(const lsim_config* c) {
     if (c->terrain_num_rows > LSIM_TERRAIN_LEVELS_MAX || c->terrain_num_cols > LSIM_TERRAIN_TYPES_MAX) return LSIM_E_INVALID;
     if (c->solver_type != LSIM_SOLVER_PGS && c->solver_type != LSIM_SOLVER_TGS) return LSIM_E_INVALID;
     if (c->solver_type == LSIM_SOLVER_TGS && (c->num_position_iterations < 1 || c->num_position_iterations > LSIM_MAX_POSITION_ITERATIONS)) return LSIM_E_INVALID;
+    if (c->tgs_limit_passes < 0 || c->tgs_limit_passes > LSIM_MAX_POSITION_ITERATIONS || (c->lin_vel_at_com != 0 && c->lin_vel_at_com != 1)) return LSIM_E_INVALID;
     return LSIM_OK;
 }
 
@@ -874,6 +875,17 @@ int orc_step_ex(orc_sim* s, const float* actions, uint32_t flags) {
         if (at_com) /* the root tensor's linear velocity is row 0's of the body tensor: the centre of mass's from here on */
             for (int k = 0; k < 3; ++k) ORC_F(s, LSIM_BUF_ROOT_STATES)[13 * e + 7 + k] = ORC_F(s, LSIM_BUF_RIGID_BODY_STATES)[13 * N_BODY * e + 7 + k];
     }
+    /* robots whose simulated state is not finite (LSIM_BUF_NONFINITE / LSIM_STATS_NONFINITE, include/lsim.h) */
+    int bad = 0;
+    if (!(flags & LSIM_STEP_SKIP_PHYSICS))
+        for (int e = 0; e < N; ++e) {
+            int b = 0;
+            for (int k = 0; k < 13; ++k) b |= !isfinite(ORC_F(s, LSIM_BUF_ROOT_STATES)[13 * e + k]);
+            for (int k = 0; k < 2 * N_DOF; ++k) b |= !isfinite(ORC_F(s, LSIM_BUF_DOF_STATE)[2 * N_DOF * e + k]);
+            bad += b;
+        }
+    stats_row(s)[LSIM_STATS_NONFINITE] = (float)bad;
+    if (bad) { ORC_I64(s, LSIM_BUF_NONFINITE)[0] += bad; ORC_I64(s, LSIM_BUF_NONFINITE)[1] = s->step_counter + 1; }
     post_physics_step(s, flags);
     return LSIM_OK;
 }

@@ -210,8 +210,9 @@ void orc_terrain_contact(const orc_sim* s, const double cw[3], double radius, do
     double hs = c->horizontal_scale, vs = c->vertical_scale;
     double gx = (cw[0] + c->border_size) / hs, gy = (cw[1] + c->border_size) / hs;
     double fi = floor(gx), fj = floor(gy);
-    if (fi < 0) fi = 0; if (fi > c->grid_rows - 2) fi = c->grid_rows - 2;
-    if (fj < 0) fj = 0; if (fj > c->grid_cols - 2) fj = c->grid_cols - 2;
+    /* (written so that a NaN position -- a robot that blew up, counted in LSIM_BUF_NONFINITE -- lands in cell 0 instead of indexing with (int)NaN) */
+    if (!(fi >= 0)) fi = 0; if (fi > c->grid_rows - 2) fi = c->grid_rows - 2;
+    if (!(fj >= 0)) fj = 0; if (fj > c->grid_cols - 2) fj = c->grid_cols - 2;
     int i = (int)fi, j = (int)fj;
     const int16_t* g = ORC_I16(s, LSIM_BUF_HEIGHT_GRID);
     double h00 = g[i * c->grid_cols + j] * vs, h10 = g[(i + 1) * c->grid_cols + j] * vs;
