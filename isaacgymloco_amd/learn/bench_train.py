@@ -102,6 +102,11 @@ def run_train_bench(env, cfg, args, dev, rank, world, barrier, clocks=None):
     env._L.lsim_set_profiling(env._h, n_prof)
     coll = learn = 0.0
     per_iter = []
+    multi_diag = alg.dist_ctx is not None and alg.dist_ctx.enabled        # N > 1 (or the forced 1-rank group): how long this rank stands in the collectives
+    if multi_diag:
+        alg.dist_ctx.timing = True
+        alg.dist_ctx.take_blocked_seconds()
+    blocked = 0.0
     barrier()
     nf0 = int(env.nonfinite_envs)                # (a host read: outside the timed region)
     if clocks is not None:
@@ -112,6 +117,8 @@ def run_train_bench(env, cfg, args, dev, rank, world, barrier, clocks=None):
         coll += c
         learn += l
         per_iter.append([round(c, 5), round(l, 5)])
+        if multi_diag:
+            blocked += alg.dist_ctx.take_blocked_seconds()       # (one_iteration ended with a device synchronisation)
     barrier()
     elapsed = time.perf_counter() - t0
     nonfinite = int(env.nonfinite_envs) - nf0
@@ -124,14 +131,23 @@ def run_train_bench(env, cfg, args, dev, rank, world, barrier, clocks=None):
     # which robot this rank really simulated: total mass of the model table the simulator was created with (aliengo 24.9 kg, go1 11.3 kg)
     mass = float(sum(b.mass for b in env.model.bodies))
     import torch.distributed as dist
+    walls_local = [c + l for c, l in per_iter]
+    mine = [coll / iters, learn / iters, blocked / iters, min(walls_local), max(walls_local), 1.0 if two_streams else 0.0]
     if dist.is_initialized():               # N > 1, or the 1-rank RCCL group of LSIM_DEBUG_FORCE_COLLECTIVES
-        d = torch.tensor(digest + [mass], device=dev, dtype=torch.float64)
+        d = torch.tensor(digest + [mass] + mine, device=dev, dtype=torch.float64)
         all_d = [torch.zeros_like(d) for _ in range(world)]
         dist.all_gather(all_d, d)
         digests = [x.tolist()[:2] for x in all_d]
         masses = [x.tolist()[2] for x in all_d]
+        per_rank = [x.tolist()[3:] for x in all_d]
+        # every rank's wall time of every timed iteration: max - min ACROSS ranks per iteration = how far the slowest rank trails the fastest
+        w = torch.tensor(walls_local, device=dev, dtype=torch.float64)
+        all_w = [torch.zeros_like(w) for _ in range(world)]
+        dist.all_gather(all_w, w)
+        wm = torch.stack(all_w)
+        skew = (wm.max(dim=0).values - wm.min(dim=0).values).tolist()
     else:
-        digests, masses = [digest], [mass]
+        digests, masses, per_rank, skew = [digest], [mass], [mine], [0.0] * len(walls_local)
     walls = sorted(c + l for c, l in per_iter)
     med = walls[len(walls) // 2] if len(walls) % 2 else 0.5 * (walls[len(walls) // 2 - 1] + walls[len(walls) // 2])
     extra = {"kernel_a_ms": ka, "kernel_b_ms": kb, "timed_env_steps": iters * T, "nonfinite_envs": nonfinite, "ppo_updates_timed": iters, "warmup_iterations": warm_iters,
@@ -144,6 +160,14 @@ def run_train_bench(env, cfg, args, dev, rank, world, barrier, clocks=None):
              "iteration_spread_frac": (walls[-1] - walls[0]) / med,
              "value_from_median_iteration": world * env.num_envs * T / med,
              "update_two_streams": two_streams, "tunableop": tun,
+             # where a multi-rank run's time goes, per rank (VERDICT r5 task 6: the first scaling curve must be able to say where lost efficiency went):
+             # a rank's iteration = collection + learn; `collective_blocked_s` = the part of learn its compute stream stood still waiting for a gradient
+             # all-reduce (expected ~1-2 ms of 84 on xGMI); `iteration_skew_s` = slowest minus fastest rank, per timed iteration
+             "per_rank": {"collection_s": [round(r[0], 5) for r in per_rank], "learn_s": [round(r[1], 5) for r in per_rank],
+                          "collective_blocked_s": [round(r[2], 5) for r in per_rank], "iteration_wall_s_min": [round(r[3], 5) for r in per_rank],
+                          "iteration_wall_s_max": [round(r[4], 5) for r in per_rank], "update_two_streams": [bool(r[5] > 0.5) for r in per_rank],
+                          "collective_timing": bool(multi_diag)},
+             "iteration_skew_s_max_mean": [round(max(skew), 5), round(sum(skew) / max(len(skew), 1), 5)],
              # which form the hidden layers' forward ran in (learn/fused_linear.py: linear_elu_forward): "aligned" = the library's MFMA kernel with bias + ELU in
              # the epilogue on the layers with 16-byte-aligned rows, BLAS + torch ELU on the rest; "0" = BLAS + ELU everywhere; "all"
              "linear_elu_forward": os.environ.get("LSIM_ELU_FORWARD", "aligned"),

@@ -16,6 +16,7 @@ every collective issued cost 4.5 % (0.0997 vs 0.0954 s per iteration), of which 
 the rest is host time (profiles/r04_collective_overhead.json, profiles/r04_trace_idle_rccl.txt).  CPU tensors (gloo tests) keep the concatenated form of the same bucket.
 """
 import os
+import time
 
 import torch
 import torch.nn as nn
@@ -132,6 +133,12 @@ class DistCtx:
         self.enabled = dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or forced)
         self.world = dist.get_world_size() if self.enabled else 1
         self.collectives = 0            # number of collectives issued so far (tests / DESIGN.md section 8 count them per iteration)
+        # time the rank spends BLOCKED in gradient collectives (bench.py's multi-rank line, VERDICT r5 task 6): off by default.  On a GPU the wait of
+        # finish_bucket() is a stream dependency, so the blocked time is device time -- an event pair on the compute stream around the wait: elapsed =
+        # how long that stream stood still for the collective (~ 0 when it had finished under the kernels issued in between); on the CPU (gloo) the
+        # wait blocks the host and is timed with the host clock
+        self.timing = False
+        self._ev_pool, self._ev_live, self._blocked_host_s = [], [], 0.0
 
     def average_grads(self, params):
         """one flattened all-reduce per optimiser step; the parameters' .grad are (or become) views of the reduced buffer"""
@@ -200,7 +207,18 @@ class DistCtx:
     def finish_bucket(self, handle):
         """wait; every parameter's .grad becomes a view of its slice of the reduced buffer; returns the averaged `extra` values (or None)"""
         flat, work, params, n_extra, averaged = handle
-        work.wait()
+        if not self.timing:
+            work.wait()
+        elif flat.is_cuda:
+            e0, e1 = self._ev_pool.pop() if self._ev_pool else (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            e0.record()
+            work.wait()
+            e1.record()
+            self._ev_live.append((e0, e1))
+        else:
+            t0 = time.perf_counter()
+            work.wait()
+            self._blocked_host_s += time.perf_counter() - t0
         if not averaged:
             flat.div_(self.world)
         if params is None:                  # arena bucket: the gradients ARE the buffer
@@ -210,6 +228,16 @@ class DistCtx:
         for p, v in zip(params, pieces):
             p.grad = v.view_as(p.grad)
         return pieces[-1] if n_extra else None
+
+    def take_blocked_seconds(self):
+        """seconds blocked in gradient collectives since the last call (timing = True); call after a device synchronisation"""
+        s = self._blocked_host_s
+        self._blocked_host_s = 0.0
+        for e0, e1 in self._ev_live:
+            s += e0.elapsed_time(e1) * 1e-3
+        self._ev_pool += self._ev_live
+        self._ev_live = []
+        return s
 
     def agree(self, flag, device):
         """True iff `flag` is true on EVERY rank (one tiny MIN all-reduce; used once per configuration, not per iteration, and not counted in

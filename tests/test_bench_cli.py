@@ -87,6 +87,13 @@ def test_two_ranks_on_the_fused_gpu_path_stay_in_lockstep():
     assert j["ppo_updates_timed"] >= 1
     assert len(j["weights_digest_by_rank"]) == 2 and j["ranks_in_lockstep"] is True
     assert abs(j["value"] - 2 * 256 * j["timed_env_steps"] / (j["ppo_iteration_wall_s"] * j["ppo_updates_timed"])) / j["value"] < 0.02
+    # a multi-rank line explains itself (VERDICT r5 task 6): per-rank halves of the iteration, time blocked in the gradient collectives, rank skew
+    pr = j["per_rank"]
+    assert pr["collective_timing"] is True and all(len(pr[k]) == 2 for k in ("collection_s", "learn_s", "collective_blocked_s", "update_two_streams"))
+    assert all(0.0 <= b <= l for b, l in zip(pr["collective_blocked_s"], pr["learn_s"])) and all(c > 0 for c in pr["collection_s"])
+    assert len(set(pr["update_two_streams"])) == 1                     # the side-stream decision is taken jointly
+    assert len(j["iteration_skew_s_max_mean"]) == 2 and 0.0 <= j["iteration_skew_s_max_mean"][1] <= j["iteration_skew_s_max_mean"][0]
+    assert j["nonfinite_envs"] == 0
 
 
 @pytest.mark.gpu

@@ -216,12 +216,15 @@ def _worker8(rank, world, port, out_dir):
     torch.manual_seed(100 + rank)                         # different initial weights per rank: the broadcast must fix that
     runner = HIMOnPolicyRunner(FakeEnv(4, seed=7 + rank), tc, log_dir=None, device="cpu")
     torch.manual_seed(5 + rank)
-    per_iter = []
+    per_iter, blocked = [], []
+    runner.dist_ctx.timing = True                         # what bench.py's multi-rank line reports per rank (per_rank.collective_blocked_s)
     for _ in range(2):
         c0 = runner.dist_ctx.collectives
         runner.learn(1, init_at_random_ep_len=False)
         per_iter.append(runner.dist_ctx.collectives - c0)
-    torch.save({"digest": weights_digest(runner.alg.actor_critic), "lr": runner.alg.learning_rate, "collectives": per_iter, "world": runner.dist_ctx.world},
+        blocked.append(runner.dist_ctx.take_blocked_seconds())
+    torch.save({"digest": weights_digest(runner.alg.actor_critic), "lr": runner.alg.learning_rate, "collectives": per_iter, "world": runner.dist_ctx.world,
+                "blocked": blocked},
                os.path.join(out_dir, f"rank{rank}.pt"))
     dist.destroy_process_group()
 
@@ -236,6 +239,8 @@ def test_eight_ranks_stay_in_lockstep_with_21_collectives_per_iteration(tmp_path
     assert all(o["world"] == 8 for o in outs)
     assert all(o["collectives"] == [21, 21] for o in outs), [o["collectives"] for o in outs]
     assert all(o["digest"] == outs[0]["digest"] and o["lr"] == outs[0]["lr"] for o in outs), [o["digest"] for o in outs]
+    # every rank timed its waits on the gradient collectives (host clock on gloo): positive, and far below the iteration's wall time
+    assert all(len(o["blocked"]) == 2 and all(0.0 < b < 60.0 for b in o["blocked"]) for o in outs), [o["blocked"] for o in outs]
 
 
 def test_mixed_robot_mapping_puts_ranks_4_to_7_on_the_go2_table():
