@@ -2,10 +2,13 @@
 host cores: BASELINE.md section 3 plan A, the "build CPU baseline" of SURVEY.md 8(d).  kind = "port": this is NOT the reference's
 PhysX CPU path, which cannot run here.  Started by bench.py as a child process (never imported by the product); touches no GPU.
 
-Legs (one oracle instance each, OpenMP over envs inside liborc.so, N(0,1) actions, seed 1):
-    N = 64   on 1 thread     -- the scalar port (BASELINE config 1's size)
-    N = 64   on all cores
-    N = 4096 on all cores    -- the headline `value`: the size bench.py runs on the GPU
+Legs (one oracle instance each; the timing loop is orc_run_steps in C -- actions, step, clock -- so no Python runs inside the timed region;
+OpenMP over envs in contiguous blocks, threads pinned, every per-env buffer first touched by the thread that owns the block):
+    N = 64   on 1 thread, N(0,1) actions     -- the scalar port (BASELINE config 1's size)
+    N = 4096 on all cores, N(0,1) actions    -- the headline `value`: the size bench.py runs on the GPU
+    N = 4096 on all cores, zero actions      -- standing robots
+    N = 4096 on all cores, closed loop       -- a randomly initialised HIMActorCritic (torch.manual_seed(1)) evaluated in C, mean + N(0,1) noise
+(the three action sources of SURVEY.md 8d)
 
     python oracle/cpu_bench.py --task aliengo --seconds 24   ->  one JSON line
 """
@@ -33,24 +36,59 @@ def cpu_model():
     return "unknown"
 
 
-def leg(task, envs, threads, seconds, gomp):
+class _Layer(ctypes.Structure):
+    _fields_ = [("w", ctypes.c_void_p), ("b", ctypes.c_void_p), ("n_in", ctypes.c_int), ("n_out", ctypes.c_int), ("elu", ctypes.c_int)]
+
+
+class _Policy(ctypes.Structure):
+    _fields_ = [("enc", _Layer * 3), ("act", _Layer * 4)]
+
+
+def random_policy():
+    """HIMActorCritic as the runner creates it, torch.manual_seed(1): the C struct of its encoder / actor weights (+ the arrays that keep them alive)"""
+    import numpy as np
+    import torch
+    import torch.nn as nn
+    from isaacgymloco_amd.learn.bench_train import train_cfg_dict
+    from isaacgymloco_amd.learn.modules import HIMActorCritic
+    torch.manual_seed(1)
+    ac = HIMActorCritic(270, 238, 45, 12, **train_cfg_dict("aliengo")["policy"])
+    P, keep = _Policy(), []
+    for dst, seq in ((P.enc, ac.estimator.encoder), (P.act, ac.actor)):
+        lin = [m for m in seq if isinstance(m, nn.Linear)]
+        for i, l in enumerate(lin):
+            w, b = np.ascontiguousarray(l.weight.detach().numpy(), np.float32), np.ascontiguousarray(l.bias.detach().numpy(), np.float32)
+            keep += [w, b]
+            dst[i].w, dst[i].b, dst[i].n_in, dst[i].n_out, dst[i].elu = w.ctypes.data, b.ctypes.data, l.in_features, l.out_features, int(i + 1 < len(lin))
+    return P, keep
+
+
+def leg(task, envs, threads, seconds, gomp, source="normal", policy=None):
     import numpy as np
     from helpers import C, make_oracle
     gomp.omp_set_num_threads(threads)
     cfg = C.TASKS[task][0]()
-    orc, lc, model, ter = make_oracle(cfg, envs, seed=1)
+    orc, lc, model, ter = make_oracle(cfg, envs, seed=1)      # (orc_create: parallel first touch by the pinned threads)
+    L = orc._L
+    L.orc_run_steps.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
     orc.reset_all()
     rs = np.random.RandomState(1)
-    acts = [rs.normal(0, 1, (envs, 12)).astype(np.float32) for _ in range(8)]
-    orc.step(acts[0])
-    t0 = time.perf_counter()
-    n = 0
-    while time.perf_counter() - t0 < seconds or n < 2:
-        orc.step(acts[n % 8])
-        n += 1
-    dt = time.perf_counter() - t0
+    table = np.ascontiguousarray(rs.normal(0, 1, (8, envs, 12)).astype(np.float32))
+    mode = {"zeros": 0, "normal": 1, "policy": 2}[source]
+    pol = ctypes.byref(policy[0]) if mode == 2 else None
+    sec = ctypes.c_double()
+
+    def run(n):
+        rc = L.orc_run_steps(orc._h, n, mode, table.ctypes.data_as(ctypes.c_void_p), 8, pol, ctypes.byref(sec))
+        assert rc == 0, rc
+        return sec.value
+    run(2)                                                      # warm-up (page faults of the scratch, thread pool)
+    probe = max(run(3) / 3, 1e-6)
+    n = max(int(seconds / probe), 2)
+    dt = run(n)
+    bad = int(np.array(orc.buf["nonfinite"])[0])
     orc.close()
-    return {"envs": envs, "threads": threads, "steps": n, "seconds": round(dt, 3), "env_steps_per_s": envs * n / dt}
+    return {"envs": envs, "threads": threads, "actions": source, "steps": n, "seconds": round(dt, 3), "env_steps_per_s": envs * n / dt, "nonfinite_env_steps": bad}
 
 
 if __name__ == "__main__":
@@ -61,18 +99,23 @@ if __name__ == "__main__":
     a = ap.parse_args()
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     threads = a.threads if a.threads > 0 else avail
-    os.environ.setdefault("OMP_PROC_BIND", "false")
+    # threads pinned (one place per hardware thread): with schedule(static) every thread then owns the same env block in every loop of every step, the
+    # block's pages were first touched by it (orc_create) and stay in its caches.  Must be in the environment before libgomp initialises.
+    os.environ.setdefault("OMP_PROC_BIND", "true")
+    os.environ.setdefault("OMP_PLACES", "threads")
+    os.environ.setdefault("OMP_WAIT_POLICY", "active")
     gomp = ctypes.CDLL("libgomp.so.1")
-    legs = [leg(a.task, 64, 1, a.seconds * 0.2, gomp), leg(a.task, 64, threads, a.seconds * 0.2, gomp),
-            leg(a.task, 4096, threads, a.seconds * 0.6, gomp)]
-    scaling = legs[2]["env_steps_per_s"] / max(legs[0]["env_steps_per_s"], 1e-9)
+    pol = random_policy()
+    legs = [leg(a.task, 64, 1, a.seconds * 0.15, gomp), leg(a.task, 4096, threads, a.seconds * 0.35, gomp),
+            leg(a.task, 4096, threads, a.seconds * 0.2, gomp, "zeros"), leg(a.task, 4096, threads, a.seconds * 0.3, gomp, "policy", pol)]
+    scaling = legs[1]["env_steps_per_s"] / max(legs[0]["env_steps_per_s"], 1e-9)
     print(json.dumps({
-        "value": legs[2]["env_steps_per_s"], "unit": "env-steps/s", "cores": threads, "kind": "port",
+        "value": legs[1]["env_steps_per_s"], "unit": "env-steps/s", "cores": threads, "kind": "port",
         "parallel_speedup_over_one_core": scaling,
-        "value_1core": legs[0]["env_steps_per_s"], "value_n64_all_cores": legs[1]["env_steps_per_s"],
+        "value_1core": legs[0]["env_steps_per_s"], "value_zero_actions": legs[2]["env_steps_per_s"], "value_closed_loop_random_policy": legs[3]["env_steps_per_s"],
         "nproc": os.cpu_count(), "cores_available": avail, "cpu_model": cpu_model(), "legs": legs,
-        "sample": f"task {a.task}, N(0,1) actions: {legs[2]['steps']} steps x 4096 envs on {threads} OpenMP threads (value); "
-                  f"{legs[1]['steps']} steps x 64 envs on {threads} threads; {legs[0]['steps']} steps x 64 envs on 1 thread (value_1core); "
-                  f"CPU oracle = the build's scalar C restatement, fp64 physics -- not the reference's PhysX CPU path.  A WEAK baseline: {threads} "
-                  f"threads give only {scaling:.1f} x one core (the per-env loops are OpenMP-parallel, reset_idx's cross-env part and the Python "
-                  f"driver are serial; N = 64 on all threads is about one core), so a GPU / CPU ratio from this line says nothing about either"}))
+        "omp": {k: os.environ.get(k) for k in ("OMP_PROC_BIND", "OMP_PLACES", "OMP_WAIT_POLICY")},
+        "sample": f"task {a.task}: {legs[1]['steps']} steps x 4096 envs, N(0,1) actions, on {threads} pinned OpenMP threads (value); {legs[2]['steps']} steps with zero "
+                  f"actions; {legs[3]['steps']} steps closed loop with a randomly initialised HIMActorCritic evaluated in C; {legs[0]['steps']} steps x 64 envs on 1 thread "
+                  f"(value_1core).  Timing loop in C (orc_run_steps), static env blocks, first-touch placement: {threads} threads = {scaling:.0f} x one core.  "
+                  f"CPU oracle = the build's scalar C restatement with fp64 physics -- not the reference's PhysX CPU path (closed binary, absent here)"}))

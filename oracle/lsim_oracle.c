@@ -19,6 +19,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "orc_internal.h"
 #include "orc_philox.h"
@@ -587,7 +588,7 @@ static void post_physics_step(orc_sim* s, uint32_t flags) {
     const float gvec[3] = {0.0f, 0.0f, -1.0f};
     const float fwd[3] = {1.0f, 0.0f, 0.0f};
 
-    #pragma omp parallel for schedule(dynamic, 16) reduction(+ : n_reset)
+    #pragma omp parallel for schedule(static) reduction(+ : n_reset)
     for (int e = 0; e < N; ++e) {
         float* root = ORC_F(s, LSIM_BUF_ROOT_STATES) + 13 * e;
         const float* cf = ORC_F(s, LSIM_BUF_CONTACT_FORCES) + 3 * N_BODY * e;
@@ -753,8 +754,22 @@ int orc_create(const lsim_config* cfg, const lsim_robot_model* model, const int1
     const int N = c->num_envs;
     for (int id = 0; id < LSIM_NUM_BUFFERS; ++id) {
         size_t b = lsim_buffer_bytes(c, id);
-        s->buf[id] = calloc(1, b ? b : 1);
-        if (!s->buf[id]) return LSIM_E_NOMEM;
+        int64_t shp[4]; int nd, dt;
+        (void)lsim_buffer_desc(c, id, shp, &nd, &dt);
+        if (shp[0] == N && b >= (size_t)N) {
+            /* per-env buffer: zeroed -- i.e. its pages first touched, and so placed on the NUMA node of -- by the thread that will own the env block
+             * in every schedule(static) loop over envs below (cpu_bench.py pins the threads); 64-byte aligned: blocks of different threads share
+             * at most one cache line per buffer */
+            const size_t row = b / (size_t)N;
+            void* p = NULL;
+            if (posix_memalign(&p, 64, b) != 0) return LSIM_E_NOMEM;
+            s->buf[id] = p;
+            #pragma omp parallel for schedule(static)
+            for (int e = 0; e < N; ++e) memset((char*)p + row * (size_t)e, 0, row);
+        } else {
+            s->buf[id] = calloc(1, b ? b : 1);
+            if (!s->buf[id]) return LSIM_E_NOMEM;
+        }
     }
     if (c->mesh_type != 0) {
         if (!grid || !origins) return LSIM_E_INVALID;
@@ -768,6 +783,7 @@ int orc_create(const lsim_config* cfg, const lsim_robot_model* model, const int1
         if (id != LSIM_R_TERMINATION && c->reward_scales[id] != 0.0f) s->active_terms[s->num_active++] = id;
     /* init-time draws (LR:999-1032, LR:1172-1179, LR:506-513, LR:1232-1239) */
     const uint32_t W = 0xFFFFFFFFu;
+    #pragma omp parallel for schedule(static)      /* every draw is a pure function of (env, tag, index) */
     for (int e = 0; e < N; ++e) {
         for (int j = 0; j < N_DOF; ++j)
             ORC_F(s, LSIM_BUF_MOTOR_STRENGTH)[N_DOF * e + j] =
@@ -852,7 +868,9 @@ int orc_step_ex(orc_sim* s, const float* actions, uint32_t flags) {
     s->stats_row ^= 1;
     /* envs are independent (no robot-robot contact, LR:1193) and every random draw is a pure function of (env, step, tag): the
        result does not depend on the thread count.  OMP_NUM_THREADS = 1 is the scalar port. */
-    #pragma omp parallel for schedule(dynamic, 1)
+    /* schedule(static): a contiguous block of envs per thread.  (Round 1-5: dynamic, 1 -- neighbouring envs, i.e. neighbouring rows of every [N, k]
+     * buffer and often the same cache line, on different threads: false sharing on every store of the step; 256 threads gave 7 x one core.) */
+    #pragma omp parallel for schedule(static)
     for (int e = 0; e < N; ++e) {
         float* act = ORC_F(s, LSIM_BUF_ACTIONS) + N_DOF * e;
         const float* last = ORC_F(s, LSIM_BUF_LAST_ACTIONS) + N_DOF * e;
@@ -896,6 +914,92 @@ int orc_get_step_counter(orc_sim* s, int64_t* out) { *out = s->step_counter; ret
 int orc_set_step_counter(orc_sim* s, int64_t v) { s->step_counter = v; return LSIM_OK; }
 int orc_set_init_done(orc_sim* s, int v) { s->init_done = v; return LSIM_OK; }
 int orc_get_command_ranges(orc_sim* s, double out[8]) { memcpy(out, s->command_ranges, sizeof(double) * 8); return LSIM_OK; }
+
+/* ---- the CPU baseline's timing loop (oracle/cpu_bench.py; SURVEY.md 8d: three action sources), entirely in C: n_steps x { actions for every env,
+ * orc_step } with the wall clock around it.  mode 0: zero actions (standing); 1: the caller's table of pre-drawn N(0,1) action sets [table_len][N][12],
+ * cycled (= an untrained policy's samples, init_noise_std = 1, AGC:299); 2: closed loop with the caller's HIMActorCritic weights (HAC:136-163,
+ * HES:64-68: encoder 270 -> .. -> 3 + 16, L2-normalised latent, actor on [obs[:45], v, z]) -- mean action + the table's noise.  fp32, one env per
+ * thread at a time; weights [out][in] row-major as torch.nn.Linear keeps them. */
+typedef struct orc_mlp_layer { const float* w; const float* b; int n_in, n_out, elu; } orc_mlp_layer;
+typedef struct orc_policy { orc_mlp_layer enc[3]; orc_mlp_layer act[4]; } orc_policy;
+static void mlp_layer(const orc_mlp_layer* L, const float* x, float* y) {
+    for (int o = 0; o < L->n_out; ++o) {
+        const float* w = L->w + (size_t)o * L->n_in;
+        float a = 0.0f;
+        #pragma omp simd reduction(+ : a)      /* (lets the compiler vectorise the dot product: a different summation order than torch's, irrelevant for a timing loop) */
+        for (int i = 0; i < L->n_in; ++i) a += w[i] * x[i];
+        a += L->b[o];
+        y[o] = (L->elu && a < 0.0f) ? expm1f(a) : a;
+    }
+}
+static void policy_mean(const orc_policy* p, const float* obs, float* out12) {
+    float a[512], b[512];
+    mlp_layer(&p->enc[0], obs, a); mlp_layer(&p->enc[1], a, b); mlp_layer(&p->enc[2], b, a);     /* a[0..2] velocity, a[3..18] latent */
+    float in[64], ss = 0.0f;
+    for (int k = 0; k < 16; ++k) ss += a[3 + k] * a[3 + k];
+    const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+    for (int k = 0; k < 45; ++k) in[k] = obs[k];
+    for (int k = 0; k < 3; ++k) in[45 + k] = a[k];
+    for (int k = 0; k < 16; ++k) in[48 + k] = a[3 + k] * inv;
+    mlp_layer(&p->act[0], in, a); mlp_layer(&p->act[1], a, b); mlp_layer(&p->act[2], b, a); mlp_layer(&p->act[3], a, out12);
+}
+int orc_run_steps(orc_sim* s, int n_steps, int mode, const float* table, int table_len, const orc_policy* pol, double* seconds) {
+    if (!s || n_steps < 0 || !seconds || (mode != 0 && (!table || table_len <= 0)) || (mode == 2 && !pol)) return LSIM_E_INVALID;
+    if (mode == 2 && (pol->enc[0].n_in != LSIM_NUM_OBS || pol->enc[2].n_out != 19 || pol->act[0].n_in != 64 || pol->act[3].n_out != N_DOF ||
+                      pol->enc[0].n_out > 512 || pol->enc[1].n_out > 512 || pol->act[0].n_out > 512 || pol->act[1].n_out > 512 || pol->act[2].n_out > 512))
+        return LSIM_E_UNSUPPORTED;
+    const int N = s->cfg.num_envs;
+    float* act = NULL;
+    if (posix_memalign((void**)&act, 64, (size_t)N * N_DOF * sizeof(float)) != 0) return LSIM_E_NOMEM;
+    #pragma omp parallel for schedule(static)
+    for (int e = 0; e < N; ++e) memset(act + N_DOF * e, 0, N_DOF * sizeof(float));
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int t = 0; t < n_steps; ++t) {
+        if (mode != 0) {
+            const float* z = table + (size_t)(t % table_len) * N * N_DOF;
+            #pragma omp parallel for schedule(static)
+            for (int e = 0; e < N; ++e) {
+                float m[N_DOF] = {0};
+                if (mode == 2) policy_mean(pol, ORC_F(s, LSIM_BUF_OBS) + LSIM_NUM_OBS * e, m);
+                for (int j = 0; j < N_DOF; ++j) act[N_DOF * e + j] = m[j] + z[N_DOF * e + j];
+            }
+        }
+        int rc = orc_step_ex(s, act, LSIM_STEP_DEFAULT);
+        if (rc != LSIM_OK) { free(act); return rc; }
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    *seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+    free(act);
+    return LSIM_OK;
+}
+
+/* Diagnostic for the modelling-distance tables of DESIGN.md section 4 (tools/trained_policy_physics.py), not part of the step: clearance of an arbitrary
+ * set of points RIGIDLY ATTACHED TO A BODY -- pts [n][4] = (x, y, z in the body frame, radius) -- from the terrain surface, for every env:
+ * out[e] = min over the points of (signed distance of the point's centre - radius).  Used with a dense sampling of the trunk's true box to see
+ * whether terrain passes between the shipped model's trunk sample points (negative clearance while the simulated base reports no contact). */
+int orc_body_clearance(orc_sim* s, int body, const float* pts, int n, float* out) {
+    if (!s || !pts || !out || body < 0 || body >= N_BODY) return LSIM_E_INVALID;
+    const int N = s->cfg.num_envs;
+    #pragma omp parallel for schedule(static)
+    for (int e = 0; e < N; ++e) {
+        const float* b = ORC_F(s, LSIM_BUF_RIGID_BODY_STATES) + 13 * (N_BODY * e + body);
+        const double qx = b[3], qy = b[4], qz = b[5], qw = b[6];
+        const double R[3][3] = {{1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw)},
+                                {2 * (qx * qy + qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw)},
+                                {2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy)}};
+        double best = 1e30;
+        for (int i = 0; i < n; ++i) {
+            const float* p = pts + 4 * i;
+            double cw[3], dist, nn[3];
+            for (int k = 0; k < 3; ++k) cw[k] = b[k] + R[k][0] * p[0] + R[k][1] * p[1] + R[k][2] * p[2];
+            orc_terrain_contact(s, cw, (double)p[3], &dist, nn);
+            if (dist - p[3] < best) best = dist - p[3];
+        }
+        out[e] = (float)best;
+    }
+    return LSIM_OK;
+}
 
 void orc_destroy(orc_sim* s) {
     if (!s) return;

@@ -1,6 +1,8 @@
 """Learnability check (not a benchmark): train aliengo (flat-ish terrain mix of the task config, 4096 envs) for a number of PPO
 iterations with the build's runner and record mean episode reward / length / tracking reward per iteration.
-usage: python tools/train_probe.py [iterations] [out.json]"""
+usage: python tools/train_probe.py [iterations] [out.json] [task] [seed] [checkpoint.pt]
+checkpoint.pt: the trained actor-critic + the simulator's curriculum state (LeggedRobot.state_dict) + what the product's own physics did under the trained
+policy in a closed-loop evaluation rollout (tools/trained_policy_physics.py replays the same policy through the CPU oracle's variants)"""
 import json
 import os
 import sys
@@ -58,4 +60,31 @@ for it in range(iters):
     if it % 10 == 0 or it == iters - 1:
         print(json.dumps(rec), flush=True)
 os.makedirs(os.path.dirname(out), exist_ok=True)
-json.dump(dict(task=task, num_envs=N, steps_per_iteration=T, curve=curve), open(out, "w"))
+ckpt = sys.argv[5] if len(sys.argv) > 5 else None
+evals = None
+if ckpt:
+    # closed loop under the TRAINED policy (mean actions, as play.py runs it): the quantities the modelling-distance tables of DESIGN.md section 4 read
+    ac = runner.alg.actor_critic
+    ac.eval()
+    pen, term = env.penalised_contact_indices, env.termination_contact_indices
+    acc = torch.zeros(6, device="cuda:0", dtype=torch.float64)
+    steps_eval = 1000
+    with torch.inference_mode():
+        obs = env.get_observations()
+        for _ in range(steps_eval):
+            env.step_device(ac.act_inference(obs))
+            obs = env.obs_buf
+            cf = env.contact_forces
+            hit = (torch.linalg.norm(cf[:, term, :], dim=-1) > 1.0).any(dim=1)
+            acc += torch.stack(((env.reset_buf & ~env.time_out_buf).double().sum(), hit.double().sum(),
+                                (torch.linalg.norm(cf[:, pen, :], dim=-1) > 0.1).double().sum(), (env.buf["contact_count"][:, 0] > 8).double().sum(),
+                                env.reset_buf.double().sum(), env.terrain_levels.double().sum() / steps_eval))
+    a = acc.tolist()
+    es = N * steps_eval
+    evals = dict(steps=steps_eval, num_envs=N, terminations_not_timeout_per_env_step=a[0] / es, base_contact_per_env_step=a[1] / es,
+                 collision_count_per_env_step=a[2] / es, contact_cap_hits_per_env_step=a[3] / es, resets_per_env_step=a[4] / es,
+                 mean_terrain_level=a[5] / N, nonfinite_envs=int(env.nonfinite_envs))
+    print("eval", json.dumps(evals), flush=True)
+    torch.save({"task": task, "model_state_dict": {k: v.cpu() for k, v in ac.state_dict().items()}, "env_state": env.state_dict(), "eval_hip": evals,
+                "iterations": iters}, ckpt)
+json.dump(dict(task=task, num_envs=N, steps_per_iteration=T, curve=curve, eval_hip=evals), open(out, "w"))
