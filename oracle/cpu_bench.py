@@ -44,22 +44,38 @@ class _Policy(ctypes.Structure):
     _fields_ = [("enc", _Layer * 3), ("act", _Layer * 4)]
 
 
+_POLICY_CHILD = r"""
+import sys, numpy as np, torch, torch.nn as nn
+sys.path.insert(0, sys.argv[1])
+from isaacgymloco_amd.learn.bench_train import train_cfg_dict
+from isaacgymloco_amd.learn.modules import HIMActorCritic
+torch.manual_seed(1)
+ac = HIMActorCritic(270, 238, 45, 12, **train_cfg_dict("aliengo")["policy"])
+out = {}
+for name, seq in (("enc", ac.estimator.encoder), ("act", ac.actor)):
+    for i, l in enumerate([m for m in seq if isinstance(m, nn.Linear)]):
+        out[f"{name}{i}_w"], out[f"{name}{i}_b"] = l.weight.detach().numpy(), l.bias.detach().numpy()
+np.savez(sys.argv[2], **out)
+"""
+
+
 def random_policy():
-    """HIMActorCritic as the runner creates it, torch.manual_seed(1): the C struct of its encoder / actor weights (+ the arrays that keep them alive)"""
+    """HIMActorCritic as the runner creates it, torch.manual_seed(1): the C struct of its encoder / actor weights (+ the arrays that keep them alive).
+    The weights are drawn in a CHILD process: importing torch here would bring a second OpenMP runtime (the wheel's own libgomp) into this process, the
+    oracle's parallel regions would bind to that one and run with whatever thread count / places IT derived -- measured: one thread (256 = 1 x one core)."""
+    import subprocess
+    import tempfile
     import numpy as np
-    import torch
-    import torch.nn as nn
-    from isaacgymloco_amd.learn.bench_train import train_cfg_dict
-    from isaacgymloco_amd.learn.modules import HIMActorCritic
-    torch.manual_seed(1)
-    ac = HIMActorCritic(270, 238, 45, 12, **train_cfg_dict("aliengo")["policy"])
+    path = os.path.join(tempfile.mkdtemp(prefix="lsim_cpu_bench_"), "policy.npz")
+    env = {k: v for k, v in os.environ.items() if not k.startswith("OMP_")}
+    subprocess.check_call([sys.executable, "-c", _POLICY_CHILD, ROOT, path], env=env, stdout=subprocess.DEVNULL)
+    z = np.load(path)
     P, keep = _Policy(), []
-    for dst, seq in ((P.enc, ac.estimator.encoder), (P.act, ac.actor)):
-        lin = [m for m in seq if isinstance(m, nn.Linear)]
-        for i, l in enumerate(lin):
-            w, b = np.ascontiguousarray(l.weight.detach().numpy(), np.float32), np.ascontiguousarray(l.bias.detach().numpy(), np.float32)
+    for dst, name, n in ((P.enc, "enc", 3), (P.act, "act", 4)):
+        for i in range(n):
+            w, b = np.ascontiguousarray(z[f"{name}{i}_w"], np.float32), np.ascontiguousarray(z[f"{name}{i}_b"], np.float32)
             keep += [w, b]
-            dst[i].w, dst[i].b, dst[i].n_in, dst[i].n_out, dst[i].elu = w.ctypes.data, b.ctypes.data, l.in_features, l.out_features, int(i + 1 < len(lin))
+            dst[i].w, dst[i].b, dst[i].n_in, dst[i].n_out, dst[i].elu = w.ctypes.data, b.ctypes.data, w.shape[1], w.shape[0], int(i + 1 < n)
     return P, keep
 
 
@@ -82,13 +98,16 @@ def leg(task, envs, threads, seconds, gomp, source="normal", policy=None):
         rc = L.orc_run_steps(orc._h, n, mode, table.ctypes.data_as(ctypes.c_void_p), 8, pol, ctypes.byref(sec))
         assert rc == 0, rc
         return sec.value
+    used = L.orc_parallel_threads()                             # what a parallel region of the oracle really runs with
+    assert used == threads, f"asked OpenMP for {threads} threads, the oracle's parallel regions run with {used} (a second OpenMP runtime in this process?)"
     run(2)                                                      # warm-up (page faults of the scratch, thread pool)
     probe = max(run(3) / 3, 1e-6)
     n = max(int(seconds / probe), 2)
     dt = run(n)
     bad = int(np.array(orc.buf["nonfinite"])[0])
     orc.close()
-    return {"envs": envs, "threads": threads, "actions": source, "steps": n, "seconds": round(dt, 3), "env_steps_per_s": envs * n / dt, "nonfinite_env_steps": bad}
+    return {"envs": envs, "threads": threads, "actions": source, "steps": n, "seconds": round(dt, 3), "env_steps_per_s": envs * n / dt, "nonfinite_env_steps": bad,
+            "threads_in_parallel_region": used}
 
 
 if __name__ == "__main__":
@@ -104,8 +123,9 @@ if __name__ == "__main__":
     os.environ.setdefault("OMP_PROC_BIND", "true")
     os.environ.setdefault("OMP_PLACES", "threads")
     os.environ.setdefault("OMP_WAIT_POLICY", "active")
+    pol = random_policy()                    # (a child process: no torch, i.e. no second OpenMP runtime, in this one)
     gomp = ctypes.CDLL("libgomp.so.1")
-    pol = random_policy()
+    assert "torch" not in sys.modules
     legs = [leg(a.task, 64, 1, a.seconds * 0.15, gomp), leg(a.task, 4096, threads, a.seconds * 0.35, gomp),
             leg(a.task, 4096, threads, a.seconds * 0.2, gomp, "zeros"), leg(a.task, 4096, threads, a.seconds * 0.3, gomp, "policy", pol)]
     scaling = legs[1]["env_steps_per_s"] / max(legs[0]["env_steps_per_s"], 1e-9)

@@ -20,6 +20,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <omp.h>
 
 #include "orc_internal.h"
 #include "orc_philox.h"
@@ -942,6 +943,16 @@ static void policy_mean(const orc_policy* p, const float* obs, float* out12) {
     for (int k = 0; k < 3; ++k) in[45 + k] = a[k];
     for (int k = 0; k < 16; ++k) in[48 + k] = a[3 + k] * inv;
     mlp_layer(&p->act[0], in, a); mlp_layer(&p->act[1], a, b); mlp_layer(&p->act[2], b, a); mlp_layer(&p->act[3], a, out12);
+}
+/* the number of threads an OpenMP parallel region of this library really runs with (cpu_bench.py reports it as `cores`) */
+int orc_parallel_threads(void) {
+    int n = 1;
+    #pragma omp parallel
+    {
+        #pragma omp master
+        n = omp_get_num_threads();
+    }
+    return n;
 }
 int orc_run_steps(orc_sim* s, int n_steps, int mode, const float* table, int table_len, const orc_policy* pol, double* seconds) {
     if (!s || n_steps < 0 || !seconds || (mode != 0 && (!table || table_len <= 0)) || (mode == 2 && !pol)) return LSIM_E_INVALID;

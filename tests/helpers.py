@@ -35,7 +35,7 @@ def quiet_cfg(task="aliengo", flat=True):
 def make_oracle(cfg, num_envs, seed=1, terrain_seed=1, using_amp=False, library=None):
     from oracle import oracle
     ter = T.Terrain(cfg.terrain, num_envs, seed=terrain_seed)
-    from isaacgymloco_amd.envs.legged_robot import build_robot_model
+    from isaacgymloco_amd.robots.model import build_robot_model
     model = build_robot_model(cfg.asset)
     lc = LC.make_lsim_config(cfg, num_envs=num_envs, terrain=ter, model=model, seed=seed, using_amp=using_amp)
     if not hasattr(ter, "heightsamples"):      # mesh_type plane / none: no grid (TER:52-53)
