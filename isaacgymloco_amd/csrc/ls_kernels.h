@@ -140,6 +140,13 @@ LS_FN void ph_load_a(const LsCtx& cx, WaveShared& sh, LaneRegs& rg, int lane, in
     const float v_rng = LS_G(const float, cx.accum)[a.row_in * LSIM_STATS_SIZE + LSIM_STATS_CMD_RANGES + (lane & 7)];   // live command ranges (no kernel of this step writes row_in's)
     const float v_mp = lane < LSIM_MAX_HEIGHT_PTS_X ? c.measured_points_x[lane] : c.measured_points_y[lane - LSIM_MAX_HEIGHT_PTS_X];
     static_assert(LSIM_MAX_HEIGHT_PTS_X + LSIM_MAX_HEIGHT_PTS_Y == 64, "one lane per measured-point coordinate");
+    // lsim_config.lin_vel_at_com: the root tensor's linear velocity is the centre of mass's (PhysX); the dynamics work on the link origin's,
+    // v_origin = v_com - w x (R c).  Lane 14 fetches what that needs (the same cache line as v_root) with everything else and converts below:
+    // until round 6 this was a one-lane phase of its own between the load and the first kinematics phase (an LDS round trip + a barrier per step)
+    const bool to_origin = c.lin_vel_at_com != 0 && !(a.flags & LSIM_STEP_SKIP_PHYSICS);
+    float v_r10[10], v_cd3[3];
+    for (int k = 0; k < 10; ++k) v_r10[k] = LSB(cx, LSIM_BUF_ROOT_STATES, float)[13 * env + 3 + k];
+    for (int k = 0; k < 3; ++k) v_cd3[k] = LSB(cx, LSIM_BUF_COM_DISPLACEMENT, float)[3 * env + k];
     float v_jc[7];
     {
         const lsim_robot_model& m = cx.model;
@@ -152,7 +159,14 @@ LS_FN void ph_load_a(const LsCtx& cx, WaveShared& sh, LaneRegs& rg, int lane, in
     static_assert(sizeof(sh.u.I6) <= sizeof(sh.u.c.Y) && sizeof(sh.u.c.Y) - sizeof(sh.u.I6) <= 2 * LS_NV * sizeof(float), "rows of Y beyond the inertias: at most the two zeroed here");
     if (lane < 2 * LS_NV) (&sh.u.c.Y[LS_MAXR - 2][0])[lane] = 0.0f;
     if (lane < LSIM_MAX_HEIGHT_PTS_X) sh.mpx[lane] = v_mp; else sh.mpy[lane - LSIM_MAX_HEIGHT_PTS_X] = v_mp;
-    if (lane < 13) sh.root[lane] = v_root;
+    if (lane < 13 && !(to_origin && lane >= 7 && lane < 10)) sh.root[lane] = v_root;
+    if (to_origin && lane == 14) {
+        const lsim_body& b0 = cx.model.bodies[0];
+        const V3 cl = v3(b0.com[0] + v_cd3[0], b0.com[1] + v_cd3[1], b0.com[2] + v_cd3[2]);            // ls_body_com_local(sh, 0)
+        const V3 r = quat_apply(v_r10, cl);
+        const V3 v = v3p(v_r10 + 4) - cross(v3p(v_r10 + 7), r);
+        v3st(sh.root + 7, v);
+    }
     if (lane < 12) {
         sh.jc_q0[lane] = v_jc[0]; sh.jc_kp[lane] = v_jc[1]; sh.jc_kd[lane] = v_jc[2]; sh.jc_taumax[lane] = v_jc[3];
         sh.jc_lo[lane] = v_jc[4]; sh.jc_hi[lane] = v_jc[5]; sh.jc_vmax[lane] = v_jc[6];
@@ -219,15 +233,6 @@ LS_FN void ph_torques(const LsCtx& cx, WaveShared& sh, int lane, int env, int su
     t = clampf(t, -sh.jc_taumax[lane], sh.jc_taumax[lane]);
     sh.tau[lane] = t;
     if (flags & LSIM_STEP_RECORD_SUBSTEPS) LSB(cx, LSIM_BUF_SUBSTEP_TORQUES, float)[12 * (c.decimation * env + sub) + lane] = t;   // test hook (wave-uniform branch)
-}
-
-// lsim_config.lin_vel_at_com: the root state tensor carries the linear velocity of the base's centre of mass (PhysX); the dynamics work on
-// the link origin's: v_origin = v_com - w x (R c), once per step, after the load and before the first kinematics phase
-LS_FN void ph_root_lin_vel_to_origin(WaveShared& sh, int lane) {
-    if (lane != 0) return;
-    const V3 r = quat_apply(sh.root + 3, ls_body_com_local(sh, 0));
-    const V3 v = v3p(sh.root + 7) - cross(v3p(sh.root + 10), r);
-    v3st(sh.root + 7, v);
 }
 
 // ---- after the last sub-step: publish the simulator state tensors (LR:187-190 refresh_* equivalents)
@@ -690,7 +695,6 @@ template <int SOLVER> LS_WAVE_FN void ls_wave_step_a(const LsCtx& cx, const LsSt
     [[maybe_unused]] int ls_sub = -1, ls_k = 0;
 #endif
     LS_PHASE(ph_load_a(cx, sh, rg, lane, env, a));
-    if (!skip && c.lin_vel_at_com) LS_PHASE(ph_root_lin_vel_to_origin(sh, lane));
     LS_CP(0);
     for (int sub = 0; sub < c.decimation; ++sub) {
 #if defined(LS_WAVE_TIMES) && LS_WAVE_TIMES == 2

@@ -174,6 +174,10 @@ LS_FN void ph_body_inertia(const LsCtx& cx, WaveShared& sh, int lane, bool apply
             I6[6 * (3 + i) + j] = mass * cx9[3 * j + i];
             I6[6 * (3 + i) + 3 + j] = (i == j) ? mass : 0.0f;
         }
+#if LS_I6_STRIDE > 36
+    // padding floats of the row: they lie inside constraint rows Y that the solver may read as "holds no row yet" slots (times a zero impulse): finite
+    for (int k = 36; k < LS_I6_STRIDE; ++k) I6[k] = 0.0f;
+#endif
     S6 V = s6p(sh.V[lane]);
     S6 a = s6p(sh.Ab[lane]) - s6(v3(0, 0, 0), v3p(cx.cfg.gravity));
     S6 F = m6v(I6, a) + crf(V, m6v(I6, V));

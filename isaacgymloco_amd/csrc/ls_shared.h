@@ -13,13 +13,13 @@
 #include "ls_math.h"
 
 #define LS_NB LSIM_NUM_BODIES
-// row stride of the spatial-inertia array (lane = body).  36 floats put bodies b, b + 8 and b + 16 on the same LDS banks (36 b mod 32 = 4 b).
-// Round 5 measured 38 (8-byte alignment kept, only bodies 0 and 16 left on one bank; free: the array lives in a union with the larger
-// constraint rows Y): kernel A 0.1101 -> 0.1097 ms -- and NaNs in the GPU suite: the two padding floats of a row are never written, they lie
-// inside Y rows that the solver reads as "stale but finite" slots (times a zero impulse), and uninitialised LDS is not finite.  Not worth a
-// zero-fill and a new invariant for 0.4 %: the stride stays 36 (-DLS_I6_STRIDE=38 still builds, for measurements only).
+// row stride of the spatial-inertia array (lane = body).  36 floats put bodies b, b + 8 and b + 16 on the same LDS banks (36 b mod 32 = 4 b); 38 keeps the
+// 8-byte alignment and leaves only bodies 0 and 16 on one bank.  Free: the array lives in a union with the larger constraint rows Y.  Round 5 measured it
+// (0.1101 -> 0.1097 ms) and got NaNs in the GPU suite: the two padding floats of a row were never written, and they lie inside Y rows that the solver reads as
+// "holds no row yet" slots (times a zero impulse) -- uninitialised LDS is not finite.  Round 6: ph_body_inertia zeroes them with the row (two LDS stores per
+// body lane and sub-step); interleaved A/B on one lease: flat 0.1103 -> 0.1097 ms, stairs 0.1209 -> 0.1197 (tools/gpu_ab_kernel_a.sh), GPU suite green.
 #ifndef LS_I6_STRIDE
-#define LS_I6_STRIDE 36
+#define LS_I6_STRIDE 38
 #endif
 #define LS_NV 18
 #define LS_MAXC LSIM_MAX_CONTACTS

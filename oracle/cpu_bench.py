@@ -36,6 +36,23 @@ def cpu_model():
     return "unknown"
 
 
+def cpu_quota():
+    """CPUs' worth of time this process's cgroup grants (cgroup v2 cpu.max, v1 cfs quota), or None: a container may SHOW every hardware thread of the
+    host in its affinity mask and still be throttled to a few CPUs of run time -- 256 busy-waiting OpenMP threads then spend the quota spinning
+    (measured on the GPU box in round 6: 256 pinned, actively waiting threads ran at 0.12 x ONE core; rounds 1-5's "256 threads = 7 x" was the same cap)"""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
 class _Layer(ctypes.Structure):
     _fields_ = [("w", ctypes.c_void_p), ("b", ctypes.c_void_p), ("n_in", ctypes.c_int), ("n_out", ctypes.c_int), ("elu", ctypes.c_int)]
 
@@ -117,12 +134,13 @@ if __name__ == "__main__":
     ap.add_argument("--threads", type=int, default=0, help="0 = all cores this process may run on")
     a = ap.parse_args()
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    threads = a.threads if a.threads > 0 else avail
+    quota = cpu_quota()
+    threads = a.threads if a.threads > 0 else (avail if quota is None else max(1, min(avail, int(quota))))
     # threads pinned (one place per hardware thread): with schedule(static) every thread then owns the same env block in every loop of every step, the
     # block's pages were first touched by it (orc_create) and stay in its caches.  Must be in the environment before libgomp initialises.
     os.environ.setdefault("OMP_PROC_BIND", "true")
     os.environ.setdefault("OMP_PLACES", "threads")
-    os.environ.setdefault("OMP_WAIT_POLICY", "active")
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive" if quota is not None else "active")     # under a CPU-time quota a spinning thread burns the others' time
     pol = random_policy()                    # (a child process: no torch, i.e. no second OpenMP runtime, in this one)
     gomp = ctypes.CDLL("libgomp.so.1")
     assert "torch" not in sys.modules
@@ -133,9 +151,10 @@ if __name__ == "__main__":
         "value": legs[1]["env_steps_per_s"], "unit": "env-steps/s", "cores": threads, "kind": "port",
         "parallel_speedup_over_one_core": scaling,
         "value_1core": legs[0]["env_steps_per_s"], "value_zero_actions": legs[2]["env_steps_per_s"], "value_closed_loop_random_policy": legs[3]["env_steps_per_s"],
-        "nproc": os.cpu_count(), "cores_available": avail, "cpu_model": cpu_model(), "legs": legs,
+        "nproc": os.cpu_count(), "cores_available": avail, "cgroup_cpu_quota": quota, "cpu_model": cpu_model(), "legs": legs,
         "omp": {k: os.environ.get(k) for k in ("OMP_PROC_BIND", "OMP_PLACES", "OMP_WAIT_POLICY")},
         "sample": f"task {a.task}: {legs[1]['steps']} steps x 4096 envs, N(0,1) actions, on {threads} pinned OpenMP threads (value); {legs[2]['steps']} steps with zero "
                   f"actions; {legs[3]['steps']} steps closed loop with a randomly initialised HIMActorCritic evaluated in C; {legs[0]['steps']} steps x 64 envs on 1 thread "
-                  f"(value_1core).  Timing loop in C (orc_run_steps), static env blocks, first-touch placement: {threads} threads = {scaling:.0f} x one core.  "
-                  f"CPU oracle = the build's scalar C restatement with fp64 physics -- not the reference's PhysX CPU path (closed binary, absent here)"}))
+                  f"(value_1core).  Timing loop in C (orc_run_steps), static env blocks, first-touch placement: {threads} threads = {scaling:.1f} x one core"
+                  + (f" (the box shows {avail} hardware threads but its cgroup grants {quota:g} CPUs of run time: the thread count follows the grant)" if quota is not None else "") + ".  "
+                  "CPU oracle = the build's scalar C restatement with fp64 physics -- not the reference's PhysX CPU path (closed binary, absent here)"}))

@@ -1,4 +1,4 @@
-"""Copy the judged summaries of one tools/gpu_round5.sh (or an earlier round's script) run (gpurun_out/<tag>/) into profiles/ under round-prefixed names.
+"""Copy the judged summaries of one tools/gpu_round6.sh (or an earlier round's script, tools/archive/) run (gpurun_out/<tag>/) into profiles/ under round-prefixed names.
 usage: python tools/publish_profiles.py r02a r02"""
 import csv
 import os
@@ -18,7 +18,8 @@ for src, dst in (("bench_default", "bench_default_train"), ("bench_driver_args",
                  ("bench_env_aliengo_stairs", "bench_env_only_aliengo_stairs"), ("bench_env_aliengo_stairs_pgs", "bench_env_only_aliengo_stairs_pgs_solver"),
                  ("bench_rccl_1rank_4queues", "bench_rccl_1rank_forced_collectives_4_hw_queues"), ("bench_plain_again", "bench_default_train_repeat"),
                  ("bench_env_flat_priority", "bench_env_only_flat_wave_priority"), ("bench_env_aliengo_stairs_flat_priority", "bench_env_only_aliengo_stairs_flat_wave_priority"),
-                 ("bench_env_r4_conventions", "bench_env_only_link_origin_velocities_no_limit_pass"), ("bench_driver_args_again", "bench_driver_args_steps20_warmup5_repeat")):
+                 ("bench_env_r4_conventions", "bench_env_only_link_origin_velocities_no_limit_pass"), ("bench_driver_args_again", "bench_driver_args_steps20_warmup5_repeat"),
+                 ("bench_aliengo_amp_round5_path", "bench_aliengo_amp_torch_rollout_step_and_update")):
     f = os.path.join(O, src + ".json")
     if os.path.exists(f) and open(f).read().lstrip().startswith("{"):
         shutil.copy(f, os.path.join(P, f"{rnd}_{dst}.json"))
@@ -39,7 +40,7 @@ for src, dst in (("prof_env/env_kernel_stats.csv", "kernel_stats_env_only"), ("p
         for r in rows:
             r[0] = r[0][:160]     # torch's templated kernel names run to kilobytes
             w.writerow(r)
-for name in ("pmc_stairs_N4096.csv", "phase_profile_aliengo.txt", "phase_profile_aliengo_stairs.txt", "trace_idle_rccl.txt", "free_running_parity.jsonl", "policy_time.txt",
+for name in ("pmc_stairs_N4096.csv", "phase_profile_aliengo.txt", "phase_profile_aliengo_stairs.txt", "trace_idle_rccl.txt", "free_running_parity.jsonl", "policy_time.txt", "amp_step_time.txt",
              "wave_times_aliengo.txt", "wave_times_aliengo_stairs.txt", "wave_times_aliengo_N256.txt", "wave_phases_aliengo.txt", "wave_phases_aliengo_N256.txt"):
     f = os.path.join(O, name)
     if os.path.exists(f):
