@@ -680,9 +680,9 @@ struct LsWgradPlan {
     int split;            // 1: 128 x 128 tiles on the bf16 pipe (lsim_k_linear_wgrad_split) when the operands turn out 16-byte aligned
 };
 static int ls_wgrad_plan(long batch, int k_in, int n_out, LsWgradPlan* p) {
-    // measured against TunableOp-selected hipBLASLt (tools/wgrad_sweep.sh): the block-cooperative tiled kernel wins up to 512 -> 256
+    // measured against TunableOp-selected hipBLASLt (tools/archive/wgrad_sweep.sh): the block-cooperative tiled kernel wins up to 512 -> 256
     // (295 vs 363 us) when the operand rows are 16-byte aligned; with unaligned rows (k_in % 4 != 0: 238 -> 512) it ties on dW + db alone
-    // (394 + 7 vs 350 + 64 us, tools/wgrad_one.sh) and wins once the ELU backward rides along (saves elu_backward's 100 us pass)
+    // (394 + 7 vs 350 + 64 us, tools/archive/wgrad_one.sh) and wins once the ELU backward rides along (saves elu_backward's 100 us pass)
     const long count = (long)k_in * n_out;
     if (batch <= 0 || k_in <= 0 || n_out <= 0 || count > 140000) return LSIM_E_UNSUPPORTED;
     const int nt = (n_out + 15) / 16, kt = (k_in + 15) / 16;

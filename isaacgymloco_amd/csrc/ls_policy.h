@@ -198,7 +198,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4
     // independent: separate blocks halve the serial layer chain.
     // LDS map (floats): input rows (stride 272) | buffer A (<= 512 wide, stride 528) | buffer B (<= 272 wide, stride 272); columns swizzled: ls_pol_col
     const bool critic = blockIdx.y != 0;
-#if defined(LS_POL_EXP) && LS_POL_EXP == 1      // timing probes (tools/policy_ab.sh): one half of the blocks returns at once
+#if defined(LS_POL_EXP) && LS_POL_EXP == 1      // timing probes (tools/archive/policy_ab.sh): one half of the blocks returns at once
     if (critic) return;
 #elif defined(LS_POL_EXP) && LS_POL_EXP == 2
     if (!critic) return;
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4
         act.st.dones[row] = act.prev_dones[env];
     }
     __syncthreads();
-#if defined(LS_POL_STOP_AFTER)      // timing probe (tools/gpu_r5_f.sh): every block returns after that many layers (0: after the staging)
+#if defined(LS_POL_STOP_AFTER)      // timing probe (tools/archive/gpu_r5_f.sh): every block returns after that many layers (0: after the staging)
     int ls_layers_left = LS_POL_STOP_AFTER;
 #define LS_RUN(L, XO, XS, YO, YS, ELU) do { if (ls_layers_left-- <= 0) return; ls_pol_run_layer<ROWS, WAVES>(L, XO, XS, YO, YS, ELU, wave, lane); } while (0)
 #else
