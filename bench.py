@@ -39,7 +39,7 @@ WORLD1_HW_QUEUES = None            # GPU_MAX_HW_QUEUES of a single-rank run when
 
 def cpu_baseline(task, budget_s=24.0):
     """Time the CPU oracle (the build's scalar-C twin of the same step, fp64 physics; kind='port') on the host cores of this box,
-    BASELINE.md section 3 plan A: OpenMP over envs on all host cores at N = 64 and N = 4096, plus the 1-core figure.  A child process
+    BASELINE.md section 3 plan A: OpenMP over envs on the CPUs the cgroup grants at N = 4096 with three action sources, plus the 1-core figure at N = 64.  A child process
     (oracle/cpu_bench.py: no GPU, no torch), started before this process touches the GPU."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_bench.py"), "--task", task, "--seconds", str(budget_s)],
                          capture_output=True, text=True, timeout=900)

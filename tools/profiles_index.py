@@ -8,6 +8,7 @@ P = os.path.join(ROOT, "profiles")
 CUR = "r06"
 RULES = [   # (regex on the name without its round prefix, what it is, section)
     (r"^bench_default_train(_repeat)?\.json$", "bench.py default line: aliengo, 4096 envs, HIMOnPolicyRunner loop (the driver's command)", "8"),
+    (r"^bench_driver_command_run\d\.json$", "the driver's exact command (`--gpus 1 --steps 20 --warmup 5`, CPU baseline included) three times on one lease: run-to-run spread on a shared host", "8"),
     (r"^bench_driver_args.*\.json$", "the same with the driver's `--gpus 1 --steps 20 --warmup 5`", "8"),
     (r"^bench_default_train_pgs_solver\.json$", "default line with the PGS solver", "4"),
     (r"^bench_env_only\.json$", "env-only line: LeggedRobot.step() back to back, N(0,1) actions (kernel A + finish)", "6, 8"),
