@@ -267,15 +267,30 @@ def _eligible_fused_elu(batch, k_in, n_out):
 
 
 def _fused_forward_wanted(x, k_in):
-    """Default: the library kernel for the hidden layers whose rows are 16-byte aligned (k_in % 4 == 0: 64 -> 512, 512 -> 256, 256 -> 128, 128 -> 64); the
-    238- / 270- / 45-wide first layers stay on BLAS + torch ELU -- their 8- and 4-byte loads double and quadruple the kernel's fetch instructions, and the
-    fetch is what bounds it (in the training loop's trace 238 -> 512 took 415 us against ~325 for BLAS + ELU).  Update in the loop, interleaved on one lease:
-    66.9-67.3 ms this way, 69.0-71.4 with the kernel on every hidden layer, 69.8-70.5 with BLAS + ELU everywhere (profiles/r05_linear_elu_forward.txt).
+    """Default: the library kernel for the hidden layers whose rows are 16-byte aligned -- k_in % 4 == 0 (64 -> 512, 512 -> 256, 256 -> 128, 128 -> 64) or,
+    since round 6, rows an aligned pitch apart (the shuffled 238- / 270-wide observation fields, learn/storage.py: the weights are then zero-padded to the
+    pitch's width, see linear_elu_forward).  Unaligned rows stay on BLAS + torch ELU: their 8- and 4-byte loads double and quadruple the kernel's fetch
+    instructions, and the fetch is what bounds it (238 -> 512 took 415 us against ~325 for BLAS + ELU in round 5's loop).
     LSIM_ELU_FORWARD=0 / all: A/B switches"""
     mode = os.environ.get("LSIM_ELU_FORWARD", "aligned")
     if mode == "aligned":
-        return k_in % 4 == 0 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
+        return x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and (k_in % 4 == 0 or x.stride(0) >= (k_in + 3) // 4 * 4)
     return mode != "0"
+
+
+_padded_weights = {}
+
+
+def _padded_weight(weight, k4):
+    """[n_out, k4] copy of `weight` [n_out, k_in] with zero columns k_in .. k4 - 1, refreshed on every call (the weights move with every optimiser step;
+    0.5 MB for 238 -> 512).  With it x's columns beyond k_in -- the zero padding of a shuffled observation row, or whatever finite values follow in a wider
+    row -- meet zero weights: the product is the unpadded one exactly."""
+    key = (weight.data_ptr(), k4, torch.cuda.current_stream(weight.device).cuda_stream)
+    wp = _padded_weights.get(key)
+    if wp is None or wp.shape[0] != weight.shape[0]:
+        wp = _padded_weights[key] = torch.zeros(weight.shape[0], k4, device=weight.device, dtype=torch.float32)
+    wp[:, :weight.shape[1]].copy_(weight.detach())
+    return wp
 
 
 def linear_elu_forward(x, weight, bias):
@@ -286,11 +301,15 @@ def linear_elu_forward(x, weight, bias):
             and x.shape[1] == weight.shape[1] and (bias is None or (bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == weight.shape[0]))
             and x.stride(1) == 1 and _fused_forward_wanted(x, weight.shape[1])):
         from .. import abi, lib
-        xx = x
+        k_in = weight.shape[1]
+        w = weight
+        if k_in % 4 != 0:            # aligned pitch, unaligned width: the kernel runs over the padded width against zero-padded weights
+            k_in = (k_in + 3) // 4 * 4
+            w = _padded_weight(weight, k_in)
         z = torch.empty(x.shape[0], weight.shape[0], device=x.device, dtype=torch.float32)
         b = bias.detach() if bias is not None else None
-        rc = lib.load().lsim_linear_elu_forward(xx.data_ptr(), xx.stride(0), weight.data_ptr(), b.data_ptr() if b is not None else None, x.shape[0],
-                                                weight.shape[1], weight.shape[0], z.data_ptr(), z.stride(0), torch.cuda.current_stream(x.device).cuda_stream)
+        rc = lib.load().lsim_linear_elu_forward(x.data_ptr(), x.stride(0), w.data_ptr(), b.data_ptr() if b is not None else None, x.shape[0],
+                                                k_in, weight.shape[0], z.data_ptr(), z.stride(0), torch.cuda.current_stream(x.device).cuda_stream)
         if rc == 0:
             return z
         if rc != abi.E_UNSUPPORTED:

@@ -154,16 +154,31 @@ class HIMRolloutStorage:
     def _shuffle(self, fields, perm):
         """every field gathered through the permutation.  On the GPU the destinations are PERSISTENT buffers (allocated at the first call):
         minibatch i of every update lives at the same addresses and the update stops allocating 0.4 GB per call.
-        (Rows of the 238- / 270-wide observation fields padded to 16 bytes, so that the first layers read aligned rows, were measured in round 5
-        and cost the update 1 ms: the BLAS kernels of those layers are TunableOp-selected per leading dimension)"""
+        Round 6: the rows of 2-D fields whose width is not a multiple of four floats (the 270-wide observation history, the 238-wide privileged
+        observations) are laid out 16-byte aligned -- row pitch rounded up to 4 floats, the padding zero and never written -- and handed out as
+        [B, width] VIEWS of the padded buffer: the first layers of the networks then read aligned rows and join the library's fused Linear + ELU
+        forward (fused_linear.linear_elu_forward with a zero-padded weight copy) and the 16-byte form of the weight-gradient kernel.  (Round 5
+        measured padded rows with the BLAS forward kept: -1 %, the BLAS kernels are TunableOp-selected per leading dimension.)
+        LSIM_PAD_SHUFFLED=0: contiguous rows (A/B switch)."""
         if not fields[0].is_cuda:
             return tuple(_gather_rows(f, perm) for f in fields)
+        import os
+        pad_on = os.environ.get("LSIM_PAD_SHUFFLED", "0") == "1"
+        pitch = lambda f: (f.shape[1] + 3) // 4 * 4 if (pad_on and f.dim() == 2 and f.shape[1] % 4 != 0 and f.shape[1] >= 64 and f.element_size() == 4) else None
         bufs = getattr(self, "_shuffled", None)
-        ok = bufs is not None and len(bufs) == len(fields) and all(b.shape[0] == perm.numel() and b.shape[1:] == f.shape[1:] and b.dtype == f.dtype
-                                                                      and b.device == f.device for b, f in zip(bufs, fields))
+        ok = bufs is not None and len(bufs) == len(fields) and all(
+            b.shape[0] == perm.numel() and b.dtype == f.dtype and b.device == f.device and
+            (b.shape[1:] == f.shape[1:] if pitch(f) is None else (b.dim() == 2 and b.shape[1] == pitch(f))) for b, f in zip(bufs, fields))
         if not ok:
-            bufs = self._shuffled = tuple(torch.empty((perm.numel(),) + tuple(f.shape[1:]), dtype=f.dtype, device=f.device) for f in fields)
-        return tuple(_gather_rows(f, perm, out=b) for f, b in zip(fields, bufs))
+            bufs = self._shuffled = tuple(torch.empty((perm.numel(),) + tuple(f.shape[1:]), dtype=f.dtype, device=f.device) if pitch(f) is None
+                                          else torch.zeros(perm.numel(), pitch(f), dtype=f.dtype, device=f.device) for f in fields)
+        out = []
+        for f, b in zip(fields, bufs):
+            if pitch(f) is None:
+                out.append(_gather_rows(f, perm, out=b))
+            else:
+                out.append(_gather_rows(f, perm, out=b[:, :f.shape[1]]))          # rows pitch(f) floats apart; columns beyond the width stay zero
+        return tuple(out)
 
 
 def _gather_rows(f, perm, out=None):

@@ -1126,3 +1126,39 @@ def test_weight_gradient_on_the_bf16_pipe_is_an_fp32_result(k_in, n_out, B):
     bmag = gp64.abs().sum(0)
     assert float(((db1.double() - ref_b).abs() / bmag).max()) < 2e-6
     assert not torch.equal(dw0, dw1) or parts0 != parts1                       # the switch did select another kernel
+
+
+def test_padded_shuffle_rows_and_padded_first_layers_change_the_update_only_by_rounding(monkeypatch):
+    """Round 6: the shuffled 270- / 238-wide observation fields live in rows 272 / 240 floats apart (zero padding) and the networks' first layers run
+    the library's fused Linear + ELU forward against zero-padded weight copies (learn/storage.py: _shuffle, learn/fused_linear.py: linear_elu_forward).
+    Against the same two iterations with contiguous rows (LSIM_PAD_SHUFFLED=0: those layers on BLAS + torch ELU): the minibatch views hold the same
+    values, the fused first layer equals F.elu(F.linear) to fp32 rounding, and the trained weights agree far inside one optimiser step."""
+    import torch.nn.functional as F
+    from isaacgymloco_amd.learn import fused_linear as FL
+
+    def run(pad):
+        monkeypatch.setenv("LSIM_PAD_SHUFFLED", "1" if pad else "0")
+        FL.set_grad_arena(None)
+        env, r = _make(seed=9)
+        r.enable_graphs()
+        r.learn(2, init_at_random_ep_len=False)
+        st = r.alg.storage
+        gen = st.mini_batch_generator(4, 1)
+        mb = next(gen)
+        gen.close()
+        return r, {k: v.clone() for k, v in r.alg.actor_critic.state_dict().items()}, mb
+    ra, a, mba = run(True)
+    obs, crit = mba[0], mba[1]
+    assert obs.shape[1] == 270 and obs.stride(0) == 272 and crit.shape[1] == 238 and crit.stride(0) == 240 and obs.data_ptr() % 16 == 0
+    ac = ra.alg.actor_critic
+    lin = ac.critic[0]
+    with torch.no_grad():
+        z = FL.linear_elu_forward(crit, lin.weight, lin.bias)
+        ref = F.elu(F.linear(crit.contiguous().double(), lin.weight.double(), lin.bias.double())).float()
+    assert FL._padded_weights, "the padded-weight form of the fused forward did not run"
+    torch.testing.assert_close(z, ref, rtol=1e-5, atol=2e-5)
+    rb, b, mbb = run(False)
+    assert mbb[0].is_contiguous() and mbb[1].is_contiguous()
+    for k in a:        # 2 iterations x 20 Adam steps at lr 1e-3 from identical states and identical rollouts of iteration 1
+        torch.testing.assert_close(a[k], b[k], rtol=0, atol=2e-3, msg=lambda m, k=k: f"{k}: {m}")
+    FL.set_grad_arena(None)
