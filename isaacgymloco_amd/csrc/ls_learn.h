@@ -323,6 +323,9 @@ __device__ __forceinline__ void ls_wgrad_ld(const float* __restrict__ r, const i
     else if (VEC == 1) { const float2 ta = *(const float2*)(r + o[0]), tb = *(const float2*)(r + o[2]); v[0] = ta.x; v[1] = ta.y; v[2] = tb.x; v[3] = tb.y; }
     else { v[0] = r[o[0]]; v[1] = r[o[1]]; v[2] = r[o[2]]; v[3] = r[o[3]]; }
 }
+#ifndef LS_WG_KNOCK
+#define LS_WG_KNOCK 0        /* diagnostic builds only (wrong results): 1 = no operand loads in the steady-state loop, 2 = no MFMAs (one FMA per accumulator instead) */
+#endif
 template <int KG> struct LsWgradStage { float a[4], z[4], x[KG][4]; };
 
 template <int VX, int VG, int KG, bool FZ, bool LIVE1 /* the second 64-column k group exists (compile-time: no branch between MFMAs) */,
@@ -368,12 +371,13 @@ __device__ __forceinline__ long ls_wgrad_tile_loop3(const float* __restrict__ x,
 #define LS_GRP(ST, J) do {                                                                                                   \
         dbacc[J] += ST.a[J];                                                                                                 \
         __builtin_amdgcn_s_setprio(1);          /* the wave entering an MFMA group wins arbitration over the one issuing loads: +5 % */  \
+        if (LS_WG_KNOCK != 2) {                                                                                              \
         _Pragma("unroll") for (int kt = 0; kt < 4; ++kt)                                                                     \
             acc[J][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ST.a[J], ST.x[0][kt], acc[J][kt], 0, 0, 0);                    \
         if (live_k1) {                                                                                                       \
             _Pragma("unroll") for (int kt = 4; kt < 4 * KG; ++kt)                                                            \
                 acc[J][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ST.a[J], ST.x[KG - 1][kt & 3], acc[J][kt], 0, 0, 0);       \
-        }                                                                                                                    \
+        } } else { _Pragma("unroll") for (int kt = 0; kt < 4 * KG; ++kt) acc[J][kt][0] += ST.a[J] * ST.x[(kt >> 2) ? KG - 1 : 0][kt & 3]; }  \
         __builtin_amdgcn_s_setprio(0); } while (0)
 #define LS_STEP(CS, CROW, LS, LROW) do { const long lr_ = (LROW);                                                            \
         if (FZ) {     /* g_z * elu'(z) for the whole step up front: spread between the MFMA groups it costs 10 % (measured) */   \
@@ -381,13 +385,13 @@ __device__ __forceinline__ long ls_wgrad_tile_loop3(const float* __restrict__ x,
             if (WGY) *(float4*)(gy + (CROW) * (long)n_out + n_base + 4 * col) = make_float4(CS.a[0], CS.a[1], CS.a[2], CS.a[3]);  \
         }                                                                                                                    \
         LS_SB(); LS_GRP(CS, 0); LS_SB();                                                                                     \
-        ls_wgrad_ld<VG>(g + lr_ * ldg, og, LS.a); LS_SB();                                                                   \
+        if (LS_WG_KNOCK != 1) ls_wgrad_ld<VG>(g + lr_ * ldg, og, LS.a); LS_SB();                                             \
         LS_GRP(CS, 1); LS_SB();                                                                                              \
-        if (FZ) ls_wgrad_ld<VG>(z + lr_ * ldz, og, LS.z); else ls_wgrad_ld<VX>(x + lr_ * ldx, ox0, LS.x[0]);                 \
+        if (LS_WG_KNOCK != 1) { if (FZ) ls_wgrad_ld<VG>(z + lr_ * ldz, og, LS.z); else ls_wgrad_ld<VX>(x + lr_ * ldx, ox0, LS.x[0]); }   \
         LS_SB(); LS_GRP(CS, 2); LS_SB();                                                                                     \
-        if (FZ) ls_wgrad_ld<VX>(x + lr_ * ldx, ox0, LS.x[0]); else if (live_k1) ls_wgrad_ld<VX>(x + lr_ * ldx, ox1, LS.x[KG - 1]);  \
+        if (LS_WG_KNOCK != 1) { if (FZ) ls_wgrad_ld<VX>(x + lr_ * ldx, ox0, LS.x[0]); else if (live_k1) ls_wgrad_ld<VX>(x + lr_ * ldx, ox1, LS.x[KG - 1]); }  \
         LS_SB(); LS_GRP(CS, 3); LS_SB();                                                                                     \
-        if (FZ && live_k1) ls_wgrad_ld<VX>(x + lr_ * ldx, ox1, LS.x[KG - 1]);                                                \
+        if (LS_WG_KNOCK != 1) { if (FZ && live_k1) ls_wgrad_ld<VX>(x + lr_ * ldx, ox1, LS.x[KG - 1]); }                      \
         LS_SB(); } while (0)
     long b = b0;
     LS_LD(s0, b + sub);

@@ -32,6 +32,7 @@ RULES = [   # (regex on the name without its round prefix, what it is, section)
     (r"^trained_policy_physics_.*\.json$", "closed-loop replay of the trained 1000-iteration policy through the CPU oracle's variants (shipped / cap 32 / true shapes / PGS); `_calf6`: with round 6's calf points", "4"),
     (r"^policy_.*\.pt$", "the trained actor-critic + simulator curriculum state after 1000 iterations (tools/train_probe.py ... checkpoint.pt): input of tools/trained_policy_physics.py", "4"),
     (r"^train_curve_.*\.json$", "learning curve (tools/train_probe.py): per-iteration reward, episode length, terrain level, losses", "4"),
+    (r"^wgrad_knockouts\.txt$", "the shipped weight-gradient kernels alone: product / no operand loads in the loop / no MFMAs (-DLS_WG_KNOCK builds): where the time of VERDICT r5 task 3 is", "7.3"),
     (r"^padded_shuffle_ab\.txt$", "default train line with 16-byte-aligned shuffled observation rows + padded-weight fused first layers against contiguous rows (no gain: opt-in)", "7.3"),
     (r"^cpu_scaling_probe\.txt$", "the GPU box's host: cgroup CPU grant and oracle/cpu_bench.py at 8 .. 256 threads", "8"),
     (r"^kernel_a_ab\.txt$", "kernel A, product against build variants, interleaved on one lease (tools/gpu_ab_kernel_a.sh)", "6"),
