@@ -487,6 +487,15 @@ def main():
                   "hbm": hbm, "hbm_frac": hbm["frac"], "hbm_achieved_gbs": achieved,      # flat copies: parsers that drop nested objects keep these
                   "valu_issue_frac": valu_frac, "valu_cycles_per_wave_inst": VALU_CYCLES_PER_WAVE_INST,
                   "pmc_source": ({k: pmc.get(k) for k in ("task", "envs_per_gpu", "mode", "actions", "effective_clock_hz", "file")} if pmc else None)}
+        # Two clocks can be quoted for kernel A: `effective_clock_hz` of the PMC pass = GRBM_GUI_ACTIVE / 8 XCDs / kernel duration, which counts
+        # dispatch time outside the kernel and therefore EXCEEDS the part's 2.4 GHz maximum (2.54 GHz), and the shader clock sampled from sysfs during this
+        # run's collection phase (2.35-2.39 GHz).  The sampled clock is the believed one; `frac` keeps the counter-derived clock (the lower, conservative
+        # fraction, comparable with earlier rounds) and `valu_issue_frac_at_sampled_sclk` says what the sampled clock gives.
+        sclk_mhz = ((extra.get("sclk_during_timed_region") or {}).get("mean_mhz_collection") or (extra.get("sclk_during_timed_region") or {}).get("mean_mhz"))
+        if valu_frac is not None and sclk_mhz:
+            common["valu_issue_frac_at_sampled_sclk"] = pmc["valu_wave_insts_per_launch"] * VALU_CYCLES_PER_WAVE_INST / (N_SIMD * sclk_mhz * 1e6 * ka * 1e-3)
+            common["clock_note"] = ("frac uses the PMC pass's GRBM_GUI_ACTIVE-derived clock (includes dispatch time outside the kernel, hence above the 2.4 GHz maximum: "
+                                    "conservative); the sysfs-sampled shader clock of this run is the believed one")
         if valu_frac is not None:
             clk = pmc.get("effective_clock_hz") or MAX_CLOCK_HZ
             peak_rate = N_SIMD * clk / VALU_CYCLES_PER_WAVE_INST / 1e9                       # G wave64 VALU instructions per second, whole chip
