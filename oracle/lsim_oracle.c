@@ -20,7 +20,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#ifdef _OPENMP
 #include <omp.h>
+#endif
 
 #include "orc_internal.h"
 #include "orc_philox.h"
@@ -947,11 +949,13 @@ static void policy_mean(const orc_policy* p, const float* obs, float* out12) {
 /* the number of threads an OpenMP parallel region of this library really runs with (cpu_bench.py reports it as `cores`) */
 int orc_parallel_threads(void) {
     int n = 1;
+#ifdef _OPENMP            /* (the sanitizer build of tests/test_sanitizers.py compiles this file without OpenMP) */
     #pragma omp parallel
     {
         #pragma omp master
         n = omp_get_num_threads();
     }
+#endif
     return n;
 }
 int orc_run_steps(orc_sim* s, int n_steps, int mode, const float* table, int table_len, const orc_policy* pol, double* seconds) {
