@@ -990,6 +990,80 @@ __device__ __forceinline__ void ls_delassus_mfma16(WaveShared& sh, int lane, boo
     if (act) wd = row[t];
     __syncthreads();                          // the scratch is the next phase's to overwrite only after every lane has read its row
 }
+template <int I>
+__device__ __forceinline__ void ls_delassus_mfma32_row(WaveShared& sh, int lane, int vk, float (&W)[LS_MAXR]) {
+    float* Jd = &sh.R[0][0];
+    const int r16 = lane & 15, kq = lane >> 4;
+    ls_v4f_t accA = {0.0f, 0.0f, 0.0f, 0.0f}, accB = accA;           // tiles (I, 0) and (I, 1)
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        const int k = 4 * s + kq;
+        const bool in = k < LS_NV;
+        const int kk = in ? k : 0;
+        const float a = in ? Jd[18 * (16 * I + r16) + kk] : 0.0f;
+        const float b0 = in ? sh.u.c.Y[r16][kk] : 0.0f, b1 = in ? sh.u.c.Y[16 + r16][kk] : 0.0f;
+        accA = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, accA, 0, 0, 0);
+        accB = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, accB, 0, 0, 0);
+    }
+    __syncthreads();                      // every lane has read its A operands of this tile row: its half of the scratch now takes D tiles
+    float* Wt = Jd + 288 * I;             // [16][17]
+    const bool mine = vk < 0 && (lane >> 4) == I && lane < 32;
+    // D[i = 4 kq + r][j = r16]; the constraint-force-mixing term on the diagonal (tile (I, I))
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Wt[17 * (4 * kq + r) + r16] = accA[r] + ((I == 0 && (4 * kq + r) == r16) ? 1e-6f : 0.0f);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { const float t = Wt[17 * r16 + j]; W[j] = mine ? t : W[j]; }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Wt[17 * (4 * kq + r) + r16] = accB[r] + ((I == 1 && (4 * kq + r) == r16) ? 1e-6f : 0.0f);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { const float t = Wt[17 * r16 + j]; W[16 + j] = mine ? t : W[16 + j]; }
+    __syncthreads();
+}
+// Round 6, BUILT, CORRECT (GPU physics suite green with it) AND NOT SHIPPED (-DLS_DELASSUS_MFMA32 enables it): kernel A 0.1096 -> 0.1148 ms flat, 0.1194 ->
+// 0.1230 stairs, interleaved on one lease (profiles/r06_kernel_a_ab.txt).  The micro-benchmark's 3.5 against 6.4-7.8 us per build assumed LDS for the whole D
+// matrix; squeezed into the 582 free floats the transposition needs ten barriers and 64 register selects per lane (conditional stores into W in divergent
+// branches sent the whole array to scratch memory), on exactly the waves the launch waits for.  The FMA rows stay for more than 16 rows.
+// The same for up to 32 rows -- every contact count, up to 8 limit rows (slots 0 .. 31, tile row = slot): 2 x 2 tiles, 20 MFMAs.  The robots that
+// need it are the ones with five or more contacts, i.e. the SLOWEST waves of a launch that is one round of waves and ends with its slowest (DESIGN.md
+// section 6): the FMA rows cost them 6.4-7.8 us per build against 3.5 on the matrix core (tools/micro/delassus_mfma, profiles/r03_delassus_mfma.json).
+// Round 3 stopped at 16 rows because the D tiles of 32 rows need 4 KB of LDS.  Here the scratch (the kinematics arrays, 582 floats) holds J' [32][18]
+// (576 floats) and is then reused HALF BY HALF: tile row 1 first (its A operands, rows 16 .. 31 of J', are then dead: 288 floats take one [16][17] D tile at a
+// time), then tile row 0 the same way in the lower half -- only two accumulator tiles (8 registers) are alive at any time, the kernel sits at its 128-register
+// limit (four tiles alive pushed the scalar-register spills out of the vector file into scratch memory).
+__device__ __forceinline__ void ls_delassus_mfma32(WaveShared& sh, int lane, bool act, int leg, const float (&jb)[6], float jl0, float jl1, float jl2,
+                                                   float (&W)[LS_MAXR], float& wd, int vk = -1) {
+    float* Jd = &sh.R[0][0];                 // [32][18]; each half [16][18] later one [16][17] D tile
+    static_assert(sizeof(sh.R) + sizeof(sh.p) + sizeof(sh.S) + sizeof(sh.V) + sizeof(sh.Ab) + sizeof(sh.Fb) >= 32 * 18 * sizeof(float), "scratch of the 32-row MFMA Delassus build");
+    static_assert(16 * 17 <= 16 * 18 && LS_LIM0 == 24 && LS_MAXR == 36, "a D tile fits where half of J' was; slots 0 .. 31 are tile rows 0 .. 31");
+    if (lane < 32) {                         // jb / jl are zero for an inactive slot: its tile row is zero
+        float* d = Jd + 18 * lane;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) d[k] = jb[k];
+#pragma unroll
+        for (int l = 0; l < 4; ++l) { d[6 + 3 * l] = leg == l ? jl0 : 0.0f; d[7 + 3 * l] = leg == l ? jl1 : 0.0f; d[8 + 3 * l] = leg == l ? jl2 : 0.0f; }
+    }
+    // velocity lanes: column vk of Y at the 32 slots (no D involved); lanes that hold no row: something finite
+    if (vk >= 0) {
+#pragma unroll
+        for (int j = 0; j < 32; ++j) W[j] = sh.u.c.Y[j][vk];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 32; ++j) W[j] = 0.0f;          // row lanes: filled below; lanes that hold no row: something finite
+    }
+    __syncthreads();
+    ls_delassus_mfma32_row<1>(sh, lane, vk, W);      // tile row 1 first: its half of J' is the first to die
+    ls_delassus_mfma32_row<0>(sh, lane, vk, W);
+    W[32] = 0.0f; W[33] = 0.0f; W[34] = 0.0f; W[35] = 0.0f;     // the sweep relaxes limit slots in triples: slots past nlim must hold something finite
+    if (act) {                                 // (act implies lane < 32 here: slot < 3 nc <= 24 or a limit slot < LS_LIM0 + 8); the diagonal entry by selects
+        float d = W[0];
+#pragma unroll
+        for (int j = 1; j < 32; ++j) d = lane == j ? W[j] : d;
+        wd = d;
+    }
+}
 #endif
 
 // GPU form: Delassus row and sweep fused so that the 36-entry row lives in registers only between here and the end of
@@ -1009,6 +1083,11 @@ LS_FN void wc_delassus_pgs(WaveShared& sh, const LaneRegs& rg, int lane, int ite
     if (nc <= LS_DELASSUS_MFMA_NC && nlim <= 4) {
         ls_delassus_mfma16(sh, lane, act, leg, jb, jl0, jl1, jl2, W, wd);      // <= 16 rows (91 % of the sub-steps): one 16 x 16 MFMA tile
     } else
+#if defined(LS_DELASSUS_MFMA32)      /* measured slower: see ls_delassus_mfma32 */
+    if (nlim <= 8) {
+        ls_delassus_mfma32(sh, lane, act, leg, jb, jl0, jl1, jl2, W, wd);      // <= 32 rows: 2 x 2 tiles (round 6)
+    } else
+#endif
 #endif
     {
         ls_delassus_rows<0, LS_LIM0>(sh, 3 * nc, lane, lo, jb, jl0, jl1, jl2, W, wd);
@@ -1088,6 +1167,11 @@ LS_FN void wc_delassus_tgs(const LsCtx& cx, WaveShared& sh, const LaneRegs& rg, 
     if (nc <= LS_DELASSUS_MFMA_NC && nlim <= 4) {
         ls_delassus_mfma16(sh, lane, act, leg, jb, jl0, jl1, jl2, W, wd, vk);
     } else
+#if defined(LS_DELASSUS_MFMA32)      /* measured slower: see ls_delassus_mfma32 */
+    if (nlim <= 8) {
+        ls_delassus_mfma32(sh, lane, act, leg, jb, jl0, jl1, jl2, W, wd, vk);
+    } else
+#endif
 #endif
     {
         ls_delassus_rows<0, LS_LIM0>(sh, 3 * nc, lane, lo, jb, jl0, jl1, jl2, W, wd);
