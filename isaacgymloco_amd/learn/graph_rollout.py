@@ -178,6 +178,13 @@ class HybridFusedRollout(GraphedRollout):
         disc = self.alg.discriminator
         ok = os.environ.get("LSIM_AMP_FUSED_STEP") != "0" and PackedAmpDisc.supported(disc) and self.alg.amp_storage.buffer_size >= N
         self.packed_disc = PackedAmpDisc(disc, self.alg.amp_normalizer, N) if ok else None
+        self._amp_stale = False
+
+    def flush(self):
+        """(also the env's before_external_step hook) something else is about to step / reset the env: the AMP observation this rollout carries from step to
+        step is then no longer the env's current one -- the next rollout step re-reads it (the eager runner does the same at the start of learn(), HYBR:118)"""
+        super().flush()
+        self._amp_stale = True
 
     @property
     def _amp_obs(self):
@@ -191,6 +198,9 @@ class HybridFusedRollout(GraphedRollout):
     def step(self):
         env, alg = self.env, self.alg
         amp_obs = self._amp_bufs[self._cur]
+        if self._amp_stale:           # (after an ordinary end of iteration the two already hold the same values: the copy changes nothing)
+            amp_obs.copy_(env.get_amp_observations())
+            self._amp_stale = False
         self._sync_weights()
         if self.packed is not None:
             self._act()
