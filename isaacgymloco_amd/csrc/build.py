@@ -90,6 +90,11 @@ def build_variant(out, extra_flags=(), workdir=None):
     return out
 
 
+def variant_is_stale(out):
+    """a diagnostics build made from older sources than the tree's (round 5 shipped such a file to the GPU box: its tool failed on a missing symbol)"""
+    return not os.path.exists(out) or any(os.path.getmtime(f) > os.path.getmtime(out) for f in all_sources() + [os.path.abspath(__file__)])
+
+
 def all_sources():
     return sorted({os.path.join(HERE, f) for src, hdrs, _ in UNITS for f in [src] + hdrs})
 

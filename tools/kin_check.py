@@ -21,7 +21,8 @@ def build():
 if __name__ == "__main__":
     if "--build-only" in sys.argv:
         build(); sys.exit(0)
-    if not os.path.exists(OUT):
+    from isaacgymloco_amd.csrc.build import variant_is_stale
+    if variant_is_stale(OUT):
         build()
     os.environ["LSIM_LIB"] = OUT
     from isaacgymloco_amd.envs import config as C

@@ -63,7 +63,8 @@ if __name__ == "__main__":
     sys.path.insert(0, ROOT)
     if "--build-only" in sys.argv:
         print(build()); sys.exit(0)
-    if not os.path.exists(OUT):
+    from isaacgymloco_amd.csrc.build import variant_is_stale
+    if variant_is_stale(OUT):
         build()
     os.environ["LSIM_LIB"] = OUT
     import torch

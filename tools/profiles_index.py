@@ -35,6 +35,7 @@ RULES = [   # (regex on the name without its round prefix, what it is, section)
     (r"^wgrad_knockouts\.txt$", "the shipped weight-gradient kernels alone: product / no operand loads in the loop / no MFMAs (-DLS_WG_KNOCK builds): where the time of VERDICT r5 task 3 is", "7.3"),
     (r"^padded_shuffle_ab\.txt$", "default train line with 16-byte-aligned shuffled observation rows + padded-weight fused first layers against contiguous rows (no gain: opt-in)", "7.3"),
     (r"^cpu_scaling_probe\.txt$", "the GPU box's host: cgroup CPU grant and oracle/cpu_bench.py at 8 .. 256 threads", "8"),
+    (r"^kernel_a_ifetch_pmc\.txt$", "kernel A: instruction-cache and fetch counters (93 KB of code against a 64 KB cache: hit rate 99.76 %, not the limiter)", "6"),
     (r"^kernel_a_ab\.txt$", "kernel A, product against build variants, interleaved on one lease (tools/gpu_ab_kernel_a.sh)", "6"),
     (r"^free_running_parity\.jsonl$", "HIP vs fp64 oracle free-running: per-case flags agreement and error percentiles (tests/test_gpu_free_running.py)", "4"),
     (r"^gpu_tests\.log$", "tail of `pytest -m gpu` on the MI355X", "8"),
@@ -83,6 +84,11 @@ def describe(name):
 
 
 files = sorted(f for f in os.listdir(P))
+# a published profile must be a measurement: round 5 published the error text of a tool that had loaded a stale diagnostics build
+broken = [f for f in files if f.endswith((".txt", ".log", ".json", ".jsonl", ".csv")) and b"Traceback (most recent call last)" in open(os.path.join(P, f), "rb").read()
+          and not f.endswith("gpu_tests.log")]
+if broken:
+    raise SystemExit("profiles/ holds error text instead of a measurement: " + ", ".join(broken))
 lines = ["# profiles/ — index", "",
          f"Files of the current round ({CUR}) are cited by `DESIGN.md`; files of earlier rounds by `HISTORY.md` (same section numbers as listed: HISTORY keeps the",
          "numbering of the rounds 1-5 document: 4 physics, 6 kernel A, 7 measurement, 8 multi-GPU, 9 AMP, 11 open items).  Generated by `tools/profiles_index.py`.", "",

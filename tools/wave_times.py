@@ -29,8 +29,8 @@ PHASES = ["torques + kinematics", "body inertias + bias forces", "leg composites
 def phases(task, N):
     """--phases: the 14 phases of sub-step 1, product code path (a -DLS_WAVE_TIMES=2 build: the 16 checkpoints sit behind those phases)"""
     out = OUT.replace("wavetimes", "wavephases")
-    if not os.path.exists(out):
-        from isaacgymloco_amd.csrc import build as B
+    from isaacgymloco_amd.csrc import build as B
+    if B.variant_is_stale(out):
         B.build_variant(out, ["-DLS_WAVE_TIMES=2"])
     os.environ["LSIM_LIB"] = out
     import torch
@@ -68,7 +68,8 @@ def main():
     N = int(args[1]) if len(args) > 1 else 4096
     if "--phases" in sys.argv:
         return phases(task, N)
-    if not os.path.exists(OUT):
+    from isaacgymloco_amd.csrc.build import variant_is_stale
+    if variant_is_stale(OUT):
         build()
     os.environ["LSIM_LIB"] = OUT
     import torch
