@@ -9,7 +9,7 @@ from isaacgymloco_amd.envs.legged_robot import LeggedRobot
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
-for task in ("aliengo", "aliengo_stairs", "aliengo_amp", "go1"):
+for task in ("aliengo", "aliengo_stairs", "aliengo_amp", "aliengo_recover", "go1", "go2"):
     cfg = C.TASKS[task][0]()
     cfg.env.num_envs = N
     env = LeggedRobot(cfg, sim_device="cuda:0", seed=3, using_amp=(task == "aliengo_amp"))
@@ -39,6 +39,6 @@ for task in ("aliengo", "aliengo_stairs", "aliengo_amp", "go1"):
         n_pen += (over > 0.05).sum(); n_fast += (qd.abs() > 1.05 * vlim).sum()
         qdmax = torch.maximum(qdmax, qd.abs().max())
     torch.cuda.synchronize()
-    print(f"{task:15s} steps {steps} non-finite checks failed {bad}  resets/env/1000 steps {float(resets) / N / steps * 1000:.1f}  "
+    print(f"{task:15s} steps {steps} non-finite checks failed {bad}  kernel non-finite counter {int(env.nonfinite_envs)}  resets/env/1000 steps {float(resets) / N / steps * 1000:.1f}  "
           f"max |z| {float(zmax):.2f} m  max |v| {float(vmax):.1f}  max |contact force| {float(fmax):.0f} N  joint stops: max overshoot {float(pen):.3f} rad, {float(n_pen) / (N * 12 * steps) * 1e6:.1f} ppm of joint-steps beyond 0.05 rad; joint speed: max {float(qdmax):.1f}, {float(n_fast) / (N * 12 * steps) * 1e6:.1f} ppm above 1.05 x limit  ({time.time() - t0:.1f} s)", flush=True)
     del env
