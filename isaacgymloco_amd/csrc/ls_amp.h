@@ -13,8 +13,9 @@
 //             stored, each wave leaves one partial dot product per row
 //   finish    d = sum of the partials + head bias; the style reward; rewards_out / disc_out
 // gridDim.y = NSPLIT blocks share one row group: each evaluates trunk[0] (11 % of the work) and 1 / NSPLIT of trunk[1]'s output tiles, so
-// that 4096 envs fill 256 CUs instead of 128; the last block of a group to arrive (device-scope counter, release / acquire fences) adds the
-// partial sums in a fixed order -- the result does not depend on which block that is.
+// that 4096 envs fill 256 CUs instead of 128; the last block of a group to arrive (device-scope ticket; the partial sums travel as write-through
+// sc1 stores acknowledged before the ticket is drawn, see the exchange below -- no L2 write-back fence) adds the partial sums in a fixed order --
+// the result does not depend on which block that is.
 #pragma once
 #include <hip/hip_runtime.h>
 
