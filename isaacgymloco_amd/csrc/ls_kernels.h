@@ -75,12 +75,12 @@ __device__ unsigned int g_ls_wave_cp[16 * 65536];              // per env: shade
 #define LS_MARK() do { } while (0)
 #endif
 #if defined(LS_EXP_TWICE)      // diagnostics only (tools/phase_cost.py): the phase at source line LS_EXP_TWICE runs twice -- its marginal cost is the
-#define LS_AGAIN(call) do { if (__LINE__ == LS_EXP_TWICE) { { const int lane = ls_opaque_lane(lane0); call; } __syncthreads(); } } while (0)   /* change of the kernel time (idempotent phases only) */
+#define LS_AGAIN(call) do { if (__LINE__ == LS_EXP_TWICE) { { const int lane = ls_opaque_lane(lane0); call; } LS_WAVE_SYNC(); } } while (0)   /* change of the kernel time (idempotent phases only) */
 #else
 #define LS_AGAIN(call) do { } while (0)
 #endif
-#define LS_PHASE(call) do { { const int lane = ls_opaque_lane(lane0); call; } __syncthreads(); LS_AGAIN(call); LS_MARK(); LS_TICK(__LINE__ - ls_line0); LS_SUBCP(); } while (0)
-#define LS_COLLECTIVE(gpu_call, emu_call) do { { const int lane = ls_opaque_lane(lane0); gpu_call; } __syncthreads(); LS_AGAIN(gpu_call); LS_MARK(); LS_TICK(__LINE__ - ls_line0); LS_SUBCP(); } while (0)
+#define LS_PHASE(call) do { { const int lane = ls_opaque_lane(lane0); call; } LS_WAVE_SYNC(); LS_AGAIN(call); LS_MARK(); LS_TICK(__LINE__ - ls_line0); LS_SUBCP(); } while (0)
+#define LS_COLLECTIVE(gpu_call, emu_call) do { { const int lane = ls_opaque_lane(lane0); gpu_call; } LS_WAVE_SYNC(); LS_AGAIN(gpu_call); LS_MARK(); LS_TICK(__LINE__ - ls_line0); LS_SUBCP(); } while (0)
 #define LS_KINEMATICS() LS_COLLECTIVE(wc_kinematics(sh, lane), (void)0)
 #define LS_TORQUES_KINEMATICS() LS_COLLECTIVE(ph_torques(cx, sh, lane, env, sub, a.flags); wc_kinematics(sh, lane), (void)0)
 #define LS_ATOMIC_ADD(ptr, v) atomicAdd((ptr), (v))
@@ -90,7 +90,7 @@ __device__ unsigned int g_ls_wave_cp[16 * 65536];              // per env: shade
 #define LS_ATOMIC_READ_I64(ptr) ((long long)atomicAdd((unsigned long long*)(ptr), 0ull))
 #define LS_THREADFENCE() __threadfence()
 #define LS_WAVE_FN __device__ __forceinline__
-#define LS_LDS_FENCE() __syncthreads()       // inside a phase, in wave-uniform control flow only
+#define LS_LDS_FENCE() LS_WAVE_SYNC()        // inside a phase, in wave-uniform control flow only
 #define LS_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
 #endif
 

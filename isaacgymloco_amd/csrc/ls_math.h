@@ -29,6 +29,19 @@
 #define LS_STRIDED(k, lane, N) _Pragma("unroll") for (int it_ = 0, k = (lane); it_ < ((N) + 63) / 64; ++it_, k += 64) if (k < (N))
 #endif
 
+// The synchronisation between two phases of a ONE-WAVE workgroup (kernels A / B: __launch_bounds__(64), one robot per wave).  __syncthreads() is a
+// workgroup-scope release + acquire: the compiler drops the s_barrier for a single wave but keeps `s_waitcnt lgkmcnt(0)` -- every LDS write of the
+// phase acknowledged before the next phase issues anything.  A wave's LDS instructions execute in issue order, so between lanes of ONE wave that
+// wait buys nothing: a wavefront-scope fence orders the memory operations for the compiler and emits no instruction, and the next phase's address
+// arithmetic may start while the writes drain.  Measured (round 6, interleaved, profiles/r06_kernel_a_ab.txt): kernel A 0.1097 -> 0.1094 ms flat,
+// 0.1200 -> 0.1186 ms stairs; 34 of 730 lgkmcnt(0) waits gone (most phases begin with an LDS read, which has to wait for its data anyway).
+// -DLS_NO_WAVE_FENCE: the __syncthreads() form.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(LS_NO_WAVE_FENCE)
+#define LS_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#else
+#define LS_WAVE_SYNC() __syncthreads()
+#endif
+
 // a value every lane of the wave holds identically (read from LDS, so the compiler cannot know): moved to a scalar register, which turns
 // branches and loop bounds on it into scalar compares instead of per-lane compares with hoisted lane masks
 #if defined(__HIP_DEVICE_COMPILE__)

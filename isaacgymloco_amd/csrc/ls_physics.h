@@ -563,7 +563,7 @@ __device__ __forceinline__ void wc_wall_contacts(const LsCtx& cx, WaveShared& sh
             float* o = own + 8 * (rank - c0);
             o[0] = cw.x; o[1] = cw.y; o[2] = cw.z; o[3] = reach; o[4] = __int_as_float(gi); o[5] = __int_as_float(gj);
         }
-        __syncthreads();
+        LS_WAVE_SYNC();
         {
             const int o = lane / 9, k = lane - 9 * o;
             if (lane < 9 * LS_WALL_OWNERS && c0 + o < m) {
@@ -574,7 +574,7 @@ __device__ __forceinline__ void wc_wall_contacts(const LsCtx& cx, WaveShared& sh
                 r[0] = d2; r[1] = q.x; r[2] = q.y; r[3] = q.z; r[4] = fn.x; r[5] = fn.y; r[6] = fn.z;
             }
         }
-        __syncthreads();
+        LS_WAVE_SYNC();
         if (posting) {
             const float* r = res + 8 * 9 * (rank - c0);
             float best = 1e30f;
@@ -583,7 +583,7 @@ __device__ __forceinline__ void wc_wall_contacts(const LsCtx& cx, WaveShared& sh
             const float* w = r + 8 * win;
             ls_wall_finish(cw, radius, best, v3(w[1], w[2], w[3]), v3(w[4], w[5], w[6]), dist, n);
         }
-        __syncthreads();
+        LS_WAVE_SYNC();
     }
 }
 #endif
@@ -963,7 +963,7 @@ __device__ __forceinline__ void ls_delassus_mfma16(WaveShared& sh, int lane, boo
 #pragma unroll
         for (int l = 0; l < 4; ++l) { d[6 + 3 * l] = leg == l ? jl0 : 0.0f; d[7 + 3 * l] = leg == l ? jl1 : 0.0f; d[8 + 3 * l] = leg == l ? jl2 : 0.0f; }
     }
-    __syncthreads();
+    LS_WAVE_SYNC();
     const int r16 = lane & 15, kq = lane >> 4;
     const int bslot = r16 < 12 ? r16 : LS_LIM0 + r16 - 12;          // B rows: Y of the slot that tile column r16 stands for
     ls_v4f_t acc = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -977,7 +977,7 @@ __device__ __forceinline__ void ls_delassus_mfma16(WaveShared& sh, int lane, boo
     // D[i = 4 kq + r][j = r16]; the constraint-force-mixing term on the diagonal
 #pragma unroll
     for (int r = 0; r < 4; ++r) Wt[17 * (4 * kq + r) + r16] = acc[r] + ((4 * kq + r) == r16 ? 1e-6f : 0.0f);
-    __syncthreads();
+    LS_WAVE_SYNC();
     // a row lane reads its row of the D tile, a velocity lane column vk of Y at the 16 slots of the tile: one address pattern, 16 reads
     const float* row = vk >= 0 ? &sh.u.c.Y[0][vk] : Wt + 17 * (t >= 0 ? t : 0);
     const float* rowl = vk >= 0 ? &sh.u.c.Y[LS_LIM0][vk] : row + 12;
@@ -988,7 +988,7 @@ __device__ __forceinline__ void ls_delassus_mfma16(WaveShared& sh, int lane, boo
     for (int j = 0; j < 4; ++j) W[LS_LIM0 + j] = rowl[j * stride];
     W[LS_LIM0 + 4] = 0.0f; W[LS_LIM0 + 5] = 0.0f;     // the sweep relaxes limit slots in triples: slots past nlim must hold something finite
     if (act) wd = row[t];
-    __syncthreads();                          // the scratch is the next phase's to overwrite only after every lane has read its row
+    LS_WAVE_SYNC();                          // the scratch is the next phase's to overwrite only after every lane has read its row
 }
 template <int I>
 __device__ __forceinline__ void ls_delassus_mfma32_row(WaveShared& sh, int lane, int vk, float (&W)[LS_MAXR]) {
@@ -1005,22 +1005,22 @@ __device__ __forceinline__ void ls_delassus_mfma32_row(WaveShared& sh, int lane,
         accA = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, accA, 0, 0, 0);
         accB = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, accB, 0, 0, 0);
     }
-    __syncthreads();                      // every lane has read its A operands of this tile row: its half of the scratch now takes D tiles
+    LS_WAVE_SYNC();                      // every lane has read its A operands of this tile row: its half of the scratch now takes D tiles
     float* Wt = Jd + 288 * I;             // [16][17]
     const bool mine = vk < 0 && (lane >> 4) == I && lane < 32;
     // D[i = 4 kq + r][j = r16]; the constraint-force-mixing term on the diagonal (tile (I, I))
 #pragma unroll
     for (int r = 0; r < 4; ++r) Wt[17 * (4 * kq + r) + r16] = accA[r] + ((I == 0 && (4 * kq + r) == r16) ? 1e-6f : 0.0f);
-    __syncthreads();
+    LS_WAVE_SYNC();
 #pragma unroll
     for (int j = 0; j < 16; ++j) { const float t = Wt[17 * r16 + j]; W[j] = mine ? t : W[j]; }
-    __syncthreads();
+    LS_WAVE_SYNC();
 #pragma unroll
     for (int r = 0; r < 4; ++r) Wt[17 * (4 * kq + r) + r16] = accB[r] + ((I == 1 && (4 * kq + r) == r16) ? 1e-6f : 0.0f);
-    __syncthreads();
+    LS_WAVE_SYNC();
 #pragma unroll
     for (int j = 0; j < 16; ++j) { const float t = Wt[17 * r16 + j]; W[16 + j] = mine ? t : W[16 + j]; }
-    __syncthreads();
+    LS_WAVE_SYNC();
 }
 // Round 6, BUILT, CORRECT (GPU physics suite green with it) AND NOT SHIPPED (-DLS_DELASSUS_MFMA32 enables it): kernel A 0.1096 -> 0.1148 ms flat, 0.1194 ->
 // 0.1230 stairs, interleaved on one lease (profiles/r06_kernel_a_ab.txt).  The micro-benchmark's 3.5 against 6.4-7.8 us per build assumed LDS for the whole D
@@ -1053,7 +1053,7 @@ __device__ __forceinline__ void ls_delassus_mfma32(WaveShared& sh, int lane, boo
 #pragma unroll
         for (int j = 0; j < 32; ++j) W[j] = 0.0f;          // row lanes: filled below; lanes that hold no row: something finite
     }
-    __syncthreads();
+    LS_WAVE_SYNC();
     ls_delassus_mfma32_row<1>(sh, lane, vk, W);      // tile row 1 first: its half of J' is the first to die
     ls_delassus_mfma32_row<0>(sh, lane, vk, W);
     W[32] = 0.0f; W[33] = 0.0f; W[34] = 0.0f; W[35] = 0.0f;     // the sweep relaxes limit slots in triples: slots past nlim must hold something finite
