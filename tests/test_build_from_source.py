@@ -69,3 +69,24 @@ def test_library_compiled_on_this_machine_reproduces_the_shipped_one(tmp_path):
         assert r.returncode == 0, r.stderr[-2000:]
         return [l for l in r.stdout.splitlines() if l.startswith("DIGEST")][-1]
     assert digest({"LSIM_LIB": fresh}) == digest({})
+
+
+def test_wavefront_fences_only_in_one_wave_kernels():
+    """LS_WAVE_SYNC (ls_math.h) replaces __syncthreads() by wavefront-scope fences: correct only where the workgroup IS one wavefront.  Every kernel
+    that runs the wave drivers must be compiled for, and launched with, 64 threads; kernels of more than one wave keep __syncthreads()."""
+    import re
+    from isaacgymloco_amd.csrc import build as B
+    src = open(os.path.join(B.HERE, "lsim_hip.hip")).read()
+    # kernels (or kernel macros) whose body reaches a wave driver
+    bodies = re.findall(r"__global__\s+__launch_bounds__\((\d+)\)[^\n]*\n((?:[^\n]*\n){1,12}?)\}", src)
+    wave = [(int(n), body) for n, body in bodies if re.search(r"ls_wave_step_[ab]|ls_wave_debug|LS_PHASE|LS_WAVE_SYNC|wc_", body)]
+    assert wave, "no wave-driver kernel found: the pattern of this test is out of date"
+    assert all(n == 64 for n, _ in wave), [n for n, _ in wave]
+    for name in ("lsim_k_step_a_tgs", "lsim_k_step_a_pgs", "lsim_k_step_b"):
+        launches = re.findall(r"hipLaunchKernelGGL\(\s*" + name + r"\s*,\s*dim3\(.*?\)\s*,\s*dim3\((\d+)\)", src)
+        assert launches and all(int(t) == 64 for t in launches), (name, launches)
+    multi = [body for n, body in bodies if int(n) > 64]
+    assert multi and not any("LS_WAVE_SYNC" in body or "LS_PHASE" in body for body in multi)
+    # the learn translation unit (multi-wave blocks everywhere) never uses the macro
+    for f in set(B.LEARN_HEADERS + ["lsim_learn.hip"]) - set(B.SIM_HEADERS):       # (ls_math.h, where the macro is defined, belongs to both)
+        assert "LS_WAVE_SYNC" not in open(os.path.join(B.HERE, f)).read(), f
