@@ -29,6 +29,13 @@ def test_library_exports_every_declared_symbol():
     assert [L.lsim_buffer_name(i).decode() for i in range(abi.NUM_BUFFERS)] == names
 
 
+def test_integration_document_names_every_entry_point():
+    """INTEGRATION.md's table maps the reference's calls to the C-ABI: an entry point added to include/lsim.h without a row there is undocumented"""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = [fn for fn in abi.declared_functions() if fn not in doc]
+    assert not missing, missing
+
+
 def test_query_arena_validates_config():
     from isaacgymloco_amd.csrc import build
     L = ctypes.CDLL(build.build())
