@@ -53,6 +53,8 @@ def run_train_bench(env, cfg, args, dev, rank, world, barrier, clocks=None):
 
     spans = {"collection": [], "update": []}      # wall-clock intervals of the two halves of every iteration (the clock sampler splits its samples by them)
 
+    enqueue = []       # host seconds the update took to ENQUEUE (HIMPPO.update: up to its first read-back), every iteration incl. warm-up
+
     def one_iteration():
         """HIMR:105-157 without the logging: returns (collection seconds, learn seconds), each closed by a device sync"""
         t0 = time.perf_counter()
@@ -72,6 +74,7 @@ def run_train_bench(env, cfg, args, dev, rank, world, barrier, clocks=None):
         runner.alg.update()
         torch.cuda.synchronize(dev)
         t2 = time.perf_counter()
+        enqueue.append(getattr(runner.alg, "update_enqueue_s", 0.0))
         spans["collection"].append((t0, t1)); spans["update"].append((t1, t2))
         return t1 - t0, t2 - t1
 
@@ -160,6 +163,9 @@ def run_train_bench(env, cfg, args, dev, rank, world, barrier, clocks=None):
              "iteration_spread_frac": (walls[-1] - walls[0]) / med,
              "value_from_median_iteration": world * env.num_envs * T / med,
              "update_two_streams": two_streams, "tunableop": tun,
+             # host time to enqueue one update (Python + launches, no read-back inside) against learn_s_per_update: close to it = the host's launch rate,
+             # not the device, bounds the update on this box (the spread of the line between leases)
+             "update_host_enqueue_s": sum(enqueue[-iters:]) / max(len(enqueue[-iters:]), 1),
              # where a multi-rank run's time goes, per rank (VERDICT r5 task 6: the first scaling curve must be able to say where lost efficiency went):
              # a rank's iteration = collection + learn; `collective_blocked_s` = the part of learn its compute stream stood still waiting for a gradient
              # all-reduce (expected ~1-2 ms of 84 on xGMI); `iteration_skew_s` = slowest minus fastest rank, per timed iteration

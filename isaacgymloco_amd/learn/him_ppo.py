@@ -588,6 +588,7 @@ class HIMPPO:
 
     def update(self):
         ac = self.actor_critic
+        t_enqueue = time.perf_counter()
         self._grad_arena()
         sums = torch.zeros(4, device=self.device)
         last_est = last_swap = None
@@ -615,6 +616,9 @@ class HIMPPO:
             sums += torch.stack((f["value_loss"].detach(), f["surrogate_loss"].detach(), est, swap))
             last_est, last_swap = est, swap
         n = self.num_learning_epochs * self.num_mini_batches
+        # host time to ENQUEUE the update (no read-back before this point): against the update's wall time it says whether the device or the
+        # host's launch rate bounds it (bench line: update_host_enqueue_s)
+        self.update_enqueue_s = time.perf_counter() - t_enqueue
         if self._lr_t is not None:
             self.learning_rate = float(self._lr_t)       # one read-back per update (logging, checkpoints)
         sums = (sums / n).tolist()

@@ -8,6 +8,7 @@ transition pairs go to a 1 M-entry replay buffer (HYBP:144-145).  The update add
 HYBP:252-273), clamps std >= min_std (HYBP:276-277) and feeds the running normaliser with the *normalised* policy /
 expert states exactly like the reference does (HYBP:236-241, HYBP:279-281).
 """
+import time
 import torch
 import torch.nn as nn
 
@@ -51,6 +52,7 @@ class HybridPPO(HIMPPO):
         mb = self.storage.num_envs * self.storage.num_transitions_per_env // self.num_mini_batches
         sums = torch.zeros(6, device=dev)
         est = swap = None
+        t_enqueue = time.perf_counter()
         self._grad_arena()
         gens = zip(self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs),
                    self.amp_storage.feed_forward_generator(n_updates, mb), self.amp_data.feed_forward_generator(n_updates, mb))
@@ -100,6 +102,7 @@ class HybridPPO(HIMPPO):
                 self.amp_normalizer.update(exp_s)
             sums += torch.stack((value_loss.detach(), surrogate_loss.detach(), amp_loss.detach(), grad_pen.detach(),
                                  policy_d_mean, expert_d_mean))
+        self.update_enqueue_s = time.perf_counter() - t_enqueue      # (him_ppo.HIMPPO.update: host time to enqueue, no read-back before here)
         if self._lr_t is not None:
             self.learning_rate = float(self._lr_t)
         s = (sums / n_updates).tolist()

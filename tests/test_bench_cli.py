@@ -71,6 +71,8 @@ def test_the_line_explains_its_update_and_announces_a_rejected_gemm_table():
     assert j["gemm_probe_after_timed_region"]["tflops"] > 20 and "gpu_max_hw_queues" in j and j["linear_elu_forward"] == "aligned"
     s = j["sclk_during_timed_region"]
     assert s["mean_mhz"] is None or 300 < s["mean_mhz"] < 3000
+    # the update is enqueued without a read-back: the host finishes enqueueing before the device finishes computing
+    assert 0.0 < j["update_host_enqueue_s"] < j["learn_s_per_update"]
 
 
 @pytest.mark.gpu

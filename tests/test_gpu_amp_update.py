@@ -170,3 +170,25 @@ def test_hybrid_update_with_fused_discriminator_path_matches_torch_statements(mo
     np.testing.assert_allclose(nz_f.var, nz_t.var, rtol=1e-5, atol=1e-6)
     for k in par_t:                                       # four Adam steps from identical states: parameters agree far inside one step's size (lr 1e-3)
         torch.testing.assert_close(par_f[k], par_t[k], rtol=0, atol=3e-4, msg=lambda m, k=k: f"{k}: {m}")
+
+
+@pytest.mark.gpu
+def test_index_upload_without_a_pipeline_drain_delivers_every_vector():
+    """learn/amp.py: _IndexUploader -- host-drawn indices through a ring of page-locked buffers with asynchronous copies: 200 uploads (the ring of 64
+    wraps three times) behind a long-running kernel queue, checked only at the end: a buffer overwritten before its copy ran would show"""
+    from isaacgymloco_amd.learn.amp import _IndexUploader
+    up = _IndexUploader(slots=64)
+    rs = np.random.RandomState(0)
+    a = torch.randn(4096, 4096, device="cuda:0")
+    host, dev = [], []
+    for i in range(200):
+        if i % 10 == 0:
+            a = a @ a * 1e-3                  # keep the stream busy: the host runs ahead of the copies
+        idx = rs.choice(1 << 20, size=102400 if i % 3 else 1000)
+        host.append(idx.copy())
+        dev.append(up(idx, "cuda:0"))
+        idx[:] = -1                           # the caller's array is free to change once the call has returned
+    torch.cuda.synchronize()
+    for h, d in zip(host, dev):
+        assert d.dtype == torch.int64 and d.device.type == "cuda" and np.array_equal(d.cpu().numpy(), h)
+    assert up(np.arange(5), "cpu").tolist() == [0, 1, 2, 3, 4]
