@@ -661,6 +661,13 @@ int lsim_running_moments_workspace(size_t* bytes);
 int lsim_running_moments_update(const float* x, int64_t ldx, int64_t batch, int dim, double* mean, double* var, double* count,
                                 void* workspace, size_t workspace_bytes, void* stream);
 
+/* The discriminator's input rows of one sampled block in HybridPPO.update (hybrid_ppo.py:247-251 normalize_torch on state and next state, then
+ * amp_discriminator.py:57 / :37 torch.cat([state, next_state], dim=-1)):  out[b, 0:dim] = f(states[b]), out[b, dim:2 dim] = f(next_states[b]),
+ * f(x) = clamp((x - float32(mean)) / sqrt(float32(var + eps)), +-clip) (utils/utils.py:124-130), or the identity when norm_mean == NULL (the gradient
+ * penalty's un-normalised pair).  One launch; `out` may point into a larger stacked evaluation (row pitch ld_out >= 2 dim). */
+int lsim_amp_pair_rows(const float* states, int64_t ld_states, const float* next_states, int64_t ld_next, const double* norm_mean,
+                       const double* norm_var, double norm_eps, double norm_clip, int64_t batch, int dim, float* out, int64_t ld_out, void* stream);
+
 /* Opt-in form of the two calls above for layers whose k_in and n_out are multiples of 128 (and whose operands are 16-byte aligned): the same fp32
  * sums on the bf16 matrix pipe.  Every fp32 operand is split exactly into three bf16 terms (3 x 8 significand bits) and the six products of
  * order <= 2 are accumulated in fp32: products exact, truncation 2^-24 |a||b| per product -- fp32's own rounding (measured against fp64 sums:

@@ -438,3 +438,35 @@ extern "C" int lsim_running_moments_update(const float* x, int64_t ldx, int64_t 
     hipLaunchKernelGGL(lsim_k_moments_merge, dim3(1), dim3(256), 0, s, (const double*)workspace, slices, (long)batch, dim, mean, var, count);
     return hipGetLastError() == hipSuccess ? LSIM_OK : LSIM_E_HIP;
 }
+
+// lsim_amp_pair_rows -- the discriminator's input rows of one sampled block (HYBP:247-251 normalize_torch on state and next state, DISC:57 / DISC:37
+// torch.cat([state, next_state], dim=-1)): out[b, 0:D] = f(s[b]), out[b, D:2D] = f(ns[b]) with f = clamp((x - float32(mean)) / sqrt(float32(var + eps)),
+// +-clip) (UT:124-130; the arithmetic of lsim_k_amp_step's stage) or the identity when mean == NULL (the gradient penalty's un-normalised pair).
+// One pass instead of 14 elementwise launches and a cat per pair; the caller points `out` at this block's rows of the stacked evaluation.
+__global__ __launch_bounds__(256) void lsim_k_amp_pair_rows(const float* __restrict__ s, long lds, const float* __restrict__ ns, long ldns,
+                                                           const double* __restrict__ mean, const double* __restrict__ var, double eps, double clip,
+                                                           long batch, int D, float* __restrict__ out, long ldo) {
+    const long total = batch * 2 * D;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long b = e / (2 * D);
+        const int c2 = (int)(e - b * 2 * D), c = c2 < D ? c2 : c2 - D;
+        float x = c2 < D ? s[b * lds + c] : ns[b * ldns + c];
+        if (mean) {
+            const float m = (float)mean[c], sd = sqrtf((float)(var[c] + eps)), cl = (float)clip;
+            x = fminf(fmaxf((x - m) / sd, -cl), cl);
+        }
+        out[b * ldo + c2] = x;
+    }
+}
+extern "C" int lsim_amp_pair_rows(const float* states, int64_t ld_states, const float* next_states, int64_t ld_next, const double* norm_mean,
+                                  const double* norm_var, double norm_eps, double norm_clip, int64_t batch, int dim, float* out, int64_t ld_out, void* stream) {
+    if (!states || !next_states || !out || batch <= 0 || dim <= 0 || ld_states < dim || ld_next < dim || ld_out < 2 * dim) return LSIM_E_INVALID;
+    if ((norm_mean == nullptr) != (norm_var == nullptr)) return LSIM_E_INVALID;
+    const long total = (long)batch * 2 * dim;
+    long blocks = (total + 4 * 256 - 1) / (4 * 256);        // ~4 elements per thread
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(lsim_k_amp_pair_rows, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, states, (long)ld_states, next_states, (long)ld_next,
+                       norm_mean, norm_var, norm_eps, norm_clip, (long)batch, dim, out, (long)ld_out);
+    return hipGetLastError() == hipSuccess ? LSIM_OK : LSIM_E_HIP;
+}

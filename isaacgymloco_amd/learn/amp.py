@@ -474,20 +474,56 @@ class AMPDiscriminator(nn.Module):
         h = _trunk_fused(self.trunk, x)
         return self.amp_linear(h if h is not None else self.trunk(x))
 
+    def pair_inputs(self, exp_s, exp_ns, pol_s, pol_ns, normalizer):
+        """(expert_in, policy_in, expert_raw, expert_state_n, policy_state_n): the [B, 2 D] rows the update feeds the discriminator -- normalised (state,
+        next state) pairs of the expert and the policy block (HYBP:247-251 + DISC:57), the un-normalised expert pair of the gradient penalty (HYBP:262-263,
+        DISC:37) -- and the normalised states by themselves ([B, D]; views of the rows on the GPU), which the reference feeds its normaliser (HYBP:279-281).  On the GPU three
+        launches of lsim_amp_pair_rows (normalise + cat in one pass; the two normalised blocks land in ONE [2 B, 2 D] buffer, so lsgan_loss needs no
+        second cat) instead of 28 elementwise launches and three cats; the reference's statements otherwise."""
+        B, D = exp_s.shape
+        fused = (_fused_update_wanted() and exp_s.is_cuda and exp_s.dtype == torch.float32 and pol_s.shape == exp_s.shape and B >= 16384
+                 and all(t.dim() == 2 and t.stride(1) == 1 and t.dtype == torch.float32 for t in (exp_s, exp_ns, pol_s, pol_ns))
+                 and (normalizer is None or (normalizer._mean.is_cuda and normalizer._mean.dtype == torch.float64)))
+        if not fused:
+            raw = torch.cat([exp_s, exp_ns], dim=-1)
+            if normalizer is not None:
+                with torch.no_grad():
+                    nz = normalizer.normalize_torch
+                    exp_s, exp_ns, pol_s, pol_ns = nz(exp_s, self.device), nz(exp_ns, self.device), nz(pol_s, self.device), nz(pol_ns, self.device)
+            return torch.cat([exp_s, exp_ns], dim=-1), torch.cat([pol_s, pol_ns], dim=-1), raw, exp_s, pol_s
+        from .. import lib
+        L = lib.load()
+        st = torch.cuda.current_stream(exp_s.device).cuda_stream
+        stacked = torch.empty(2 * B, 2 * D, device=exp_s.device)
+        raw = torch.empty(B, 2 * D, device=exp_s.device)
+        mean = normalizer._mean.data_ptr() if normalizer is not None else None
+        var = normalizer._var.data_ptr() if normalizer is not None else None
+        eps, clip = (float(normalizer.epsilon), float(normalizer.clip_obs)) if normalizer is not None else (0.0, 0.0)
+        for s_, ns_, out, m, v in ((exp_s, exp_ns, stacked[:B], mean, var), (pol_s, pol_ns, stacked[B:], mean, var), (exp_s, exp_ns, raw, None, None)):
+            lib.check(L.lsim_amp_pair_rows(s_.data_ptr(), s_.stride(0), ns_.data_ptr(), ns_.stride(0), m, v, eps, clip, B, D, out.data_ptr(), out.stride(0), st),
+                      what="lsim_amp_pair_rows")
+        return stacked[:B], stacked[B:], raw, stacked[:B, :D], stacked[B:, :D]
+
     def lsgan_loss(self, expert_in, policy_in):
         """0.5 * (mse(D(expert), 1) + mse(D(policy), -1)) (HYBP:258-261) -> (loss, mean D(policy), mean D(expert)); both blocks through ONE closed-form
         forward / backward (_LsganFn) on the GPU, else the reference's statements"""
         if expert_in.shape == policy_in.shape and _fused_disc_ok(expert_in, self.trunk, self.amp_linear):
             l1, l2, h = self.trunk[0], self.trunk[2], self.amp_linear
-            loss, means = _LsganFn.apply(torch.cat([expert_in, policy_in], dim=0), l1.weight, l1.bias, l2.weight, l2.bias, h.weight, h.bias, (1.0, -1.0),
-                                         expert_in.shape[0])
+            B = expert_in.shape[0]
+            if (expert_in.is_contiguous() and policy_in.is_contiguous() and expert_in.untyped_storage().data_ptr() == policy_in.untyped_storage().data_ptr()
+                    and policy_in.data_ptr() == expert_in.data_ptr() + expert_in.numel() * 4 and expert_in.storage_offset() == 0
+                    and expert_in.untyped_storage().nbytes() >= 2 * expert_in.numel() * 4):
+                both = torch.as_strided(expert_in, (2 * B, expert_in.shape[1]), (expert_in.shape[1], 1))     # pair_inputs' stacked buffer: no second cat
+            else:
+                both = torch.cat([expert_in, policy_in], dim=0)
+            loss, means = _LsganFn.apply(both, l1.weight, l1.bias, l2.weight, l2.bias, h.weight, h.bias, (1.0, -1.0), B)
             return 0.5 * loss, means[1], means[0]
         policy_d, expert_d = self(policy_in), self(expert_in)
         loss = 0.5 * (torch.nn.functional.mse_loss(expert_d, torch.ones_like(expert_d)) + torch.nn.functional.mse_loss(policy_d, -torch.ones_like(policy_d)))
         return loss, policy_d.mean().detach(), expert_d.mean().detach()
 
-    def compute_grad_pen(self, expert_state, expert_next_state, lambda_=10):   # DISC:36-53
-        data = torch.cat([expert_state, expert_next_state], dim=-1)
+    def compute_grad_pen(self, expert_state, expert_next_state, lambda_=10, pair=None):   # DISC:36-53; pair: the two already concatenated (pair_inputs)
+        data = pair if pair is not None else torch.cat([expert_state, expert_next_state], dim=-1)
         if (data.is_cuda and len(self.trunk) == 4 and isinstance(self.trunk[0], nn.Linear) and isinstance(self.trunk[1], nn.ReLU)
                 and isinstance(self.trunk[2], nn.Linear) and isinstance(self.trunk[3], nn.ReLU)):
             l1, l2 = self.trunk[0], self.trunk[2]

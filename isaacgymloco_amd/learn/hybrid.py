@@ -75,13 +75,11 @@ class HybridPPO(HIMPPO):
                 if adaptive:
                     self._adapt_lr(mu, sigma, old_mu, old_sigma, kl_mean)
                 est, swap = ac.estimator.update(obs, next_critic_obs, lr=None if self._lr_t is not None else self.learning_rate)
-            exp_s, exp_ns = exp_s_raw, exp_ns_raw
-            if self.amp_normalizer is not None:
-                with torch.no_grad():
-                    nz = self.amp_normalizer.normalize_torch
-                    pol_s, pol_ns, exp_s, exp_ns = nz(pol_s, dev), nz(pol_ns, dev), nz(exp_s, dev), nz(exp_ns, dev)
-            amp_loss, policy_d_mean, expert_d_mean = disc.lsgan_loss(torch.cat([exp_s, exp_ns], dim=-1), torch.cat([pol_s, pol_ns], dim=-1))   # HYBP:252-261
-            grad_pen = disc.compute_grad_pen(exp_s_raw, exp_ns_raw, lambda_=10)     # on the un-normalised expert pair (HYBP:262-263)
+            # normalise + concatenate the sampled pairs (HYBP:247-251, DISC:57): three launches on the GPU (AMPDiscriminator.pair_inputs)
+            expert_in, policy_in, expert_raw, exp_s, pol_s = disc.pair_inputs(exp_s_raw, exp_ns_raw, pol_s, pol_ns, self.amp_normalizer)
+            # (exp_s, pol_s: the NORMALISED states -- what the reference feeds its normaliser at the end of the minibatch, HYBP:279-281)
+            amp_loss, policy_d_mean, expert_d_mean = disc.lsgan_loss(expert_in, policy_in)   # HYBP:252-261
+            grad_pen = disc.compute_grad_pen(exp_s_raw, exp_ns_raw, lambda_=10, pair=expert_raw)     # on the un-normalised expert pair (HYBP:262-263)
             loss = ppo_loss + amp_loss + grad_pen
             if dist_on:      # two collectives per minibatch, the estimator's in flight during this backward (him_ppo.py)
                 est, swap = self._step_minibatch_data_parallel(ac, obs, next_critic_obs, loss, mu, sigma, old_mu, old_sigma, kl_mean, adaptive,

@@ -93,6 +93,7 @@ def load_path(path):
     L.lsim_masked_colsum.argtypes = [vp, i64, vp, i64, i64, i32, vp, vp, ctypes.c_size_t, vp]
     L.lsim_running_moments_workspace.argtypes = [ctypes.POINTER(ctypes.c_size_t)]
     L.lsim_running_moments_update.argtypes = [vp, i64, i64, i32, vp, vp, vp, vp, ctypes.c_size_t, vp]
+    L.lsim_amp_pair_rows.argtypes = [vp, i64, vp, i64, vp, vp, ctypes.c_double, ctypes.c_double, i64, i32, vp, i64, vp]
     L.lsim_amp_step_workspace.argtypes = [i64, ctypes.POINTER(ctypes.c_size_t)]
     L.lsim_amp_step.argtypes = [ctypes.POINTER(abi.LsimAmpDisc), vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, i64, i64, vp, ctypes.c_size_t, vp]
     L.lsim_destroy.argtypes = [vp]

@@ -192,3 +192,33 @@ def test_index_upload_without_a_pipeline_drain_delivers_every_vector():
     for h, d in zip(host, dev):
         assert d.dtype == torch.int64 and d.device.type == "cuda" and np.array_equal(d.cpu().numpy(), h)
     assert up(np.arange(5), "cpu").tolist() == [0, 1, 2, 3, 4]
+
+
+@pytest.mark.gpu
+def test_pair_inputs_match_the_reference_statements():
+    """lsim_amp_pair_rows through AMPDiscriminator.pair_inputs: normalise_torch on the four sampled blocks + torch.cat (HYBP:247-251, DISC:57, DISC:37),
+    bit for bit (the same float32 operations per element); the two normalised blocks are adjacent rows of one buffer and lsgan_loss takes them without a copy"""
+    from isaacgymloco_amd.learn.amp import AMPDiscriminator, Normalizer
+    torch.manual_seed(3)
+    B, D = 20000, 30
+    disc = AMPDiscriminator(2 * D, 2.0, [1024, 512], DEV, 0.3).to(DEV)
+    nz = Normalizer(D, device=DEV)
+    nz.update(torch.randn(4096, D, device=DEV) * 3.0 + 1.0)
+    big = torch.randn(4, B, D + 2, device=DEV) * 4.0                       # strided rows (pitch D + 2)
+    big[:, ::7, 3] *= 50.0                                                  # ... and values beyond the clip
+    es, ens, ps, pns = (big[i, :, :D] for i in range(4))
+    e_in, p_in, raw, e_n, p_n = disc.pair_inputs(es, ens, ps, pns, nz)
+    f = nz.normalize_torch
+    assert torch.equal(e_in, torch.cat([f(es), f(ens)], dim=-1)) and torch.equal(p_in, torch.cat([f(ps), f(pns)], dim=-1))
+    assert torch.equal(raw, torch.cat([es, ens], dim=-1)) and torch.equal(e_n, f(es)) and torch.equal(p_n, f(ps))
+    assert float(e_in.abs().max()) == nz.clip_obs                           # the clamp is exercised
+    assert p_in.data_ptr() == e_in.data_ptr() + e_in.numel() * 4            # one stacked buffer
+    a = disc.lsgan_loss(e_in, p_in)
+    b = disc.lsgan_loss(e_in.clone(), p_in.clone())                         # separate tensors: the cat path
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    # without a normaliser: plain concatenation
+    e2, p2, raw2, e2n, p2n = disc.pair_inputs(es, ens, ps, pns, None)
+    assert torch.equal(e2, torch.cat([es, ens], dim=-1)) and torch.equal(p2, torch.cat([ps, pns], dim=-1)) and torch.equal(e2n, es)
+    # small batches keep the torch statements (same values)
+    s_in = disc.pair_inputs(es[:100], ens[:100], ps[:100], pns[:100], nz)
+    assert torch.equal(s_in[0], e_in[:100]) and torch.equal(s_in[1], p_in[:100])

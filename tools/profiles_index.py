@@ -37,6 +37,7 @@ RULES = [   # (regex on the name without its round prefix, what it is, section)
     (r"^cpu_scaling_probe\.txt$", "the GPU box's host: cgroup CPU grant and oracle/cpu_bench.py at 8 .. 256 threads", "8"),
     (r"^kernel_a_ifetch_pmc\.txt$", "kernel A: instruction-cache and fetch counters (93 KB of code against a 64 KB cache: hit rate 99.76 %, not the limiter)", "6"),
     (r"^amp_host_enqueue\.txt$", "host time to enqueue one update against its wall time, default and AMP, before / after the sample indices stopped draining the pipeline (learn/amp.py: _IndexUploader)", "10"),
+    (r"^update_host_profile_.*\.txt$", "cProfile of the host side of one update (tools/update_host_profile.py): where the enqueue time goes", "10"),
     (r"^kernel_a_sched_flags\.txt$", "kernel A built with the compiler's other instruction-scheduling strategies (max-ilp, max-memory-clause, latency bias, iterative ilp): all within 0.6 % (negative result)", "6"),
     (r"^kernel_a_ab\.txt$", "kernel A, product against build variants, interleaved on one lease (tools/gpu_ab_kernel_a.sh)", "6"),
     (r"^free_running_parity\.jsonl$", "HIP vs fp64 oracle free-running: per-case flags agreement and error percentiles (tests/test_gpu_free_running.py)", "4"),
