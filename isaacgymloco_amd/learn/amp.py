@@ -65,7 +65,10 @@ class _IndexUploader:
         self._next = (i + 1) % len(self._slots)
         slot = self._slots[i]
         if slot is None or slot[0].numel() < t.numel() or slot[0].dtype != t.dtype:
-            buf = torch.empty(t.numel(), dtype=t.dtype).pin_memory()
+            try:
+                buf = torch.empty(t.numel(), dtype=t.dtype).pin_memory()
+            except RuntimeError:               # no page-locked memory to be had (memlock limit): the pageable copy still works, it only drains the pipeline
+                return t.to(device)
             slot = [buf, None, buf.numpy()]
             self._slots[i] = slot
         buf, ev, host = slot
